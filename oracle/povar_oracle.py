@@ -1,0 +1,228 @@
+"""ctypes binding of oracle/libpovar_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module (see oracle/povar_oracle.h).  Build with ``make -C oracle``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+NORM = {"NONE": 0, "HUBER": 1, "CAUCHY": 2}
+POWER_VARPROJ, POWER_SCHUR_COMPLEMENT = 0, 1
+
+
+class _Problem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("n_lms", C.c_int32), ("n_obs", C.c_int64),
+                ("lm_off", C.c_void_p), ("cam_idx", C.c_void_p), ("obs", C.c_void_p)]
+
+
+class _Options(C.Structure):
+    _fields_ = [("robust_norm", C.c_int32), ("huber_parameter", C.c_double),
+                ("jacobi_scaling_eps", C.c_double)]
+
+
+class ResidualInfo(C.Structure):
+    _fields_ = [("all_num_obs", C.c_int64), ("all_error", C.c_double),
+                ("all_residual_sum", C.c_double), ("valid_num_obs", C.c_int64),
+                ("valid_error", C.c_double), ("valid_residual_sum", C.c_double),
+                ("is_numerically_valid", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libpovar_oracle.so")
+    src = os.path.join(_HERE, "povar_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpovar_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        for name in ("orc_back_substitute_pose", "orc_back_substitute_poba",
+                     "orc_back_substitute_joint"):
+            getattr(_LIB, name).restype = C.c_double
+    return _LIB
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    """Reference-faithful CPU pipeline over one problem (storage_pOSE_ layout [4k x 16])."""
+
+    def __init__(self, n_cams, lm_off, cam_idx, obs, robust_norm="NONE", huber=1.0, eps=1e-5):
+        self.lm_off = np.ascontiguousarray(lm_off, dtype=np.int32)
+        self.cam_idx = np.ascontiguousarray(cam_idx, dtype=np.int32)
+        self.obs = _f64(obs).reshape(-1, 2)
+        self.n_cams = int(n_cams)
+        self.n_lms = self.lm_off.shape[0] - 1
+        self.n_obs = self.cam_idx.shape[0]
+        self.prob = _Problem(self.n_cams, self.n_lms, self.n_obs, self.lm_off.ctypes.data,
+                             self.cam_idx.ctypes.data, self.obs.ctypes.data)
+        self.opts = _Options(NORM[robust_norm], huber, eps)
+        self.L = lib()
+
+    # ---- step 1 ----
+    def init_landmarks_pose(self, alpha, cams):
+        lms = np.zeros((self.n_lms, 3))
+        self.L.orc_init_landmarks_pose(C.byref(self.prob), C.c_double(alpha), _p(_f64(cams)), _p(lms))
+        return lms
+
+    def error_pose(self, alpha, cams, lms):
+        ri = ResidualInfo()
+        self.L.orc_error_pose(C.byref(self.prob), C.byref(self.opts), C.c_double(alpha),
+                              _p(_f64(cams)), _p(_f64(lms)), C.byref(ri))
+        return ri
+
+    def linearize_pose(self, alpha, cams, lms):
+        st = np.zeros((4 * self.n_obs, 16))
+        ok = self.L.orc_linearize_pose(C.byref(self.prob), C.byref(self.opts), C.c_double(alpha),
+                                       _p(_f64(cams)), _p(_f64(lms)), _p(st))
+        return st, bool(ok)
+
+    def jp_diag2_pose(self, st):
+        d = np.zeros(12 * self.n_cams)
+        self.L.orc_jp_diag2_pose(C.byref(self.prob), _p(st), _p(d))
+        return d
+
+    def scale_jl_cols_pose(self, st):
+        s = np.zeros((self.n_lms, 3))
+        self.L.orc_scale_jl_cols_pose(C.byref(self.prob), C.byref(self.opts), _p(st), _p(s))
+        return s
+
+    def scale_jp_cols_pose(self, st, scaling):
+        self.L.orc_scale_jp_cols_pose(C.byref(self.prob), _p(st), _p(_f64(scaling)))
+
+    def prepare_hb_pose(self, st, lambda_pose, lambda_lm=0.0):
+        hll = np.zeros((self.n_lms, 9))
+        b = np.zeros(12 * self.n_cams)
+        binv = np.zeros((self.n_cams, 144))
+        self.L.orc_prepare_hb_pose(C.byref(self.prob), _p(st), C.c_double(lambda_pose),
+                                   C.c_double(lambda_lm), _p(hll), _p(b), _p(binv))
+        return hll, b, binv
+
+    def right_mul_b_inv(self, binv, x, dim=12):
+        y = np.zeros(dim * self.n_cams)
+        self.L.orc_right_mul_b_inv(self.n_cams, dim, _p(binv), _p(_f64(x)), _p(y))
+        return y
+
+    def right_mul_e0_pose(self, st, hll, x, n_threads=1):
+        y = np.zeros(12 * self.n_cams)
+        self.L.orc_right_mul_e0_pose_mt(C.byref(self.prob), _p(st), _p(hll), _p(_f64(x)), _p(y),
+                                        C.c_int32(n_threads))
+        return y
+
+    def solve_pose(self, st, hll, binv, b, m, q_tol=0.0, r_tol=-1.0, want_terms=False, n_threads=1):
+        accum = np.zeros(12 * self.n_cams)
+        it = C.c_int32(0)
+        terms = np.zeros((m + 1, 12 * self.n_cams)) if want_terms else None
+        status = self.L.orc_solve_pose(C.byref(self.prob), _p(st), _p(hll), _p(binv), _p(_f64(b)),
+                                       C.c_int32(m), C.c_double(q_tol), C.c_double(r_tol), _p(accum),
+                                       C.byref(it), _p(terms) if want_terms else None,
+                                       C.c_int32(n_threads))
+        return accum, it.value, status, terms
+
+    def back_substitute_pose(self, alpha, st, cams_new, lms, inc):
+        lms = _f64(lms).copy()
+        l_diff = self.L.orc_back_substitute_pose(C.byref(self.prob), C.c_double(alpha), _p(st),
+                                                 _p(_f64(cams_new)), _p(lms), _p(_f64(inc)))
+        return l_diff, lms
+
+    def back_substitute_poba(self, st, jl_col_scale, lambda_lm, lms, inc):
+        lms = _f64(lms).copy()
+        l_diff = self.L.orc_back_substitute_poba(C.byref(self.prob), _p(st), _p(_f64(jl_col_scale)),
+                                                 C.c_double(lambda_lm), _p(lms), _p(_f64(inc)))
+        return l_diff, lms
+
+    # ---- step 2 ----
+    def error_homogeneous(self, cams, lms_h):
+        ri = ResidualInfo()
+        self.L.orc_error_homogeneous(C.byref(self.prob), C.byref(self.opts), _p(_f64(cams)),
+                                     _p(_f64(lms_h)), C.byref(ri))
+        return ri
+
+    def linearize_homogeneous(self, cams, lms_h):
+        st = np.zeros((2 * self.n_obs, 17))
+        ok = self.L.orc_linearize_homogeneous(C.byref(self.prob), C.byref(self.opts), _p(_f64(cams)),
+                                              _p(_f64(lms_h)), _p(st))
+        return st, bool(ok)
+
+    def jp_diag2_homogeneous(self, st_h):
+        d = np.zeros(12 * self.n_cams)
+        self.L.orc_jp_diag2_homogeneous(C.byref(self.prob), _p(st_h), _p(d))
+        return d
+
+    def scale_jl_cols_homogeneous(self, st_h):
+        s = np.zeros((self.n_lms, 4))
+        self.L.orc_scale_jl_cols_homogeneous(C.byref(self.prob), C.byref(self.opts), _p(st_h), _p(s))
+        return s
+
+    def scale_jp_cols_joint(self, st_h, scaling):
+        self.L.orc_scale_jp_cols_joint(C.byref(self.prob), _p(st_h), _p(_f64(scaling)))
+
+    def linearize_nullspace(self, cams, lms_h, st_h):
+        st_n = np.zeros((2 * self.n_obs, 14))
+        self.L.orc_linearize_nullspace(C.byref(self.prob), _p(_f64(cams)), _p(_f64(lms_h)), _p(st_h), _p(st_n))
+        return st_n
+
+    def prepare_hb_joint(self, st_h, st_n, lam):
+        hll = np.zeros((self.n_lms, 9))
+        b = np.zeros(11 * self.n_cams)
+        binv = np.zeros((self.n_cams, 121))
+        self.L.orc_prepare_hb_joint(C.byref(self.prob), _p(st_h), _p(st_n), C.c_double(lam), _p(hll),
+                                    _p(b), _p(binv))
+        return hll, b, binv
+
+    def right_mul_e0_joint(self, st_n, hll, x):
+        y = np.zeros(11 * self.n_cams)
+        self.L.orc_right_mul_e0_joint(C.byref(self.prob), _p(st_n), _p(hll), _p(_f64(x)), _p(y))
+        return y
+
+    def solve_joint(self, st_n, hll, binv, b, m, q_tol=0.0, r_tol=-1.0, want_terms=False):
+        accum = np.zeros(11 * self.n_cams)
+        it = C.c_int32(0)
+        terms = np.zeros((m + 1, 11 * self.n_cams)) if want_terms else None
+        status = self.L.orc_solve_joint(C.byref(self.prob), _p(st_n), _p(hll), _p(binv), _p(_f64(b)),
+                                        C.c_int32(m), C.c_double(q_tol), C.c_double(r_tol), _p(accum),
+                                        C.byref(it), _p(terms) if want_terms else None)
+        return accum, it.value, status, terms
+
+    def back_substitute_joint(self, st_h, jl_col_scale_h, lam, cams, lms_h, inc):
+        lms_h = _f64(lms_h).copy()
+        l_diff = self.L.orc_back_substitute_joint(C.byref(self.prob), _p(st_h), _p(_f64(jl_col_scale_h)),
+                                                  C.c_double(lam), _p(_f64(cams)), _p(lms_h), _p(_f64(inc)))
+        return l_diff, lms_h
+
+    def apply_cam_inc_joint(self, cams, inc11, scaling):
+        cams = _f64(cams).copy()
+        self.L.orc_apply_cam_inc_joint(self.n_cams, _p(cams), _p(_f64(inc11)), _p(_f64(scaling)))
+        return cams
+
+    def normalize_joint(self, cams, lms_h):
+        cams, lms_h = _f64(cams).copy(), _f64(lms_h).copy()
+        self.L.orc_normalize_joint(self.n_cams, self.n_lms, _p(cams), _p(lms_h))
+        return cams, lms_h
+
+    # ---- composite drivers restating LinearizorPowerVarproj (LZR) ----
+    def stage1_pose(self, alpha, cams, lms):
+        """LZR:45-76: linearize, diag2, Jl scaling, pose scaling vector."""
+        st, ok = self.linearize_pose(alpha, cams, lms)
+        diag2 = self.jp_diag2_pose(st)
+        jl_scale = self.scale_jl_cols_pose(st)
+        sigma = 1.0 / (self.opts.jacobi_scaling_eps + np.sqrt(diag2))
+        return st, diag2, jl_scale, sigma, ok

@@ -1,0 +1,184 @@
+"""Seeded synthetic BAL-shaped problems and the PoVar ``data_custom`` text format.
+
+No BAL files ship with this repo (the reference downloads them from
+grail.cs.washington.edu, scripts/download-bal-problems.sh:200), so benchmarks and tests
+use generated problems with the exact BAL shapes (scripts/num_ops/bal_numbers.csv:1-5).
+
+The generator follows SURVEY.md section 8(d): landmark degrees ``2 + Geometric`` clipped to
+``[2, min(n_cams, 200)]`` and adjusted to hit ``n_obs`` exactly, cameras per landmark drawn
+without replacement with Zipf(1.0) popularity over a random camera permutation (hub
+cameras), observations = ground-truth pinhole projection + N(0, 0.5^2) px, initial
+cameras as ``--create-dataset`` writes them (rows 0-1 ~ N(0,1), row 2 = [0 0 0 1],
+bal_problem.cpp:398-407) but from a seeded generator, all values rounded to the 6 decimals
+the ``%lf`` writer keeps (bal_problem.cpp:373-434).
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+# cams / landmarks / observations (scripts/num_ops/bal_numbers.csv; ladybug-49 obs count from
+# the BAL site)
+BAL_SHAPES = {
+    "ladybug-49": (49, 7776, 31843),
+    "trafalgar-257": (257, 65132, 225911),
+    "venice-1778": (1778, 993923, 5001946),
+    "final-13682": (13682, 4456117, 28987644),
+}
+BAL_SEEDS = {"ladybug-49": 49, "trafalgar-257": 257, "venice-1778": 1778, "final-13682": 13682}
+
+
+@dataclasses.dataclass
+class Problem:
+    """Loaded problem in the layout of include/povar_hip.h (v already negated)."""
+
+    n_cams: int
+    n_lms: int
+    lm_off: np.ndarray  # int32 [n_lms + 1]
+    cam_idx: np.ndarray  # int32 [n_obs], ascending inside a landmark
+    obs: np.ndarray  # float64 [n_obs, 2]
+    cams: np.ndarray  # float64 [n_cams, 12] initial space matrices
+    lms: np.ndarray  # float64 [n_lms, 3] (arbitrary; overwritten by the VarPro init)
+
+    @property
+    def n_obs(self) -> int:
+        return int(self.cam_idx.shape[0])
+
+
+def _degrees(rng, n_cams, n_lms, n_obs):
+    kmax = min(n_cams, 200)
+    mean = n_obs / n_lms
+    assert 2 <= mean <= kmax
+    p = 1.0 / max(mean - 1.0, 1e-9)
+    k = 1 + rng.geometric(min(p, 1.0), size=n_lms).astype(np.int64)
+    k = np.clip(k, 2, kmax)
+    # adjust to hit n_obs exactly
+    diff = int(n_obs - k.sum())
+    while diff != 0:
+        step = 1 if diff > 0 else -1
+        ok = np.flatnonzero((k < kmax) if step > 0 else (k > 2))
+        take = rng.choice(ok, size=min(abs(diff), ok.size), replace=False)
+        k[take] += step
+        diff = int(n_obs - k.sum())
+    return k
+
+
+def _sample_cameras(rng, n_cams, lm_off):
+    """Zipf(1.0)-weighted sampling without replacement per landmark (redraw duplicates)."""
+    n_obs = int(lm_off[-1])
+    n_lms = lm_off.shape[0] - 1
+    perm = rng.permutation(n_cams)
+    w = 1.0 / np.arange(1, n_cams + 1)
+    cdf = np.cumsum(w / w.sum())
+    cdf[-1] = 1.0
+    lm_of = np.repeat(np.arange(n_lms, dtype=np.int64), np.diff(lm_off))
+    cam = perm[np.searchsorted(cdf, rng.random(n_obs), side="right")].astype(np.int64)
+    active = np.arange(n_obs)
+    while True:
+        key = lm_of[active] * n_cams + cam[active]
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        dup = np.zeros(active.shape[0], dtype=bool)
+        dup[order[1:]] = ks[1:] == ks[:-1]
+        if not dup.any():
+            break
+        # keep working only on landmarks that still have duplicates
+        bad_lm = np.unique(lm_of[active[dup]])
+        redraw = active[dup]
+        cam[redraw] = perm[np.searchsorted(cdf, rng.random(redraw.shape[0]), side="right")]
+        mask = np.zeros(n_lms, dtype=bool)
+        mask[bad_lm] = True
+        active = active[mask[lm_of[active]]]
+    # ascending camera index inside each landmark (std::map order, bal_problem.hpp:226)
+    order = np.lexsort((cam, lm_of))
+    return cam[order].astype(np.int32)
+
+
+def make_problem(n_cams, n_lms, n_obs, seed=0, noise_px=0.5) -> Problem:
+    rng = np.random.default_rng(seed)
+    k = _degrees(rng, n_cams, n_lms, n_obs)
+    lm_off = np.zeros(n_lms + 1, dtype=np.int64)
+    np.cumsum(k, out=lm_off[1:])
+    cam_idx = _sample_cameras(rng, n_cams, lm_off)
+    lm_of = np.repeat(np.arange(n_lms), k)
+
+    # ground truth: points in a unit cube, cameras 5-15 units away looking at it
+    X = rng.random((n_lms, 3)) - 0.5
+    f = rng.uniform(500.0, 2000.0, size=n_cams)
+    d = rng.normal(size=(n_cams, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    centre = -d * rng.uniform(5.0, 15.0, size=(n_cams, 1))
+    up = rng.normal(size=(n_cams, 3))
+    xax = np.cross(up, d)
+    xax /= np.linalg.norm(xax, axis=1, keepdims=True)
+    yax = np.cross(d, xax)
+    R = np.stack([xax, yax, d], axis=1)  # rows: camera axes, z looks at the cube
+    t = -np.einsum("cij,cj->ci", R, centre)
+    pc = np.einsum("oij,oj->oi", R[cam_idx], X[lm_of]) + t[cam_idx]
+    uv = f[cam_idx, None] * pc[:, :2] / pc[:, 2:3]
+    uv += rng.normal(scale=noise_px, size=uv.shape)
+    uv = np.round(uv, 6)  # what "%lf" keeps (bal_problem.cpp:373-375)
+
+    cams = np.zeros((n_cams, 12))
+    cams[:, :8] = rng.normal(size=(n_cams, 8))
+    cams[:, 11] = 1.0
+    cams = np.round(cams, 6)
+    lms = np.round(rng.normal(size=(n_lms, 3)), 6)
+    return Problem(n_cams, n_lms, lm_off.astype(np.int32), cam_idx, np.ascontiguousarray(uv), cams, lms)
+
+
+def make_bal_problem(name: str) -> Problem:
+    """Seeded synthetic problem with the exact shape of a BAL problem (BASELINE.json configs)."""
+    n_c, n_l, n_o = BAL_SHAPES[name]
+    return make_problem(n_c, n_l, n_o, seed=BAL_SEEDS[name])
+
+
+def write_data_custom(path: str, prob: Problem) -> None:
+    """PoVar ``data_custom/<name>`` text format (written bal_problem.cpp:334-434, read by
+    ``load_bal_eccv`` bal_problem.cpp:193-268): header ``n_c n_l n_o``; ``cam lm x y`` per
+    observation in the ORIGINAL BAL sign (the loader negates y, bal_problem.cpp:240); 15
+    values per camera (row-major 3x4 + f k1 k2); 3 values per landmark."""
+    lm_of = np.repeat(np.arange(prob.n_lms), np.diff(prob.lm_off))
+    with open(path, "w") as fh:
+        fh.write(f"{prob.n_cams} {prob.n_lms} {prob.n_obs}")
+        for c, l, (u, v) in zip(prob.cam_idx, lm_of, prob.obs):
+            fh.write(f"\n{c} {l} {u:.6f} {-v:.6f}")
+        for P in prob.cams:
+            for x in P:
+                fh.write(f"\n{x:.6f}")
+            fh.write("\n1.000000\n0.000000\n0.000000")
+        for p in prob.lms:
+            for x in p:
+                fh.write(f"\n{x:.6f}")
+        fh.write("\n")
+
+
+def read_data_custom(path: str) -> Problem:
+    """Python mirror of ``BalProblem::load_bal_eccv`` (bal_problem.cpp:183-303): parses the
+    file, negates y, groups observations per landmark with ascending camera index and rejects
+    duplicate (camera, landmark) pairs (bal_problem.cpp:227)."""
+    with open(path) as fh:
+        tok = fh.read().split()
+    n_c, n_l, n_o = int(tok[0]), int(tok[1]), int(tok[2])
+    if min(n_c, n_l, n_o) <= 0:
+        raise ValueError("invalid header")
+    body = np.array(tok[3 : 3 + 4 * n_o], dtype=np.float64).reshape(n_o, 4)
+    cam = body[:, 0].astype(np.int64)
+    lm = body[:, 1].astype(np.int64)
+    if cam.min() < 0 or cam.max() >= n_c or lm.min() < 0 or lm.max() >= n_l:
+        raise ValueError("index out of range")
+    uv = body[:, 2:4].copy()
+    uv[:, 1] = -uv[:, 1]
+    order = np.lexsort((cam, lm))
+    cam, lm, uv = cam[order], lm[order], uv[order]
+    if np.any((cam[1:] == cam[:-1]) & (lm[1:] == lm[:-1])):
+        raise ValueError("duplicate observation")
+    lm_off = np.zeros(n_l + 1, dtype=np.int64)
+    np.cumsum(np.bincount(lm, minlength=n_l), out=lm_off[1:])
+    p = 3 + 4 * n_o
+    cp = np.array(tok[p : p + 15 * n_c], dtype=np.float64).reshape(n_c, 15)
+    p += 15 * n_c
+    lms = np.array(tok[p : p + 3 * n_l], dtype=np.float64).reshape(n_l, 3)
+    return Problem(n_c, n_l, lm_off.astype(np.int32), cam.astype(np.int32),
+                   np.ascontiguousarray(uv), np.ascontiguousarray(cp[:, :12]), lms)
