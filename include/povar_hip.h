@@ -1,0 +1,161 @@
+/*
+ * povar_hip.h -- C ABI of the MI355X (gfx950) implementation of PoVar's power-series
+ * Schur-complement inner solve.
+ *
+ * The reference (tum-vision/povar, C++17, CPU only) has no C ABI.  Its operator boundary for
+ * this path is the abstract class Linearizor<Scalar> (src/rootba_povar/solver/linearizor.hpp:48-82)
+ * as implemented by LinearizorPowerVarproj (solver/linearizor_power_varproj.cpp:21-308) on top
+ * of LinearizationPowerVarproj (sc/linearization_power_varproj.hpp:28-469).  Each entry point
+ * below names the reference interface it replaces.  A reference-side binding (a Linearizor
+ * subclass forwarding to these calls) is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, caller-allocated HOST buffers, fp64 values, int32
+ * indices, row-major 3x4 camera matrices flattened to 12 (bal_problem.hpp:147-157).  Every
+ * function returns an int status: 0 = ok, POVAR_NUMERIC_FAILURE (1) = non-finite values where
+ * the reference would flag numerical failure, < 0 = HIP / RCCL / argument error (text via
+ * povar_last_error()).  No exceptions cross the ABI.  A context is single-threaded, like the
+ * reference Linearizor (not re-entrant: linearizor_base.hpp:80-86).
+ */
+#ifndef POVAR_HIP_H
+#define POVAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct povar_ctx povar_ctx;
+
+#define POVAR_OK 0
+#define POVAR_NUMERIC_FAILURE 1
+
+/* BalResidualOptions::RobustNorm  (bal/bal_residual_options.hpp:45-49) */
+enum { POVAR_NORM_NONE = 0, POVAR_NORM_HUBER = 1, POVAR_NORM_CAUCHY = 2 };
+/* SolverOptions::SolverType values served by this path (bal/solver_options.hpp:60-66;
+ * factory solver/linearizor.cpp:51-56) */
+enum { POVAR_POWER_VARPROJ = 0, POVAR_POWER_SCHUR_COMPLEMENT = 1 };
+/* LinearizationPowerVarproj::Summary::TerminationType (sc/linearization_power_varproj.hpp:52-56) */
+enum { POVAR_LINEAR_SOLVER_NO_CONVERGENCE = 0, POVAR_LINEAR_SOLVER_SUCCESS = 1,
+       POVAR_LINEAR_SOLVER_FAILURE = 2 };
+/* how E0*x is evaluated: 0 = implicit (tiles recomputed from cameras/landmarks/observations,
+ * deterministic two-pass scatter), 1 = stored tiles (the reference's [Jp|Jl] blocks kept in HBM
+ * and streamed once per term, fp64 atomics scatter) */
+enum { POVAR_E0_IMPLICIT = 0, POVAR_E0_TILES = 1 };
+
+/* LandmarkBlockSC::Options (sc/landmark_block.hpp:61-75) + device selection */
+typedef struct {
+  int32_t robust_norm;       /* POVAR_NORM_* */
+  double huber_parameter;    /* bal_residual_options.hpp:61-62 */
+  double jacobi_scaling_eps; /* effective epsilon, linearizor_base.cpp:94-100 (1e-5 if option is 0) */
+  int32_t device;            /* HIP device ordinal */
+  int32_t e0_mode;           /* POVAR_E0_* */
+} povar_options;
+
+/* ResidualInfo (bal/residual_info.hpp:59-92) */
+typedef struct {
+  int64_t all_num_obs;
+  double all_error;
+  double all_residual_sum;
+  int64_t valid_num_obs;
+  double valid_error;
+  double valid_residual_sum;
+  int32_t is_numerically_valid;
+} povar_residual_info;
+
+/* per-kernel-class device time measured with HIP events on the context's stream */
+typedef struct {
+  double e0_ms;      /* sum over launches of the E0 (SpMV) kernels of one term */
+  int64_t e0_launches;
+  double binv_ms;    /* B^-1 / AXPY kernel */
+  int64_t binv_launches;
+  double comm_ms;    /* RCCL all-reduce */
+  int64_t comm_launches;
+} povar_profile_info;
+
+const char* povar_last_error(void);
+
+/* LinearizorPowerVarproj ctor (linearizor_power_varproj.cpp:21-38) + LinearizationVarProj ctor /
+ * allocate_landmark (linearization_varproj.hpp:42-61, landmark_block.hpp:101-133).
+ * lm_offsets[n_lms+1] CSR over observations, cam_idx ascending inside a landmark (std::map
+ * order, bal_problem.hpp:226), obs = (u, v) with v already negated (bal_problem.cpp:240).
+ * With povar_comm_init() the arrays describe this rank's landmark shard only. */
+int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
+                 const int32_t* lm_offsets, const int32_t* cam_idx, const double* obs,
+                 const povar_options* options);
+void povar_destroy(povar_ctx* ctx);
+
+/* BalProblem state shared with the caller (linearizor_base.hpp:80; bal_problem.hpp:290-294) */
+int povar_set_cameras(povar_ctx* ctx, const double* cams /*12 n_cams*/);
+int povar_get_cameras(povar_ctx* ctx, double* cams);
+int povar_set_landmarks(povar_ctx* ctx, const double* lms /*3 n_lms*/);
+int povar_get_landmarks(povar_ctx* ctx, double* lms);
+/* BalProblem::backup_pOSE / restore_pOSE (bal_problem.cpp:670-677, 701-708) */
+int povar_backup_pose(povar_ctx* ctx);
+int povar_restore_pose(povar_ctx* ctx);
+
+/* Linearizor::initialize_varproj_lm_pOSE (linearizor_base.cpp:60-67; helper.cpp:76-114) */
+int povar_init_landmarks_pose(povar_ctx* ctx, double alpha);
+/* Linearizor::compute_error_pOSE (linearizor_base.cpp:69-77; helper.cpp:117-154) */
+int povar_error_pose(povar_ctx* ctx, double alpha, povar_residual_info* out);
+/* Linearizor::linearize_pOSE (linearizor_power_varproj.cpp:45-76) */
+int povar_linearize_pose(povar_ctx* ctx, double alpha);
+/* Linearizor::solve (linearizor_power_varproj.cpp:178-243): scale_Jp_cols on a new
+ * linearisation point, prepare_Hb_pOSE[_poBA], solve_pOSE.  inc[12 n_cams] in scaled
+ * coordinates; *num_iterations / *termination as Summary (linearization_power_varproj.hpp:51-61).
+ * q_tolerance = SolverOptions::eta, r_tolerance = SolverOptions::r_tolerance. */
+int povar_solve_pose(povar_ctx* ctx, double lambda, int32_t solver_type, int32_t power_sc_iterations,
+                     double q_tolerance, double r_tolerance, double* inc, int32_t* num_iterations,
+                     int32_t* termination);
+/* Linearizor::apply (linearizor_power_varproj.cpp:246-273): camera update + back substitution;
+ * *l_diff = model cost change. */
+int povar_apply_pose(povar_ctx* ctx, int32_t solver_type, double alpha, const double* inc,
+                     double* l_diff);
+
+/* ---- the two halves of povar_solve_pose, separately (bench / parity tests) ---- */
+/* LinearizationPowerVarproj::prepare_Hb_pOSE / _poBA (linearization_power_varproj.hpp:124-188) */
+int povar_prepare_pose(povar_ctx* ctx, double lambda, int32_t solver_type);
+/* LinearizationPowerVarproj::solve_pOSE (linearization_power_varproj.hpp:191-237); asynchronous
+ * when both tolerances are <= 0 (result stays on the device; see povar_get_increment). */
+int povar_power_series_pose(povar_ctx* ctx, int32_t power_sc_iterations, double q_tolerance,
+                            double r_tolerance, int32_t* num_iterations, int32_t* termination);
+int povar_get_increment(povar_ctx* ctx, double* inc /*12 n_cams*/);
+/* term-by-term access: begin = accum = tmp = B^-1(-b) (hpp:196-200), step = one pass of the loop
+ * body (hpp:202-203); get_term copies the current term. */
+int povar_power_series_begin(povar_ctx* ctx);
+int povar_power_series_step(povar_ctx* ctx);
+int povar_get_term(povar_ctx* ctx, double* term /*12 n_cams*/);
+/* LinearizationPowerVarproj::right_mul_e0_pOSE (linearization_power_varproj.hpp:364-406) */
+int povar_right_mul_e0_pose(povar_ctx* ctx, const double* x, double* y);
+int povar_set_e0_mode(povar_ctx* ctx, int32_t e0_mode);
+int povar_synchronize(povar_ctx* ctx);
+
+/* ---- inspection of internal state in the reference's layouts (parity tests) ---- */
+enum {
+  POVAR_BUF_DIAG2 = 0,     /* get_Jp_diag2_pOSE, 12 n_cams (linearization_varproj.hpp:183-222) */
+  POVAR_BUF_POSE_SCALING,  /* pose_jacobian_scaling_pOSE_, 12 n_cams (linearizor_power_varproj.cpp:68-70) */
+  POVAR_BUF_JL_COL_SCALE,  /* Jl_col_scale_pOSE, 3 n_lms (landmark_block.hpp:289-292) */
+  POVAR_BUF_HLL_INV,       /* hll_inv_pOSE_, 9 n_lms (linearization_power_varproj.hpp:469) */
+  POVAR_BUF_B,             /* b_p, 12 n_cams */
+  POVAR_BUF_B_INV,         /* b_inv_pOSE_, 144 n_cams */
+  POVAR_BUF_STORAGE        /* storage_pOSE_ of every landmark, [4 n_obs][16] (landmark_block.hpp:726) */
+};
+int povar_get_buffer(povar_ctx* ctx, int32_t which, double* out, int64_t n);
+
+/* ---- measurement ---- */
+int povar_profile_enable(povar_ctx* ctx, int32_t enable);
+int povar_profile_get(povar_ctx* ctx, povar_profile_info* out);
+/* bytes of device memory held by the context */
+int64_t povar_device_bytes(povar_ctx* ctx);
+
+/* ---- multi-GPU: landmarks sharded over ranks, one RCCL all-reduce per exchange step ---- */
+/* host-only: contiguous landmark range of `rank`, balanced by observation count */
+int povar_shard_range(int32_t n_lms, const int32_t* lm_offsets, int32_t world, int32_t rank,
+                      int32_t* lm_begin, int32_t* lm_end);
+int povar_comm_unique_id(uint8_t id[128]);
+int povar_comm_init(povar_ctx* ctx, int32_t world, int32_t rank, const uint8_t id[128]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,821 @@
+// povar_hip.hip -- host side of the C ABI in include/povar_hip.h: device layout construction,
+// kernel sequencing on one HIP stream, RCCL exchange steps.  Device code: povar_kernels.hpp.
+#include "../../include/povar_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "povar_kernels.hpp"
+
+using namespace povar;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(-(int)e_ - 1000, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+#define NCCL_TRY(expr)                                                                      \
+  do {                                                                                      \
+    ncclResult_t e_ = (expr);                                                               \
+    if (e_ != ncclSuccess)                                                                  \
+      return fail(-(int)e_ - 2000, std::string(#expr) + ": " + ncclGetErrorString(e_));     \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count, size_t* total) {
+    n = count;
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess && total) *total += count * sizeof(T);
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+};
+
+}  // namespace
+
+struct povar_ctx {
+  int n_cams = 0, n_lms = 0;
+  int64_t n_obs = 0;
+  int n_bins = 0, n_slots = 0, n_items = 0, n_long = 0;
+  int n_reg_blocks = 0, n_cam_blocks = 0;
+  povar_options opt{};
+  hipStream_t stream = nullptr;
+  size_t bytes = 0;
+
+  std::vector<int> slot_of_obs;  // host copy for exports in the reference's order
+  std::vector<int> lm_off;
+
+  // static
+  DevBuf<double2> uv, cm_uv, tiles;
+  DevBuf<int> cam, lm, meta, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
+      cam_item_off, flags;
+  // state
+  DevBuf<double4> cams4, cams_lin4, cams_bak4, lms4, lms_lin4, lms_bak4, jl_scale4, rres, q4;
+  DevBuf<double> hll_inv, sw, sigma, diag2, G, binv, b, tmp, accum, z, y, inc, item_part,
+      item_partG, norm_part, norms, part, scal, stage;
+
+  Dp d{};
+  bool new_linearization_point = false;  // linearizor_power_varproj.cpp:75, 192, 240
+  bool linearized = false;
+  bool tiles_valid = false;
+  double alpha_lin = 0;
+
+  // multi-GPU
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+
+  // profiling
+  bool profile = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ev_kind;  // 0 e0, 1 binv, 2 comm  (interval between ev[i], ev[i+1])
+  size_t ev_used = 0;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// layout construction (host)
+// ------------------------------------------------------------------------------------------
+struct Layout {
+  std::vector<double2> uv, cm_uv;
+  std::vector<int> cam, lm, meta, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off,
+      item_cam, cam_item_off, slot_of_obs;
+  int n_bins = 0;
+};
+
+void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx,
+                  const double* obs, Layout& L) {
+  const int64_t n_obs = lm_off[n_lms];
+  L.slot_of_obs.resize(n_obs);
+  // pass 1: assign slots.  Regular landmarks are packed greedily, in order, into 64-lane wave
+  // bins that never split a landmark; a landmark with more than 64 observations gets
+  // ceil(k/64) bins of its own and is handled by the lm_long driver.
+  int bin = 0, fill = 0;
+  std::vector<int> seg_first(n_obs), seg_last(n_obs);
+  std::vector<char> is_long(n_obs, 0);
+  for (int l = 0; l < n_lms; ++l) {
+    const int b = lm_off[l], k = lm_off[l + 1] - b;
+    if (k == 0) continue;
+    if (k > WAVE) {
+      if (fill > 0) { ++bin; fill = 0; }
+      L.long_lm.push_back(l);
+      L.long_first.push_back(bin * WAVE);
+      L.long_cnt.push_back(k);
+      for (int j = 0; j < k; ++j) {
+        L.slot_of_obs[b + j] = bin * WAVE + j;
+        is_long[b + j] = 1;
+      }
+      bin += (k + WAVE - 1) / WAVE;
+      continue;
+    }
+    if (fill + k > WAVE) { ++bin; fill = 0; }
+    for (int j = 0; j < k; ++j) {
+      L.slot_of_obs[b + j] = bin * WAVE + fill + j;
+      seg_first[b + j] = fill;
+      seg_last[b + j] = fill + k - 1;
+    }
+    fill += k;
+  }
+  if (fill > 0) ++bin;
+  L.n_bins = std::max(bin, 1);
+  const size_t n_slots = (size_t)L.n_bins * WAVE;
+  L.uv.assign(n_slots, make_double2(0, 0));
+  L.cam.assign(n_slots, -1);
+  L.lm.assign(n_slots, 0);
+  L.meta.resize(n_slots);
+  for (size_t s = 0; s < n_slots; ++s) {
+    const int lane = (int)(s & 63);
+    L.meta[s] = lane | (lane << 8);
+  }
+  for (int l = 0; l < n_lms; ++l)
+    for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) {
+      const int s = L.slot_of_obs[i];
+      L.uv[s] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
+      L.cam[s] = cam_idx[i];
+      L.lm[s] = l;
+      if (is_long[i]) {
+        const int lane = s & 63;
+        L.meta[s] = lane | (lane << 8) | META_REAL | META_LONG;
+      } else {
+        L.meta[s] = seg_first[i] | (seg_last[i] << 8) | META_REAL;
+      }
+    }
+  // pass 2: camera-major inverse index, ascending slot order inside a camera, cut into work
+  // items of at most CM_ITEM_MAX observations of one camera.
+  std::vector<int64_t> cnt(n_cams + 1, 0);
+  for (int64_t i = 0; i < n_obs; ++i) cnt[cam_idx[i] + 1]++;
+  for (int c = 0; c < n_cams; ++c) cnt[c + 1] += cnt[c];
+  L.cm_slot.resize(n_obs);
+  L.cm_lm.resize(n_obs);
+  L.cm_uv.resize(n_obs);
+  {
+    // slots ascend with the observation index, so a stable counting sort by camera over the
+    // observations in order yields ascending slots per camera
+    std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+    for (int l = 0; l < n_lms; ++l)
+      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) {
+        const int64_t p = pos[cam_idx[i]]++;
+        L.cm_slot[p] = L.slot_of_obs[i];
+        L.cm_lm[p] = l;
+        L.cm_uv[p] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
+      }
+  }
+  L.cam_item_off.assign(n_cams + 1, 0);
+  L.item_off.clear();
+  L.item_cam.clear();
+  for (int c = 0; c < n_cams; ++c) {
+    L.cam_item_off[c] = (int)L.item_cam.size();
+    for (int64_t p = cnt[c]; p < cnt[c + 1]; p += CM_ITEM_MAX) {
+      L.item_off.push_back((int)p);
+      L.item_cam.push_back(c);
+    }
+  }
+  L.cam_item_off[n_cams] = (int)L.item_cam.size();
+  L.item_off.push_back((int)n_obs);
+}
+
+template <class T>
+int upload(DevBuf<T>& buf, const std::vector<T>& v, povar_ctx* c) {
+  HIP_TRY(buf.alloc(std::max<size_t>(v.size(), 1), &c->bytes));
+  if (!v.empty()) HIP_TRY(hipMemcpy(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
+
+// ------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------
+template <class Op>
+void launch_lm(povar_ctx* c, const Op& op) {
+  hipLaunchKernelGGL((lm_regular<Op>), dim3(c->n_reg_blocks), dim3(LM_BLOCK), 0, c->stream, c->d, op,
+                     c->part.p);
+  if (c->n_long > 0)
+    hipLaunchKernelGGL((lm_long<Op>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, op, c->part.p);
+}
+
+template <int N>
+void launch_reduce(povar_ctx* c, double* out) {
+  hipLaunchKernelGGL((reduce_partials<N>), dim3(1), dim3(256), 0, c->stream, c->part.p,
+                     c->n_reg_blocks + c->n_long, out);
+}
+
+void prof_mark(povar_ctx* c, int kind) {
+  if (!c->profile) return;
+  if (c->ev_used == c->ev.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    c->ev.push_back(e);
+    c->ev_kind.push_back(-1);
+  }
+  c->ev_kind[c->ev_used] = kind;
+  (void)hipEventRecord(c->ev[c->ev_used], c->stream);
+  ++c->ev_used;
+}
+
+int allreduce(povar_ctx* c, double* buf, size_t n) {
+  if (!c->comm) return 0;
+  prof_mark(c, 2);
+  NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c->comm, c->stream));
+  return 0;
+}
+
+// E0 x for the current term: implicit (LM pass, CM pass) or stored tiles.  The per-camera
+// result is consumed by cam_binv_axpy (mode 1: scatter items, mode 2: dense y).
+int launch_e0(povar_ctx* c, int* binv_mode) {
+  prof_mark(c, 0);
+  if (c->opt.e0_mode == POVAR_E0_TILES) {
+    launch_lm(c, OpE0Tiles{});
+    *binv_mode = 2;
+  } else {
+    launch_lm(c, OpE0{});
+    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 1);
+    *binv_mode = 1;
+    if (c->comm) {
+      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 16)), dim3(192), 0, c->stream, c->d,
+                         c->d.y, 1);
+      *binv_mode = 2;
+    }
+  }
+  if (c->comm) {
+    int rc = allreduce(c, c->d.y, 12 * (size_t)c->n_cams);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+void launch_binv(povar_ctx* c, int mode, int want_norms) {
+  prof_mark(c, 1);
+  hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 12), 0, c->stream, c->d, mode,
+                     want_norms);
+}
+
+int ensure_tiles(povar_ctx* c) {
+  if (c->opt.e0_mode != POVAR_E0_TILES) return 0;
+  if (!c->tiles.p) {
+    HIP_TRY(c->tiles.alloc((size_t)c->n_bins * TILE_PAIRS * WAVE, &c->bytes));
+    c->d.tiles = c->tiles.p;
+    c->tiles_valid = false;
+  }
+  if (!c->tiles_valid) {
+    hipLaunchKernelGGL(materialize_tiles, dim3(grid_for(c->n_slots, LM_BLOCK)), dim3(LM_BLOCK), 0,
+                       c->stream, c->d);
+    c->tiles_valid = true;
+  }
+  return 0;
+}
+
+int check_ctx(povar_ctx* c) {
+  if (!c) return fail(-1, "null context");
+  HIP_TRY(hipSetDevice(c->opt.device));
+  return 0;
+}
+
+int read_flags(povar_ctx* c, int (&f)[4]) {
+  HIP_TRY(hipMemcpyAsync(f, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* povar_last_error(void) { return g_err.c_str(); }
+
+int povar_shard_range(int32_t n_lms, const int32_t* lm_offsets, int32_t world, int32_t rank,
+                      int32_t* lm_begin, int32_t* lm_end) {
+  if (!lm_offsets || world < 1 || rank < 0 || rank >= world) return fail(-1, "bad shard arguments");
+  // contiguous landmark ranges balanced by observation count (prefix sum over k_l): boundary r is
+  // the first landmark whose observations start at or after r/world of the total.
+  const int64_t n_obs = lm_offsets[n_lms];
+  auto bound = [&](int r) -> int32_t {
+    if (r <= 0) return 0;
+    if (r >= world) return n_lms;
+    const int64_t target = n_obs * (int64_t)r / world;
+    return (int32_t)(std::lower_bound(lm_offsets, lm_offsets + n_lms + 1, (int32_t)target) - lm_offsets);
+  };
+  *lm_begin = bound(rank);
+  *lm_end = bound(rank + 1);
+  return 0;
+}
+
+int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
+                 const int32_t* lm_offsets, const int32_t* cam_idx, const double* obs,
+                 const povar_options* options) {
+  if (!out || !lm_offsets || !cam_idx || !obs || !options) return fail(-1, "null argument");
+  if (n_cams <= 0 || n_lms <= 0 || n_obs <= 0 || lm_offsets[0] != 0 || lm_offsets[n_lms] != n_obs)
+    return fail(-1, "invalid problem sizes");
+  for (int l = 0; l < n_lms; ++l) {
+    if (lm_offsets[l + 1] < lm_offsets[l]) return fail(-1, "lm_offsets not monotone");
+    for (int i = lm_offsets[l]; i < lm_offsets[l + 1]; ++i) {
+      if (cam_idx[i] < 0 || cam_idx[i] >= n_cams) return fail(-1, "camera index out of range");
+      // duplicate (camera, landmark) pairs abort the reference loader (bal_problem.cpp:227)
+      if (i > lm_offsets[l] && cam_idx[i] <= cam_idx[i - 1])
+        return fail(-1, "camera indices of a landmark must be strictly ascending");
+    }
+  }
+  int n_dev = 0;
+  HIP_TRY(hipGetDeviceCount(&n_dev));
+  if (n_dev <= 0) return fail(-2, "no HIP device: the MI355X path has no CPU fallback");
+  HIP_TRY(hipSetDevice(options->device));
+
+  povar_ctx* c = new povar_ctx();
+  c->opt = *options;
+  c->n_cams = n_cams;
+  c->n_lms = n_lms;
+  c->n_obs = n_obs;
+  c->lm_off.assign(lm_offsets, lm_offsets + n_lms + 1);
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+  Layout L;
+  build_layout(n_cams, n_lms, lm_offsets, cam_idx, obs, L);
+  c->n_bins = L.n_bins;
+  c->n_slots = L.n_bins * WAVE;
+  c->n_items = (int)L.item_cam.size();
+  c->n_long = (int)L.long_lm.size();
+  c->n_reg_blocks = grid_for(c->n_slots, LM_BLOCK);
+  c->n_cam_blocks = grid_for(n_cams, K9_CAMS);
+  c->slot_of_obs = L.slot_of_obs;
+
+  int rc = 0;
+  if ((rc = upload(c->uv, L.uv, c)) || (rc = upload(c->cam, L.cam, c)) || (rc = upload(c->lm, L.lm, c)) ||
+      (rc = upload(c->meta, L.meta, c)) || (rc = upload(c->long_lm, L.long_lm, c)) ||
+      (rc = upload(c->long_first, L.long_first, c)) || (rc = upload(c->long_cnt, L.long_cnt, c)) ||
+      (rc = upload(c->cm_slot, L.cm_slot, c)) || (rc = upload(c->cm_lm, L.cm_lm, c)) ||
+      (rc = upload(c->cm_uv, L.cm_uv, c)) || (rc = upload(c->item_off, L.item_off, c)) ||
+      (rc = upload(c->item_cam, L.item_cam, c)) || (rc = upload(c->cam_item_off, L.cam_item_off, c))) {
+    povar_destroy(c);
+    return rc;
+  }
+  const size_t nc = n_cams, nl = n_lms, ns = c->n_slots, ni = std::max(c->n_items, 1);
+  const size_t n_part = (size_t)(c->n_reg_blocks + c->n_long) * 4;
+#define ALLOC(buf, count)                                  \
+  do {                                                     \
+    hipError_t e_ = c->buf.alloc((count), &c->bytes);      \
+    if (e_ != hipSuccess) {                                \
+      povar_destroy(c);                                    \
+      return fail(-(int)e_ - 1000, "hipMalloc " #buf);     \
+    }                                                      \
+  } while (0)
+  ALLOC(cams4, 3 * nc); ALLOC(cams_lin4, 3 * nc); ALLOC(cams_bak4, 3 * nc);
+  ALLOC(lms4, nl); ALLOC(lms_lin4, nl); ALLOC(lms_bak4, nl); ALLOC(jl_scale4, nl);
+  ALLOC(hll_inv, 9 * nl);
+  ALLOC(sw, ns); ALLOC(rres, ns); ALLOC(q4, ns);
+  ALLOC(sigma, 12 * nc); ALLOC(diag2, 12 * nc); ALLOC(G, 40 * nc); ALLOC(binv, 144 * nc);
+  ALLOC(b, 12 * nc); ALLOC(tmp, 12 * nc); ALLOC(accum, 12 * nc); ALLOC(z, 12 * nc); ALLOC(y, 12 * nc);
+  ALLOC(inc, 12 * nc);
+  ALLOC(item_part, 12 * ni); ALLOC(item_partG, 40 * ni);
+  ALLOC(norm_part, 2 * (size_t)c->n_cam_blocks); ALLOC(norms, 4); ALLOC(flags, 4);
+  ALLOC(part, n_part); ALLOC(scal, 8);
+  ALLOC(stage, std::max(3 * nl, 144 * nc));
+#undef ALLOC
+  HIP_TRY(hipMemset(c->flags.p, 0, sizeof(int) * 4));
+  HIP_TRY(hipMemset(c->y.p, 0, sizeof(double) * 12 * nc));
+  HIP_TRY(hipMemset(c->q4.p, 0, sizeof(double4) * ns));
+  HIP_TRY(hipMemset(c->sw.p, 0, sizeof(double) * ns));
+  HIP_TRY(hipMemset(c->rres.p, 0, sizeof(double4) * ns));
+
+  Dp& d = c->d;
+  d.n_cams = n_cams; d.n_lms = n_lms; d.n_bins = c->n_bins; d.n_items = c->n_items;
+  d.n_long = c->n_long; d.n_reg_blocks = c->n_reg_blocks;
+  d.uv = c->uv.p; d.cam = c->cam.p; d.lm = c->lm.p; d.meta = c->meta.p;
+  d.long_lm = c->long_lm.p; d.long_first = c->long_first.p; d.long_cnt = c->long_cnt.p;
+  d.cm_slot = c->cm_slot.p; d.cm_lm = c->cm_lm.p; d.cm_uv = c->cm_uv.p;
+  d.item_off = c->item_off.p; d.item_cam = c->item_cam.p; d.cam_item_off = c->cam_item_off.p;
+  d.cams4 = c->cams4.p; d.cams_lin4 = c->cams_lin4.p; d.lms4 = c->lms4.p; d.lms_lin4 = c->lms_lin4.p;
+  d.jl_scale4 = c->jl_scale4.p; d.hll_inv = c->hll_inv.p;
+  d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.tiles = nullptr;
+  d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
+  d.tmp = c->tmp.p; d.accum = c->accum.p; d.z = c->z.p; d.y = c->y.p; d.inc = c->inc.p;
+  d.item_part = c->item_part.p; d.item_partG = c->item_partG.p;
+  d.flags = c->flags.p; d.norm_part = c->norm_part.p; d.norms = c->norms.p;
+  d.sa = 0; d.sb = 1; d.eps = options->jacobi_scaling_eps; d.huber = options->huber_parameter;
+  d.lambda_lm = 0; d.robust = options->robust_norm;
+  *out = c;
+  return 0;
+}
+
+void povar_destroy(povar_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->opt.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  c->uv.release(); c->cm_uv.release(); c->tiles.release();
+  c->cam.release(); c->lm.release(); c->meta.release(); c->long_lm.release(); c->long_first.release();
+  c->long_cnt.release(); c->cm_slot.release(); c->cm_lm.release(); c->item_off.release();
+  c->item_cam.release(); c->cam_item_off.release(); c->flags.release();
+  c->cams4.release(); c->cams_lin4.release(); c->cams_bak4.release(); c->lms4.release();
+  c->lms_lin4.release(); c->lms_bak4.release(); c->jl_scale4.release(); c->rres.release(); c->q4.release();
+  c->hll_inv.release(); c->sw.release(); c->sigma.release(); c->diag2.release(); c->G.release();
+  c->binv.release(); c->b.release(); c->tmp.release(); c->accum.release(); c->z.release(); c->y.release();
+  c->inc.release(); c->item_part.release(); c->item_partG.release(); c->norm_part.release();
+  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int64_t povar_device_bytes(povar_ctx* c) { return c ? (int64_t)c->bytes : 0; }
+
+int povar_synchronize(povar_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int povar_set_cameras(povar_ctx* c, const double* cams) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->cams4.p, cams, sizeof(double) * 12 * c->n_cams, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int povar_get_cameras(povar_ctx* c, double* cams) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(cams, c->cams4.p, sizeof(double) * 12 * c->n_cams, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int povar_set_landmarks(povar_ctx* c, const double* lms) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->stage.p, lms, sizeof(double) * 3 * c->n_lms, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(lms3_to_4, dim3(grid_for(c->n_lms, 256)), dim3(256), 0, c->stream, c->stage.p,
+                     c->lms4.p, c->n_lms);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int povar_get_landmarks(povar_ctx* c, double* lms) {
+  if (int rc = check_ctx(c)) return rc;
+  hipLaunchKernelGGL(lms4_to_3, dim3(grid_for(c->n_lms, 256)), dim3(256), 0, c->stream, c->lms4.p,
+                     c->stage.p, c->n_lms);
+  HIP_TRY(hipMemcpyAsync(lms, c->stage.p, sizeof(double) * 3 * c->n_lms, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int povar_backup_pose(povar_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->cams_bak4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->lms_bak4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+int povar_restore_pose(povar_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->cams4.p, c->cams_bak4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->lms4.p, c->lms_bak4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+static void set_alpha(povar_ctx* c, double alpha) {
+  c->d.sa = std::sqrt(alpha);
+  c->d.sb = std::sqrt(1.0 - alpha);
+}
+
+int povar_init_landmarks_pose(povar_ctx* c, double alpha) {
+  if (int rc = check_ctx(c)) return rc;
+  set_alpha(c, alpha);
+  launch_lm(c, OpInit{});
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!out) return fail(-1, "null argument");
+  set_alpha(c, alpha);
+  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  launch_lm(c, OpError{});
+  launch_reduce<3>(c, c->scal.p);
+  HIP_TRY(hipGetLastError());
+  if (int rc = allreduce(c, c->scal.p, 3)) return rc;
+  double h[3];
+  int f[4];
+  HIP_TRY(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  if (int rc = read_flags(c, f)) return rc;
+  out->all_num_obs = (int64_t)std::llround(h[2]);
+  out->all_error = h[0];
+  out->all_residual_sum = h[1];
+  out->valid_num_obs = out->all_num_obs;  // projection_valid is always true on pOSE (helper.cpp:263)
+  out->valid_error = h[0];
+  out->valid_residual_sum = h[1];
+  out->is_numerically_valid = f[0] ? 0 : 1;
+  return 0;
+}
+
+int povar_linearize_pose(povar_ctx* c, double alpha) {
+  if (int rc = check_ctx(c)) return rc;
+  set_alpha(c, alpha);
+  c->alpha_lin = alpha;
+  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
+  launch_lm(c, OpLinearize{});
+  hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
+  if (c->comm) {
+    // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(64), 0, c->stream, c->d, (const double*)nullptr);
+    if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(64), 0, c->stream, c->d, (const double*)c->d.G);
+  } else {
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(64), 0, c->stream, c->d, (const double*)nullptr);
+  }
+  HIP_TRY(hipGetLastError());
+  int f[4];
+  if (int rc = read_flags(c, f)) return rc;
+  c->new_linearization_point = true;
+  c->linearized = true;
+  c->tiles_valid = false;
+  return f[0] ? POVAR_NUMERIC_FAILURE : 0;
+}
+
+int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!c->linearized) return fail(-1, "povar_prepare_pose before povar_linearize_pose");
+  set_alpha(c, c->alpha_lin);
+  // scale_Jp_cols_pOSE on a new linearisation point (linearizor_power_varproj.cpp:192-195):
+  // the scaling is part of the implicit tile; only stored tiles need (re)materialising.
+  c->new_linearization_point = false;
+  c->d.lambda_lm = solver_type == POVAR_POWER_SCHUR_COMPLEMENT ? lambda : 0.0;  // cpp:197-200
+  launch_lm(c, OpPrepare{});
+  hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0);
+  hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 16)), dim3(192), 0, c->stream, c->d, c->d.b, 1);
+  if (int rc = allreduce(c, c->d.b, 12 * (size_t)c->n_cams)) return rc;
+  hipLaunchKernelGGL(cam_build_binv, dim3(grid_for(c->n_cams, K8_THREADS)), dim3(K8_THREADS), 0, c->stream,
+                     c->d, lambda);
+  if (int rc = ensure_tiles(c)) return rc;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int povar_power_series_begin(povar_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
+  launch_binv(c, 0, 0);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int povar_power_series_step(povar_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  int mode = 1;
+  if (int rc = launch_e0(c, &mode)) return rc;
+  launch_binv(c, mode, 0);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol, int32_t* num_iterations,
+                            int32_t* termination) {
+  if (int rc = check_ctx(c)) return rc;
+  if (m < 0) return fail(-1, "power_sc_iterations < 0");
+  const bool norms = q_tol > 0 || r_tol > 0;
+  HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
+  launch_binv(c, 0, (m > 0 && r_tol > 0) ? 1 : 0);
+  if (m > 0 && r_tol > 0)
+    hipLaunchKernelGGL(series_check, dim3(1), dim3(64), 0, c->stream, c->d, c->n_cam_blocks, 0, q_tol, r_tol);
+  for (int i = 1; i <= m; ++i) {
+    int mode = 1;
+    if (int rc = launch_e0(c, &mode)) return rc;
+    launch_binv(c, mode, norms ? 1 : 0);
+    if (norms)
+      hipLaunchKernelGGL(series_check, dim3(1), dim3(64), 0, c->stream, c->d, c->n_cam_blocks, i, q_tol, r_tol);
+  }
+  prof_mark(c, -1);
+  HIP_TRY(hipGetLastError());
+  int iters = m, status = POVAR_LINEAR_SOLVER_NO_CONVERGENCE;
+  if (norms) {
+    int f[4];
+    if (int rc = read_flags(c, f)) return rc;
+    if (f[1]) {
+      iters = f[2];
+      status = POVAR_LINEAR_SOLVER_SUCCESS;
+    }
+  }
+  if (num_iterations) *num_iterations = iters;
+  if (termination) *termination = status;
+  return 0;
+}
+
+int povar_get_increment(povar_ctx* c, double* inc) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(inc, c->accum.p, sizeof(double) * 12 * c->n_cams, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int povar_get_term(povar_ctx* c, double* term) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(term, c->tmp.p, sizeof(double) * 12 * c->n_cams, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int povar_solve_pose(povar_ctx* c, double lambda, int32_t solver_type, int32_t m, double q_tol,
+                     double r_tol, double* inc, int32_t* num_iterations, int32_t* termination) {
+  if (int rc = povar_prepare_pose(c, lambda, solver_type)) return rc;
+  if (int rc = povar_power_series_pose(c, m, q_tol, r_tol, num_iterations, termination)) return rc;
+  if (int rc = povar_get_increment(c, inc)) return rc;
+  for (size_t i = 0; i < 12 * (size_t)c->n_cams; ++i)
+    if (!std::isfinite(inc[i])) return POVAR_NUMERIC_FAILURE;  // bal_bundle_adjustment.cpp:362
+  return 0;
+}
+
+int povar_right_mul_e0_pose(povar_ctx* c, const double* x, double* y) {
+  if (int rc = check_ctx(c)) return rc;
+  const size_t n = 12 * (size_t)c->n_cams;
+  HIP_TRY(hipMemcpyAsync(c->tmp.p, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
+  // z = sigma * x
+  HIP_TRY(hipMemcpyAsync(c->inc.p, c->tmp.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 1);
+  int mode = 1;
+  if (int rc = launch_e0(c, &mode)) return rc;
+  if (mode == 1)
+    hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 16)), dim3(192), 0, c->stream, c->d, c->d.y, 1);
+  HIP_TRY(hipMemcpyAsync(y, c->y.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemsetAsync(c->y.p, 0, sizeof(double) * n, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const double* inc, double* l_diff) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!c->linearized) return fail(-1, "povar_apply_pose before povar_linearize_pose");
+  const size_t n = 12 * (size_t)c->n_cams;
+  set_alpha(c, alpha);
+  HIP_TRY(hipMemcpyAsync(c->inc.p, inc, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  if (solver_type == POVAR_POWER_VARPROJ) {
+    // cpp:250-256: scale, update cameras, unscale, back-substitute at the new cameras
+    hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 0);
+    launch_lm(c, OpBackVarproj{});
+  } else {
+    // cpp:260-270: back-substitute with the stored tiles, then update cameras
+    hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 1);
+    launch_lm(c, OpBackPoba{});
+    hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 2);
+  }
+  launch_reduce<1>(c, c->scal.p);
+  HIP_TRY(hipGetLastError());
+  if (int rc = allreduce(c, c->scal.p, 1)) return rc;
+  double h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, c->scal.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (l_diff) *l_diff = h;
+  return 0;
+}
+
+int povar_set_e0_mode(povar_ctx* c, int32_t mode) {
+  if (int rc = check_ctx(c)) return rc;
+  if (mode != POVAR_E0_IMPLICIT && mode != POVAR_E0_TILES) return fail(-1, "bad e0 mode");
+  c->opt.e0_mode = mode;
+  if (c->linearized) return ensure_tiles(c);
+  return 0;
+}
+
+int povar_get_buffer(povar_ctx* c, int32_t which, double* out, int64_t n) {
+  if (int rc = check_ctx(c)) return rc;
+  const size_t nc = c->n_cams, nl = c->n_lms;
+  auto copy = [&](const void* src, size_t count) -> int {
+    if ((size_t)n != count) return fail(-1, "povar_get_buffer: wrong size");
+    HIP_TRY(hipMemcpyAsync(out, src, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+  };
+  switch (which) {
+    case POVAR_BUF_DIAG2: return copy(c->diag2.p, 12 * nc);
+    case POVAR_BUF_POSE_SCALING: return copy(c->sigma.p, 12 * nc);
+    case POVAR_BUF_HLL_INV: return copy(c->hll_inv.p, 9 * nl);
+    case POVAR_BUF_B: return copy(c->b.p, 12 * nc);
+    case POVAR_BUF_B_INV: return copy(c->binv.p, 144 * nc);
+    case POVAR_BUF_JL_COL_SCALE: {
+      if ((size_t)n != 3 * nl) return fail(-1, "povar_get_buffer: wrong size");
+      std::vector<double4> h(nl);
+      HIP_TRY(hipMemcpyAsync(h.data(), c->jl_scale4.p, nl * sizeof(double4), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      for (size_t l = 0; l < nl; ++l) {
+        out[3 * l] = h[l].x;
+        out[3 * l + 1] = h[l].y;
+        out[3 * l + 2] = h[l].z;
+      }
+      return 0;
+    }
+    case POVAR_BUF_STORAGE: {
+      if ((size_t)n != 64 * (size_t)c->n_obs) return fail(-1, "povar_get_buffer: wrong size");
+      if (!c->linearized) return fail(-1, "not linearized");
+      set_alpha(c, c->alpha_lin);
+      const size_t cnt = (size_t)c->n_bins * TILE_PAIRS * WAVE;
+      double2* tmp_tiles = nullptr;
+      Dp d = c->d;
+      if (!c->tiles.p) {
+        HIP_TRY(hipMalloc((void**)&tmp_tiles, cnt * sizeof(double2)));
+        d.tiles = tmp_tiles;
+      }
+      hipLaunchKernelGGL(materialize_tiles, dim3(grid_for(c->n_slots, LM_BLOCK)), dim3(LM_BLOCK), 0, c->stream, d);
+      std::vector<double2> h(cnt);
+      HIP_TRY(hipMemcpyAsync(h.data(), d.tiles, cnt * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (tmp_tiles) (void)hipFree(tmp_tiles);
+      else c->tiles_valid = true;
+      // blocked [bin][pair][lane] -> reference rows [4*obs + r][16] = [Jp(12) | Jl(3) | r]
+      for (int64_t i = 0; i < c->n_obs; ++i) {
+        const int s = c->slot_of_obs[i];
+        const double2* t = h.data() + ((size_t)(s >> 6) * TILE_PAIRS) * WAVE + (s & 63);
+        double v[64];
+        for (int p = 0; p < TILE_PAIRS; ++p) {
+          v[2 * p] = t[(size_t)p * WAVE].x;
+          v[2 * p + 1] = t[(size_t)p * WAVE].y;
+        }
+        for (int r = 0; r < 4; ++r) {
+          double* row = out + ((size_t)4 * i + r) * 16;
+          for (int j = 0; j < 12; ++j) row[j] = v[12 * r + j];
+          for (int j = 0; j < 3; ++j) row[12 + j] = v[48 + 3 * r + j];
+          row[15] = v[60 + r];
+        }
+      }
+      return 0;
+    }
+    default:
+      return fail(-1, "povar_get_buffer: unknown buffer");
+  }
+}
+
+int povar_profile_enable(povar_ctx* c, int32_t enable) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->profile = enable != 0;
+  c->ev_used = 0;
+  return 0;
+}
+
+int povar_profile_get(povar_ctx* c, povar_profile_info* out) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!out) return fail(-1, "null argument");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  std::memset(out, 0, sizeof(*out));
+  for (size_t i = 0; i + 1 < c->ev_used; ++i) {
+    const int kind = c->ev_kind[i];
+    if (kind < 0) continue;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+    if (kind == 0) { out->e0_ms += ms; out->e0_launches++; }
+    else if (kind == 1) { out->binv_ms += ms; out->binv_launches++; }
+    else { out->comm_ms += ms; out->comm_launches++; }
+  }
+  c->ev_used = 0;
+  return 0;
+}
+
+int povar_comm_unique_id(uint8_t id[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId u;
+  NCCL_TRY(ncclGetUniqueId(&u));
+  std::memcpy(id, &u, 128);
+  return 0;
+}
+
+int povar_comm_init(povar_ctx* c, int32_t world, int32_t rank, const uint8_t id[128]) {
+  if (int rc = check_ctx(c)) return rc;
+  if (world < 1 || rank < 0 || rank >= world) return fail(-1, "bad communicator arguments");
+  ncclUniqueId u;
+  std::memcpy(&u, id, 128);
+  NCCL_TRY(ncclCommInitRank(&c->comm, world, u, rank));
+  c->world = world;
+  c->rank = rank;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,1093 @@
+// povar_kernels.hpp -- gfx950 device code for the power-series Schur-complement path (step 1).
+//
+// Mapping of the reference's TBB regions onto kernels.  Work decomposition:
+//
+//  * LM ("landmark-major") kernels: one lane per observation.  Observations live in 64-wide
+//    wave bins that hold WHOLE landmarks (host packs them, povar_hip.hip: build_layout), so the
+//    per-landmark 3x3 reductions (Jl^T Jl, Jl^T r, Jl^T t) are wavefront segmented scans over
+//    __shfl_up -- no LDS, no barriers, no atomics.  Landmarks with more than 64 observations
+//    take the lm_long driver (one workgroup per landmark, LDS block reduction).
+//  * CM ("camera-major") kernels: every per-camera sum the reference guards with
+//    std::mutex (linearization_power_varproj.hpp:393-397, landmark_block.hpp:531-537) is a
+//    gather over a camera->observation inverse index, cut into work items of <= 512
+//    observations of ONE camera, one wavefront per item, fixed summation order: deterministic,
+//    atomics-free.
+//  * camera kernels: 12x12 block work per camera (B^-1 build, B^-1 x, AXPY, norms).
+//
+// "Implicit" operator form.  The stored tile of one observation (landmark_block.hpp:167-169
+// after scale_Jl_cols/scale_Jp_cols, :284-295, :324-334) is a closed-form function of
+// (P_c, x_l, u, v, sqrt(w), sigma_c, s_l) (bal_bundle_adjustment_helper.cpp:244-313):
+//     Jp = sw * [ sb*(h,0,-u h) ; sb*(0,h,-v h) ; sa*(h,0,0) ; sa*(0,h,0) ] * diag(sigma_c)
+//     Jl = sw * [ sb*(P0-uP2) ; sb*(P1-vP2) ; sa*P0 ; sa*P1 ][:, :3] * diag(s_l)
+// with h=[x_l;1], sa=sqrt(alpha), sb=sqrt(1-alpha).  Hence
+//     Jp x      = sw*( sb*(d0-u d2), sb*(d1-v d2), sa*d0, sa*d1 ),   d_k = h . (sigma*x)[4k:4k+4]
+//     Jp^T s    = sigma * ( h q0 ; h q1 ; h q2 ),  q0 = sw(sb s0+sa s2), q1 = sw(sb s1+sa s3),
+//                                                  q2 = -sw sb (u s0 + v s1)
+// so the E0 product needs 28 B of per-observation input instead of the 480 B tile, and the
+// transpose-scatter needs three scalars per observation.  The stored-tile variant
+// (POVAR_E0_TILES) keeps the reference's tiles in HBM and streams them once per term.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace povar {
+
+constexpr int WAVE = 64;
+constexpr int LM_BLOCK = 256;   // 4 wave bins per workgroup
+constexpr int CM_ITEM_MAX = 512; // observations of one camera per CM work item
+constexpr int TILE_PAIRS = 32;  // double2 pairs per observation in the blocked tile layout
+
+// meta[slot]: bits 0-7 seg_first lane, 8-15 seg_last lane, 16 = real observation, 17 = slot of
+// a long (>64 obs) landmark
+constexpr int META_REAL = 1 << 16;
+constexpr int META_LONG = 1 << 17;
+
+struct Dp {
+  int n_cams, n_lms, n_bins, n_items, n_long, n_reg_blocks;
+  // static landmark-major slot arrays
+  const double2* uv;
+  const int* cam;
+  const int* lm;
+  const int* meta;
+  const int* long_lm;
+  const int* long_first;
+  const int* long_cnt;
+  // static camera-major arrays
+  const int* cm_slot;
+  const int* cm_lm;
+  const double2* cm_uv;
+  const int* item_off;
+  const int* item_cam;
+  const int* cam_item_off;
+  // state
+  double4* cams4;      // [n_cams][3]
+  double4* cams_lin4;  // cameras at the linearisation point
+  double4* lms4;       // [n_lms] (x, y, z, 1)
+  double4* lms_lin4;
+  // per landmark
+  double4* jl_scale4;  // (s0, s1, s2, -)
+  double* hll_inv;     // [n_lms][9]
+  // per slot, dynamic
+  double* sw;          // sqrt(robust weight)
+  double4* rres;       // weighted residual at the linearisation point
+  double4* q4;         // (q0, q1, q2, sw): transpose-scatter scalars
+  double2* tiles;      // stored-tile mode: [n_bins][TILE_PAIRS][64] double2
+  // per camera
+  double* sigma;       // pose_jacobian_scaling [n_cams][12]
+  double* diag2;
+  double* G;           // [n_cams][40]
+  double* binv;        // [n_cams][144]
+  double* b;           // [n_cams][12]
+  double* tmp;         // current series term
+  double* accum;
+  double* z;           // sigma * tmp (implicit mode input of E0)
+  double* y;           // dense E0 output (tile mode / after all-reduce)
+  double* inc;         // pose increment handed to apply
+  double* item_part;   // [n_items][12]
+  double* item_partG;  // [n_items][40]
+  // control
+  int* flags;          // [0] non-finite seen, [1] series done, [2] iterations, [3] status
+  double* norm_part;   // [n_cam_blocks][2]
+  double* norms;       // [0] norm_0, [1] last term norm, [2] accum norm
+  // scalars
+  double sa, sb, eps, huber, lambda_lm;
+  int robust;
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+// Eigen fixed-size 3x3 inverse: cofactors / determinant (landmark_block.hpp:518)
+__device__ inline void inv3(const double (&m)[9], double (&r)[9]) {
+  const double k00 = m[4] * m[8] - m[5] * m[7];
+  const double k10 = m[2] * m[7] - m[1] * m[8];
+  const double k20 = m[1] * m[5] - m[2] * m[4];
+  const double det = k00 * m[0] + k10 * m[3] + k20 * m[6];
+  const double id = 1.0 / det;
+  r[0] = k00 * id;
+  r[1] = k10 * id;
+  r[2] = k20 * id;
+  r[3] = (m[5] * m[6] - m[3] * m[8]) * id;
+  r[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+  r[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  r[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+  r[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+  r[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// symmetric 3x3 from the 6 accumulated upper entries (00,01,02,11,12,22)
+__device__ inline void sym3(const double* u, double (&m)[9]) {
+  m[0] = u[0]; m[1] = u[1]; m[2] = u[2];
+  m[3] = u[1]; m[4] = u[3]; m[5] = u[4];
+  m[6] = u[2]; m[7] = u[4]; m[8] = u[5];
+}
+
+// compute_error_weight, bal_bundle_adjustment_helper.cpp:52-74
+__device__ inline void error_weight(const Dp& d, double r2, double& e, double& w) {
+  if (d.robust == 1) {
+    const double t = d.huber;
+    w = r2 < t * t ? 1.0 : t / sqrt(r2);
+    e = 0.5 * (2 - w) * w * r2;
+  } else if (d.robust == 2) {
+    w = 1.0;
+    e = log(1.0 + r2);
+  } else {
+    w = 1.0;
+    e = 0.5 * r2;
+  }
+}
+
+struct Cam {
+  double4 r0, r1, r2;
+};
+__device__ inline Cam load_cam(const double4* cams4, int c) {
+  Cam P;
+  P.r0 = cams4[3 * c];
+  P.r1 = cams4[3 * c + 1];
+  P.r2 = cams4[3 * c + 2];
+  return P;
+}
+__device__ inline double dot4(const double4& a, const double4& b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// pOSE residual (bal_bundle_adjustment_helper.cpp:250-261): M = [sb(P0-uP2); sb(P1-vP2); saP0; saP1]
+__device__ inline void pose_residual(const Dp& d, const Cam& P, const double4& h, double u, double v,
+                                     double (&res)[4]) {
+  double4 m0, m1, m2, m3;
+  m0.x = d.sb * (P.r0.x - P.r2.x * u); m0.y = d.sb * (P.r0.y - P.r2.y * u);
+  m0.z = d.sb * (P.r0.z - P.r2.z * u); m0.w = d.sb * (P.r0.w - P.r2.w * u);
+  m1.x = d.sb * (P.r1.x - P.r2.x * v); m1.y = d.sb * (P.r1.y - P.r2.y * v);
+  m1.z = d.sb * (P.r1.z - P.r2.z * v); m1.w = d.sb * (P.r1.w - P.r2.w * v);
+  m2.x = d.sa * P.r0.x; m2.y = d.sa * P.r0.y; m2.z = d.sa * P.r0.z; m2.w = d.sa * P.r0.w;
+  m3.x = d.sa * P.r1.x; m3.y = d.sa * P.r1.y; m3.z = d.sa * P.r1.z; m3.w = d.sa * P.r1.w;
+  res[0] = dot4(m0, h);
+  res[1] = dot4(m1, h);
+  res[2] = dot4(m2, h) - d.sa * u;
+  res[3] = dot4(m3, h) - d.sa * v;
+}
+
+// Jl = scale * M[:, :3] * diag(s)  (row-major 4x3); scale = sqrt(w), s = Jl column scale
+__device__ inline void pose_jl(const Dp& d, const Cam& P, double u, double v, double scale,
+                               const double4& s, double (&jl)[12]) {
+  const double cb = d.sb * scale, ca = d.sa * scale;
+  jl[0] = cb * (P.r0.x - P.r2.x * u) * s.x;
+  jl[1] = cb * (P.r0.y - P.r2.y * u) * s.y;
+  jl[2] = cb * (P.r0.z - P.r2.z * u) * s.z;
+  jl[3] = cb * (P.r1.x - P.r2.x * v) * s.x;
+  jl[4] = cb * (P.r1.y - P.r2.y * v) * s.y;
+  jl[5] = cb * (P.r1.z - P.r2.z * v) * s.z;
+  jl[6] = ca * P.r0.x * s.x;
+  jl[7] = ca * P.r0.y * s.y;
+  jl[8] = ca * P.r0.z * s.z;
+  jl[9] = ca * P.r1.x * s.x;
+  jl[10] = ca * P.r1.y * s.y;
+  jl[11] = ca * P.r1.z * s.z;
+}
+
+// t = Jp x for the structured Jp, zc = (sigma*x)[12c..12c+12) as three double4
+__device__ inline void pose_jp_x(const Dp& d, const double4& h, double u, double v, double scale,
+                                 const double4* zc, double (&t)[4]) {
+  const double d0 = dot4(h, zc[0]), d1 = dot4(h, zc[1]), d2 = dot4(h, zc[2]);
+  t[0] = d.sb * scale * (d0 - u * d2);
+  t[1] = d.sb * scale * (d1 - v * d2);
+  t[2] = d.sa * scale * d0;
+  t[3] = d.sa * scale * d1;
+}
+
+// q of Jp^T s = sigma * (h q0; h q1; h q2)
+__device__ inline double4 pose_q(const Dp& d, double u, double v, double scale, const double (&s)[4]) {
+  double4 q;
+  q.x = scale * (d.sb * s[0] + d.sa * s[2]);
+  q.y = scale * (d.sb * s[1] + d.sa * s[3]);
+  q.z = -scale * d.sb * (u * s[0] + v * s[1]);
+  q.w = scale;
+  return q;
+}
+
+__device__ inline double shfl_up_d(double v, int delta) { return __shfl_up(v, delta, WAVE); }
+__device__ inline double shfl_d(double v, int src) { return __shfl(v, src, WAVE); }
+__device__ inline double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, WAVE); }
+
+// inclusive segmented scan inside a wavefront, then broadcast of the segment total
+template <int N>
+__device__ inline void seg_reduce(double (&v)[N], int lane, int seg_first, int seg_last) {
+#pragma unroll
+  for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
+    const bool take = lane - dlt >= seg_first;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double o = shfl_up_d(v[k], dlt);
+      if (take) v[k] += o;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = shfl_d(v[k], seg_last);
+}
+
+template <int N>
+__device__ inline void wave_sum(double (&v)[N]) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += shfl_xor_d(v[k], m);
+  }
+}
+
+// deterministic workgroup sum of N per-thread values -> out[N] valid in every thread
+template <int N, int BLOCK>
+__device__ inline void block_sum(double (&v)[N], double* sh /* [BLOCK/64][N] */) {
+  wave_sum<N>(v);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) sh[w * N + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double s = 0;
+    for (int i = 0; i < BLOCK / 64; ++i) s += sh[i * N + k];
+    v[k] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// landmark-major drivers
+// ------------------------------------------------------------------------------------------
+//
+// An Op provides
+//   NRED  per-landmark reduction width, NSC  global scalar reduction width
+//   Local per-observation registers carried from phase1 to phase2
+//   phase1(d, slot, cam, lm, uv, L, red)            per observation: inputs -> partial sums
+//   phase2(d, slot, cam, lm, uv, L, tot, sc)        per observation: totals -> outputs
+//   finish_lm(d, lm, tot)                           once per landmark
+
+template <class Op>
+__global__ __launch_bounds__(LM_BLOCK) void lm_regular(Dp d, Op op, double* part) {
+  if (Op::CHECK_DONE && d.flags[1]) return;
+  const int slot = blockIdx.x * LM_BLOCK + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool in = slot < d.n_bins * WAVE;
+  const int meta = in ? d.meta[slot] : (lane | (lane << 8));
+  const bool valid = in && (meta & META_REAL) && !(meta & META_LONG);
+  const int seg_first = meta & 255, seg_last = (meta >> 8) & 255;
+  int cam = 0, lm = 0;
+  double2 uv = make_double2(0, 0);
+  if (valid) {
+    cam = d.cam[slot];
+    lm = d.lm[slot];
+    uv = d.uv[slot];
+  }
+  typename Op::Local L;
+  double red[Op::NRED > 0 ? Op::NRED : 1];
+#pragma unroll
+  for (int k = 0; k < (Op::NRED > 0 ? Op::NRED : 1); ++k) red[k] = 0;
+  if (valid) op.phase1(d, slot, cam, lm, uv, L, red);
+  if constexpr (Op::NRED > 0) seg_reduce<Op::NRED>(red, lane, seg_first, seg_last);
+  double sc[Op::NSC > 0 ? Op::NSC : 1];
+#pragma unroll
+  for (int k = 0; k < (Op::NSC > 0 ? Op::NSC : 1); ++k) sc[k] = 0;
+  if (valid) {
+    op.phase2(d, slot, cam, lm, uv, L, red, sc);
+    if (lane == seg_last) op.finish_lm(d, lm, red);
+  }
+  if constexpr (Op::NSC > 0) {
+    __shared__ double sh[(LM_BLOCK / 64) * Op::NSC];
+    block_sum<Op::NSC, LM_BLOCK>(sc, sh);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < Op::NSC; ++k) part[(size_t)blockIdx.x * Op::NSC + k] = sc[k];
+    }
+  }
+}
+
+template <class Op>
+__global__ __launch_bounds__(LM_BLOCK) void lm_long(Dp d, Op op, double* part) {
+  if (Op::CHECK_DONE && d.flags[1]) return;
+  const int lm = d.long_lm[blockIdx.x];
+  const int first = d.long_first[blockIdx.x];
+  const int cnt = d.long_cnt[blockIdx.x];
+  constexpr int NR = Op::NRED > 0 ? Op::NRED : 1;
+  constexpr int NS = Op::NSC > 0 ? Op::NSC : 1;
+  __shared__ double sh[(LM_BLOCK / 64) * (NR > NS ? NR : NS)];
+  double tot[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) tot[k] = 0;
+  for (int i = threadIdx.x; i < cnt; i += LM_BLOCK) {
+    const int slot = first + i;
+    typename Op::Local L;
+    double red[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) red[k] = 0;
+    op.phase1(d, slot, d.cam[slot], lm, d.uv[slot], L, red);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) tot[k] += red[k];
+  }
+  if constexpr (Op::NRED > 0) block_sum<NR, LM_BLOCK>(tot, sh);
+  double sc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sc[k] = 0;
+  for (int i = threadIdx.x; i < cnt; i += LM_BLOCK) {
+    const int slot = first + i;
+    typename Op::Local L;
+    double red[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) red[k] = 0;
+    op.phase1(d, slot, d.cam[slot], lm, d.uv[slot], L, red);
+    op.phase2(d, slot, d.cam[slot], lm, d.uv[slot], L, tot, sc);
+  }
+  __syncthreads();  // every phase1 read of per-landmark state is done before finish_lm writes it
+  if (threadIdx.x == 0) op.finish_lm(d, lm, tot);
+  if constexpr (Op::NSC > 0) {
+    block_sum<NS, LM_BLOCK>(sc, sh);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) part[(size_t)(d.n_reg_blocks + blockIdx.x) * NS + k] = sc[k];
+    }
+  }
+}
+
+// fixed-order sum of per-workgroup partials: out[k] = sum_i part[i*N + k]
+template <int N>
+__global__ __launch_bounds__(256) void reduce_partials(const double* part, int n, double* out) {
+  __shared__ double sh[4 * N];
+  double v[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += part[(size_t)i * N + k];
+  }
+  block_sum<N, 256>(v, sh);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = v[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// landmark-major ops
+// ------------------------------------------------------------------------------------------
+
+struct NoLocal {};
+
+// K1: initialize_varproj_lm_pOSE (bal_bundle_adjustment_helper.cpp:76-99, 221-241).
+// x_l = argmin |G x - z|: the reference solves it with bdcSvd; here the 3x3 normal equations
+// (G^T G) x = G^T z are accumulated and solved with the closed-form inverse.
+struct OpInit {
+  static constexpr int NRED = 9, NSC = 0;
+  static constexpr bool CHECK_DONE = false;
+  using Local = NoLocal;
+  __device__ void phase1(const Dp& d, int, int cam, int, double2 uv, Local&, double* red) const {
+    const Cam P = load_cam(d.cams4, cam);
+    const double4 one = make_double4(1, 1, 1, 1);
+    double g[12];
+    pose_jl(d, P, uv.x, uv.y, 1.0, one, g);
+    const double z[4] = {d.sb * (P.r2.w * uv.x - P.r0.w), d.sb * (P.r2.w * uv.y - P.r1.w),
+                         d.sa * (uv.x - P.r0.w), d.sa * (uv.y - P.r1.w)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[0] += g[3 * r] * g[3 * r];
+      red[1] += g[3 * r] * g[3 * r + 1];
+      red[2] += g[3 * r] * g[3 * r + 2];
+      red[3] += g[3 * r + 1] * g[3 * r + 1];
+      red[4] += g[3 * r + 1] * g[3 * r + 2];
+      red[5] += g[3 * r + 2] * g[3 * r + 2];
+      red[6] += g[3 * r] * z[r];
+      red[7] += g[3 * r + 1] * z[r];
+      red[8] += g[3 * r + 2] * z[r];
+    }
+  }
+  __device__ void phase2(const Dp&, int, int, int, double2, Local&, const double*, double*) const {}
+  __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    double H[9], Hi[9];
+    sym3(tot, H);
+    inv3(H, Hi);
+    double4 x;
+    x.x = Hi[0] * tot[6] + Hi[1] * tot[7] + Hi[2] * tot[8];
+    x.y = Hi[3] * tot[6] + Hi[4] * tot[7] + Hi[5] * tot[8];
+    x.z = Hi[6] * tot[6] + Hi[7] * tot[7] + Hi[8] * tot[8];
+    x.w = 1.0;
+    d.lms4[lm] = x;
+  }
+};
+
+// K2: compute_error_pOSE (bal_bundle_adjustment_helper.cpp:117-154)
+struct OpError {
+  static constexpr int NRED = 0, NSC = 3;
+  static constexpr bool CHECK_DONE = false;
+  using Local = NoLocal;
+  __device__ void phase1(const Dp&, int, int, int, double2, Local&, double*) const {}
+  __device__ void phase2(const Dp& d, int, int cam, int lm, double2 uv, Local&, const double*,
+                         double* sc) const {
+    const Cam P = load_cam(d.cams4, cam);
+    const double4 h = d.lms4[lm];
+    double res[4];
+    pose_residual(d, P, h, uv.x, uv.y, res);
+    const double r2 = res[0] * res[0] + res[1] * res[1] + res[2] * res[2] + res[3] * res[3];
+    if (!isfinite(r2)) atomicOr(&d.flags[0], 1);
+    double e, w;
+    error_weight(d, r2, e, w);
+    sc[0] += e;
+    sc[1] += sqrt(r2);
+    sc[2] += 1.0;
+  }
+  __device__ void finish_lm(const Dp&, int, const double*) const {}
+};
+
+// K3 + K5: linearize_landmark_pOSE (landmark_block.hpp:135-178) and scale_Jl_cols_pOSE
+// (landmark_block.hpp:284-295).  Keeps sqrt(w) and the weighted residual per observation and
+// the Jl column scale per landmark; the tiles themselves are implicit.
+struct OpLinearize {
+  static constexpr int NRED = 3, NSC = 0;
+  static constexpr bool CHECK_DONE = false;
+  using Local = NoLocal;
+  __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local&, double* red) const {
+    const Cam P = load_cam(d.cams_lin4, cam);
+    const double4 h = d.lms_lin4[lm];
+    double res[4];
+    pose_residual(d, P, h, uv.x, uv.y, res);
+    const double r2 = res[0] * res[0] + res[1] * res[1] + res[2] * res[2] + res[3] * res[3];
+    double e, w;
+    error_weight(d, r2, e, w);
+    const double sw = sqrt(w);
+    if (!isfinite(r2) || !isfinite(sw)) atomicOr(&d.flags[0], 1);
+    d.sw[slot] = sw;
+    d.rres[slot] = make_double4(sw * res[0], sw * res[1], sw * res[2], sw * res[3]);
+    d.q4[slot] = make_double4(0, 0, 0, sw);
+    double jl[12];
+    pose_jl(d, P, uv.x, uv.y, sw, make_double4(1, 1, 1, 1), jl);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[0] += jl[3 * r] * jl[3 * r];
+      red[1] += jl[3 * r + 1] * jl[3 * r + 1];
+      red[2] += jl[3 * r + 2] * jl[3 * r + 2];
+    }
+  }
+  __device__ void phase2(const Dp&, int, int, int, double2, Local&, const double*, double*) const {}
+  __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    d.jl_scale4[lm] = make_double4(1.0 / (d.eps + sqrt(tot[0])), 1.0 / (d.eps + sqrt(tot[1])),
+                                   1.0 / (d.eps + sqrt(tot[2])), 0.0);
+  }
+};
+
+// K7 (landmark part): get_Hll_inv_add_Hpp_b_pOSE / _poBA (landmark_block.hpp:510-572).
+// Hll = Jl^T Jl (+ lambda I for POWER_SCHUR_COMPLEMENT), Hll^-1, w = Hll^-1 Jl^T r and the
+// scatter scalars of Jp^T (r - Jl w); the per-camera sums are taken by cm_scatter.
+struct OpPrepare {
+  static constexpr int NRED = 9, NSC = 0;
+  static constexpr bool CHECK_DONE = false;
+  struct Local {
+    double jl[12];
+    double4 r;
+    double sw;
+  };
+  __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local& L, double* red) const {
+    const Cam P = load_cam(d.cams_lin4, cam);
+    L.sw = d.robust ? d.sw[slot] : 1.0;
+    L.r = d.rres[slot];
+    pose_jl(d, P, uv.x, uv.y, L.sw, d.jl_scale4[lm], L.jl);
+    const double rr[4] = {L.r.x, L.r.y, L.r.z, L.r.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[0] += L.jl[3 * r] * L.jl[3 * r];
+      red[1] += L.jl[3 * r] * L.jl[3 * r + 1];
+      red[2] += L.jl[3 * r] * L.jl[3 * r + 2];
+      red[3] += L.jl[3 * r + 1] * L.jl[3 * r + 1];
+      red[4] += L.jl[3 * r + 1] * L.jl[3 * r + 2];
+      red[5] += L.jl[3 * r + 2] * L.jl[3 * r + 2];
+      red[6] += L.jl[3 * r] * rr[r];
+      red[7] += L.jl[3 * r + 1] * rr[r];
+      red[8] += L.jl[3 * r + 2] * rr[r];
+    }
+  }
+  __device__ static void hinv(const Dp& d, const double* tot, double (&Hi)[9]) {
+    double H[9];
+    sym3(tot, H);
+    H[0] += d.lambda_lm;
+    H[4] += d.lambda_lm;
+    H[8] += d.lambda_lm;
+    inv3(H, Hi);
+  }
+  __device__ void phase2(const Dp& d, int slot, int, int, double2 uv, Local& L, const double* tot,
+                         double*) const {
+    double Hi[9];
+    hinv(d, tot, Hi);
+    const double w0 = Hi[0] * tot[6] + Hi[1] * tot[7] + Hi[2] * tot[8];
+    const double w1 = Hi[3] * tot[6] + Hi[4] * tot[7] + Hi[5] * tot[8];
+    const double w2 = Hi[6] * tot[6] + Hi[7] * tot[7] + Hi[8] * tot[8];
+    const double rr[4] = {L.r.x, L.r.y, L.r.z, L.r.w};
+    double e[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      e[r] = rr[r] - (L.jl[3 * r] * w0 + L.jl[3 * r + 1] * w1 + L.jl[3 * r + 2] * w2);
+    d.q4[slot] = pose_q(d, uv.x, uv.y, L.sw, e);
+  }
+  __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    double Hi[9];
+    hinv(d, tot, Hi);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d.hll_inv[9 * (size_t)lm + k] = Hi[k];
+  }
+};
+
+// K10 (implicit, landmark part): right_mul_e0_pOSE (linearization_power_varproj.hpp:364-406).
+// t = Jp x, u = Jl^T t (segmented sum over the landmark), v = Hll^-1 u, s = Jl v, then the three
+// scatter scalars of Jp^T s.  Input z = sigma * x.
+struct OpE0 {
+  static constexpr int NRED = 3, NSC = 0;
+  static constexpr bool CHECK_DONE = true;
+  struct Local {
+    double jl[12];
+    double sw;
+  };
+  __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local& L, double* red) const {
+    const Cam P = load_cam(d.cams_lin4, cam);
+    const double4 h = d.lms_lin4[lm];
+    const double4* zc = reinterpret_cast<const double4*>(d.z) + 3 * cam;
+    const double4 z0 = zc[0], z1 = zc[1], z2 = zc[2];
+    const double4 zz[3] = {z0, z1, z2};
+    L.sw = d.robust ? d.sw[slot] : 1.0;
+    pose_jl(d, P, uv.x, uv.y, L.sw, d.jl_scale4[lm], L.jl);
+    double t[4];
+    pose_jp_x(d, h, uv.x, uv.y, L.sw, zz, t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[0] += L.jl[3 * r] * t[r];
+      red[1] += L.jl[3 * r + 1] * t[r];
+      red[2] += L.jl[3 * r + 2] * t[r];
+    }
+  }
+  __device__ void phase2(const Dp& d, int slot, int, int lm, double2 uv, Local& L, const double* tot,
+                         double*) const {
+    const double* Hi = d.hll_inv + 9 * (size_t)lm;
+    const double v0 = Hi[0] * tot[0] + Hi[1] * tot[1] + Hi[2] * tot[2];
+    const double v1 = Hi[3] * tot[0] + Hi[4] * tot[1] + Hi[5] * tot[2];
+    const double v2 = Hi[6] * tot[0] + Hi[7] * tot[1] + Hi[8] * tot[2];
+    double s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = L.jl[3 * r] * v0 + L.jl[3 * r + 1] * v1 + L.jl[3 * r + 2] * v2;
+    d.q4[slot] = pose_q(d, uv.x, uv.y, L.sw, s);
+  }
+  __device__ void finish_lm(const Dp&, int, const double*) const {}
+};
+
+// K10 (stored tiles): right_mul_e0_pOSE on the tiles kept in HBM, blocked layout
+// tiles[bin][pair][lane] (double2): pairs 0-23 Jp (row-major 4x12), 24-29 Jl (4x3), 30-31 r.
+// Every byte of a tile is read once per term, 16 B per lane, 1 KiB contiguous per wave
+// instruction; the scatter is a hardware fp64 atomic add per output (the reference's
+// mutex-guarded +=, linearization_power_varproj.hpp:393-397).
+struct OpE0Tiles {
+  static constexpr int NRED = 3, NSC = 0;
+  static constexpr bool CHECK_DONE = true;
+  struct Local {
+    double jp[48];
+    double jl[12];
+  };
+  __device__ void phase1(const Dp& d, int slot, int cam, int, double2, Local& L, double* red) const {
+    const double2* t = d.tiles + ((size_t)(slot >> 6) * TILE_PAIRS) * WAVE + (slot & 63);
+#pragma unroll
+    for (int p = 0; p < 24; ++p) {
+      const double2 a = t[p * WAVE];
+      L.jp[2 * p] = a.x;
+      L.jp[2 * p + 1] = a.y;
+    }
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const double2 a = t[(24 + p) * WAVE];
+      L.jl[2 * p] = a.x;
+      L.jl[2 * p + 1] = a.y;
+    }
+    const double* x = d.tmp + 12 * (size_t)cam;
+    double xc[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) xc[j] = x[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double tr = 0;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) tr += L.jp[12 * r + j] * xc[j];
+      red[0] += L.jl[3 * r] * tr;
+      red[1] += L.jl[3 * r + 1] * tr;
+      red[2] += L.jl[3 * r + 2] * tr;
+    }
+  }
+  __device__ void phase2(const Dp& d, int, int cam, int lm, double2, Local& L, const double* tot,
+                         double*) const {
+    const double* Hi = d.hll_inv + 9 * (size_t)lm;
+    const double v0 = Hi[0] * tot[0] + Hi[1] * tot[1] + Hi[2] * tot[2];
+    const double v1 = Hi[3] * tot[0] + Hi[4] * tot[1] + Hi[5] * tot[2];
+    const double v2 = Hi[6] * tot[0] + Hi[7] * tot[1] + Hi[8] * tot[2];
+    double s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = L.jl[3 * r] * v0 + L.jl[3 * r + 1] * v1 + L.jl[3 * r + 2] * v2;
+    double* y = d.y + 12 * (size_t)cam;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const double o = L.jp[j] * s[0] + L.jp[12 + j] * s[1] + L.jp[24 + j] * s[2] + L.jp[36 + j] * s[3];
+      unsafeAtomicAdd(y + j, o);
+    }
+  }
+  __device__ void finish_lm(const Dp&, int, const double*) const {}
+};
+
+// K12: back_substitute_pOSE (landmark_block.hpp:670-707), POWER_VARPROJ.  Fresh unweighted,
+// unscaled res/Jl at the UPDATED cameras, exact landmark re-solve, and the reference's model
+// cost change with its mixture of scaled and unscaled quantities.
+struct OpBackVarproj {
+  static constexpr int NRED = 9, NSC = 1;
+  static constexpr bool CHECK_DONE = false;
+  struct Local {
+    double jinc[4];  // Jp_fresh * inc
+    double jls[12];  // stored Jl (weighted, column-scaled, old cameras)
+    double4 r;
+  };
+  __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local& L, double* red) const {
+    const Cam P = load_cam(d.cams4, cam);
+    const double4 h = d.lms4[lm];
+    double res[4];
+    pose_residual(d, P, h, uv.x, uv.y, res);
+    double jl[12];
+    pose_jl(d, P, uv.x, uv.y, 1.0, make_double4(1, 1, 1, 1), jl);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[0] += jl[3 * r] * jl[3 * r];
+      red[1] += jl[3 * r] * jl[3 * r + 1];
+      red[2] += jl[3 * r] * jl[3 * r + 2];
+      red[3] += jl[3 * r + 1] * jl[3 * r + 1];
+      red[4] += jl[3 * r + 1] * jl[3 * r + 2];
+      red[5] += jl[3 * r + 2] * jl[3 * r + 2];
+      red[6] += jl[3 * r] * res[r];
+      red[7] += jl[3 * r + 1] * res[r];
+      red[8] += jl[3 * r + 2] * res[r];
+    }
+    const double4* ic = reinterpret_cast<const double4*>(d.inc) + 3 * cam;
+    const double4 zz[3] = {ic[0], ic[1], ic[2]};
+    pose_jp_x(d, h, uv.x, uv.y, 1.0, zz, L.jinc);
+    const Cam Pl = load_cam(d.cams_lin4, cam);
+    const double sw = d.robust ? d.sw[slot] : 1.0;
+    pose_jl(d, Pl, uv.x, uv.y, sw, d.jl_scale4[lm], L.jls);
+    L.r = d.rres[slot];
+  }
+  __device__ static void delta(const double* tot, double (&dl)[3]) {
+    double H[9], Hi[9];
+    sym3(tot, H);
+    inv3(H, Hi);
+    dl[0] = -(Hi[0] * tot[6] + Hi[1] * tot[7] + Hi[2] * tot[8]);
+    dl[1] = -(Hi[3] * tot[6] + Hi[4] * tot[7] + Hi[5] * tot[8]);
+    dl[2] = -(Hi[6] * tot[6] + Hi[7] * tot[7] + Hi[8] * tot[8]);
+  }
+  __device__ void phase2(const Dp&, int, int, int, double2, Local& L, const double* tot, double* sc) const {
+    double dl[3];
+    delta(tot, dl);
+    const double rr[4] = {L.r.x, L.r.y, L.r.z, L.r.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double ji = L.jinc[r] + (L.jls[3 * r] * dl[0] + L.jls[3 * r + 1] * dl[1] + L.jls[3 * r + 2] * dl[2]);
+      sc[0] -= ji * (0.5 * ji + rr[r]);
+    }
+  }
+  __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    double dl[3];
+    delta(tot, dl);
+    double4 x = d.lms4[lm];
+    x.x += dl[0];
+    x.y += dl[1];
+    x.z += dl[2];
+    d.lms4[lm] = x;
+  }
+};
+
+// K12: back_substitute_poBA (landmark_block.hpp:625-656), POWER_SCHUR_COMPLEMENT: stored tiles,
+// scaled increment (d.z = sigma * inc), damped Hll, delta scaled by Jl_col_scale on update.
+struct OpBackPoba {
+  static constexpr int NRED = 9, NSC = 1;
+  static constexpr bool CHECK_DONE = false;
+  struct Local {
+    double jpi[4];
+    double jl[12];
+    double4 r;
+  };
+  __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local& L, double* red) const {
+    const Cam P = load_cam(d.cams_lin4, cam);
+    const double4 h = d.lms_lin4[lm];
+    const double sw = d.robust ? d.sw[slot] : 1.0;
+    pose_jl(d, P, uv.x, uv.y, sw, d.jl_scale4[lm], L.jl);
+    const double4* zc = reinterpret_cast<const double4*>(d.z) + 3 * cam;
+    const double4 zz[3] = {zc[0], zc[1], zc[2]};
+    pose_jp_x(d, h, uv.x, uv.y, sw, zz, L.jpi);
+    L.r = d.rres[slot];
+    const double rr[4] = {L.r.x, L.r.y, L.r.z, L.r.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[0] += L.jl[3 * r] * L.jl[3 * r];
+      red[1] += L.jl[3 * r] * L.jl[3 * r + 1];
+      red[2] += L.jl[3 * r] * L.jl[3 * r + 2];
+      red[3] += L.jl[3 * r + 1] * L.jl[3 * r + 1];
+      red[4] += L.jl[3 * r + 1] * L.jl[3 * r + 2];
+      red[5] += L.jl[3 * r + 2] * L.jl[3 * r + 2];
+      const double a = rr[r] + L.jpi[r];
+      red[6] += L.jl[3 * r] * a;
+      red[7] += L.jl[3 * r + 1] * a;
+      red[8] += L.jl[3 * r + 2] * a;
+    }
+  }
+  __device__ static void delta(const Dp& d, const double* tot, double (&dl)[3]) {
+    double H[9], Hi[9];
+    sym3(tot, H);
+    H[0] += d.lambda_lm;
+    H[4] += d.lambda_lm;
+    H[8] += d.lambda_lm;
+    inv3(H, Hi);
+    dl[0] = -(Hi[0] * tot[6] + Hi[1] * tot[7] + Hi[2] * tot[8]);
+    dl[1] = -(Hi[3] * tot[6] + Hi[4] * tot[7] + Hi[5] * tot[8]);
+    dl[2] = -(Hi[6] * tot[6] + Hi[7] * tot[7] + Hi[8] * tot[8]);
+  }
+  __device__ void phase2(const Dp& d, int, int, int, double2, Local& L, const double* tot, double* sc) const {
+    double dl[3];
+    delta(d, tot, dl);
+    const double rr[4] = {L.r.x, L.r.y, L.r.z, L.r.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double ji = L.jpi[r] + (L.jl[3 * r] * dl[0] + L.jl[3 * r + 1] * dl[1] + L.jl[3 * r + 2] * dl[2]);
+      sc[0] -= ji * (0.5 * ji + rr[r]);
+    }
+  }
+  __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    double dl[3];
+    delta(d, tot, dl);
+    const double4 s = d.jl_scale4[lm];
+    double4 x = d.lms4[lm];
+    x.x += dl[0] * s.x;
+    x.y += dl[1] * s.y;
+    x.z += dl[2] * s.z;
+    d.lms4[lm] = x;
+  }
+};
+
+// K3/K5/K6 materialised: the reference's stored tile (after Jl and Jp column scaling) of every
+// observation in the blocked layout used by OpE0Tiles and exported by povar_get_buffer.
+__global__ __launch_bounds__(LM_BLOCK) void materialize_tiles(Dp d) {
+  const int slot = blockIdx.x * LM_BLOCK + threadIdx.x;
+  if (slot >= d.n_bins * WAVE) return;
+  double2* t = d.tiles + ((size_t)(slot >> 6) * TILE_PAIRS) * WAVE + (slot & 63);
+  const int meta = d.meta[slot];
+  if (!(meta & META_REAL)) {
+#pragma unroll
+    for (int p = 0; p < TILE_PAIRS; ++p) t[p * WAVE] = make_double2(0, 0);
+    return;
+  }
+  const int cam = d.cam[slot], lm = d.lm[slot];
+  const double2 uv = d.uv[slot];
+  const Cam P = load_cam(d.cams_lin4, cam);
+  const double4 h = d.lms_lin4[lm];
+  const double sw = d.robust ? d.sw[slot] : 1.0;
+  const double hh[4] = {h.x, h.y, h.z, h.w};
+  const double* sg = d.sigma + 12 * (size_t)cam;
+  double jp[48];
+#pragma unroll
+  for (int j = 0; j < 48; ++j) jp[j] = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // ((h * sb) * sw) * sigma: the order the reference applies them (helper.cpp:273-303,
+    // landmark_block.hpp:167, 330-332)
+    jp[j] = hh[j] * d.sb * sw * sg[j];
+    jp[8 + j] = -hh[j] * uv.x * d.sb * sw * sg[8 + j];
+    jp[12 + 4 + j] = hh[j] * d.sb * sw * sg[4 + j];
+    jp[12 + 8 + j] = -hh[j] * uv.y * d.sb * sw * sg[8 + j];
+    jp[24 + j] = hh[j] * d.sa * sw * sg[j];
+    jp[36 + 4 + j] = hh[j] * d.sa * sw * sg[4 + j];
+  }
+  double jl[12];
+  pose_jl(d, P, uv.x, uv.y, sw, d.jl_scale4[lm], jl);
+  const double4 r = d.rres[slot];
+#pragma unroll
+  for (int p = 0; p < 24; ++p) t[p * WAVE] = make_double2(jp[2 * p], jp[2 * p + 1]);
+#pragma unroll
+  for (int p = 0; p < 6; ++p) t[(24 + p) * WAVE] = make_double2(jl[2 * p], jl[2 * p + 1]);
+  t[30 * WAVE] = make_double2(r.x, r.y);
+  t[31 * WAVE] = make_double2(r.z, r.w);
+}
+
+// ------------------------------------------------------------------------------------------
+// camera-major kernels
+// ------------------------------------------------------------------------------------------
+
+// Second half of every Jp^T(.) product: item_part[item] = sum over the item's observations of
+// ( h q0 ; h q1 ; h q2 ).  One wavefront per item, fixed order.
+__global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
+  if (check_done && d.flags[1]) return;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (item >= d.n_items) return;
+  const int b = d.item_off[item], e = d.item_off[item + 1];
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0;
+  for (int p = b + lane; p < e; p += WAVE) {
+    const double4 q = d.q4[d.cm_slot[p]];
+    const double4 h = d.lms_lin4[d.cm_lm[p]];
+    acc[0] += h.x * q.x; acc[1] += h.y * q.x; acc[2] += h.z * q.x; acc[3] += h.w * q.x;
+    acc[4] += h.x * q.y; acc[5] += h.y * q.y; acc[6] += h.z * q.y; acc[7] += h.w * q.y;
+    acc[8] += h.x * q.z; acc[9] += h.y * q.z; acc[10] += h.z * q.z; acc[11] += h.w * q.z;
+  }
+  wave_sum<12>(acc);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) d.item_part[12 * (size_t)item + k] = acc[k];
+  }
+}
+
+// Camera-block Gram sums of the unscaled weighted Jp: Jp^T Jp = w * (C (x) h h^T) with
+// C = [[1,0,-sb^2 u],[0,1,-sb^2 v],[.,.,sb^2(u^2+v^2)]] (sa^2 + sb^2 = 1), so four weighted
+// moments of h h^T (10 unique entries each) per camera carry both get_Jp_diag2_pOSE
+// (linearization_varproj.hpp:183-222) and the Hpp blocks (landmark_block.hpp:530-536).
+__global__ __launch_bounds__(256) void cm_gram(Dp d) {
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (item >= d.n_items) return;
+  const int b = d.item_off[item], e = d.item_off[item + 1];
+  double acc[40];
+#pragma unroll
+  for (int k = 0; k < 40; ++k) acc[k] = 0;
+  for (int p = b + lane; p < e; p += WAVE) {
+    const double sw = d.q4[d.cm_slot[p]].w;
+    const double4 h = d.lms_lin4[d.cm_lm[p]];
+    const double2 uv = d.cm_uv[p];
+    const double w = sw * sw;
+    const double m[4] = {w, w * uv.x, w * uv.y, w * (uv.x * uv.x + uv.y * uv.y)};
+    const double hh[10] = {h.x * h.x, h.x * h.y, h.x * h.z, h.x * h.w, h.y * h.y,
+                           h.y * h.z, h.y * h.w, h.z * h.z, h.z * h.w, h.w * h.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 10; ++j) acc[10 * k + j] += m[k] * hh[j];
+  }
+  wave_sum<40>(acc);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 40; ++k) d.item_partG[40 * (size_t)item + k] = acc[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// camera kernels
+// ------------------------------------------------------------------------------------------
+
+__device__ inline int sym10(int i, int j) {  // index of (i,j) in the packed upper 4x4
+  if (i > j) { const int t = i; i = j; j = t; }
+  return i * 4 - (i * (i - 1)) / 2 + (j - i);
+}
+
+// per camera: G = sum of item Gram parts; diag2 and pose scaling (linearizor_power_varproj.cpp:62-70)
+__global__ __launch_bounds__(64) void cam_finish_linearize(Dp d, const double* G_in) {
+  const int c = blockIdx.x;
+  __shared__ double g[40];
+  if (threadIdx.x < 40) {
+    double s = 0;
+    if (G_in) {
+      s = G_in[40 * (size_t)c + threadIdx.x];
+    } else {
+      for (int it = d.cam_item_off[c]; it < d.cam_item_off[c + 1]; ++it)
+        s += d.item_partG[40 * (size_t)it + threadIdx.x];
+    }
+    g[threadIdx.x] = s;
+    d.G[40 * (size_t)c + threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const int blk = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const int dj = sym10(j, j);
+    const double v = blk < 2 ? g[dj] : d.sb * d.sb * g[30 + dj];
+    d.diag2[12 * (size_t)c + threadIdx.x] = v;
+    d.sigma[12 * (size_t)c + threadIdx.x] = 1.0 / (d.eps + sqrt(v));
+  }
+}
+
+// K8: B_c = Hpp_c + lambda I, B_c^-1 by Cholesky (upper triangle) and solve against I
+// (linearization_power_varproj.hpp:141-154).  One thread per camera, matrices in LDS laid out
+// [element][thread] (bank-conflict free).
+constexpr int K8_THREADS = 32;
+__global__ __launch_bounds__(K8_THREADS) void cam_build_binv(Dp d, double lambda) {
+  __shared__ double A[144 * K8_THREADS];
+  __shared__ double X[144 * K8_THREADS];
+  const int t = threadIdx.x;
+  const int c = blockIdx.x * K8_THREADS + t;
+  if (c >= d.n_cams) return;
+#define A_(i, j) A[((i) * 12 + (j)) * K8_THREADS + t]
+#define X_(i, j) X[((i) * 12 + (j)) * K8_THREADS + t]
+  const double* g = d.G + 40 * (size_t)c;
+  const double* sg = d.sigma + 12 * (size_t)c;
+  const double sb2 = d.sb * d.sb;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b)
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          const int ij = sym10(i, j);
+          double v;
+          if (a == b) v = a < 2 ? g[ij] : sb2 * g[30 + ij];
+          else if (a + b == 1) v = 0;
+          else {
+            const int k = (a == 2 ? b : a);  // 0 -> u moment, 1 -> v moment
+            v = -sb2 * g[10 * (k + 1) + ij];
+          }
+          A_(4 * a + i, 4 * b + j) = v * sg[4 * a + i] * sg[4 * b + j];
+        }
+  for (int j = 0; j < 12; ++j) A_(j, j) += lambda;
+  // Cholesky: L stored in the lower triangle of A (reads the upper triangle of the input)
+  for (int j = 0; j < 12; ++j) {
+    double dd = A_(j, j);
+    for (int k = 0; k < j; ++k) dd -= A_(j, k) * A_(j, k);
+    dd = sqrt(dd);
+    A_(j, j) = dd;
+    for (int i = j + 1; i < 12; ++i) {
+      double s = A_(j, i);
+      for (int k = 0; k < j; ++k) s -= A_(i, k) * A_(j, k);
+      A_(i, j) = s / dd;
+    }
+  }
+  for (int col = 0; col < 12; ++col) {
+    for (int i = 0; i < 12; ++i) {
+      double s = (i == col) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) s -= A_(i, k) * X_(k, col);
+      X_(i, col) = s / A_(i, i);
+    }
+    for (int i = 11; i >= 0; --i) {
+      double s = X_(i, col);
+      for (int k = i + 1; k < 12; ++k) s -= A_(k, i) * X_(k, col);
+      X_(i, col) = s / A_(i, i);
+    }
+  }
+  double* out = d.binv + 144 * (size_t)c;
+  for (int i = 0; i < 12; ++i)
+    for (int j = 0; j < 12; ++j) out[12 * i + j] = X_(i, j);
+#undef A_
+#undef X_
+}
+
+// b_c = sigma * sum_items (scatter parts)   (landmark_block.hpp:529-534)
+__global__ __launch_bounds__(192) void cam_sum_items(Dp d, double* out, int apply_sigma) {
+  const int c = blockIdx.x * 16 + threadIdx.x / 12, r = threadIdx.x % 12;
+  if (c >= d.n_cams) return;
+  double s = 0;
+  for (int it = d.cam_item_off[c]; it < d.cam_item_off[c + 1]; ++it) s += d.item_part[12 * (size_t)it + r];
+  out[12 * (size_t)c + r] = apply_sigma ? s * d.sigma[12 * (size_t)c + r] : s;
+}
+
+// K9 + K11: tmp = B^-1 y, accum (+)= tmp, z = sigma * tmp, optional squared-norm partials
+// (right_mul_b_inv_pOSE + the loop body of solve_pOSE, linearization_power_varproj.hpp:196-207,
+// 322-340).  mode 0: y = -b (series start); 1: y = sigma * sum of scatter items (implicit E0);
+// 2: y = dense buffer d.y (stored-tile E0, or the all-reduced vector), cleared after reading.
+constexpr int K9_CAMS = 16;
+__global__ __launch_bounds__(K9_CAMS * 12) void cam_binv_axpy(Dp d, int mode, int want_norms) {
+  if (mode != 0 && d.flags[1]) return;
+  __shared__ double ys[K9_CAMS * 12];
+  __shared__ double sh[3 * 2];
+  const int lc = threadIdx.x / 12, r = threadIdx.x % 12;
+  const int c = blockIdx.x * K9_CAMS + lc;
+  const bool in = c < d.n_cams;
+  const size_t idx = 12 * (size_t)c + r;
+  double yv = 0;
+  if (in) {
+    if (mode == 0) {
+      yv = -d.b[idx];
+    } else if (mode == 1) {
+      double s = 0;
+      for (int it = d.cam_item_off[c]; it < d.cam_item_off[c + 1]; ++it) s += d.item_part[12 * (size_t)it + r];
+      yv = s * d.sigma[idx];
+    } else {
+      yv = d.y[idx];
+      d.y[idx] = 0;
+    }
+  }
+  ys[threadIdx.x] = yv;
+  __syncthreads();
+  double nrm[2] = {0, 0};
+  if (in) {
+    const double* Bi = d.binv + 144 * (size_t)c + 12 * r;
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s += Bi[j] * ys[lc * 12 + j];
+    const double acc = mode == 0 ? s : d.accum[idx] + s;
+    d.tmp[idx] = s;
+    d.accum[idx] = acc;
+    d.z[idx] = s * d.sigma[idx];
+    nrm[0] = s * s;
+    nrm[1] = acc * acc;
+  }
+  if (want_norms) {
+    block_sum<2, K9_CAMS * 12>(nrm, sh);
+    if (threadIdx.x == 0) {
+      d.norm_part[2 * (size_t)blockIdx.x] = nrm[0];
+      d.norm_part[2 * (size_t)blockIdx.x + 1] = nrm[1];
+    }
+  }
+}
+
+// convergence tests of solve_pOSE (linearization_power_varproj.hpp:198, 206-229), on the device
+// so the m-term loop needs no host round trip; later kernels of the loop see flags[1] and exit.
+__global__ __launch_bounds__(64) void series_check(Dp d, int n_blocks, int i, double q_tol, double r_tol) {
+  if (d.flags[1]) return;
+  double v[2] = {0, 0};
+  for (int k = threadIdx.x; k < n_blocks; k += 64) {
+    v[0] += d.norm_part[2 * (size_t)k];
+    v[1] += d.norm_part[2 * (size_t)k + 1];
+  }
+  wave_sum<2>(v);
+  if (threadIdx.x != 0) return;
+  const double iter_norm = sqrt(v[0]), acc_norm = sqrt(v[1]);
+  if (i == 0) {
+    d.norms[0] = acc_norm;
+    return;
+  }
+  d.norms[1] = iter_norm;
+  d.norms[2] = acc_norm;
+  bool conv = false;
+  if (q_tol > 0 && i * iter_norm / acc_norm < q_tol) conv = true;
+  if (!conv && r_tol > 0 && iter_norm / d.norms[0] < r_tol) conv = true;
+  if (conv) {
+    d.flags[1] = 1;
+    d.flags[2] = i;
+    d.flags[3] = 1;
+  }
+}
+
+// K13: P_c += reshape(inc * sigma) and the scale / unscale round trip of
+// linearizor_power_varproj.cpp:251-255.  mode 0 (VARPROJ): cams += inc*sigma, inc <- (inc*sigma)*(1/sigma)
+// mode 1 (POWER_SCHUR_COMPLEMENT, before back substitution): z = sigma*inc only
+// mode 2 (POWER_SCHUR_COMPLEMENT, after): cams += inc*sigma
+__global__ __launch_bounds__(256) void cam_apply_inc(Dp d, int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 12 * d.n_cams) return;
+  const double sg = d.sigma[i];
+  const double s = d.inc[i] * sg;
+  double* cams = reinterpret_cast<double*>(d.cams4);
+  if (mode == 0) {
+    cams[i] += s;
+    d.inc[i] = s * (1.0 / sg);
+  } else if (mode == 1) {
+    d.z[i] = s;
+  } else {
+    cams[i] += s;
+  }
+}
+
+__global__ __launch_bounds__(256) void lms3_to_4(const double* in, double4* out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = make_double4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 1.0);
+}
+__global__ __launch_bounds__(256) void lms4_to_3(const double4* in, double* out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const double4 v = in[i];
+    out[3 * i] = v.x;
+    out[3 * i + 1] = v.y;
+    out[3 * i + 2] = v.z;
+  }
+}
+
+}  // namespace povar

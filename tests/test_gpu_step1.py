@@ -1,0 +1,172 @@
+"""GPU parity of the step-1 (pOSE / VarPro) hot path against the CPU oracle, through the C ABI.
+
+Tolerances: per power-series term 1e-12 relative, after 20 terms 1e-10;
+fp64 throughout.  K1 (landmark init) uses 3x3 normal equations on the GPU where the reference
+uses an SVD solve: tolerance 1e-8.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel
+
+pytestmark = pytest.mark.gpu
+
+ALPHA, LAM, M = 0.01, 1e-4, 20
+
+
+def _setup(p, norm="NONE", huber=1.0, e0_mode=0):
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm=norm, huber=huber)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm=norm, huber=huber, e0_mode=e0_mode)
+    return orc, ctx
+
+
+def _oracle_stage(orc, cams, lms, lam, lam_lm=0.0):
+    st, diag2, jls, sigma, ok = orc.stage1_pose(ALPHA, cams, lms)
+    orc.scale_jp_cols_pose(st, sigma)
+    hll, b, binv = orc.prepare_hb_pose(st, lam, lam_lm)
+    return st, diag2, jls, sigma, hll, b, binv
+
+
+@pytest.mark.parametrize("which", ["small", "medium"])
+def test_init_and_error(which, small_problem, medium_problem):
+    p = small_problem if which == "small" else medium_problem
+    orc, ctx = _setup(p)
+    ctx.set_cameras(p.cams)
+    ctx.init_landmarks_pose(ALPHA)
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    assert rel(ctx.get_landmarks(), lms) < 1e-8
+    # identical landmarks from here on
+    ctx.set_landmarks(lms)
+    ri, ro = ctx.error_pose(ALPHA), orc.error_pose(ALPHA, p.cams, lms)
+    assert ri.all_num_obs == ro.all_num_obs == p.n_obs
+    assert abs(ri.all_error - ro.all_error) <= 1e-12 * ro.all_error
+    assert abs(ri.all_residual_sum - ro.all_residual_sum) <= 1e-12 * ro.all_residual_sum
+    assert ri.is_numerically_valid == 1 and ri.valid_num_obs == ro.valid_num_obs
+    ctx.close()
+
+
+@pytest.mark.parametrize("norm", ["NONE", "HUBER", "CAUCHY"])
+def test_linearize_prepare_buffers(norm, small_problem):
+    from povar_amd import capi
+    p = small_problem
+    orc, ctx = _setup(p, norm, huber=30.0)
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    ctx.set_cameras(p.cams)
+    ctx.set_landmarks(lms)
+    assert ctx.linearize_pose(ALPHA)
+    st, diag2, jls, sigma, hll, b, binv = _oracle_stage(orc, p.cams, lms, LAM)
+    ctx.prepare_pose(LAM)
+    assert rel(ctx.get_buffer(capi.BUF_DIAG2), diag2) < 1e-13
+    assert rel(ctx.get_buffer(capi.BUF_POSE_SCALING), sigma) < 1e-13
+    assert rel(ctx.get_buffer(capi.BUF_JL_COL_SCALE), jls.ravel()) < 1e-13
+    assert rel(ctx.get_buffer(capi.BUF_STORAGE), st.ravel()) < 1e-13
+    assert rel(ctx.get_buffer(capi.BUF_HLL_INV), hll.ravel()) < 1e-11
+    assert rel(ctx.get_buffer(capi.BUF_B), b) < 1e-12
+    assert rel(ctx.get_buffer(capi.BUF_B_INV), binv.ravel()) < 1e-10
+    ctx.close()
+
+
+@pytest.mark.parametrize("e0_mode", [0, 1])
+@pytest.mark.parametrize("which", ["small", "medium"])
+def test_power_series_term_by_term(which, e0_mode, small_problem, medium_problem):
+    p = small_problem if which == "small" else medium_problem
+    orc, ctx = _setup(p, e0_mode=e0_mode)
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    ctx.set_cameras(p.cams)
+    ctx.set_landmarks(lms)
+    assert ctx.linearize_pose(ALPHA)
+    st, diag2, jls, sigma, hll, b, binv = _oracle_stage(orc, p.cams, lms, LAM)
+    ref, it, status, terms = orc.solve_pose(st, hll, binv, b, M, want_terms=True)
+    ctx.prepare_pose(LAM)
+    x = np.random.default_rng(0).normal(size=12 * p.n_cams)
+    assert rel(ctx.right_mul_e0_pose(x), orc.right_mul_e0_pose(st, hll, x)) < 1e-12
+    ctx.power_series_begin()
+    assert rel(ctx.get_term(), terms[0]) < 1e-12
+    for i in range(1, M + 1):
+        ctx.power_series_step()
+        assert rel(ctx.get_term(), terms[i]) < 1e-11, i
+    assert rel(ctx.get_increment(), ref) < 1e-10
+    # one-shot entry point
+    inc, it2, st2, rc = ctx.solve_pose(LAM, 0, M)
+    assert rc == 0 and it2 == M and st2 == 0 and rel(inc, ref) < 1e-10
+    ctx.close()
+
+
+@pytest.mark.parametrize("q_tol,r_tol", [(1e-2, -1.0), (0.0, 0.5), (0.3, 0.9)])
+def test_early_exit(q_tol, r_tol, small_problem):
+    p = small_problem
+    orc, ctx = _setup(p)
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    ctx.set_cameras(p.cams)
+    ctx.set_landmarks(lms)
+    ctx.linearize_pose(ALPHA)
+    lam = 10.0  # strong damping so the series actually converges inside m terms
+    st, diag2, jls, sigma, hll, b, binv = _oracle_stage(orc, p.cams, lms, lam)
+    ref, it, status, _ = orc.solve_pose(st, hll, binv, b, 50, q_tol=q_tol, r_tol=r_tol)
+    inc, it2, st2, rc = ctx.solve_pose(lam, 0, 50, q_tol, r_tol)
+    assert (it2, st2) == (it, status)
+    assert rel(inc, ref) < 1e-10
+    ctx.close()
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_apply(solver, medium_problem):
+    p = medium_problem
+    orc, ctx = _setup(p)
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    ctx.set_cameras(p.cams)
+    ctx.set_landmarks(lms)
+    ctx.linearize_pose(ALPHA)
+    lam_lm = LAM if solver == 1 else 0.0
+    st, diag2, jls, sigma, hll, b, binv = _oracle_stage(orc, p.cams, lms, LAM, lam_lm)
+    ref, _, _, _ = orc.solve_pose(st, hll, binv, b, M)
+    inc, _, _, rc = ctx.solve_pose(LAM, solver, M)
+    assert rc == 0 and rel(inc, ref) < 1e-10
+    ctx.backup_pose()
+    l_diff = ctx.apply_pose(solver, ALPHA, ref)
+    inc_s = ref * sigma
+    cams_new = p.cams + inc_s.reshape(-1, 12)
+    if solver == 0:
+        ld, lms_new = orc.back_substitute_pose(ALPHA, st, cams_new, lms, inc_s * (1.0 / sigma))
+    else:
+        ld, lms_new = orc.back_substitute_poba(st, jls, LAM, lms, ref)
+    assert rel(ctx.get_cameras(), cams_new) < 1e-14
+    assert rel(ctx.get_landmarks(), lms_new) < 1e-9
+    assert abs(l_diff - ld) <= 1e-9 * abs(ld)
+    ctx.restore_pose()
+    assert rel(ctx.get_cameras(), p.cams) == 0 and rel(ctx.get_landmarks(), lms) == 0
+    ctx.close()
+
+
+def test_long_landmarks():
+    """Landmarks with more than 64 observations take the lm_long driver."""
+    from povar_amd import synth
+    rng = np.random.default_rng(5)
+    n_c = 150
+    ks = [2, 130, 3, 64, 65, 5, 100, 2, 7, 150]
+    lm_off = np.concatenate([[0], np.cumsum(ks)]).astype(np.int32)
+    cam_idx = np.concatenate([np.sort(rng.choice(n_c, k, replace=False)) for k in ks]).astype(np.int32)
+    base = synth.make_problem(n_c, 400, 1700, seed=1)
+    obs = rng.normal(scale=100.0, size=(cam_idx.shape[0], 2))
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    for e0_mode in (0, 1):
+        orc = O.Oracle(n_c, lm_off, cam_idx, obs)
+        ctx = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=e0_mode)
+        lms = orc.init_landmarks_pose(ALPHA, base.cams)
+        ctx.set_cameras(base.cams)
+        ctx.init_landmarks_pose(ALPHA)
+        assert rel(ctx.get_landmarks(), lms) < 1e-8
+        ctx.set_landmarks(lms)
+        ctx.linearize_pose(ALPHA)
+        st, diag2, jls, sigma, hll, b, binv = _oracle_stage(orc, base.cams, lms, LAM)
+        ref, _, _, _ = orc.solve_pose(st, hll, binv, b, 10)
+        inc, it, stt, rc = ctx.solve_pose(LAM, 0, 10)
+        assert rc == 0 and rel(inc, ref) < 1e-10
+        l_diff = ctx.apply_pose(0, ALPHA, ref)
+        inc_s = ref * sigma
+        ld, lms_new = orc.back_substitute_pose(ALPHA, st, base.cams + inc_s.reshape(-1, 12), lms, inc_s * (1.0 / sigma))
+        assert rel(ctx.get_landmarks(), lms_new) < 1e-9 and abs(l_diff - ld) <= 1e-9 * abs(ld)
+        ctx.close()
