@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Headline benchmark: power-series iterations/s of the reduced-camera-system inner solve.
+
+    python bench.py --gpus N --steps K --warmup W        (N=1: plain python; N>1: launched by
+    python -m torch.distributed.run --nproc-per-node N ... one rank per GPU)
+
+Workload (BASELINE.json): the shape of BAL venice-1778-993923 (1778 cameras, 993 923 landmarks,
+5 001 946 observations), seeded synthetic data (no BAL files offline), fp64, alpha = 0.01,
+lambda = 1e-4 (first LM iteration), --power-sc-iterations 20 --eta 0 (exactly 20 terms), the
+reference's own definition of the figure: solve_reduced_system_time / linear_solver_iterations
+(bal_bundle_adjustment.cpp:355-360).  One "step" = one solve_pOSE (linearization_power_varproj.hpp:
+191-237): B^-1(-b) followed by 20 x { E0 x, B^-1, accumulate }, everything resident in HBM.
+For N > 1 the landmarks are sharded over the ranks (strong scaling: the problem is fixed) and
+each term carries one RCCL all-reduce of the 12*n_cams vector.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     the E0 (SpMV) kernel pair: algorithmic bytes (SURVEY.md 8d stored-tile model,
+               484 n_obs + 76 n_lms + 288 n_cams per application) / HIP-event duration vs 8 TB/s
+  cpu_baseline the CPU restatement of the reference algorithm (oracle/, per-camera mutex scatter,
+               all host cores) on a bounded landmark sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from povar_amd import capi, synth  # noqa: E402  (loads no GPU state yet)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_e0(n_cams, n_lms, n_obs):
+    """SURVEY.md 8(d), stored-tile model, E0 application only (the 144*8*n_cams B^-1 read belongs
+    to the B^-1 kernel)."""
+    return 484 * n_obs + 76 * n_lms + 288 * n_cams
+
+
+def algorithmic_bytes_term(n_cams, n_lms, n_obs):
+    return 484 * n_obs + 76 * n_lms + 1440 * n_cams
+
+
+def cpu_baseline(prob, alpha, lam, m, target_obs=400_000):
+    """Oracle (reference-faithful layout + loop nest, per-camera mutex) on the first landmarks of
+    the workload covering ~target_obs observations, all cameras, all host cores."""
+    from oracle import povar_oracle as O
+
+    n_l = int(np.searchsorted(prob.lm_off, target_obs))
+    n_l = max(min(n_l, prob.n_lms), 1)
+    n_o = int(prob.lm_off[n_l])
+    orc = O.Oracle(prob.n_cams, prob.lm_off[: n_l + 1], prob.cam_idx[:n_o], prob.obs[:n_o])
+    lms = orc.init_landmarks_pose(alpha, prob.cams)
+    st, diag2, jls, sigma, ok = orc.stage1_pose(alpha, prob.cams, lms)
+    orc.scale_jp_cols_pose(st, sigma)
+    hll, b, binv = orc.prepare_hb_pose(st, lam)
+    cores = os.cpu_count() or 1
+    orc.solve_pose(st, hll, binv, b, 2, n_threads=cores)  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        orc.solve_pose(st, hll, binv, b, m, n_threads=cores)
+        reps += 1
+        if time.perf_counter() - t0 > 8.0 or reps >= 20:
+            break
+    dt = time.perf_counter() - t0
+    terms_per_s_sample = reps * m / dt
+    # scale to the full workload by observation count (the term cost is linear in n_obs)
+    value = terms_per_s_sample * n_o / prob.n_obs
+    return {
+        "value": value,
+        "unit": "terms/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n_l} landmarks / {n_o} observations of the workload (all {prob.n_cams} cameras), "
+                  f"{reps} solves x {m} terms in {dt:.1f} s = {terms_per_s_sample:.1f} terms/s on the sample, "
+                  f"scaled by n_obs ratio {n_o}/{prob.n_obs}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--problem", default="venice-1778", choices=sorted(synth.BAL_SHAPES))
+    ap.add_argument("--e0-mode", default="implicit", choices=["implicit", "tiles"])
+    ap.add_argument("--m", type=int, default=20, help="--power-sc-iterations")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the stored-tile comparison leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    # the HIP library first: it owns the GPU data path (HIP + RCCL); torch is only the rendezvous
+    capi.lib()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: E402
+        dist.init_process_group(backend="gloo")  # control plane only; data plane is RCCL in the library
+
+    alpha, lam, m = 0.01, 1e-4, args.m
+    prob = synth.make_bal_problem(args.problem)
+    n_c, n_l, n_o = prob.n_cams, prob.n_lms, prob.n_obs
+
+    lb, le = capi.shard_range(prob.lm_off, world, rank)
+    ob, oe = int(prob.lm_off[lb]), int(prob.lm_off[le])
+    mode = capi.E0_IMPLICIT if args.e0_mode == "implicit" else capi.E0_TILES
+    ctx = capi.Context(n_c, prob.lm_off[lb : le + 1] - prob.lm_off[lb], prob.cam_idx[ob:oe],
+                       prob.obs[ob:oe], device=local_rank, e0_mode=mode)
+    if world > 1:
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+
+    ctx.set_cameras(prob.cams)
+    ctx.init_landmarks_pose(alpha)
+    ok = ctx.linearize_pose(alpha)
+    assert ok, "numerical failure during linearization"
+    ctx.prepare_pose(lam, capi.POWER_VARPROJ)
+    ctx.synchronize()
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ctx.synchronize()
+
+    def run_steps(k):
+        for _ in range(k):
+            ctx.power_series_pose(m, 0.0, -1.0)
+
+    run_steps(args.warmup)
+    barrier()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    inc_main = ctx.get_increment()
+
+    terms = args.steps * m
+    value = terms / dt
+    e0_ms = prof.e0_ms / max(prof.e0_launches, 1)
+    binv_ms = prof.binv_ms / max(prof.binv_launches, 1)
+    comm_ms = prof.comm_ms / max(prof.comm_launches, 1)
+
+    # algorithmic bytes of ONE launch on THIS rank (its landmark shard)
+    loc_l, loc_o = le - lb, oe - ob
+    bytes_e0 = algorithmic_bytes_e0(n_c, loc_l, loc_o)
+    achieved = bytes_e0 / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as fh:
+                traffic = json.load(fh).get(f"{args.problem}:{args.e0_mode}:{world}")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "power-series iterations/s (solve_pOSE terms per second)",
+        "value": value,
+        "unit": "terms/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BAL {args.problem} shape ({n_c} cams / {n_l} landmarks / {n_o} obs), seeded synthetic, "
+                        f"solve_pOSE with power_sc_iterations={m}, eta=0, lambda={lam}, alpha={alpha}",
+            "e0_mode": args.e0_mode,
+            "parallelism": f"landmark shards x{world}, one RCCL all-reduce (12*n_cams f64) per term" if world > 1
+                           else "single GPU",
+        },
+        "spmv_effective_GBps": algorithmic_bytes_term(n_c, n_l, n_o) * value / 1e9,
+        "kernel_ms": {"e0": e0_ms, "binv_axpy": binv_ms, "allreduce": comm_ms,
+                      "e0_launches": int(prof.e0_launches)},
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "E0 x (lm_regular<OpE0> + cm_scatter)" if mode == capi.E0_IMPLICIT
+                      else "E0 x (lm_regular<OpE0Tiles>)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_e0,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # secondary leg: the other E0 variant on the same state (also a full-size parity property:
+        # both variants must give the same increment)
+        other = capi.E0_TILES if mode == capi.E0_IMPLICIT else capi.E0_IMPLICIT
+        ctx.set_e0_mode(other)
+        run_steps(1)
+        ctx.synchronize()
+        ctx.profile_enable(True)
+        t1 = time.perf_counter()
+        run_steps(max(args.steps // 4, 2))
+        ctx.synchronize()
+        dt2 = time.perf_counter() - t1
+        p2 = ctx.profile_get()
+        ctx.profile_enable(False)
+        inc_other = ctx.get_increment()
+        e0_2 = p2.e0_ms / max(p2.e0_launches, 1)
+        ach2 = bytes_e0 / (e0_2 * 1e-3) / 1e9
+        out["secondary"] = {
+            "e0_mode": "tiles" if other == capi.E0_TILES else "implicit",
+            "value": max(args.steps // 4, 2) * m / dt2,
+            "unit": "terms/s",
+            "e0_ms": e0_2,
+            "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach2 / HBM_PEAK_GBPS},
+            "rel_diff_vs_primary": float(np.linalg.norm(inc_other - inc_main) / np.linalg.norm(inc_main)),
+        }
+        ctx.set_e0_mode(mode)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(prob, alpha, lam, m)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
