@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libpovar_hip.so")
+LIB_PATH = os.environ.get("POVAR_LIB", os.path.join(_PKG, "libpovar_hip.so"))
 HEADER = os.path.join(os.path.dirname(_PKG), "include", "povar_hip.h")
 
 NORM = {"NONE": 0, "HUBER": 1, "CAUCHY": 2}

@@ -78,7 +78,7 @@ struct povar_ctx {
   // state
   DevBuf<double4> cams4, cams_lin4, cams_bak4, lms4, lms_lin4, lms_bak4, jl_scale4, rres, q4;
   DevBuf<double> hll_inv, sw, sigma, diag2, G, binv, b, tmp, accum, z, y, inc, item_part,
-      item_partG, norm_part, norms, part, scal, stage;
+      item_partG, norm_part, norms, part, scal, stage, cm_h;
 
   Dp d{};
   bool new_linearization_point = false;  // linearizor_power_varproj.cpp:75, 192, 240
@@ -250,15 +250,13 @@ int allreduce(povar_ctx* c, double* buf, size_t n) {
 // result is consumed by cam_binv_axpy (mode 1: scatter items, mode 2: dense y).
 int launch_e0(povar_ctx* c, int* binv_mode) {
   prof_mark(c, 0);
-  if (c->opt.e0_mode == POVAR_E0_TILES) {
-    launch_lm(c, OpE0Tiles{});
-    *binv_mode = 2;
-  } else {
-    launch_lm(c, OpE0{});
+  {
+    if (c->opt.e0_mode == POVAR_E0_TILES) launch_lm(c, OpE0Tiles{});
+    else launch_lm(c, OpE0{});
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 1);
     *binv_mode = 1;
     if (c->comm) {
-      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 16)), dim3(192), 0, c->stream, c->d,
+      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d,
                          c->d.y, 1);
       *binv_mode = 2;
     }
@@ -272,7 +270,7 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
 
 void launch_binv(povar_ctx* c, int mode, int want_norms) {
   prof_mark(c, 1);
-  hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 12), 0, c->stream, c->d, mode,
+  hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, c->d, mode,
                      want_norms);
 }
 
@@ -394,7 +392,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(sigma, 12 * nc); ALLOC(diag2, 12 * nc); ALLOC(G, 40 * nc); ALLOC(binv, 144 * nc);
   ALLOC(b, 12 * nc); ALLOC(tmp, 12 * nc); ALLOC(accum, 12 * nc); ALLOC(z, 12 * nc); ALLOC(y, 12 * nc);
   ALLOC(inc, 12 * nc);
-  ALLOC(item_part, 12 * ni); ALLOC(item_partG, 40 * ni);
+  ALLOC(item_part, 12 * ni); ALLOC(item_partG, 40 * ni); ALLOC(cm_h, 3 * (size_t)n_obs);
   ALLOC(norm_part, 2 * (size_t)c->n_cam_blocks); ALLOC(norms, 4); ALLOC(flags, 4);
   ALLOC(part, n_part); ALLOC(scal, 8);
   ALLOC(stage, std::max(3 * nl, 144 * nc));
@@ -417,7 +415,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.tiles = nullptr;
   d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
   d.tmp = c->tmp.p; d.accum = c->accum.p; d.z = c->z.p; d.y = c->y.p; d.inc = c->inc.p;
-  d.item_part = c->item_part.p; d.item_partG = c->item_partG.p;
+  d.item_part = c->item_part.p; d.item_partG = c->item_partG.p; d.cm_h = c->cm_h.p; d.n_obs = n_obs;
   d.flags = c->flags.p; d.norm_part = c->norm_part.p; d.norms = c->norms.p;
   d.sa = 0; d.sb = 1; d.eps = options->jacobi_scaling_eps; d.huber = options->huber_parameter;
   d.lambda_lm = 0; d.robust = options->robust_norm;
@@ -440,7 +438,7 @@ void povar_destroy(povar_ctx* c) {
   c->hll_inv.release(); c->sw.release(); c->sigma.release(); c->diag2.release(); c->G.release();
   c->binv.release(); c->b.release(); c->tmp.release(); c->accum.release(); c->z.release(); c->y.release();
   c->inc.release(); c->item_part.release(); c->item_partG.release(); c->norm_part.release();
-  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release();
+  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -543,14 +541,15 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   launch_lm(c, OpLinearize{});
+  hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d);
   hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   if (c->comm) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
-    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(64), 0, c->stream, c->d, (const double*)nullptr);
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)nullptr);
     if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
-    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(64), 0, c->stream, c->d, (const double*)c->d.G);
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)c->d.G);
   } else {
-    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(64), 0, c->stream, c->d, (const double*)nullptr);
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)nullptr);
   }
   HIP_TRY(hipGetLastError());
   int f[4];
@@ -571,7 +570,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   c->d.lambda_lm = solver_type == POVAR_POWER_SCHUR_COMPLEMENT ? lambda : 0.0;  // cpp:197-200
   launch_lm(c, OpPrepare{});
   hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0);
-  hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 16)), dim3(192), 0, c->stream, c->d, c->d.b, 1);
+  hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b, 1);
   if (int rc = allreduce(c, c->d.b, 12 * (size_t)c->n_cams)) return rc;
   hipLaunchKernelGGL(cam_build_binv, dim3(grid_for(c->n_cams, K8_THREADS)), dim3(K8_THREADS), 0, c->stream,
                      c->d, lambda);
@@ -664,7 +663,7 @@ int povar_right_mul_e0_pose(povar_ctx* c, const double* x, double* y) {
   int mode = 1;
   if (int rc = launch_e0(c, &mode)) return rc;
   if (mode == 1)
-    hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 16)), dim3(192), 0, c->stream, c->d, c->d.y, 1);
+    hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.y, 1);
   HIP_TRY(hipMemcpyAsync(y, c->y.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemsetAsync(c->y.p, 0, sizeof(double) * n, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -57,6 +57,8 @@ struct Dp {
   const int* cm_slot;
   const int* cm_lm;
   const double2* cm_uv;
+  double* cm_h;        // [3][n_obs] landmark x,y,z in camera-major order (per linearisation)
+  int64_t n_obs;
   const int* item_off;
   const int* item_cam;
   const int* cam_item_off;
@@ -546,6 +548,9 @@ struct OpE0 {
     double sw;
   };
   __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local& L, double* red) const {
+#if defined(POVAR_EXP) && (POVAR_EXP & 1)
+    cam = 0;
+#endif
     const Cam P = load_cam(d.cams_lin4, cam);
     const double4 h = d.lms_lin4[lm];
     const double4* zc = reinterpret_cast<const double4*>(d.z) + 3 * cam;
@@ -579,8 +584,11 @@ struct OpE0 {
 // K10 (stored tiles): right_mul_e0_pOSE on the tiles kept in HBM, blocked layout
 // tiles[bin][pair][lane] (double2): pairs 0-23 Jp (row-major 4x12), 24-29 Jl (4x3), 30-31 r.
 // Every byte of a tile is read once per term, 16 B per lane, 1 KiB contiguous per wave
-// instruction; the scatter is a hardware fp64 atomic add per output (the reference's
-// mutex-guarded +=, linearization_power_varproj.hpp:393-397).
+// instruction.  The forward products (Jp x, Jl^T t, Jl v) use the stored values; the scatter
+// Jp^T s (the reference's mutex-guarded +=, linearization_power_varproj.hpp:393-397) goes through
+// the same three scalars per observation + camera-major pass as the implicit variant: a first
+// version with one hardware fp64 atomic per output ran 45 ms per term on venice-1778 (hub cameras
+// with 4e5 observations serialise), profiles/r01_a_first_kernel_stats.csv.
 struct OpE0Tiles {
   static constexpr int NRED = 3, NSC = 0;
   static constexpr bool CHECK_DONE = true;
@@ -616,7 +624,7 @@ struct OpE0Tiles {
       red[2] += L.jl[3 * r + 2] * tr;
     }
   }
-  __device__ void phase2(const Dp& d, int, int cam, int lm, double2, Local& L, const double* tot,
+  __device__ void phase2(const Dp& d, int slot, int, int lm, double2 uv, Local& L, const double* tot,
                          double*) const {
     const double* Hi = d.hll_inv + 9 * (size_t)lm;
     const double v0 = Hi[0] * tot[0] + Hi[1] * tot[1] + Hi[2] * tot[2];
@@ -625,12 +633,8 @@ struct OpE0Tiles {
     double s[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[r] = L.jl[3 * r] * v0 + L.jl[3 * r + 1] * v1 + L.jl[3 * r + 2] * v2;
-    double* y = d.y + 12 * (size_t)cam;
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const double o = L.jp[j] * s[0] + L.jp[12 + j] * s[1] + L.jp[24 + j] * s[2] + L.jp[36 + j] * s[3];
-      unsafeAtomicAdd(y + j, o);
-    }
+    const double sw = d.robust ? d.sw[slot] : 1.0;
+    d.q4[slot] = pose_q(d, uv.x, uv.y, sw, s);
   }
   __device__ void finish_lm(const Dp&, int, const double*) const {}
 };
@@ -829,8 +833,12 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0;
   for (int p = b + lane; p < e; p += WAVE) {
+#if defined(POVAR_EXP) && (POVAR_EXP & 2)
+    const double4 q = d.q4[p];
+#else
     const double4 q = d.q4[d.cm_slot[p]];
-    const double4 h = d.lms_lin4[d.cm_lm[p]];
+#endif
+    const double4 h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], 1.0);
     acc[0] += h.x * q.x; acc[1] += h.y * q.x; acc[2] += h.z * q.x; acc[3] += h.w * q.x;
     acc[4] += h.x * q.y; acc[5] += h.y * q.y; acc[6] += h.z * q.y; acc[7] += h.w * q.y;
     acc[8] += h.x * q.z; acc[9] += h.y * q.z; acc[10] += h.z * q.z; acc[11] += h.w * q.z;
@@ -840,6 +848,17 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) d.item_part[12 * (size_t)item + k] = acc[k];
   }
+}
+
+// landmark coordinates at the linearisation point, copied into camera-major order once per
+// linearisation so the per-term camera-major pass streams them instead of gathering
+__global__ __launch_bounds__(256) void cm_build_h(Dp d) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= d.n_obs) return;
+  const double4 h = d.lms_lin4[d.cm_lm[p]];
+  d.cm_h[p] = h.x;
+  d.cm_h[d.n_obs + p] = h.y;
+  d.cm_h[2 * d.n_obs + p] = h.z;
 }
 
 // Camera-block Gram sums of the unscaled weighted Jp: Jp^T Jp = w * (C (x) h h^T) with
@@ -856,7 +875,7 @@ __global__ __launch_bounds__(256) void cm_gram(Dp d) {
   for (int k = 0; k < 40; ++k) acc[k] = 0;
   for (int p = b + lane; p < e; p += WAVE) {
     const double sw = d.q4[d.cm_slot[p]].w;
-    const double4 h = d.lms_lin4[d.cm_lm[p]];
+    const double4 h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], 1.0);
     const double2 uv = d.cm_uv[p];
     const double w = sw * sw;
     const double m[4] = {w, w * uv.x, w * uv.y, w * (uv.x * uv.x + uv.y * uv.y)};
@@ -884,21 +903,27 @@ __device__ inline int sym10(int i, int j) {  // index of (i,j) in the packed upp
 }
 
 // per camera: G = sum of item Gram parts; diag2 and pose scaling (linearizor_power_varproj.cpp:62-70)
-__global__ __launch_bounds__(64) void cam_finish_linearize(Dp d, const double* G_in) {
+__global__ __launch_bounds__(256) void cam_finish_linearize(Dp d, const double* G_in) {
   const int c = blockIdx.x;
+  __shared__ double part[4][40];
   __shared__ double g[40];
-  if (threadIdx.x < 40) {
-    double s = 0;
-    if (G_in) {
-      s = G_in[40 * (size_t)c + threadIdx.x];
-    } else {
-      for (int it = d.cam_item_off[c]; it < d.cam_item_off[c + 1]; ++it)
-        s += d.item_partG[40 * (size_t)it + threadIdx.x];
+  if (G_in) {
+    if (threadIdx.x < 40) g[threadIdx.x] = G_in[40 * (size_t)c + threadIdx.x];
+  } else {
+    // thread (q, e): quarter q of the camera's items, element e; fixed order
+    const int e = threadIdx.x % 64, q = threadIdx.x / 64;
+    if (e < 40) {
+      double s = 0;
+      for (int it = d.cam_item_off[c] + q; it < d.cam_item_off[c + 1]; it += 4)
+        s += d.item_partG[40 * (size_t)it + e];
+      part[q][e] = s;
     }
-    g[threadIdx.x] = s;
-    d.G[40 * (size_t)c + threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 40)
+      g[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
   }
   __syncthreads();
+  if (threadIdx.x < 40) d.G[40 * (size_t)c + threadIdx.x] = g[threadIdx.x];
   if (threadIdx.x < 12) {
     const int blk = threadIdx.x >> 2, j = threadIdx.x & 3;
     const int dj = sym10(j, j);
@@ -969,58 +994,79 @@ __global__ __launch_bounds__(K8_THREADS) void cam_build_binv(Dp d, double lambda
 #undef X_
 }
 
-// b_c = sigma * sum_items (scatter parts)   (landmark_block.hpp:529-534)
-__global__ __launch_bounds__(192) void cam_sum_items(Dp d, double* out, int apply_sigma) {
-  const int c = blockIdx.x * 16 + threadIdx.x / 12, r = threadIdx.x % 12;
+// b_c = sigma * sum_items (scatter parts)   (landmark_block.hpp:529-534); one wavefront per camera
+__global__ __launch_bounds__(256) void cam_sum_items(Dp d, double* out, int apply_sigma) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.n_cams) return;
-  double s = 0;
-  for (int it = d.cam_item_off[c]; it < d.cam_item_off[c + 1]; ++it) s += d.item_part[12 * (size_t)it + r];
-  out[12 * (size_t)c + r] = apply_sigma ? s * d.sigma[12 * (size_t)c + r] : s;
+  double y[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) y[j] = 0;
+  for (int it = d.cam_item_off[c] + lane; it < d.cam_item_off[c + 1]; it += WAVE) {
+    const double* ip = d.item_part + 12 * (size_t)it;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) y[j] += ip[j];
+  }
+  wave_sum<12>(y);
+  if (lane < 12) {
+    double v = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) v = (lane == j) ? y[j] : v;
+    out[12 * (size_t)c + lane] = apply_sigma ? v * d.sigma[12 * (size_t)c + lane] : v;
+  }
 }
 
 // K9 + K11: tmp = B^-1 y, accum (+)= tmp, z = sigma * tmp, optional squared-norm partials
 // (right_mul_b_inv_pOSE + the loop body of solve_pOSE, linearization_power_varproj.hpp:196-207,
 // 322-340).  mode 0: y = -b (series start); 1: y = sigma * sum of scatter items (implicit E0);
 // 2: y = dense buffer d.y (stored-tile E0, or the all-reduced vector), cleared after reading.
-constexpr int K9_CAMS = 16;
-__global__ __launch_bounds__(K9_CAMS * 12) void cam_binv_axpy(Dp d, int mode, int want_norms) {
+constexpr int K9_CAMS = 4;  // one wavefront per camera, 4 cameras per workgroup
+__global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, int want_norms) {
   if (mode != 0 && d.flags[1]) return;
-  __shared__ double ys[K9_CAMS * 12];
-  __shared__ double sh[3 * 2];
-  const int lc = threadIdx.x / 12, r = threadIdx.x % 12;
-  const int c = blockIdx.x * K9_CAMS + lc;
+  __shared__ double sh[K9_CAMS * 2];
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * K9_CAMS + (threadIdx.x >> 6);
   const bool in = c < d.n_cams;
-  const size_t idx = 12 * (size_t)c + r;
-  double yv = 0;
+  double y[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) y[j] = 0;
   if (in) {
+    const size_t base = 12 * (size_t)c;
     if (mode == 0) {
-      yv = -d.b[idx];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) y[j] = -d.b[base + j];
     } else if (mode == 1) {
-      double s = 0;
-      for (int it = d.cam_item_off[c]; it < d.cam_item_off[c + 1]; ++it) s += d.item_part[12 * (size_t)it + r];
-      yv = s * d.sigma[idx];
+      // fixed-order sum of the camera's scatter items: lanes stride over items, then a butterfly
+      for (int it = d.cam_item_off[c] + lane; it < d.cam_item_off[c + 1]; it += WAVE) {
+        const double* ip = d.item_part + 12 * (size_t)it;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) y[j] += ip[j];
+      }
+      wave_sum<12>(y);
+#pragma unroll
+      for (int j = 0; j < 12; ++j) y[j] *= d.sigma[base + j];
     } else {
-      yv = d.y[idx];
-      d.y[idx] = 0;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) y[j] = d.y[base + j];
     }
   }
-  ys[threadIdx.x] = yv;
-  __syncthreads();
   double nrm[2] = {0, 0};
-  if (in) {
-    const double* Bi = d.binv + 144 * (size_t)c + 12 * r;
+  if (in && lane < 12) {
+    const size_t idx = 12 * (size_t)c + lane;
+    const double* Bi = d.binv + 144 * (size_t)c + 12 * lane;
     double s = 0;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) s += Bi[j] * ys[lc * 12 + j];
+    for (int j = 0; j < 12; ++j) s += Bi[j] * y[j];
     const double acc = mode == 0 ? s : d.accum[idx] + s;
     d.tmp[idx] = s;
     d.accum[idx] = acc;
     d.z[idx] = s * d.sigma[idx];
+    if (mode == 2) d.y[idx] = 0;
     nrm[0] = s * s;
     nrm[1] = acc * acc;
   }
   if (want_norms) {
-    block_sum<2, K9_CAMS * 12>(nrm, sh);
+    block_sum<2, K9_CAMS * 64>(nrm, sh);
     if (threadIdx.x == 0) {
       d.norm_part[2 * (size_t)blockIdx.x] = nrm[0];
       d.norm_part[2 * (size_t)blockIdx.x + 1] = nrm[1];
