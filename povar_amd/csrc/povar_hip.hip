@@ -64,6 +64,7 @@ struct povar_ctx {
   int64_t n_obs = 0;
   int n_bins = 0, n_slots = 0, n_items = 0, n_long = 0;
   int n_reg_blocks = 0, n_cam_blocks = 0;
+  int n_hot = 0, e0c_grid = 0, e0c_bins_per_wg = 0;
   povar_options opt{};
   hipStream_t stream = nullptr;
   size_t bytes = 0;
@@ -73,12 +74,12 @@ struct povar_ctx {
 
   // static
   DevBuf<double2> uv, cm_uv, tiles;
-  DevBuf<int> cam, lm, meta, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
+  DevBuf<int> cam, lm, meta, hot_cams, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
       cam_item_off, flags;
   // state
   DevBuf<double4> cams4, cams_lin4, cams_bak4, lms4, lms_lin4, lms_bak4, jl_scale4, rres, q4;
   DevBuf<double> hll_inv, sw, sigma, diag2, G, binv, b, tmp, accum, z, y, inc, item_part,
-      item_partG, norm_part, norms, part, scal, stage, cm_h;
+      item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec;
 
   Dp d{};
   bool new_linearization_point = false;  // linearizor_power_varproj.cpp:75, 192, 240
@@ -104,7 +105,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 struct Layout {
   std::vector<double2> uv, cm_uv;
-  std::vector<int> cam, lm, meta, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off,
+  std::vector<int> cam, lm, meta, hot_cams, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off,
       item_cam, cam_item_off, slot_of_obs;
   int n_bins = 0;
 };
@@ -186,6 +187,19 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
         L.cm_uv[p] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
       }
   }
+  // LDS camera cache of e0_lm_cached: the HOT_MAX cameras with most observations (ties: lower index)
+  {
+    std::vector<int> order(n_cams);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return cnt[a + 1] - cnt[a] > cnt[b + 1] - cnt[b]; });
+    const int n_hot = std::min(n_cams, HOT_MAX);
+    std::vector<int> rank(n_cams, 0);
+    L.hot_cams.assign(order.begin(), order.begin() + n_hot);
+    for (int r = 0; r < n_hot; ++r) rank[order[r]] = r + 1;
+    for (size_t s = 0; s < n_slots; ++s)
+      if (L.meta[s] & META_REAL) L.meta[s] |= rank[L.cam[s]] << META_HOT_SHIFT;
+  }
   L.cam_item_off.assign(n_cams + 1, 0);
   L.item_off.clear();
   L.item_cam.clear();
@@ -252,7 +266,12 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
   prof_mark(c, 0);
   {
     if (c->opt.e0_mode == POVAR_E0_TILES) launch_lm(c, OpE0Tiles{});
-    else launch_lm(c, OpE0{});
+    else {
+      hipLaunchKernelGGL(e0_lm_cached, dim3(c->e0c_grid), dim3(E0C_BLOCK),
+                         (size_t)c->n_hot * HOT_REC * sizeof(double2), c->stream, c->d, c->e0c_bins_per_wg);
+      if (c->n_long > 0)
+        hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0{}, c->part.p);
+    }
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 1);
     *binv_mode = 1;
     if (c->comm) {
@@ -364,10 +383,21 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   c->n_reg_blocks = grid_for(c->n_slots, LM_BLOCK);
   c->n_cam_blocks = grid_for(n_cams, K9_CAMS);
   c->slot_of_obs = L.slot_of_obs;
+  {
+    // one 1024-thread workgroup per CU for the LDS-cached E0 kernel
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, options->device));
+    const int cus = std::max(prop.multiProcessorCount, 1);
+    c->e0c_bins_per_wg = std::max((c->n_bins + cus - 1) / cus, 1);
+    c->e0c_grid = (c->n_bins + c->e0c_bins_per_wg - 1) / c->e0c_bins_per_wg;
+    c->n_hot = (int)L.hot_cams.size();
+    HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HOT_MAX * HOT_REC * (int)sizeof(double2)));
+  }
 
   int rc = 0;
   if ((rc = upload(c->uv, L.uv, c)) || (rc = upload(c->cam, L.cam, c)) || (rc = upload(c->lm, L.lm, c)) ||
-      (rc = upload(c->meta, L.meta, c)) || (rc = upload(c->long_lm, L.long_lm, c)) ||
+      (rc = upload(c->meta, L.meta, c)) || (rc = upload(c->hot_cams, L.hot_cams, c)) || (rc = upload(c->long_lm, L.long_lm, c)) ||
       (rc = upload(c->long_first, L.long_first, c)) || (rc = upload(c->long_cnt, L.long_cnt, c)) ||
       (rc = upload(c->cm_slot, L.cm_slot, c)) || (rc = upload(c->cm_lm, L.cm_lm, c)) ||
       (rc = upload(c->cm_uv, L.cm_uv, c)) || (rc = upload(c->item_off, L.item_off, c)) ||
@@ -387,7 +417,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   } while (0)
   ALLOC(cams4, 3 * nc); ALLOC(cams_lin4, 3 * nc); ALLOC(cams_bak4, 3 * nc);
   ALLOC(lms4, nl); ALLOC(lms_lin4, nl); ALLOC(lms_bak4, nl); ALLOC(jl_scale4, nl);
-  ALLOC(hll_inv, 9 * nl);
+  ALLOC(hll_inv, 9 * nl); ALLOC(lmrec, 12 * nl);
   ALLOC(sw, ns); ALLOC(rres, ns); ALLOC(q4, ns);
   ALLOC(sigma, 12 * nc); ALLOC(diag2, 12 * nc); ALLOC(G, 40 * nc); ALLOC(binv, 144 * nc);
   ALLOC(b, 12 * nc); ALLOC(tmp, 12 * nc); ALLOC(accum, 12 * nc); ALLOC(z, 12 * nc); ALLOC(y, 12 * nc);
@@ -411,7 +441,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.cm_slot = c->cm_slot.p; d.cm_lm = c->cm_lm.p; d.cm_uv = c->cm_uv.p;
   d.item_off = c->item_off.p; d.item_cam = c->item_cam.p; d.cam_item_off = c->cam_item_off.p;
   d.cams4 = c->cams4.p; d.cams_lin4 = c->cams_lin4.p; d.lms4 = c->lms4.p; d.lms_lin4 = c->lms_lin4.p;
-  d.jl_scale4 = c->jl_scale4.p; d.hll_inv = c->hll_inv.p;
+  d.jl_scale4 = c->jl_scale4.p; d.hll_inv = c->hll_inv.p; d.lmrec = c->lmrec.p;
+  d.hot_cams = c->hot_cams.p; d.n_hot = (int)L.hot_cams.size();
   d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.tiles = nullptr;
   d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
   d.tmp = c->tmp.p; d.accum = c->accum.p; d.z = c->z.p; d.y = c->y.p; d.inc = c->inc.p;
@@ -438,7 +469,7 @@ void povar_destroy(povar_ctx* c) {
   c->hll_inv.release(); c->sw.release(); c->sigma.release(); c->diag2.release(); c->G.release();
   c->binv.release(); c->b.release(); c->tmp.release(); c->accum.release(); c->z.release(); c->y.release();
   c->inc.release(); c->item_part.release(); c->item_partG.release(); c->norm_part.release();
-  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release();
+  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

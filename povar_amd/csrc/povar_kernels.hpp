@@ -39,9 +39,13 @@ constexpr int CM_ITEM_MAX = 512; // observations of one camera per CM work item
 constexpr int TILE_PAIRS = 32;  // double2 pairs per observation in the blocked tile layout
 
 // meta[slot]: bits 0-7 seg_first lane, 8-15 seg_last lane, 16 = real observation, 17 = slot of
-// a long (>64 obs) landmark
+// a long (>64 obs) landmark, bits 18-31 = 1 + rank of the camera in the LDS camera cache (0: not cached)
 constexpr int META_REAL = 1 << 16;
 constexpr int META_LONG = 1 << 17;
+constexpr int META_HOT_SHIFT = 18;
+constexpr int HOT_MAX = 912;        // cameras cached per workgroup: 912 * 176 B = 156.75 KiB of the 160 KiB LDS
+constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :3] (4.5) + pad
+constexpr int E0C_BLOCK = 1024;     // one workgroup per CU
 
 struct Dp {
   int n_cams, n_lms, n_bins, n_items, n_long, n_reg_blocks;
@@ -50,6 +54,8 @@ struct Dp {
   const int* cam;
   const int* lm;
   const int* meta;
+  const int* hot_cams;  // cameras cached in LDS by e0_lm_cached, most observed first
+  int n_hot;
   const int* long_lm;
   const int* long_first;
   const int* long_cnt;
@@ -70,10 +76,11 @@ struct Dp {
   // per landmark
   double4* jl_scale4;  // (s0, s1, s2, -)
   double* hll_inv;     // [n_lms][9]
+  double* lmrec;       // [n_lms][12] packed (x,y,z, s0,s1,s2, Hi00,Hi01,Hi02,Hi11,Hi12,Hi22)
   // per slot, dynamic
   double* sw;          // sqrt(robust weight)
   double4* rres;       // weighted residual at the linearisation point
-  double4* q4;         // (q0, q1, q2, sw): transpose-scatter scalars
+  double4* q4;         // (q0, q1, q2, sw): transpose-scatter scalars per slot
   double2* tiles;      // stored-tile mode: [n_bins][TILE_PAIRS][64] double2
   // per camera
   double* sigma;       // pose_jacobian_scaling [n_cams][12]
@@ -534,52 +541,174 @@ struct OpPrepare {
     hinv(d, tot, Hi);
 #pragma unroll
     for (int k = 0; k < 9; ++k) d.hll_inv[9 * (size_t)lm + k] = Hi[k];
+    // packed per-landmark record for the per-term kernels (Hll^-1 is exactly symmetric)
+    const double4 h = d.lms_lin4[lm], s = d.jl_scale4[lm];
+    double4* rec = reinterpret_cast<double4*>(d.lmrec) + 3 * (size_t)lm;
+    rec[0] = make_double4(h.x, h.y, h.z, s.x);
+    rec[1] = make_double4(s.y, s.z, Hi[0], Hi[1]);
+    rec[2] = make_double4(Hi[2], Hi[4], Hi[5], Hi[8]);
   }
 };
 
 // K10 (implicit, landmark part): right_mul_e0_pOSE (linearization_power_varproj.hpp:364-406).
 // t = Jp x, u = Jl^T t (segmented sum over the landmark), v = Hll^-1 u, s = Jl v, then the three
 // scatter scalars of Jp^T s.  Input z = sigma * x.
+struct E0Core {
+  double jl[12];
+  double sw;
+  // P3 = P[:, :3] row-major (9), zz = z_c (12), rec = packed landmark record
+  __device__ inline void forward(const Dp& d, const double* P3, const double* zz, const double4& rec0,
+                                 const double4& rec1, double2 uv, double sw_, double* red) {
+    sw = sw_;
+    const double cb = d.sb * sw, ca = d.sa * sw;
+    const double s0 = rec0.w, s1 = rec1.x, s2 = rec1.y;
+    jl[0] = cb * (P3[0] - P3[6] * uv.x) * s0;
+    jl[1] = cb * (P3[1] - P3[7] * uv.x) * s1;
+    jl[2] = cb * (P3[2] - P3[8] * uv.x) * s2;
+    jl[3] = cb * (P3[3] - P3[6] * uv.y) * s0;
+    jl[4] = cb * (P3[4] - P3[7] * uv.y) * s1;
+    jl[5] = cb * (P3[5] - P3[8] * uv.y) * s2;
+    jl[6] = ca * P3[0] * s0;
+    jl[7] = ca * P3[1] * s1;
+    jl[8] = ca * P3[2] * s2;
+    jl[9] = ca * P3[3] * s0;
+    jl[10] = ca * P3[4] * s1;
+    jl[11] = ca * P3[5] * s2;
+    const double hx = rec0.x, hy = rec0.y, hz = rec0.z;
+    const double d0 = hx * zz[0] + hy * zz[1] + hz * zz[2] + zz[3];
+    const double d1 = hx * zz[4] + hy * zz[5] + hz * zz[6] + zz[7];
+    const double d2 = hx * zz[8] + hy * zz[9] + hz * zz[10] + zz[11];
+    const double t[4] = {cb * (d0 - uv.x * d2), cb * (d1 - uv.y * d2), ca * d0, ca * d1};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[0] += jl[3 * r] * t[r];
+      red[1] += jl[3 * r + 1] * t[r];
+      red[2] += jl[3 * r + 2] * t[r];
+    }
+  }
+  __device__ inline double4 backward(const Dp& d, const double4& rec1, const double4& rec2, double2 uv,
+                                     const double* tot) const {
+    const double h00 = rec1.z, h01 = rec1.w, h02 = rec2.x, h11 = rec2.y, h12 = rec2.z, h22 = rec2.w;
+    const double v0 = h00 * tot[0] + h01 * tot[1] + h02 * tot[2];
+    const double v1 = h01 * tot[0] + h11 * tot[1] + h12 * tot[2];
+    const double v2 = h02 * tot[0] + h12 * tot[1] + h22 * tot[2];
+    double s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = jl[3 * r] * v0 + jl[3 * r + 1] * v1 + jl[3 * r + 2] * v2;
+    return pose_q(d, uv.x, uv.y, sw, s);
+  }
+};
+
+__device__ inline void load_cam_global(const Dp& d, int cam, double* P3, double* zz) {
+  const Cam P = load_cam(d.cams_lin4, cam);
+  P3[0] = P.r0.x; P3[1] = P.r0.y; P3[2] = P.r0.z;
+  P3[3] = P.r1.x; P3[4] = P.r1.y; P3[5] = P.r1.z;
+  P3[6] = P.r2.x; P3[7] = P.r2.y; P3[8] = P.r2.z;
+  const double4* zc = reinterpret_cast<const double4*>(d.z) + 3 * cam;
+  const double4 z0 = zc[0], z1 = zc[1], z2 = zc[2];
+  zz[0] = z0.x; zz[1] = z0.y; zz[2] = z0.z; zz[3] = z0.w;
+  zz[4] = z1.x; zz[5] = z1.y; zz[6] = z1.z; zz[7] = z1.w;
+  zz[8] = z2.x; zz[9] = z2.y; zz[10] = z2.z; zz[11] = z2.w;
+}
+
+// Op form (used by the lm_long driver for landmarks with more than 64 observations)
 struct OpE0 {
   static constexpr int NRED = 3, NSC = 0;
   static constexpr bool CHECK_DONE = true;
   struct Local {
-    double jl[12];
-    double sw;
+    E0Core core;
+    double4 rec1, rec2;
   };
   __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local& L, double* red) const {
-#if defined(POVAR_EXP) && (POVAR_EXP & 1)
-    cam = 0;
-#endif
-    const Cam P = load_cam(d.cams_lin4, cam);
-    const double4 h = d.lms_lin4[lm];
-    const double4* zc = reinterpret_cast<const double4*>(d.z) + 3 * cam;
-    const double4 z0 = zc[0], z1 = zc[1], z2 = zc[2];
-    const double4 zz[3] = {z0, z1, z2};
-    L.sw = d.robust ? d.sw[slot] : 1.0;
-    pose_jl(d, P, uv.x, uv.y, L.sw, d.jl_scale4[lm], L.jl);
-    double t[4];
-    pose_jp_x(d, h, uv.x, uv.y, L.sw, zz, t);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      red[0] += L.jl[3 * r] * t[r];
-      red[1] += L.jl[3 * r + 1] * t[r];
-      red[2] += L.jl[3 * r + 2] * t[r];
-    }
+    double P3[9], zz[12];
+    load_cam_global(d, cam, P3, zz);
+    const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 3 * (size_t)lm;
+    const double4 rec0 = rec[0];
+    L.rec1 = rec[1];
+    L.rec2 = rec[2];
+    L.core.forward(d, P3, zz, rec0, L.rec1, uv, d.robust ? d.sw[slot] : 1.0, red);
   }
-  __device__ void phase2(const Dp& d, int slot, int, int lm, double2 uv, Local& L, const double* tot,
+  __device__ void phase2(const Dp& d, int slot, int, int, double2 uv, Local& L, const double* tot,
                          double*) const {
-    const double* Hi = d.hll_inv + 9 * (size_t)lm;
-    const double v0 = Hi[0] * tot[0] + Hi[1] * tot[1] + Hi[2] * tot[2];
-    const double v1 = Hi[3] * tot[0] + Hi[4] * tot[1] + Hi[5] * tot[2];
-    const double v2 = Hi[6] * tot[0] + Hi[7] * tot[1] + Hi[8] * tot[2];
-    double s[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[r] = L.jl[3 * r] * v0 + L.jl[3 * r + 1] * v1 + L.jl[3 * r + 2] * v2;
-    d.q4[slot] = pose_q(d, uv.x, uv.y, L.sw, s);
+    d.q4[slot] = L.core.backward(d, L.rec1, L.rec2, uv, tot);
   }
   __device__ void finish_lm(const Dp&, int, const double*) const {}
 };
+
+// The per-term landmark-major E0 kernel.  One 1024-thread workgroup per CU walks a contiguous
+// range of wave bins.  The divergent per-observation camera gather (z_c and P_c[:, :3], 168 B,
+// 12 x 16-B loads that hit 64 different lines per wave instruction) was the bottleneck of the
+// plain version (162 us of venice-1778's term, 70 us with the gather made uniform,
+// profiles/r01_b_*): the records of the HOT_MAX most observed cameras are therefore staged in LDS
+// once per launch (<= 157 KiB, read back from L2) and only observations of colder cameras gather
+// from global memory.
+__global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg) {
+  if (d.flags[1]) return;
+  extern __shared__ double2 hot[];  // [n_hot][HOT_REC]
+  {
+    const double2* z2 = reinterpret_cast<const double2*>(d.z);
+    const double* cl = reinterpret_cast<const double*>(d.cams_lin4);
+    for (int i = threadIdx.x; i < d.n_hot * HOT_REC; i += E0C_BLOCK) {
+      const int r = i / HOT_REC, j = i - r * HOT_REC;
+      const int c = d.hot_cams[r];
+      double2 v;
+      if (j < 6) {
+        v = z2[6 * (size_t)c + j];
+      } else {
+        const int e = 2 * (j - 6);  // flat index into P3 (row-major 3x3)
+        v.x = cl[12 * (size_t)c + (e / 3) * 4 + (e % 3)];
+        v.y = e + 1 < 9 ? cl[12 * (size_t)c + ((e + 1) / 3) * 4 + ((e + 1) % 3)] : 0.0;
+      }
+      hot[i] = v;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bin0 = blockIdx.x * bins_per_wg;
+  const int bin1 = min(bin0 + bins_per_wg, d.n_bins);
+  for (int bin = bin0 + wave; bin < bin1; bin += E0C_BLOCK / WAVE) {
+    const int slot = bin * WAVE + lane;
+    const int meta = d.meta[slot];
+    const bool valid = (meta & META_REAL) && !(meta & META_LONG);
+    const int seg_first = meta & 255, seg_last = (meta >> 8) & 255;
+    double red[3] = {0, 0, 0};
+    E0Core core;
+    double4 rec1 = make_double4(0, 0, 0, 0), rec2 = rec1;
+    double2 uv = make_double2(0, 0);
+    if (valid) {
+      const int cam = d.cam[slot];
+      const int lm = d.lm[slot];
+      uv = d.uv[slot];
+      const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 3 * (size_t)lm;
+      const double4 rec0 = rec[0];
+      rec1 = rec[1];
+      rec2 = rec[2];
+      double P3[9], zz[12];
+      const int hr = (meta >> META_HOT_SHIFT);
+      if (hr > 0) {
+        const double2* h = hot + (hr - 1) * HOT_REC;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double2 v = h[j];
+          zz[2 * j] = v.x;
+          zz[2 * j + 1] = v.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double2 v = h[6 + j];
+          P3[2 * j] = v.x;
+          P3[2 * j + 1] = v.y;
+        }
+        P3[8] = h[10].x;
+      } else {
+        load_cam_global(d, cam, P3, zz);
+      }
+      core.forward(d, P3, zz, rec0, rec1, uv, d.robust ? d.sw[slot] : 1.0, red);
+    }
+    seg_reduce<3>(red, lane, seg_first, seg_last);
+    if (valid) d.q4[slot] = core.backward(d, rec1, rec2, uv, red);
+  }
+}
 
 // K10 (stored tiles): right_mul_e0_pOSE on the tiles kept in HBM, blocked layout
 // tiles[bin][pair][lane] (double2): pairs 0-23 Jp (row-major 4x12), 24-29 Jl (4x3), 30-31 r.
@@ -833,11 +962,7 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0;
   for (int p = b + lane; p < e; p += WAVE) {
-#if defined(POVAR_EXP) && (POVAR_EXP & 2)
-    const double4 q = d.q4[p];
-#else
     const double4 q = d.q4[d.cm_slot[p]];
-#endif
     const double4 h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], 1.0);
     acc[0] += h.x * q.x; acc[1] += h.y * q.x; acc[2] += h.z * q.x; acc[3] += h.w * q.x;
     acc[4] += h.x * q.y; acc[5] += h.y * q.y; acc[6] += h.z * q.y; acc[7] += h.w * q.y;
