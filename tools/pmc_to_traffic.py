@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
+MI355X_MICROARCH.md's HBM section prescribes) into profiles/traffic.json for bench.py.
+
+HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (counter unit KB; on gfx950 FETCH_SIZE
+reports half of a wide coalesced read stream, so it is doubled; WRITE_SIZE is exact for 16-B
+streaming stores).  For the 32-B gathers of cm_scatter the doubling is an upper bound.
+
+usage: pmc_to_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <key> [out.json]
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) * 1024.0 for k, v in agg.items()}
+
+
+def main():
+    fetch, write, key = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
+    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic.json")
+    e0 = [k for k in fetch if "e0_lm_cached" in k or "OpE0Tiles" in k or "cm_scatter" in k]
+    table = {k: {"fetch_raw_bytes": fetch[k], "write_bytes": write.get(k, 0.0),
+                 "hbm_bytes": 2 * fetch[k] + write.get(k, 0.0)} for k in sorted(fetch)}
+    data = {}
+    if os.path.exists(out):
+        data = json.load(open(out))
+    problem, mode, world = key.split(":")
+    lm = [k for k in e0 if ("e0_lm_cached" in k if mode == "implicit" else "OpE0Tiles" in k)]
+    cm = [k for k in e0 if "cm_scatter" in k]
+    data[key] = sum(table[k]["hbm_bytes"] for k in lm + cm)
+    data.setdefault("_per_kernel", {})[key] = {k: table[k] for k in lm + cm}
+    json.dump(data, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps({key: data[key]}))
+
+
+if __name__ == "__main__":
+    main()
