@@ -170,3 +170,71 @@ def test_long_landmarks():
         ld, lms_new = orc.back_substitute_pose(ALPHA, st, base.cams + inc_s.reshape(-1, 12), lms, inc_s * (1.0 / sigma))
         assert rel(ctx.get_landmarks(), lms_new) < 1e-9 and abs(l_diff - ld) <= 1e-9 * abs(ld)
         ctx.close()
+
+
+@pytest.mark.parametrize("name,norm", [("step1_small_none.npz", "NONE"), ("step1_small_huber.npz", "HUBER"),
+                                       ("step1_medium_none.npz", "NONE")])
+def test_against_golden_fixtures(name, norm):
+    """HIP path vs the committed golden vectors (tests/golden, NumPy restatement)."""
+    import os
+    from povar_amd import capi
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", name)))
+    ctx = capi.Context(int(g["n_cams"]), g["lm_off"], g["cam_idx"], g["obs"], robust_norm=norm,
+                       huber=float(g["huber"]), eps=float(g["eps"]))
+    alpha, lam, m = float(g["alpha"]), float(g["lam"]), int(g["m"])
+    ctx.set_cameras(g["cams"])
+    ctx.init_landmarks_pose(alpha)
+    assert rel(ctx.get_landmarks(), g["lms"]) < 1e-8
+    ctx.set_landmarks(g["lms"])
+    ri = ctx.error_pose(alpha)
+    assert abs(ri.all_error - float(g["cost"])) <= 1e-12 * float(g["cost"])
+    assert ctx.linearize_pose(alpha)
+    ctx.prepare_pose(lam)
+    assert rel(ctx.get_buffer(capi.BUF_DIAG2), g["diag2"]) < 1e-13
+    assert rel(ctx.get_buffer(capi.BUF_JL_COL_SCALE), g["jl_scale"].ravel()) < 1e-13
+    assert rel(ctx.get_buffer(capi.BUF_HLL_INV), g["hll_inv"].ravel()) < 1e-11
+    assert rel(ctx.get_buffer(capi.BUF_B), g["b"]) < 1e-12
+    if "storage" in g:
+        assert rel(ctx.get_buffer(capi.BUF_STORAGE), g["storage"].ravel()) < 1e-13
+    ctx.power_series_begin()
+    assert rel(ctx.get_term(), g["terms"][0]) < 1e-12
+    for i in range(1, m + 1):
+        ctx.power_series_step()
+        assert rel(ctx.get_term(), g["terms"][i]) < 1e-11, i
+    assert rel(ctx.get_increment(), g["inc"]) < 1e-10
+    if "varproj_l_diff" in g:
+        ld = ctx.apply_pose(0, alpha, g["inc"])
+        assert rel(ctx.get_cameras(), g["varproj_cams_new"]) < 1e-14
+        assert rel(ctx.get_landmarks(), g["varproj_lms_new"]) < 1e-9
+        assert abs(ld - float(g["varproj_l_diff"])) <= 1e-9 * abs(float(g["varproj_l_diff"]))
+    ctx.close()
+
+
+def test_full_size_properties():
+    """Size-independent properties at a BASELINE size (trafalgar-257 shape): E0 symmetric PSD,
+    stored-tile and implicit operators agree, determinism run to run, observation count."""
+    from povar_amd import capi, synth
+    p = synth.make_bal_problem("trafalgar-257")
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs)
+    ctx.set_cameras(p.cams)
+    ctx.init_landmarks_pose(ALPHA)
+    assert ctx.error_pose(ALPHA).all_num_obs == p.n_obs
+    assert ctx.linearize_pose(ALPHA)
+    ctx.prepare_pose(LAM)
+    rng = np.random.default_rng(1)
+    x, y = rng.normal(size=12 * p.n_cams), rng.normal(size=12 * p.n_cams)
+    ex, ey = ctx.right_mul_e0_pose(x), ctx.right_mul_e0_pose(y)
+    assert abs(y @ ex - x @ ey) <= 1e-11 * abs(y @ ex)
+    assert x @ ex > 0
+    assert np.array_equal(ctx.right_mul_e0_pose(x), ex)  # deterministic (no atomics on the path)
+    inc_a, it, st, rc = ctx.solve_pose(LAM, 0, M)
+    ctx.set_e0_mode(capi.E0_TILES)
+    assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-13
+    inc_b, _, _, _ = ctx.solve_pose(LAM, 0, M)
+    assert rc == 0 and rel(inc_b, inc_a) < 1e-12
+    # S = B - E0 is positive definite: x^T B x > x^T E0 x with B^-1 from the library
+    binv = ctx.get_buffer(capi.BUF_B_INV).reshape(p.n_cams, 12, 12)
+    xb = x.reshape(p.n_cams, 12)
+    xBx = sum(v @ np.linalg.solve(bi, v) for v, bi in zip(xb, binv))
+    assert xBx > x @ ex
+    ctx.close()
