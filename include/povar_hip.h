@@ -130,6 +130,31 @@ int povar_right_mul_e0_pose(povar_ctx* ctx, const double* x, double* y);
 int povar_set_e0_mode(povar_ctx* ctx, int32_t e0_mode);
 int povar_synchronize(povar_ctx* ctx);
 
+/* ---- step 2: projective refinement on the Riemannian manifold (RIPOBA) ---- */
+/* BalProblem::Landmark::p_w_homogeneous (bal_problem.hpp:225), 4 n_lms; shares storage with p_w */
+int povar_set_landmarks_homogeneous(povar_ctx* ctx, const double* lms_h);
+int povar_get_landmarks_homogeneous(povar_ctx* ctx, double* lms_h);
+/* BalProblem::backup_joint / restore_joint (bal_problem.cpp:658-665, 691-698) */
+int povar_backup_joint(povar_ctx* ctx);
+int povar_restore_joint(povar_ctx* ctx);
+/* Linearizor::compute_error_homogeneous (linearizor_base.cpp:79-87; helper.cpp:157-196) */
+int povar_error_homogeneous(povar_ctx* ctx, povar_residual_info* out);
+/* Linearizor::linearize_projective_space_homogeneous (linearizor_power_varproj.cpp:80-110) */
+int povar_linearize_homogeneous(povar_ctx* ctx);
+/* LinearizationPowerVarproj::prepare_Hb_joint (linearization_power_varproj.hpp:74-122) incl. the
+ * scale_Jp_cols_joint + linearize_nullspace of a new linearisation point (cpp:129-133) */
+int povar_prepare_joint(povar_ctx* ctx, double lambda);
+/* Linearizor::solve_joint (linearizor_power_varproj.cpp:114-175); inc[11 n_cams] in tangent
+ * coordinates of the Householder bases N_c (see povar_get_buffer POVAR_BUF_NC_HOUSEHOLDER) */
+int povar_solve_joint(povar_ctx* ctx, double lambda, int32_t power_sc_iterations, double q_tolerance,
+                      double r_tolerance, double* inc, int32_t* num_iterations, int32_t* termination);
+/* Linearizor::apply_joint (linearizor_power_varproj.cpp:277-308) */
+int povar_apply_joint(povar_ctx* ctx, const double* inc, double* l_diff);
+/* the renormalisation the outer loop performs after apply_joint (bal_bundle_adjustment.cpp:700-705) */
+int povar_normalize_joint(povar_ctx* ctx);
+/* povar_power_series_pose / _begin / _step / povar_get_term / povar_get_increment act on the system
+ * prepared last (povar_prepare_pose: 12 n_cams vectors, povar_prepare_joint: 11 n_cams vectors) */
+
 /* ---- inspection of internal state in the reference's layouts (parity tests) ---- */
 enum {
   POVAR_BUF_DIAG2 = 0,     /* get_Jp_diag2_pOSE, 12 n_cams (linearization_varproj.hpp:183-222) */
@@ -138,7 +163,11 @@ enum {
   POVAR_BUF_HLL_INV,       /* hll_inv_pOSE_, 9 n_lms (linearization_power_varproj.hpp:469) */
   POVAR_BUF_B,             /* b_p, 12 n_cams */
   POVAR_BUF_B_INV,         /* b_inv_pOSE_, 144 n_cams */
-  POVAR_BUF_STORAGE        /* storage_pOSE_ of every landmark, [4 n_obs][16] (landmark_block.hpp:726) */
+  POVAR_BUF_STORAGE,       /* storage_pOSE_ of every landmark, [4 n_obs][16] (landmark_block.hpp:726) */
+  POVAR_BUF_JL_COL_SCALE_H, /* Jl_col_scale_homogeneous, 4 n_lms (landmark_block.hpp:303-306) */
+  POVAR_BUF_B_JOINT,       /* b_p of prepare_Hb_joint, 11 n_cams */
+  POVAR_BUF_B_INV_JOINT,   /* b_inv_joint_, 121 n_cams */
+  POVAR_BUF_NC_HOUSEHOLDER /* per camera (w[12], beta): N_c = (I - beta w w^T)[:, 1:], 13 n_cams */
 };
 int povar_get_buffer(povar_ctx* ctx, int32_t which, double* out, int64_t n);
 

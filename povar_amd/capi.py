@@ -20,7 +20,8 @@ POWER_VARPROJ, POWER_SCHUR_COMPLEMENT = 0, 1
 E0_IMPLICIT, E0_TILES = 0, 1
 NO_CONVERGENCE, SUCCESS, FAILURE = 0, 1, 2
 NUMERIC_FAILURE = 1
-(BUF_DIAG2, BUF_POSE_SCALING, BUF_JL_COL_SCALE, BUF_HLL_INV, BUF_B, BUF_B_INV, BUF_STORAGE) = range(7)
+(BUF_DIAG2, BUF_POSE_SCALING, BUF_JL_COL_SCALE, BUF_HLL_INV, BUF_B, BUF_B_INV, BUF_STORAGE,
+ BUF_JL_COL_SCALE_H, BUF_B_JOINT, BUF_B_INV_JOINT, BUF_NC_HOUSEHOLDER) = range(11)
 
 
 class Options(C.Structure):
@@ -179,6 +180,51 @@ class Context:
                                           C.byref(ld)))
         return ld.value
 
+    # step 2
+    def set_landmarks_homogeneous(self, lms_h):
+        lms_h = np.ascontiguousarray(lms_h, dtype=np.float64)
+        assert lms_h.size == 4 * self.n_lms
+        self._chk(self.L.povar_set_landmarks_homogeneous(self.h, _p(lms_h)))
+
+    def get_landmarks_homogeneous(self):
+        out = np.zeros((self.n_lms, 4))
+        self._chk(self.L.povar_get_landmarks_homogeneous(self.h, _p(out)))
+        return out
+
+    def backup_joint(self):
+        self._chk(self.L.povar_backup_joint(self.h))
+
+    def restore_joint(self):
+        self._chk(self.L.povar_restore_joint(self.h))
+
+    def error_homogeneous(self):
+        ri = ResidualInfo()
+        self._chk(self.L.povar_error_homogeneous(self.h, C.byref(ri)))
+        return ri
+
+    def linearize_homogeneous(self):
+        return self._chk(self.L.povar_linearize_homogeneous(self.h), allow_numeric=True) == 0
+
+    def prepare_joint(self, lam):
+        self._chk(self.L.povar_prepare_joint(self.h, C.c_double(lam)))
+
+    def solve_joint(self, lam, m, q_tol=0.0, r_tol=-1.0):
+        inc = np.zeros(11 * self.n_cams)
+        it, st = C.c_int32(), C.c_int32()
+        rc = self._chk(self.L.povar_solve_joint(self.h, C.c_double(lam), C.c_int32(m), C.c_double(q_tol),
+                                                C.c_double(r_tol), _p(inc), C.byref(it), C.byref(st)),
+                       allow_numeric=True)
+        return inc, it.value, st.value, rc
+
+    def apply_joint(self, inc):
+        inc = np.ascontiguousarray(inc, dtype=np.float64)
+        ld = C.c_double()
+        self._chk(self.L.povar_apply_joint(self.h, _p(inc), C.byref(ld)))
+        return ld.value
+
+    def normalize_joint(self):
+        self._chk(self.L.povar_normalize_joint(self.h))
+
     # finer grained
     def prepare_pose(self, lam, solver_type=POWER_VARPROJ):
         self._chk(self.L.povar_prepare_pose(self.h, C.c_double(lam), C.c_int32(solver_type)))
@@ -189,8 +235,8 @@ class Context:
                                                  C.c_double(r_tol), C.byref(it), C.byref(st)))
         return it.value, st.value
 
-    def get_increment(self):
-        out = np.zeros(12 * self.n_cams)
+    def get_increment(self, dim=12):
+        out = np.zeros(dim * self.n_cams)
         self._chk(self.L.povar_get_increment(self.h, _p(out)))
         return out
 
@@ -200,8 +246,8 @@ class Context:
     def power_series_step(self):
         self._chk(self.L.povar_power_series_step(self.h))
 
-    def get_term(self):
-        out = np.zeros(12 * self.n_cams)
+    def get_term(self, dim=12):
+        out = np.zeros(dim * self.n_cams)
         self._chk(self.L.povar_get_term(self.h, _p(out)))
         return out
 
@@ -220,7 +266,9 @@ class Context:
     def get_buffer(self, which):
         n = {BUF_DIAG2: 12 * self.n_cams, BUF_POSE_SCALING: 12 * self.n_cams,
              BUF_JL_COL_SCALE: 3 * self.n_lms, BUF_HLL_INV: 9 * self.n_lms, BUF_B: 12 * self.n_cams,
-             BUF_B_INV: 144 * self.n_cams, BUF_STORAGE: 64 * self.n_obs}[which]
+             BUF_B_INV: 144 * self.n_cams, BUF_STORAGE: 64 * self.n_obs,
+             BUF_JL_COL_SCALE_H: 4 * self.n_lms, BUF_B_JOINT: 11 * self.n_cams,
+             BUF_B_INV_JOINT: 121 * self.n_cams, BUF_NC_HOUSEHOLDER: 13 * self.n_cams}[which]
         out = np.zeros(n)
         self._chk(self.L.povar_get_buffer(self.h, C.c_int32(which), _p(out), C.c_int64(n)))
         return out

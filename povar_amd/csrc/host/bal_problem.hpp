@@ -1,0 +1,67 @@
+// BalProblem: the data model and loaders of the drop-in surface (bal/bal_problem.hpp:66-339,
+// bal/bal_problem.cpp:183-471, 658-708), restated without Eigen/Sophus.
+#pragma once
+#include <array>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace povar_host {
+
+// a device-resident Linearizor owns the authoritative state; BalProblem forwards its
+// backup/restore calls (bal_bundle_adjustment.cpp:402, 508, 696, 808) through this hook
+struct StateMirror {
+  virtual ~StateMirror() = default;
+  virtual void backup_pOSE() = 0;
+  virtual void restore_pOSE() = 0;
+  virtual void backup_joint() = 0;
+  virtual void restore_joint() = 0;
+  virtual void normalize_joint() = 0;                 // bal_bundle_adjustment.cpp:700-705
+  virtual void pull_state() = 0;                      // device -> BalProblem
+};
+
+class BalProblem {
+ public:
+  struct Camera {
+    std::array<double, 12> space_matrix{};  // row-major 3x4 (bal_problem.hpp:102)
+    std::array<double, 3> intrinsics{};     // f, k1, k2: parsed, carried, never used
+    std::array<double, 12> space_matrix_backup{};
+  };
+  struct Landmark {
+    std::array<double, 3> p_w{};
+    std::array<double, 4> p_w_homogeneous{};
+    std::map<int, std::array<double, 2>> obs;  // camera index -> (u, v), v negated on load
+    std::array<double, 3> p_w_backup{};
+    std::array<double, 4> p_w_homogeneous_backup{};
+  };
+
+  void load_bal_eccv(const std::string& path);                        // bal_problem.cpp:183-303
+  void load_bal_varproj_space_matrix_write(const std::string& path, int seed);  // bal_problem.cpp:307-471
+
+  std::vector<Camera>& cameras() { return cameras_; }
+  std::vector<Landmark>& landmarks() { return landmarks_; }
+  const std::vector<Camera>& cameras() const { return cameras_; }
+  const std::vector<Landmark>& landmarks() const { return landmarks_; }
+  int num_cameras() const { return (int)cameras_.size(); }
+  int num_landmarks() const { return (int)landmarks_.size(); }
+  long num_observations() const;
+
+  void backup_pOSE();    // bal_problem.cpp:670-677
+  void restore_pOSE();   // bal_problem.cpp:701-708
+  void backup_joint();   // bal_problem.cpp:658-665
+  void restore_joint();  // bal_problem.cpp:691-698
+
+  // CSR export in the layout of include/povar_hip.h
+  void flatten(std::vector<int>& lm_off, std::vector<int>& cam_idx, std::vector<double>& obs) const;
+
+  StateMirror* mirror = nullptr;
+  bool quiet = false;
+
+ private:
+  std::vector<Camera> cameras_;
+  std::vector<Landmark> landmarks_;
+};
+
+BalProblem load_normalized_bal_problem(const struct BalDatasetOptions& options);
+
+}  // namespace povar_host

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "povar_kernels.hpp"
+#include "povar_kernels_joint.hpp"
 
 using namespace povar;
 
@@ -79,12 +80,14 @@ struct povar_ctx {
   // state
   DevBuf<double4> cams4, cams_lin4, cams_bak4, lms4, lms_lin4, lms_bak4, jl_scale4, rres, q4;
   DevBuf<double> hll_inv, sw, sigma, diag2, G, binv, b, tmp, accum, z, y, inc, item_part,
-      item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec;
+      item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec, ncw;
 
   Dp d{};
   bool new_linearization_point = false;  // linearizor_power_varproj.cpp:75, 192, 240
   bool linearized = false;
   bool tiles_valid = false;
+  bool joint = false;        // system prepared last: step 2 (11-dim tangent) or step 1 (12-dim)
+  bool linearized_h = false;
   double alpha_lin = 0;
 
   // multi-GPU
@@ -264,7 +267,15 @@ int allreduce(povar_ctx* c, double* buf, size_t n) {
 // result is consumed by cam_binv_axpy (mode 1: scatter items, mode 2: dense y).
 int launch_e0(povar_ctx* c, int* binv_mode) {
   prof_mark(c, 0);
-  {
+  if (c->joint) {
+    launch_lm(c, OpE0H{});
+    hipLaunchKernelGGL(cm_scatter_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 1);
+    *binv_mode = 1;
+    if (c->comm) {
+      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.y, 1);
+      *binv_mode = 2;
+    }
+  } else {
     if (c->opt.e0_mode == POVAR_E0_TILES) launch_lm(c, OpE0Tiles{});
     else {
       hipLaunchKernelGGL(e0_lm_cached, dim3(c->e0c_grid), dim3(E0C_BLOCK),
@@ -289,8 +300,12 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
 
 void launch_binv(povar_ctx* c, int mode, int want_norms) {
   prof_mark(c, 1);
-  hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, c->d, mode,
-                     want_norms);
+  if (c->joint)
+    hipLaunchKernelGGL(cam_binv_axpy_h, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, c->d, mode,
+                       want_norms, (const double*)c->ncw.p);
+  else
+    hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, c->d, mode,
+                       want_norms);
 }
 
 int ensure_tiles(povar_ctx* c) {
@@ -422,9 +437,9 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(sigma, 12 * nc); ALLOC(diag2, 12 * nc); ALLOC(G, 40 * nc); ALLOC(binv, 144 * nc);
   ALLOC(b, 12 * nc); ALLOC(tmp, 12 * nc); ALLOC(accum, 12 * nc); ALLOC(z, 12 * nc); ALLOC(y, 12 * nc);
   ALLOC(inc, 12 * nc);
-  ALLOC(item_part, 12 * ni); ALLOC(item_partG, 40 * ni); ALLOC(cm_h, 3 * (size_t)n_obs);
+  ALLOC(item_part, 12 * ni); ALLOC(item_partG, 40 * ni); ALLOC(cm_h, 4 * (size_t)n_obs); ALLOC(ncw, 13 * nc);
   ALLOC(norm_part, 2 * (size_t)c->n_cam_blocks); ALLOC(norms, 4); ALLOC(flags, 4);
-  ALLOC(part, n_part); ALLOC(scal, 8);
+  ALLOC(part, n_part * 2); ALLOC(scal, 8);
   ALLOC(stage, std::max(3 * nl, 144 * nc));
 #undef ALLOC
   HIP_TRY(hipMemset(c->flags.p, 0, sizeof(int) * 4));
@@ -469,7 +484,7 @@ void povar_destroy(povar_ctx* c) {
   c->hll_inv.release(); c->sw.release(); c->sigma.release(); c->diag2.release(); c->G.release();
   c->binv.release(); c->b.release(); c->tmp.release(); c->accum.release(); c->z.release(); c->y.release();
   c->inc.release(); c->item_part.release(); c->item_partG.release(); c->norm_part.release();
-  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->hot_cams.release();
+  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->ncw.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -566,6 +581,7 @@ int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
 
 int povar_linearize_pose(povar_ctx* c, double alpha) {
   if (int rc = check_ctx(c)) return rc;
+  c->linearized_h = false;
   set_alpha(c, alpha);
   c->alpha_lin = alpha;
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
@@ -595,6 +611,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   if (int rc = check_ctx(c)) return rc;
   if (!c->linearized) return fail(-1, "povar_prepare_pose before povar_linearize_pose");
   set_alpha(c, c->alpha_lin);
+  c->joint = false;
   // scale_Jp_cols_pOSE on a new linearisation point (linearizor_power_varproj.cpp:192-195):
   // the scaling is part of the implicit tile; only stored tiles need (re)materialising.
   c->new_linearization_point = false;
@@ -661,14 +678,14 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
 
 int povar_get_increment(povar_ctx* c, double* inc) {
   if (int rc = check_ctx(c)) return rc;
-  HIP_TRY(hipMemcpyAsync(inc, c->accum.p, sizeof(double) * 12 * c->n_cams, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(inc, c->accum.p, sizeof(double) * (c->joint ? 11 : 12) * c->n_cams, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
 
 int povar_get_term(povar_ctx* c, double* term) {
   if (int rc = check_ctx(c)) return rc;
-  HIP_TRY(hipMemcpyAsync(term, c->tmp.p, sizeof(double) * 12 * c->n_cams, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(term, c->tmp.p, sizeof(double) * (c->joint ? 11 : 12) * c->n_cams, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -728,6 +745,123 @@ int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const doub
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// step 2
+// ------------------------------------------------------------------------------------------
+int povar_set_landmarks_homogeneous(povar_ctx* c, const double* lms_h) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->lms4.p, lms_h, sizeof(double) * 4 * c->n_lms, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int povar_get_landmarks_homogeneous(povar_ctx* c, double* lms_h) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(lms_h, c->lms4.p, sizeof(double) * 4 * c->n_lms, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int povar_backup_joint(povar_ctx* c) { return povar_backup_pose(c); }
+int povar_restore_joint(povar_ctx* c) { return povar_restore_pose(c); }
+
+int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!out) return fail(-1, "null argument");
+  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  launch_lm(c, OpErrorH{});
+  launch_reduce<6>(c, c->scal.p);
+  HIP_TRY(hipGetLastError());
+  if (int rc = allreduce(c, c->scal.p, 6)) return rc;
+  double h[6];
+  int f[4];
+  HIP_TRY(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  if (int rc = read_flags(c, f)) return rc;
+  out->all_error = h[0];
+  out->all_residual_sum = h[1];
+  out->all_num_obs = (int64_t)std::llround(h[2]);
+  out->valid_error = h[3];
+  out->valid_residual_sum = h[4];
+  out->valid_num_obs = (int64_t)std::llround(h[5]);
+  out->is_numerically_valid = f[0] ? 0 : 1;
+  return 0;
+}
+
+int povar_linearize_homogeneous(povar_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
+  launch_lm(c, OpLinearizeH{});
+  hipLaunchKernelGGL(cm_build_h4, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d);
+  hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
+  hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
+  if (c->comm) {
+    if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
+    hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)c->d.G, c->ncw.p);
+  }
+  HIP_TRY(hipGetLastError());
+  int f[4];
+  if (int rc = read_flags(c, f)) return rc;
+  c->new_linearization_point = true;
+  c->linearized = false;  // the step-1 linearisation is gone
+  c->linearized_h = true;
+  c->tiles_valid = false;
+  return f[0] ? POVAR_NUMERIC_FAILURE : 0;
+}
+
+int povar_prepare_joint(povar_ctx* c, double lambda) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!c->linearized_h) return fail(-1, "povar_prepare_joint before povar_linearize_homogeneous");
+  c->joint = true;
+  c->new_linearization_point = false;
+  c->d.lambda_lm = lambda;  // set_landmark_damping_joint, linearizor_power_varproj.cpp:136
+  launch_lm(c, OpPrepareH{});
+  hipLaunchKernelGGL(cm_scatter_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0);
+  hipLaunchKernelGGL(cam_sum_items_h, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b,
+                     (const double*)c->ncw.p);
+  if (int rc = allreduce(c, c->d.b, 11 * (size_t)c->n_cams)) return rc;
+  hipLaunchKernelGGL(cam_build_binv_h, dim3(grid_for(c->n_cams, K8_THREADS)), dim3(K8_THREADS), 0, c->stream, c->d,
+                     lambda, (const double*)c->ncw.p);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int povar_solve_joint(povar_ctx* c, double lambda, int32_t m, double q_tol, double r_tol, double* inc,
+                      int32_t* num_iterations, int32_t* termination) {
+  if (int rc = povar_prepare_joint(c, lambda)) return rc;
+  if (int rc = povar_power_series_pose(c, m, q_tol, r_tol, num_iterations, termination)) return rc;
+  if (int rc = povar_get_increment(c, inc)) return rc;
+  for (size_t i = 0; i < 11 * (size_t)c->n_cams; ++i)
+    if (!std::isfinite(inc[i])) return POVAR_NUMERIC_FAILURE;
+  return 0;
+}
+
+int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!c->linearized_h) return fail(-1, "povar_apply_joint before povar_linearize_homogeneous");
+  HIP_TRY(hipMemcpyAsync(c->inc.p, inc, sizeof(double) * 11 * c->n_cams, hipMemcpyHostToDevice, c->stream));
+  // cpp:280: back-substitute first (old cameras), then update the cameras (cpp:283-305)
+  hipLaunchKernelGGL(cam_apply_inc_h, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, 1, (const double*)c->ncw.p);
+  launch_lm(c, OpBackJoint{});
+  hipLaunchKernelGGL(cam_apply_inc_h, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, 2, (const double*)c->ncw.p);
+  launch_reduce<1>(c, c->scal.p);
+  HIP_TRY(hipGetLastError());
+  if (int rc = allreduce(c, c->scal.p, 1)) return rc;
+  double h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, c->scal.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (l_diff) *l_diff = h;
+  return 0;
+}
+
+int povar_normalize_joint(povar_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  hipLaunchKernelGGL(normalize_joint, dim3(grid_for(std::max(c->n_cams, c->n_lms), 256)), dim3(256), 0, c->stream, c->d);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int povar_set_e0_mode(povar_ctx* c, int32_t mode) {
   if (int rc = check_ctx(c)) return rc;
   if (mode != POVAR_E0_IMPLICIT && mode != POVAR_E0_TILES) return fail(-1, "bad e0 mode");
@@ -751,6 +885,22 @@ int povar_get_buffer(povar_ctx* c, int32_t which, double* out, int64_t n) {
     case POVAR_BUF_HLL_INV: return copy(c->hll_inv.p, 9 * nl);
     case POVAR_BUF_B: return copy(c->b.p, 12 * nc);
     case POVAR_BUF_B_INV: return copy(c->binv.p, 144 * nc);
+    case POVAR_BUF_B_JOINT: return copy(c->b.p, 11 * nc);
+    case POVAR_BUF_B_INV_JOINT: {
+      if ((size_t)n != 121 * nc) return fail(-1, "povar_get_buffer: wrong size");
+      std::vector<double> h(144 * nc);
+      HIP_TRY(hipMemcpyAsync(h.data(), c->binv.p, 144 * nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      for (size_t k = 0; k < nc; ++k) std::memcpy(out + 121 * k, h.data() + 144 * k, 121 * sizeof(double));
+      return 0;
+    }
+    case POVAR_BUF_NC_HOUSEHOLDER: return copy(c->ncw.p, 13 * nc);
+    case POVAR_BUF_JL_COL_SCALE_H: {
+      if ((size_t)n != 4 * nl) return fail(-1, "povar_get_buffer: wrong size");
+      HIP_TRY(hipMemcpyAsync(out, c->jl_scale4.p, nl * sizeof(double4), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      return 0;
+    }
     case POVAR_BUF_JL_COL_SCALE: {
       if ((size_t)n != 3 * nl) return fail(-1, "povar_get_buffer: wrong size");
       std::vector<double4> h(nl);

@@ -1,0 +1,580 @@
+// povar_kernels_joint.hpp -- step 2 (projective refinement on the Riemannian manifold, RIPOBA):
+// the same kernel structure as step 1 with 2-row tiles.
+//
+// Stored step-2 tile of one observation (landmark_block.hpp:180-269 after scale_Jl_cols_homogeneous
+// :298-309, scale_Jp_cols_joint :311-321 and linearize_nullspace :227-269), with pc = P X = (x,y,z),
+// D = [[1/z, 0, -x/z^2], [0, 1/z, -y/z^2]] (bal_camera.hpp:153-160):
+//     Jp12 = sw * [ D00 X, 0, D02 X ; 0, D00 X, D12 X ] * diag(sigma_c)      (helper.cpp:352-369)
+//     Jl4  = sw * (D P) * diag(s_l)                                           (helper.cpp:376)
+//     Jp11 = Jp12 N_c,  Jl3 = Jl4 N_l,  r = sw * (x/z - u, y/z - v)
+// N_c (12x11) and N_l (4x3) are orthonormal bases of null(vec(P_c)^T) and null(X_l^T).  The
+// reference takes them from Eigen's CompleteOrthogonalDecomposition (helper.cpp:202-216); every
+// orthonormal basis gives the same ambient increments, norms and convergence tests (A.7), so one
+// Householder reflector is used: N = H[:, 1:], H = I - beta w w^T, w = v + sign(v0)|v| e0,
+// beta = 2 / w^T w.  Products with N are rank-one updates:
+//     (a N)_j = a_{j+1} - beta (a.w) w_{j+1}        (N x)_i = [0;x]_i - beta w_i (w[1:].x)
+#pragma once
+#include "povar_kernels.hpp"
+
+namespace povar {
+
+struct Hom {
+  double D00, D02, D12, r0, r1;
+  bool valid;
+};
+__device__ inline Hom hom_project(const Cam& P, const double4& X, double u, double v) {
+  const double x = dot4(P.r0, X), y = dot4(P.r1, X), z = dot4(P.r2, X);
+  Hom h;
+  h.r0 = x / z - u;
+  h.r1 = y / z - v;
+  h.D00 = 1 / z;
+  h.D02 = -x / (z * z);
+  h.D12 = -y / (z * z);
+  h.valid = fabs(z) >= 1e-5;  // bal_camera.hpp:147 (Sophus epsilonSqrt<double>)
+  return h;
+}
+// Jl4 = scale * (D P) * diag(s): row0 = D00 P0 + D02 P2, row1 = D00 P1 + D12 P2
+__device__ inline void hom_jl4(const Cam& P, const Hom& h, double scale, const double4& s, double (&jl)[8]) {
+  jl[0] = scale * (h.D00 * P.r0.x + h.D02 * P.r2.x) * s.x;
+  jl[1] = scale * (h.D00 * P.r0.y + h.D02 * P.r2.y) * s.y;
+  jl[2] = scale * (h.D00 * P.r0.z + h.D02 * P.r2.z) * s.z;
+  jl[3] = scale * (h.D00 * P.r0.w + h.D02 * P.r2.w) * s.w;
+  jl[4] = scale * (h.D00 * P.r1.x + h.D12 * P.r2.x) * s.x;
+  jl[5] = scale * (h.D00 * P.r1.y + h.D12 * P.r2.y) * s.y;
+  jl[6] = scale * (h.D00 * P.r1.z + h.D12 * P.r2.z) * s.z;
+  jl[7] = scale * (h.D00 * P.r1.w + h.D12 * P.r2.w) * s.w;
+}
+// Householder vector of a 4-vector (kernel_COD of X^T, helper.cpp:202-216)
+__device__ inline void house4(const double4& X, double (&w)[4], double& beta) {
+  const double nv = sqrt(X.x * X.x + X.y * X.y + X.z * X.z + X.w * X.w);
+  w[0] = X.x + (X.x >= 0 ? nv : -nv);
+  w[1] = X.y;
+  w[2] = X.z;
+  w[3] = X.w;
+  beta = 2.0 / (w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3]);
+}
+__device__ inline void jl3_of_jl4(const double (&jl4)[8], const double (&w)[4], double beta, double (&jl3)[6]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const double aw = jl4[4 * r] * w[0] + jl4[4 * r + 1] * w[1] + jl4[4 * r + 2] * w[2] + jl4[4 * r + 3] * w[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) jl3[3 * r + j] = jl4[4 * r + j + 1] - beta * aw * w[j + 1];
+  }
+}
+// t = Jp12 * p for the structured Jp12, zc = (sigma * p)[12c..]
+__device__ inline void hom_jp_x(const Hom& h, const double4& X, double scale, const double4* zc, double (&t)[2]) {
+  const double d0 = dot4(X, zc[0]), d1 = dot4(X, zc[1]), d2 = dot4(X, zc[2]);
+  t[0] = scale * (h.D00 * d0 + h.D02 * d2);
+  t[1] = scale * (h.D00 * d1 + h.D12 * d2);
+}
+__device__ inline double4 hom_q(const Hom& h, double scale, double s0, double s1) {
+  return make_double4(scale * h.D00 * s0, scale * h.D00 * s1, scale * (h.D02 * s0 + h.D12 * s1), scale);
+}
+__device__ inline void acc_h6(double* red, const double (&jl3)[6]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    red[0] += jl3[3 * r] * jl3[3 * r];
+    red[1] += jl3[3 * r] * jl3[3 * r + 1];
+    red[2] += jl3[3 * r] * jl3[3 * r + 2];
+    red[3] += jl3[3 * r + 1] * jl3[3 * r + 1];
+    red[4] += jl3[3 * r + 1] * jl3[3 * r + 2];
+    red[5] += jl3[3 * r + 2] * jl3[3 * r + 2];
+  }
+}
+
+// K2': compute_error_projective_space_homogeneous (helper.cpp:157-196)
+struct OpErrorH {
+  static constexpr int NRED = 0, NSC = 6;
+  static constexpr bool CHECK_DONE = false;
+  using Local = NoLocal;
+  __device__ void phase1(const Dp&, int, int, int, double2, Local&, double*) const {}
+  __device__ void phase2(const Dp& d, int, int cam, int lm, double2 uv, Local&, const double*, double* sc) const {
+    const Hom h = hom_project(load_cam(d.cams4, cam), d.lms4[lm], uv.x, uv.y);
+    const double r2 = h.r0 * h.r0 + h.r1 * h.r1;
+    if (!isfinite(r2)) atomicOr(&d.flags[0], 1);
+    double e, w;
+    error_weight(d, r2, e, w);
+    sc[0] += e; sc[1] += sqrt(r2); sc[2] += 1.0;
+    if (h.valid) { sc[3] += e; sc[4] += sqrt(r2); sc[5] += 1.0; }
+  }
+  __device__ void finish_lm(const Dp&, int, const double*) const {}
+};
+
+// K3' + K5': linearize_landmark_projective_space_homogeneous (landmark_block.hpp:180-225) and
+// scale_Jl_cols_homogeneous (:298-309)
+struct OpLinearizeH {
+  static constexpr int NRED = 4, NSC = 0;
+  static constexpr bool CHECK_DONE = false;
+  using Local = NoLocal;
+  __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local&, double* red) const {
+    const Cam P = load_cam(d.cams_lin4, cam);
+    const Hom h = hom_project(P, d.lms_lin4[lm], uv.x, uv.y);
+    const double r2 = h.r0 * h.r0 + h.r1 * h.r1;
+    double e, w;
+    error_weight(d, r2, e, w);
+    const double sw = sqrt(w);
+    if (!isfinite(r2) || !isfinite(sw) || !isfinite(h.D02) || !isfinite(h.D12)) atomicOr(&d.flags[0], 1);
+    d.sw[slot] = sw;
+    d.rres[slot] = make_double4(sw * h.r0, sw * h.r1, 0, 0);
+    d.q4[slot] = make_double4(0, 0, 0, sw);
+    double jl[8];
+    hom_jl4(P, h, sw, make_double4(1, 1, 1, 1), jl);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[j] += jl[j] * jl[j] + jl[4 + j] * jl[4 + j];
+  }
+  __device__ void phase2(const Dp&, int, int, int, double2, Local&, const double*, double*) const {}
+  __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    d.jl_scale4[lm] = make_double4(1.0 / (d.eps + sqrt(tot[0])), 1.0 / (d.eps + sqrt(tot[1])),
+                                   1.0 / (d.eps + sqrt(tot[2])), 1.0 / (d.eps + sqrt(tot[3])));
+  }
+};
+
+struct HomObs {  // everything an observation needs from the linearisation point
+  Hom h;
+  double jl4[8], jl3[6], sw;
+  double4 X;
+  __device__ inline void load(const Dp& d, int slot, int cam, int lm, double2 uv) {
+    const Cam P = load_cam(d.cams_lin4, cam);
+    X = d.lms_lin4[lm];
+    h = hom_project(P, X, uv.x, uv.y);
+    sw = d.robust ? d.sw[slot] : 1.0;
+    hom_jl4(P, h, sw, d.jl_scale4[lm], jl4);
+    double w[4], beta;
+    house4(X, w, beta);
+    jl3_of_jl4(jl4, w, beta, jl3);
+  }
+};
+
+__device__ inline void hinv_damped(const double* tot, double lambda, double (&Hi)[9]) {
+  double H[9];
+  sym3(tot, H);
+  H[0] += lambda; H[4] += lambda; H[8] += lambda;  // Proj^T lambda Proj = lambda I_3 (landmark_block.hpp:485)
+  inv3(H, Hi);
+}
+
+// K7' (landmark part): get_Hll_inv_add_Hpp_b_joint (landmark_block.hpp:474-507)
+struct OpPrepareH {
+  static constexpr int NRED = 9, NSC = 0;
+  static constexpr bool CHECK_DONE = false;
+  struct Local { HomObs o; double4 r; };
+  __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local& L, double* red) const {
+    L.o.load(d, slot, cam, lm, uv);
+    L.r = d.rres[slot];
+    acc_h6(red, L.o.jl3);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) red[6 + j] += L.o.jl3[j] * L.r.x + L.o.jl3[3 + j] * L.r.y;
+  }
+  __device__ void phase2(const Dp& d, int slot, int, int, double2, Local& L, const double* tot, double*) const {
+    double Hi[9];
+    hinv_damped(tot, d.lambda_lm, Hi);
+    const double w0 = Hi[0] * tot[6] + Hi[1] * tot[7] + Hi[2] * tot[8];
+    const double w1 = Hi[3] * tot[6] + Hi[4] * tot[7] + Hi[5] * tot[8];
+    const double w2 = Hi[6] * tot[6] + Hi[7] * tot[7] + Hi[8] * tot[8];
+    const double e0 = L.r.x - (L.o.jl3[0] * w0 + L.o.jl3[1] * w1 + L.o.jl3[2] * w2);
+    const double e1 = L.r.y - (L.o.jl3[3] * w0 + L.o.jl3[4] * w1 + L.o.jl3[5] * w2);
+    d.q4[slot] = hom_q(L.o.h, L.o.sw, e0, e1);
+  }
+  __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    double Hi[9];
+    hinv_damped(tot, d.lambda_lm, Hi);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d.hll_inv[9 * (size_t)lm + k] = Hi[k];
+  }
+};
+
+// K10': right_mul_e0_joint (linearization_power_varproj.hpp:408-453); input z = sigma * (N_c x_c)
+struct OpE0H {
+  static constexpr int NRED = 3, NSC = 0;
+  static constexpr bool CHECK_DONE = true;
+  struct Local { HomObs o; };
+  __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local& L, double* red) const {
+    L.o.load(d, slot, cam, lm, uv);
+    const double4* zc = reinterpret_cast<const double4*>(d.z) + 3 * cam;
+    const double4 zz[3] = {zc[0], zc[1], zc[2]};
+    double t[2];
+    hom_jp_x(L.o.h, L.o.X, L.o.sw, zz, t);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) red[j] += L.o.jl3[j] * t[0] + L.o.jl3[3 + j] * t[1];
+  }
+  __device__ void phase2(const Dp& d, int slot, int, int lm, double2, Local& L, const double* tot, double*) const {
+    const double* Hi = d.hll_inv + 9 * (size_t)lm;
+    const double v0 = Hi[0] * tot[0] + Hi[1] * tot[1] + Hi[2] * tot[2];
+    const double v1 = Hi[3] * tot[0] + Hi[4] * tot[1] + Hi[5] * tot[2];
+    const double v2 = Hi[6] * tot[0] + Hi[7] * tot[1] + Hi[8] * tot[2];
+    const double s0 = L.o.jl3[0] * v0 + L.o.jl3[1] * v1 + L.o.jl3[2] * v2;
+    const double s1 = L.o.jl3[3] * v0 + L.o.jl3[4] * v1 + L.o.jl3[5] * v2;
+    d.q4[slot] = hom_q(L.o.h, L.o.sw, s0, s1);
+  }
+  __device__ void finish_lm(const Dp&, int, const double*) const {}
+};
+
+// K12': back_substitute_joint (landmark_block.hpp:574-623); d.z = sigma * (N_c inc_c)
+struct OpBackJoint {
+  static constexpr int NRED = 9, NSC = 1;
+  static constexpr bool CHECK_DONE = false;
+  struct Local { HomObs o; double4 r; double jpi[2]; };
+  __device__ void phase1(const Dp& d, int slot, int cam, int lm, double2 uv, Local& L, double* red) const {
+    L.o.load(d, slot, cam, lm, uv);
+    L.r = d.rres[slot];
+    const double4* zc = reinterpret_cast<const double4*>(d.z) + 3 * cam;
+    const double4 zz[3] = {zc[0], zc[1], zc[2]};
+    hom_jp_x(L.o.h, L.o.X, L.o.sw, zz, L.jpi);
+    acc_h6(red, L.o.jl3);
+    const double a0 = L.r.x + L.jpi[0], a1 = L.r.y + L.jpi[1];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) red[6 + j] += L.o.jl3[j] * a0 + L.o.jl3[3 + j] * a1;
+  }
+  __device__ static void delta4(const Dp& d, const double4& X, const double* tot, double (&dp)[4]) {
+    double Hi[9];
+    hinv_damped(tot, d.lambda_lm, Hi);
+    const double d0 = -(Hi[0] * tot[6] + Hi[1] * tot[7] + Hi[2] * tot[8]);
+    const double d1 = -(Hi[3] * tot[6] + Hi[4] * tot[7] + Hi[5] * tot[8]);
+    const double d2 = -(Hi[6] * tot[6] + Hi[7] * tot[7] + Hi[8] * tot[8]);
+    double w[4], beta;
+    house4(X, w, beta);
+    const double wd = w[1] * d0 + w[2] * d1 + w[3] * d2;  // inc_proj = Proj * inc (landmark_block.hpp:615)
+    dp[0] = -beta * w[0] * wd;
+    dp[1] = d0 - beta * w[1] * wd;
+    dp[2] = d1 - beta * w[2] * wd;
+    dp[3] = d2 - beta * w[3] * wd;
+  }
+  __device__ void phase2(const Dp& d, int, int, int, double2, Local& L, const double* tot, double* sc) const {
+    double dp[4];
+    delta4(d, L.o.X, tot, dp);
+    const double rr[2] = {L.r.x, L.r.y};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double ji = L.jpi[r] + (L.o.jl4[4 * r] * dp[0] + L.o.jl4[4 * r + 1] * dp[1] + L.o.jl4[4 * r + 2] * dp[2] +
+                                    L.o.jl4[4 * r + 3] * dp[3]);
+      sc[0] -= ji * (0.5 * ji + rr[r]);
+    }
+  }
+  __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    double dp[4];
+    delta4(d, d.lms_lin4[lm], tot, dp);
+    const double4 s = d.jl_scale4[lm];
+    double4 X = d.lms4[lm];
+    X.x += dp[0] * s.x; X.y += dp[1] * s.y; X.z += dp[2] * s.z; X.w += dp[3] * s.w;  // :621-622
+    d.lms4[lm] = X;
+  }
+};
+
+// camera-major pass of step 2: item_part[item] = sum ( X q0 ; X q1 ; X q2 ) with 4-component X
+__global__ __launch_bounds__(256) void cm_scatter_h(Dp d, int check_done) {
+  if (check_done && d.flags[1]) return;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (item >= d.n_items) return;
+  const int b = d.item_off[item], e = d.item_off[item + 1];
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0;
+  for (int p = b + lane; p < e; p += WAVE) {
+    const double4 q = d.q4[d.cm_slot[p]];
+    const double4 h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], d.cm_h[3 * d.n_obs + p]);
+    acc[0] += h.x * q.x; acc[1] += h.y * q.x; acc[2] += h.z * q.x; acc[3] += h.w * q.x;
+    acc[4] += h.x * q.y; acc[5] += h.y * q.y; acc[6] += h.z * q.y; acc[7] += h.w * q.y;
+    acc[8] += h.x * q.z; acc[9] += h.y * q.z; acc[10] += h.z * q.z; acc[11] += h.w * q.z;
+  }
+  wave_sum<12>(acc);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) d.item_part[12 * (size_t)item + k] = acc[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void cm_build_h4(Dp d) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= d.n_obs) return;
+  const double4 h = d.lms_lin4[d.cm_lm[p]];
+  d.cm_h[p] = h.x;
+  d.cm_h[d.n_obs + p] = h.y;
+  d.cm_h[2 * d.n_obs + p] = h.z;
+  d.cm_h[3 * d.n_obs + p] = h.w;
+}
+
+// Gram moments of the unscaled weighted Jp12: Jp12^T Jp12 = w * (C (x) X X^T),
+// C = [[D00^2, 0, D00 D02], [0, D00^2, D00 D12], [., ., D02^2 + D12^2]]
+__global__ __launch_bounds__(256) void cm_gram_h(Dp d) {
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (item >= d.n_items) return;
+  const int b = d.item_off[item], e = d.item_off[item + 1];
+  const Cam P = load_cam(d.cams_lin4, d.item_cam[item]);
+  double acc[40];
+#pragma unroll
+  for (int k = 0; k < 40; ++k) acc[k] = 0;
+  for (int p = b + lane; p < e; p += WAVE) {
+    const double sw = d.q4[d.cm_slot[p]].w;
+    const double4 X = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], d.cm_h[3 * d.n_obs + p]);
+    const double2 uv = d.cm_uv[p];
+    const Hom h = hom_project(P, X, uv.x, uv.y);
+    const double w = sw * sw;
+    const double m[4] = {w * h.D00 * h.D00, w * h.D00 * h.D02, w * h.D00 * h.D12, w * (h.D02 * h.D02 + h.D12 * h.D12)};
+    const double hh[10] = {X.x * X.x, X.x * X.y, X.x * X.z, X.x * X.w, X.y * X.y,
+                           X.y * X.z, X.y * X.w, X.z * X.z, X.z * X.w, X.w * X.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 10; ++j) acc[10 * k + j] += m[k] * hh[j];
+  }
+  wave_sum<40>(acc);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 40; ++k) d.item_partG[40 * (size_t)item + k] = acc[k];
+  }
+}
+
+// per camera after the Gram sums: diag2 / sigma (get_Jp_diag2_projective_space,
+// linearization_varproj.hpp:225-264; linearizor_power_varproj.cpp:97-105) and the Householder
+// vector of vec(P_c) for the tangent basis N_c
+__global__ __launch_bounds__(256) void cam_finish_linearize_h(Dp d, const double* G_in, double* ncw) {
+  const int c = blockIdx.x;
+  __shared__ double part[4][40];
+  __shared__ double g[40];
+  if (G_in) {
+    if (threadIdx.x < 40) g[threadIdx.x] = G_in[40 * (size_t)c + threadIdx.x];
+  } else {
+    const int e = threadIdx.x % 64, q = threadIdx.x / 64;
+    if (e < 40) {
+      double s = 0;
+      for (int it = d.cam_item_off[c] + q; it < d.cam_item_off[c + 1]; it += 4) s += d.item_partG[40 * (size_t)it + e];
+      part[q][e] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 40)
+      g[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 40) d.G[40 * (size_t)c + threadIdx.x] = g[threadIdx.x];
+  if (threadIdx.x < 12) {
+    const int blk = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const int dj = sym10(j, j);
+    const double v = blk < 2 ? g[dj] : g[30 + dj];
+    d.diag2[12 * (size_t)c + threadIdx.x] = v;
+    d.sigma[12 * (size_t)c + threadIdx.x] = 1.0 / (d.eps + sqrt(v));
+  }
+  if (threadIdx.x == 0) {
+    const double* P = reinterpret_cast<const double*>(d.cams_lin4) + 12 * (size_t)c;
+    double nv = 0;
+    for (int k = 0; k < 12; ++k) nv += P[k] * P[k];
+    nv = sqrt(nv);
+    double w[12], wtw = 0;
+    for (int k = 0; k < 12; ++k) w[k] = P[k];
+    w[0] += P[0] >= 0 ? nv : -nv;
+    for (int k = 0; k < 12; ++k) wtw += w[k] * w[k];
+    for (int k = 0; k < 12; ++k) ncw[13 * (size_t)c + k] = w[k];
+    ncw[13 * (size_t)c + 12] = 2.0 / wtw;
+  }
+}
+
+// K8': B_c = N_c^T (Hpp12 + lambda I) N_c = N_c^T Hpp12 N_c + lambda I_11, Cholesky inverse 11x11
+// (linearization_power_varproj.hpp:91-121).  One thread per camera, matrices in LDS [element][thread].
+__global__ __launch_bounds__(K8_THREADS) void cam_build_binv_h(Dp d, double lambda, const double* ncw) {
+  __shared__ double A[144 * K8_THREADS];
+  __shared__ double X[144 * K8_THREADS];
+  const int t = threadIdx.x;
+  const int c = blockIdx.x * K8_THREADS + t;
+  if (c >= d.n_cams) return;
+#define A_(i, j) A[((i) * 12 + (j)) * K8_THREADS + t]
+#define X_(i, j) X[((i) * 12 + (j)) * K8_THREADS + t]
+  const double* g = d.G + 40 * (size_t)c;
+  const double* sg = d.sigma + 12 * (size_t)c;
+  const double* w = ncw + 13 * (size_t)c;
+  const double beta = w[12];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b)
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          const int ij = sym10(i, j);
+          double v;
+          if (a == b) v = a < 2 ? g[ij] : g[30 + ij];
+          else if (a + b == 1) v = 0;
+          else v = g[10 * ((a == 2 ? b : a) + 1) + ij];
+          A_(4 * a + i, 4 * b + j) = v * sg[4 * a + i] * sg[4 * b + j];
+        }
+  // T = A N (12 x 11) into X, then M = N^T T (11 x 11) back into A (row stride kept at 12)
+  for (int i = 0; i < 12; ++i) {
+    double aw = 0;
+    for (int k = 0; k < 12; ++k) aw += A_(i, k) * w[k];
+    for (int j = 0; j < 11; ++j) X_(i, j) = A_(i, j + 1) - beta * aw * w[j + 1];
+  }
+  for (int j = 0; j < 11; ++j) {
+    double wt = 0;
+    for (int k = 0; k < 12; ++k) wt += w[k] * X_(k, j);
+    for (int i = 0; i < 11; ++i) A_(i, j) = X_(i + 1, j) - beta * w[i + 1] * wt;
+  }
+  for (int j = 0; j < 11; ++j) A_(j, j) += lambda;
+  for (int j = 0; j < 11; ++j) {
+    double dd = A_(j, j);
+    for (int k = 0; k < j; ++k) dd -= A_(j, k) * A_(j, k);
+    dd = sqrt(dd);
+    A_(j, j) = dd;
+    for (int i = j + 1; i < 11; ++i) {
+      double s = A_(j, i);
+      for (int k = 0; k < j; ++k) s -= A_(i, k) * A_(j, k);
+      A_(i, j) = s / dd;
+    }
+  }
+  for (int col = 0; col < 11; ++col) {
+    for (int i = 0; i < 11; ++i) {
+      double s = (i == col) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) s -= A_(i, k) * X_(k, col);
+      X_(i, col) = s / A_(i, i);
+    }
+    for (int i = 10; i >= 0; --i) {
+      double s = X_(i, col);
+      for (int k = i + 1; k < 11; ++k) s -= A_(k, i) * X_(k, col);
+      X_(i, col) = s / A_(i, i);
+    }
+  }
+  double* out = d.binv + 144 * (size_t)c;  // 11x11 row-major in the first 121 entries
+  for (int i = 0; i < 11; ++i)
+    for (int j = 0; j < 11; ++j) out[11 * i + j] = X_(i, j);
+#undef A_
+#undef X_
+}
+
+// tangent projection of a per-camera 12-vector: out11 = N_c^T (in12)
+__device__ inline void nt_apply(const double* w, double beta, const double (&y)[12], double (&o)[11]) {
+  double wy = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) wy += w[k] * y[k];
+#pragma unroll
+  for (int j = 0; j < 11; ++j) o[j] = y[j + 1] - beta * w[j + 1] * wy;
+}
+
+// b11_c = N_c^T (sigma * sum_items); one wavefront per camera
+__global__ __launch_bounds__(256) void cam_sum_items_h(Dp d, double* out11, const double* ncw) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= d.n_cams) return;
+  double y[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) y[j] = 0;
+  for (int it = d.cam_item_off[c] + lane; it < d.cam_item_off[c + 1]; it += WAVE) {
+    const double* ip = d.item_part + 12 * (size_t)it;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) y[j] += ip[j];
+  }
+  wave_sum<12>(y);
+#pragma unroll
+  for (int j = 0; j < 12; ++j) y[j] *= d.sigma[12 * (size_t)c + j];
+  double o[11];
+  nt_apply(ncw + 13 * (size_t)c, ncw[13 * (size_t)c + 12], y, o);
+  if (lane < 11) {
+    double v = 0;
+#pragma unroll
+    for (int j = 0; j < 11; ++j) v = (lane == j) ? o[j] : v;
+    out11[11 * (size_t)c + lane] = v;
+  }
+}
+
+// K9' + K11': tmp11 = B^-1 y11, accum11 (+)= tmp11, z = sigma * (N_c tmp11)
+// (right_mul_b_inv_joint + loop body of solve_joint, linearization_power_varproj.hpp:246-257, 342-360).
+// mode 0: y11 = -b11; 1: y12 = sigma * sum of scatter items, y11 = N^T y12; 2: y12 = dense d.y (all-reduced)
+__global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy_h(Dp d, int mode, int want_norms, const double* ncw) {
+  if (mode != 0 && d.flags[1]) return;
+  __shared__ double sh[K9_CAMS * 2];
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * K9_CAMS + (threadIdx.x >> 6);
+  const bool in = c < d.n_cams;
+  double y11[11];
+#pragma unroll
+  for (int j = 0; j < 11; ++j) y11[j] = 0;
+  const double* w = ncw + 13 * (size_t)(in ? c : 0);
+  const double beta = w[12];
+  if (in) {
+    if (mode == 0) {
+#pragma unroll
+      for (int j = 0; j < 11; ++j) y11[j] = -d.b[11 * (size_t)c + j];
+    } else {
+      double y[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) y[j] = 0;
+      if (mode == 1) {
+        for (int it = d.cam_item_off[c] + lane; it < d.cam_item_off[c + 1]; it += WAVE) {
+          const double* ip = d.item_part + 12 * (size_t)it;
+#pragma unroll
+          for (int j = 0; j < 12; ++j) y[j] += ip[j];
+        }
+        wave_sum<12>(y);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) y[j] *= d.sigma[12 * (size_t)c + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) y[j] = d.y[12 * (size_t)c + j];
+      }
+      nt_apply(w, beta, y, y11);
+    }
+  }
+  double nrm[2] = {0, 0};
+  double s = 0;
+  if (in && lane < 11) {
+    const double* Bi = d.binv + 144 * (size_t)c + 11 * lane;
+#pragma unroll
+    for (int j = 0; j < 11; ++j) s += Bi[j] * y11[j];
+    const size_t idx = 11 * (size_t)c + lane;
+    const double acc = mode == 0 ? s : d.accum[idx] + s;
+    d.tmp[idx] = s;
+    d.accum[idx] = acc;
+    nrm[0] = s * s;
+    nrm[1] = acc * acc;
+  }
+  // p12 = N_c tmp11: p_i = [0; tmp]_i - beta w_i (w[1:] . tmp); lane i < 12 needs tmp_{i-1} and the dot
+  double wt = (in && lane < 11) ? w[lane + 1] * s : 0.0;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) wt += shfl_xor_d(wt, m);  // lanes 0..15 hold the 11 products
+  const double prev = shfl_up_d(s, 1);
+  if (in && lane < 12) {
+    const double p = (lane == 0 ? 0.0 : prev) - beta * w[lane] * wt;
+    d.z[12 * (size_t)c + lane] = p * d.sigma[12 * (size_t)c + lane];
+    if (mode == 2) d.y[12 * (size_t)c + lane] = 0;
+  }
+  if (want_norms) {
+    block_sum<2, K9_CAMS * 64>(nrm, sh);
+    if (threadIdx.x == 0) {
+      d.norm_part[2 * (size_t)blockIdx.x] = nrm[0];
+      d.norm_part[2 * (size_t)blockIdx.x + 1] = nrm[1];
+    }
+  }
+}
+
+// K13' (linearizor_power_varproj.cpp:283-305) and the z = sigma * (N_c inc_c) needed by K12'.
+// mode 1: z only (before back substitution); mode 2: P_c += reshape((N_c inc_c) * sigma)
+__global__ __launch_bounds__(256) void cam_apply_inc_h(Dp d, int mode, const double* ncw) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d.n_cams) return;
+  const double* w = ncw + 13 * (size_t)c;
+  const double beta = w[12];
+  const double* x = d.inc + 11 * (size_t)c;
+  double wt = 0;
+  for (int j = 0; j < 11; ++j) wt += w[j + 1] * x[j];
+  double* cams = reinterpret_cast<double*>(d.cams4) + 12 * (size_t)c;
+  for (int i = 0; i < 12; ++i) {
+    const double p = (i == 0 ? 0.0 : x[i - 1]) - beta * w[i] * wt;
+    const double v = p * d.sigma[12 * (size_t)c + i];
+    if (mode == 1) d.z[12 * (size_t)c + i] = v;
+    else cams[i] += v;
+  }
+}
+
+// K15: P_c /= |P_c|_F, X_l /= X_l[3]  (bal_bundle_adjustment.cpp:700-705)
+__global__ __launch_bounds__(256) void normalize_joint(Dp d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < d.n_cams) {
+    double* P = reinterpret_cast<double*>(d.cams4) + 12 * (size_t)i;
+    double s = 0;
+    for (int k = 0; k < 12; ++k) s += P[k] * P[k];
+    s = sqrt(s);
+    for (int k = 0; k < 12; ++k) P[k] /= s;
+  }
+  if (i < d.n_lms) {
+    double4 X = d.lms4[i];
+    const double w = X.w;
+    X.x /= w; X.y /= w; X.z /= w; X.w /= w;
+    d.lms4[i] = X;
+  }
+}
+
+}  // namespace povar
