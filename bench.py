@@ -118,9 +118,11 @@ def main():
     mode = capi.E0_IMPLICIT if args.e0_mode == "implicit" else capi.E0_TILES
     ctx = capi.Context(n_c, prob.lm_off[lb : le + 1] - prob.lm_off[lb], prob.cam_idx[ob:oe],
                        prob.obs[ob:oe], device=local_rank, e0_mode=mode)
-    if world > 1:
+    if world > 1 or os.environ.get("POVAR_FORCE_COMM"):
+        # POVAR_FORCE_COMM=1 exercises the RCCL path with a 1-rank communicator (1-GPU boxes)
         uid = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(world, rank, uid[0])
 
     ctx.set_cameras(prob.cams)
