@@ -123,7 +123,15 @@ def main():
         uid = [capi.comm_unique_id() if rank == 0 else None]
         if dist is not None:
             dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
+        # RCCL prints a version banner on stdout at communicator creation: keep stdout for the JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            ctx.comm_init(world, rank, uid[0])
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     ctx.set_cameras(prob.cams)
     ctx.init_landmarks_pose(alpha)
