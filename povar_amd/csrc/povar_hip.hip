@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -93,6 +94,13 @@ struct povar_ctx {
   // multi-GPU
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
+
+  // hipGraph of the m-term series loop (launch-bound on small problems and at 8 GPUs)
+  hipGraphExec_t series_graph = nullptr;
+  Dp series_graph_d{};
+  int series_graph_key[6] = {0, 0, 0, 0, 0, 0};
+  double series_graph_tol[2] = {0, 0};
+  bool use_graph = true;
 
   // profiling
   bool profile = false;
@@ -388,6 +396,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   c->n_obs = n_obs;
   c->lm_off.assign(lm_offsets, lm_offsets + n_lms + 1);
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
 
   Layout L;
   build_layout(n_cams, n_lms, lm_offsets, cam_idx, obs, L);
@@ -473,6 +482,7 @@ void povar_destroy(povar_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->opt.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   c->uv.release(); c->cm_uv.release(); c->tiles.release();
@@ -644,10 +654,7 @@ int povar_power_series_step(povar_ctx* c) {
   return 0;
 }
 
-int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol, int32_t* num_iterations,
-                            int32_t* termination) {
-  if (int rc = check_ctx(c)) return rc;
-  if (m < 0) return fail(-1, "power_sc_iterations < 0");
+static int enqueue_series(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
   const bool norms = q_tol > 0 || r_tol > 0;
   HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
   launch_binv(c, 0, (m > 0 && r_tol > 0) ? 1 : 0);
@@ -661,6 +668,41 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
       hipLaunchKernelGGL(series_check, dim3(1), dim3(64), 0, c->stream, c->d, c->n_cam_blocks, i, q_tol, r_tol);
   }
   prof_mark(c, -1);
+  return 0;
+}
+
+int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol, int32_t* num_iterations,
+                            int32_t* termination) {
+  if (int rc = check_ctx(c)) return rc;
+  if (m < 0) return fail(-1, "power_sc_iterations < 0");
+  const bool norms = q_tol > 0 || r_tol > 0;
+  if (c->use_graph && !c->profile && m > 0) {
+    // the whole loop (memset, B^-1, m x {E0 kernels, [all-reduce], B^-1 + AXPY, [check]}) is one graph
+    // launch; it is re-captured only when a kernel argument changes
+    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode, c->comm ? 1 : 0, norms ? 1 : 0, r_tol > 0 ? 1 : 0};
+    const bool same = c->series_graph && std::memcmp(key, c->series_graph_key, sizeof(key)) == 0 &&
+                      std::memcmp(&c->d, &c->series_graph_d, sizeof(Dp)) == 0 &&
+                      c->series_graph_tol[0] == q_tol && c->series_graph_tol[1] == r_tol;
+    if (!same) {
+      if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
+      c->series_graph = nullptr;
+      hipGraph_t g = nullptr;
+      HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      const int rc = enqueue_series(c, m, q_tol, r_tol);
+      hipError_t e = hipStreamEndCapture(c->stream, &g);
+      if (rc) return rc;
+      HIP_TRY(e);
+      HIP_TRY(hipGraphInstantiate(&c->series_graph, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      std::memcpy(c->series_graph_key, key, sizeof(key));
+      c->series_graph_d = c->d;
+      c->series_graph_tol[0] = q_tol;
+      c->series_graph_tol[1] = r_tol;
+    }
+    HIP_TRY(hipGraphLaunch(c->series_graph, c->stream));
+  } else {
+    if (int rc = enqueue_series(c, m, q_tol, r_tol)) return rc;
+  }
   HIP_TRY(hipGetLastError());
   int iters = m, status = POVAR_LINEAR_SOLVER_NO_CONVERGENCE;
   if (norms) {
