@@ -666,23 +666,33 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bin0 = blockIdx.x * bins_per_wg;
   const int bin1 = min(bin0 + bins_per_wg, d.n_bins);
-  for (int bin = bin0 + wave; bin < bin1; bin += E0C_BLOCK / WAVE) {
+  constexpr int STRIDE = E0C_BLOCK / WAVE;
+  // The loop is latency-bound (72 % of the wave cycles parked in s_waitcnt at 4 waves per SIMD,
+  // profiles/r01_c_sq_counters.txt): a bin needs two dependent memory round trips (slot data, then
+  // the landmark record it points to).  The slot data of the NEXT bin is therefore requested
+  // before the current bin's record is consumed.
+  int n_meta = lane | (lane << 8), n_cam = 0, n_lm = 0;
+  double2 n_uv = make_double2(0, 0);
+  if (bin0 + wave < bin1) {
+    const int s = (bin0 + wave) * WAVE + lane;
+    n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
+  }
+  for (int bin = bin0 + wave; bin < bin1; bin += STRIDE) {
     const int slot = bin * WAVE + lane;
-    const int meta = d.meta[slot];
+    const int meta = n_meta, cam = n_cam, lm = n_lm;
+    const double2 uv = n_uv;
     const bool valid = (meta & META_REAL) && !(meta & META_LONG);
     const int seg_first = meta & 255, seg_last = (meta >> 8) & 255;
+    // record of the current bin first (its address is known), then the next bin's slot data
+    const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 3 * (size_t)(valid ? lm : 0);
+    const double4 rec0 = rec[0], rec1 = rec[1], rec2 = rec[2];
+    if (bin + STRIDE < bin1) {
+      const int s = slot + STRIDE * WAVE;
+      n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
+    }
     double red[3] = {0, 0, 0};
     E0Core core;
-    double4 rec1 = make_double4(0, 0, 0, 0), rec2 = rec1;
-    double2 uv = make_double2(0, 0);
     if (valid) {
-      const int cam = d.cam[slot];
-      const int lm = d.lm[slot];
-      uv = d.uv[slot];
-      const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 3 * (size_t)lm;
-      const double4 rec0 = rec[0];
-      rec1 = rec[1];
-      rec2 = rec[2];
       double P3[9], zz[12];
       const int hr = (meta >> META_HOT_SHIFT);
       if (hr > 0) {
@@ -961,12 +971,30 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0;
-  for (int p = b + lane; p < e; p += WAVE) {
-    const double4 q = d.q4[d.cm_slot[p]];
-    const double4 h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], 1.0);
-    acc[0] += h.x * q.x; acc[1] += h.y * q.x; acc[2] += h.z * q.x; acc[3] += h.w * q.x;
-    acc[4] += h.x * q.y; acc[5] += h.y * q.y; acc[6] += h.z * q.y; acc[7] += h.w * q.y;
-    acc[8] += h.x * q.z; acc[9] += h.y * q.z; acc[10] += h.z * q.z; acc[11] += h.w * q.z;
+  // 4 observations per lane in flight: index loads, then the dependent 32-byte gathers, then the FMAs
+  constexpr int U = 4;
+  for (int p0 = b + lane; p0 < e; p0 += U * WAVE) {
+    int sl[U];
+    double hx[U], hy[U], hz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * WAVE;
+      const bool in = p < e;
+      const int pc = in ? p : b;
+      sl[u] = in ? d.cm_slot[pc] : -1;
+      hx[u] = d.cm_h[pc];
+      hy[u] = d.cm_h[d.n_obs + pc];
+      hz[u] = d.cm_h[2 * d.n_obs + pc];
+    }
+    double4 q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u] = sl[u] >= 0 ? d.q4[sl[u]] : make_double4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0] += hx[u] * q[u].x; acc[1] += hy[u] * q[u].x; acc[2] += hz[u] * q[u].x; acc[3] += q[u].x;
+      acc[4] += hx[u] * q[u].y; acc[5] += hy[u] * q[u].y; acc[6] += hz[u] * q[u].y; acc[7] += q[u].y;
+      acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += q[u].z;
+    }
   }
   wave_sum<12>(acc);
   if (lane == 0) {
