@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--problem", default="venice-1778", choices=sorted(synth.BAL_SHAPES))
     ap.add_argument("--e0-mode", default="implicit", choices=["implicit", "tiles"])
     ap.add_argument("--m", type=int, default=20, help="--power-sc-iterations")
+    ap.add_argument("--robust-norm", default="NONE", choices=["NONE", "HUBER", "CAUCHY"])
+    ap.add_argument("--huber", type=float, default=1.0)
+    ap.add_argument("--step", type=int, default=1, choices=[1, 2],
+                    help="1: solve_pOSE (headline); 2: solve_joint of the projective refinement (secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the stored-tile comparison leg")
     args = ap.parse_args()
@@ -117,7 +121,8 @@ def main():
     ob, oe = int(prob.lm_off[lb]), int(prob.lm_off[le])
     mode = capi.E0_IMPLICIT if args.e0_mode == "implicit" else capi.E0_TILES
     ctx = capi.Context(n_c, prob.lm_off[lb : le + 1] - prob.lm_off[lb], prob.cam_idx[ob:oe],
-                       prob.obs[ob:oe], device=local_rank, e0_mode=mode)
+                       prob.obs[ob:oe], device=local_rank, e0_mode=mode, robust_norm=args.robust_norm,
+                       huber=args.huber)
     if world > 1 or os.environ.get("POVAR_FORCE_COMM"):
         # POVAR_FORCE_COMM=1 exercises the RCCL path with a 1-rank communicator (1-GPU boxes)
         uid = [capi.comm_unique_id() if rank == 0 else None]
@@ -139,8 +144,17 @@ def main():
     ctx.init_landmarks_pose(alpha)
     ok = ctx.linearize_pose(alpha)
     assert ok, "numerical failure during linearization"
+    t_prep = time.perf_counter()
     ctx.prepare_pose(lam, capi.POWER_VARPROJ)
     ctx.synchronize()
+    t_prep = time.perf_counter() - t_prep
+    if args.step == 2:
+        # secondary: the step-2 system at the state step 1 starts from (normalised cameras, X = [x; 1])
+        ctx.normalize_joint()
+        ok = ctx.linearize_homogeneous()
+        assert ok
+        ctx.prepare_joint(lam)
+        ctx.synchronize()
 
     def barrier():
         ctx.synchronize()
@@ -215,6 +229,8 @@ def main():
         "spmv_effective_GBps": algorithmic_bytes_term(n_c, n_l, n_o) * value / 1e9,
         "kernel_ms": {"e0": e0_ms, "binv_axpy": binv_ms, "allreduce": comm_ms,
                       "e0_launches": int(prof.e0_launches)},
+        "prepare_Hb_ms": t_prep * 1e3,
+        "device_bytes": ctx.device_bytes(),
         "roofline": {
             "bound": "hbm",
             "kernel": "E0 x (lm_regular<OpE0> + cm_scatter)" if mode == capi.E0_IMPLICIT
@@ -228,7 +244,12 @@ def main():
         },
     }
 
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if args.step == 2:
+        out["metric"] = "power-series iterations/s (solve_joint terms per second, step 2)"
+        out["config"]["workload"] = out["config"]["workload"].replace("solve_pOSE", "solve_joint")
+    if args.robust_norm != "NONE":
+        out["config"]["robust_norm"] = f"{args.robust_norm}({args.huber})"
+    if rank == 0 and world == 1 and not args.no_secondary and args.step == 1:
         # secondary leg: the other E0 variant on the same state (also a full-size parity property:
         # both variants must give the same increment)
         other = capi.E0_TILES if mode == capi.E0_IMPLICIT else capi.E0_IMPLICIT
@@ -256,7 +277,7 @@ def main():
         }
         ctx.set_e0_mode(mode)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.step == 1:
         out["cpu_baseline"] = cpu_baseline(prob, alpha, lam, m)
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -238,3 +238,38 @@ def test_full_size_properties():
     xBx = sum(v @ np.linalg.solve(bi, v) for v, bi in zip(xb, binv))
     assert xBx > x @ ex
     ctx.close()
+
+
+def test_venice_size_properties():
+    """BASELINE.json's headline size (venice-1778 shape, 5M observations): size-independent
+    properties of the operator -- symmetry, positivity, agreement of the two E0 forms, bit
+    reproducibility -- and the robust (HUBER) path at scale."""
+    from povar_amd import capi, synth
+    p = synth.make_bal_problem("venice-1778")
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm="HUBER", huber=50.0)
+    ctx.set_cameras(p.cams)
+    ctx.init_landmarks_pose(ALPHA)
+    ri = ctx.error_pose(ALPHA)
+    assert ri.all_num_obs == p.n_obs and ri.is_numerically_valid == 1
+    assert ctx.linearize_pose(ALPHA)
+    ctx.prepare_pose(LAM)
+    rng = np.random.default_rng(2)
+    x, y = rng.normal(size=12 * p.n_cams), rng.normal(size=12 * p.n_cams)
+    ex, ey = ctx.right_mul_e0_pose(x), ctx.right_mul_e0_pose(y)
+    assert abs(y @ ex - x @ ey) <= 1e-10 * abs(y @ ex) and x @ ex > 0
+    assert np.array_equal(ctx.right_mul_e0_pose(x), ex)
+    inc_a, it, st, rc = ctx.solve_pose(LAM, 0, M)
+    assert rc == 0 and it == M
+    ctx.set_e0_mode(capi.E0_TILES)
+    assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-12
+    inc_b, _, _, _ = ctx.solve_pose(LAM, 0, M)
+    assert rel(inc_b, inc_a) < 1e-11
+    # accepted-step property of the model: apply, then the cost must be finite and the state moves
+    ctx.set_e0_mode(capi.E0_IMPLICIT)
+    ctx.backup_pose()
+    l_diff = ctx.apply_pose(0, ALPHA, inc_a)
+    ri2 = ctx.error_pose(ALPHA)
+    assert np.isfinite(l_diff) and ri2.is_numerically_valid == 1 and ri2.all_num_obs == p.n_obs
+    ctx.restore_pose()
+    assert abs(ctx.error_pose(ALPHA).all_error - ri.all_error) == 0
+    ctx.close()
