@@ -233,8 +233,8 @@ def main():
         "device_bytes": ctx.device_bytes(),
         "roofline": {
             "bound": "hbm",
-            "kernel": "E0 x (lm_regular<OpE0> + cm_scatter)" if mode == capi.E0_IMPLICIT
-                      else "E0 x (lm_regular<OpE0Tiles>)",
+            "kernel": "E0 x (e0_lm_cached + cm_scatter)" if mode == capi.E0_IMPLICIT
+                      else "E0 x (lm_regular<OpE0Tiles> + cm_scatter)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
