@@ -66,7 +66,9 @@ struct povar_ctx {
   int64_t n_obs = 0;
   int n_bins = 0, n_slots = 0, n_items = 0, n_long = 0;
   int n_reg_blocks = 0, n_cam_blocks = 0;
-  int n_hot = 0, e0c_grid = 0, e0c_bins_per_wg = 0;
+  int n_hot = 0, n_hot_acc = 0, e0c_grid = 0, e0c_bins_per_wg = 0;
+  int64_t n_cold = 0;
+  int n_cold_items = 0;
   povar_options opt{};
   hipStream_t stream = nullptr;
   size_t bytes = 0;
@@ -76,12 +78,12 @@ struct povar_ctx {
 
   // static
   DevBuf<double2> uv, cm_uv, tiles;
-  DevBuf<int> cam, lm, meta, hot_cams, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
+  DevBuf<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
       cam_item_off, flags;
   // state
   DevBuf<double4> cams4, cams_lin4, cams_bak4, lms4, lms_lin4, lms_bak4, jl_scale4, rres, q4;
   DevBuf<double> hll_inv, sw, sigma, diag2, G, binv, b, tmp, accum, z, y, inc, item_part,
-      item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec, ncw;
+      item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec, ncw, cc_h, cc_part, hot_part;
 
   Dp d{};
   bool new_linearization_point = false;  // linearizor_power_varproj.cpp:75, 192, 240
@@ -116,7 +118,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 struct Layout {
   std::vector<double2> uv, cm_uv;
-  std::vector<int> cam, lm, meta, hot_cams, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off,
+  std::vector<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off,
       item_cam, cam_item_off, slot_of_obs;
   int n_bins = 0;
 };
@@ -210,6 +212,27 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
     for (int r = 0; r < n_hot; ++r) rank[order[r]] = r + 1;
     for (size_t s = 0; s < n_slots; ++s)
       if (L.meta[s] & META_REAL) L.meta[s] |= rank[L.cam[s]] << META_HOT_SHIFT;
+    L.cam_hot = rank;
+    // "cold" camera-major structure for POVAR_E0_IMPLICIT_LDSACC: only the observations whose
+    // Jp^T s is NOT accumulated in LDS (camera outside the HOT_ACC_MAX hottest, or a long landmark,
+    // which the lm_long driver handles through q4)
+    const int n_acc = std::min(n_cams, HOT_ACC_MAX);
+    L.cc_cam_item_off.assign(n_cams + 1, 0);
+    for (int c = 0; c < n_cams; ++c) {
+      L.cc_cam_item_off[c] = (int)L.cc_item_off.size();
+      int64_t run = 0;
+      for (int64_t p = cnt[c]; p < cnt[c + 1]; ++p) {
+        const int s = L.cm_slot[p];
+        const bool acc = rank[c] > 0 && rank[c] <= n_acc && !(L.meta[s] & META_LONG);
+        if (acc) continue;
+        if (run % CM_ITEM_MAX == 0) L.cc_item_off.push_back((int)L.cc_slot.size());
+        L.cc_slot.push_back(s);
+        L.cc_lm.push_back(L.cm_lm[p]);
+        ++run;
+      }
+    }
+    L.cc_cam_item_off[n_cams] = (int)L.cc_item_off.size();
+    L.cc_item_off.push_back((int)L.cc_slot.size());
   }
   L.cam_item_off.assign(n_cams + 1, 0);
   L.item_off.clear();
@@ -271,6 +294,15 @@ int allreduce(povar_ctx* c, double* buf, size_t n) {
   return 0;
 }
 
+// Dp of the per-term kernels in POVAR_E0_IMPLICIT_LDSACC mode: cold camera-major view + hot partials
+Dp ldsacc_dp(povar_ctx* c) {
+  Dp dt = c->d;
+  dt.cmv = CmView{c->cc_slot.p, c->cc_h.p, c->n_cold, c->cc_item_off.p, c->cc_cam_item_off.p, c->cc_part.p,
+                  c->n_cold_items};
+  dt.hot_part = c->hot_part.p;
+  return dt;
+}
+
 // E0 x for the current term: implicit (LM pass, CM pass) or stored tiles.  The per-camera
 // result is consumed by cam_binv_axpy (mode 1: scatter items, mode 2: dense y).
 int launch_e0(povar_ctx* c, int* binv_mode) {
@@ -285,17 +317,22 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
     }
   } else {
     if (c->opt.e0_mode == POVAR_E0_TILES) launch_lm(c, OpE0Tiles{});
-    else {
-      hipLaunchKernelGGL(e0_lm_cached, dim3(c->e0c_grid), dim3(E0C_BLOCK),
-                         (size_t)c->n_hot * HOT_REC * sizeof(double2), c->stream, c->d, c->e0c_bins_per_wg);
-      if (c->n_long > 0)
-        hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0{}, c->part.p);
-    }
-    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 1);
-    *binv_mode = 1;
+    else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)
+      hipLaunchKernelGGL(e0_lm_cached<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
+                         (size_t)c->n_hot_acc * (HOT_REC * sizeof(double2) + 96), c->stream, c->d,
+                         c->e0c_bins_per_wg, c->hot_part.p);
+    else
+      hipLaunchKernelGGL(e0_lm_cached<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
+                         (size_t)c->n_hot * HOT_REC * sizeof(double2), c->stream, c->d, c->e0c_bins_per_wg,
+                         (double*)nullptr);
+    if (c->opt.e0_mode != POVAR_E0_TILES && c->n_long > 0)
+      hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0{}, c->part.p);
+    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+    const Dp dt = acc ? ldsacc_dp(c) : c->d;
+    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(dt.cmv.n_items, 1), 4)), dim3(256), 0, c->stream, dt, 1);
+    *binv_mode = acc ? 3 : 1;
     if (c->comm) {
-      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d,
-                         c->d.y, 1);
+      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, dt, c->d.y, 1);
       *binv_mode = 2;
     }
   }
@@ -311,9 +348,11 @@ void launch_binv(povar_ctx* c, int mode, int want_norms) {
   if (c->joint)
     hipLaunchKernelGGL(cam_binv_axpy_h, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, c->d, mode,
                        want_norms, (const double*)c->ncw.p);
-  else
-    hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, c->d, mode,
+  else {
+    const Dp dt = mode == 3 ? ldsacc_dp(c) : c->d;  // 3: item sums over the cold view + LDS partials
+    hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, dt, mode == 3 ? 1 : mode,
                        want_norms);
+  }
 }
 
 int ensure_tiles(povar_ctx* c) {
@@ -415,13 +454,17 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     c->e0c_bins_per_wg = std::max((c->n_bins + cus - 1) / cus, 1);
     c->e0c_grid = (c->n_bins + c->e0c_bins_per_wg - 1) / c->e0c_bins_per_wg;
     c->n_hot = (int)L.hot_cams.size();
-    HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_MAX * HOT_REC * (int)sizeof(double2)));
+    HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HOT_ACC_MAX * (HOT_REC * (int)sizeof(double2) + 96)));
   }
 
   int rc = 0;
   if ((rc = upload(c->uv, L.uv, c)) || (rc = upload(c->cam, L.cam, c)) || (rc = upload(c->lm, L.lm, c)) ||
-      (rc = upload(c->meta, L.meta, c)) || (rc = upload(c->hot_cams, L.hot_cams, c)) || (rc = upload(c->long_lm, L.long_lm, c)) ||
+      (rc = upload(c->meta, L.meta, c)) || (rc = upload(c->hot_cams, L.hot_cams, c)) || (rc = upload(c->cam_hot, L.cam_hot, c)) ||
+      (rc = upload(c->cc_slot, L.cc_slot, c)) || (rc = upload(c->cc_lm, L.cc_lm, c)) ||
+      (rc = upload(c->cc_item_off, L.cc_item_off, c)) || (rc = upload(c->cc_cam_item_off, L.cc_cam_item_off, c)) || (rc = upload(c->long_lm, L.long_lm, c)) ||
       (rc = upload(c->long_first, L.long_first, c)) || (rc = upload(c->long_cnt, L.long_cnt, c)) ||
       (rc = upload(c->cm_slot, L.cm_slot, c)) || (rc = upload(c->cm_lm, L.cm_lm, c)) ||
       (rc = upload(c->cm_uv, L.cm_uv, c)) || (rc = upload(c->item_off, L.item_off, c)) ||
@@ -447,6 +490,11 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(b, 12 * nc); ALLOC(tmp, 12 * nc); ALLOC(accum, 12 * nc); ALLOC(z, 12 * nc); ALLOC(y, 12 * nc);
   ALLOC(inc, 12 * nc);
   ALLOC(item_part, 12 * ni); ALLOC(item_partG, 40 * ni); ALLOC(cm_h, 4 * (size_t)n_obs); ALLOC(ncw, 13 * nc);
+  c->n_cold = (int64_t)L.cc_slot.size();
+  c->n_cold_items = (int)L.cc_item_off.size() - 1;
+  c->n_hot_acc = std::min(n_cams, HOT_ACC_MAX);
+  ALLOC(cc_h, 3 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
+  ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
   ALLOC(norm_part, 2 * (size_t)c->n_cam_blocks); ALLOC(norms, 4); ALLOC(flags, 4);
   ALLOC(part, n_part * 2); ALLOC(scal, 8);
   ALLOC(stage, std::max(3 * nl, 144 * nc));
@@ -466,6 +514,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.item_off = c->item_off.p; d.item_cam = c->item_cam.p; d.cam_item_off = c->cam_item_off.p;
   d.cams4 = c->cams4.p; d.cams_lin4 = c->cams_lin4.p; d.lms4 = c->lms4.p; d.lms_lin4 = c->lms_lin4.p;
   d.jl_scale4 = c->jl_scale4.p; d.hll_inv = c->hll_inv.p; d.lmrec = c->lmrec.p;
+  d.cmv = CmView{c->cm_slot.p, c->cm_h.p, n_obs, c->item_off.p, c->cam_item_off.p, c->item_part.p, c->n_items};
+  d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
   d.hot_cams = c->hot_cams.p; d.n_hot = (int)L.hot_cams.size();
   d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.tiles = nullptr;
   d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
@@ -494,7 +544,8 @@ void povar_destroy(povar_ctx* c) {
   c->hll_inv.release(); c->sw.release(); c->sigma.release(); c->diag2.release(); c->G.release();
   c->binv.release(); c->b.release(); c->tmp.release(); c->accum.release(); c->z.release(); c->y.release();
   c->inc.release(); c->item_part.release(); c->item_partG.release(); c->norm_part.release();
-  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->ncw.release(); c->hot_cams.release();
+  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->ncw.release(); c->cc_h.release(); c->cc_part.release(); c->hot_part.release();
+  c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -598,7 +649,9 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   launch_lm(c, OpLinearize{});
-  hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d);
+  hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cm_lm.p, c->cm_h.p, c->n_obs);
+  if (c->n_cold > 0)
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold);
   hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   if (c->comm) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
@@ -752,8 +805,10 @@ int povar_right_mul_e0_pose(povar_ctx* c, const double* x, double* y) {
   hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 1);
   int mode = 1;
   if (int rc = launch_e0(c, &mode)) return rc;
-  if (mode == 1)
-    hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.y, 1);
+  if (mode == 1 || mode == 3) {
+    const Dp dt = mode == 3 ? ldsacc_dp(c) : c->d;
+    hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, dt, c->d.y, 1);
+  }
   HIP_TRY(hipMemcpyAsync(y, c->y.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemsetAsync(c->y.p, 0, sizeof(double) * n, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -906,7 +961,7 @@ int povar_normalize_joint(povar_ctx* c) {
 
 int povar_set_e0_mode(povar_ctx* c, int32_t mode) {
   if (int rc = check_ctx(c)) return rc;
-  if (mode != POVAR_E0_IMPLICIT && mode != POVAR_E0_TILES) return fail(-1, "bad e0 mode");
+  if (mode != POVAR_E0_IMPLICIT && mode != POVAR_E0_TILES && mode != POVAR_E0_IMPLICIT_LDSACC) return fail(-1, "bad e0 mode");
   c->opt.e0_mode = mode;
   if (c->linearized) return ensure_tiles(c);
   return 0;

@@ -43,9 +43,21 @@ constexpr int TILE_PAIRS = 32;  // double2 pairs per observation in the blocked 
 constexpr int META_REAL = 1 << 16;
 constexpr int META_LONG = 1 << 17;
 constexpr int META_HOT_SHIFT = 18;
+constexpr int HOT_ACC_MAX = 590;    // cameras cached AND accumulated in LDS: 590 * (176 + 96) B = 156.7 KiB
 constexpr int HOT_MAX = 912;        // cameras cached per workgroup: 912 * 176 B = 156.75 KiB of the 160 KiB LDS
 constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :3] (4.5) + pad
 constexpr int E0C_BLOCK = 1024;     // one workgroup per CU
+
+// one camera-major index structure: observations sorted by camera, cut into work items
+struct CmView {
+  const int* slot;         // [n] slot of the p-th observation in camera order
+  const double* h;         // [3][n] landmark x,y,z in the same order (per linearisation)
+  int64_t n;
+  const int* item_off;     // [n_items + 1]
+  const int* cam_item_off; // [n_cams + 1]
+  double* part;            // [n_items][12]
+  int n_items;
+};
 
 struct Dp {
   int n_cams, n_lms, n_bins, n_items, n_long, n_reg_blocks;
@@ -68,6 +80,11 @@ struct Dp {
   const int* item_off;
   const int* item_cam;
   const int* cam_item_off;
+  CmView cmv;            // what cm_scatter and the per-camera item sums walk
+  // LDS-accumulated partial sums of the hottest cameras (POVAR_E0_IMPLICIT_LDSACC), else nullptr
+  const double* hot_part;  // [n_hot_wg][n_hot_acc][12]
+  const int* cam_hot;      // [n_cams] 1 + rank in the LDS cache, 0 = not cached
+  int n_hot_acc, n_hot_wg;
   // state
   double4* cams4;      // [n_cams][3]
   double4* cams_lin4;  // cameras at the linearisation point
@@ -642,13 +659,18 @@ struct OpE0 {
 // profiles/r01_b_*): the records of the HOT_MAX most observed cameras are therefore staged in LDS
 // once per launch (<= 157 KiB, read back from L2) and only observations of colder cameras gather
 // from global memory.
-__global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg) {
+template <bool ACC>
+__global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg, double* hot_out) {
   if (d.flags[1]) return;
-  extern __shared__ double2 hot[];  // [n_hot][HOT_REC]
+  extern __shared__ double2 hot[];  // [n_hot][HOT_REC] (+ [n_hot][12] doubles of accumulators if ACC)
+  const int n_hot = ACC ? d.n_hot_acc : d.n_hot;
+  double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC);
+  if (ACC)
+    for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) acc[i] = 0;
   {
     const double2* z2 = reinterpret_cast<const double2*>(d.z);
     const double* cl = reinterpret_cast<const double*>(d.cams_lin4);
-    for (int i = threadIdx.x; i < d.n_hot * HOT_REC; i += E0C_BLOCK) {
+    for (int i = threadIdx.x; i < n_hot * HOT_REC; i += E0C_BLOCK) {
       const int r = i / HOT_REC, j = i - r * HOT_REC;
       const int c = d.hot_cams[r];
       double2 v;
@@ -695,7 +717,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg)
     if (valid) {
       double P3[9], zz[12];
       const int hr = (meta >> META_HOT_SHIFT);
-      if (hr > 0) {
+      if (hr > 0 && hr <= n_hot) {
         const double2* h = hot + (hr - 1) * HOT_REC;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -716,7 +738,27 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg)
       core.forward(d, P3, zz, rec0, rec1, uv, d.robust ? d.sw[slot] : 1.0, red);
     }
     seg_reduce<3>(red, lane, seg_first, seg_last);
-    if (valid) d.q4[slot] = core.backward(d, rec1, rec2, uv, red);
+    if (valid) {
+      const double4 q = core.backward(d, rec1, rec2, uv, red);
+      const int hr = (meta >> META_HOT_SHIFT);
+      if (ACC && hr > 0 && hr <= n_hot) {
+        // Jp^T s of a cached camera goes straight into the workgroup's LDS accumulator
+        // (ds_add_f64, order not fixed); only colder cameras go through q4 + cm_scatter
+        double* a = acc + 12 * (hr - 1);
+        const double hx = rec0.x, hy = rec0.y, hz = rec0.z;
+        const double v[12] = {hx * q.x, hy * q.x, hz * q.x, q.x, hx * q.y, hy * q.y,
+                              hz * q.y, q.y, hx * q.z, hy * q.z, hz * q.z, q.z};
+#pragma unroll
+        for (int j = 0; j < 12; ++j) __hip_atomic_fetch_add(a + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        d.q4[slot] = q;
+      }
+    }
+  }
+  if (ACC) {
+    __syncthreads();
+    double* out = hot_out + (size_t)blockIdx.x * n_hot * 12;
+    for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) out[i] = acc[i];
   }
 }
 
@@ -966,8 +1008,8 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
   if (check_done && d.flags[1]) return;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (item >= d.n_items) return;
-  const int b = d.item_off[item], e = d.item_off[item + 1];
+  if (item >= d.cmv.n_items) return;
+  const int b = d.cmv.item_off[item], e = d.cmv.item_off[item + 1];
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0;
@@ -981,10 +1023,10 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
       const int p = p0 + u * WAVE;
       const bool in = p < e;
       const int pc = in ? p : b;
-      sl[u] = in ? d.cm_slot[pc] : -1;
-      hx[u] = d.cm_h[pc];
-      hy[u] = d.cm_h[d.n_obs + pc];
-      hz[u] = d.cm_h[2 * d.n_obs + pc];
+      sl[u] = in ? d.cmv.slot[pc] : -1;
+      hx[u] = d.cmv.h[pc];
+      hy[u] = d.cmv.h[d.cmv.n + pc];
+      hz[u] = d.cmv.h[2 * d.cmv.n + pc];
     }
     double4 q[U];
 #pragma unroll
@@ -999,19 +1041,19 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
   wave_sum<12>(acc);
   if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) d.item_part[12 * (size_t)item + k] = acc[k];
+    for (int k = 0; k < 12; ++k) d.cmv.part[12 * (size_t)item + k] = acc[k];
   }
 }
 
 // landmark coordinates at the linearisation point, copied into camera-major order once per
 // linearisation so the per-term camera-major pass streams them instead of gathering
-__global__ __launch_bounds__(256) void cm_build_h(Dp d) {
+__global__ __launch_bounds__(256) void cm_build_h(Dp d, const int* lm_of, double* out, int64_t n) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= d.n_obs) return;
-  const double4 h = d.lms_lin4[d.cm_lm[p]];
-  d.cm_h[p] = h.x;
-  d.cm_h[d.n_obs + p] = h.y;
-  d.cm_h[2 * d.n_obs + p] = h.z;
+  if (p >= n) return;
+  const double4 h = d.lms_lin4[lm_of[p]];
+  out[p] = h.x;
+  out[n + p] = h.y;
+  out[2 * n + p] = h.z;
 }
 
 // Camera-block Gram sums of the unscaled weighted Jp: Jp^T Jp = w * (C (x) h h^T) with
@@ -1147,20 +1189,36 @@ __global__ __launch_bounds__(K8_THREADS) void cam_build_binv(Dp d, double lambda
 #undef X_
 }
 
+// fixed-order sum of a camera's scatter items (+ the LDS-accumulated workgroup partials of a cached
+// camera): lanes stride over the parts, then a butterfly; every lane ends with the 12 sums
+__device__ inline void camera_item_sum(const Dp& d, int c, int lane, double (&y)[12]) {
+#pragma unroll
+  for (int j = 0; j < 12; ++j) y[j] = 0;
+  for (int it = d.cmv.cam_item_off[c] + lane; it < d.cmv.cam_item_off[c + 1]; it += WAVE) {
+    const double* ip = d.cmv.part + 12 * (size_t)it;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) y[j] += ip[j];
+  }
+  if (d.hot_part) {
+    const int r = d.cam_hot[c];
+    if (r > 0 && r <= d.n_hot_acc) {
+      for (int w = lane; w < d.n_hot_wg; w += WAVE) {
+        const double* ip = d.hot_part + ((size_t)w * d.n_hot_acc + (r - 1)) * 12;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) y[j] += ip[j];
+      }
+    }
+  }
+  wave_sum<12>(y);
+}
+
 // b_c = sigma * sum_items (scatter parts)   (landmark_block.hpp:529-534); one wavefront per camera
 __global__ __launch_bounds__(256) void cam_sum_items(Dp d, double* out, int apply_sigma) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.n_cams) return;
   double y[12];
-#pragma unroll
-  for (int j = 0; j < 12; ++j) y[j] = 0;
-  for (int it = d.cam_item_off[c] + lane; it < d.cam_item_off[c + 1]; it += WAVE) {
-    const double* ip = d.item_part + 12 * (size_t)it;
-#pragma unroll
-    for (int j = 0; j < 12; ++j) y[j] += ip[j];
-  }
-  wave_sum<12>(y);
+  camera_item_sum(d, c, lane, y);
   if (lane < 12) {
     double v = 0;
 #pragma unroll
@@ -1189,13 +1247,7 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, in
 #pragma unroll
       for (int j = 0; j < 12; ++j) y[j] = -d.b[base + j];
     } else if (mode == 1) {
-      // fixed-order sum of the camera's scatter items: lanes stride over items, then a butterfly
-      for (int it = d.cam_item_off[c] + lane; it < d.cam_item_off[c + 1]; it += WAVE) {
-        const double* ip = d.item_part + 12 * (size_t)it;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) y[j] += ip[j];
-      }
-      wave_sum<12>(y);
+      camera_item_sum(d, c, lane, y);
 #pragma unroll
       for (int j = 0; j < 12; ++j) y[j] *= d.sigma[base + j];
     } else {

@@ -68,7 +68,7 @@ def test_linearize_prepare_buffers(norm, small_problem):
     ctx.close()
 
 
-@pytest.mark.parametrize("e0_mode", [0, 1])
+@pytest.mark.parametrize("e0_mode", [0, 1, 2])
 @pytest.mark.parametrize("which", ["small", "medium"])
 def test_power_series_term_by_term(which, e0_mode, small_problem, medium_problem):
     p = small_problem if which == "small" else medium_problem
@@ -152,7 +152,7 @@ def test_long_landmarks():
     obs = rng.normal(scale=100.0, size=(cam_idx.shape[0], 2))
     from povar_amd import capi
     from oracle import povar_oracle as O
-    for e0_mode in (0, 1):
+    for e0_mode in (0, 1, 2):
         orc = O.Oracle(n_c, lm_off, cam_idx, obs)
         ctx = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=e0_mode)
         lms = orc.init_landmarks_pose(ALPHA, base.cams)
@@ -228,10 +228,11 @@ def test_full_size_properties():
     assert x @ ex > 0
     assert np.array_equal(ctx.right_mul_e0_pose(x), ex)  # deterministic (no atomics on the path)
     inc_a, it, st, rc = ctx.solve_pose(LAM, 0, M)
-    ctx.set_e0_mode(capi.E0_TILES)
-    assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-13
-    inc_b, _, _, _ = ctx.solve_pose(LAM, 0, M)
-    assert rc == 0 and rel(inc_b, inc_a) < 1e-12
+    for mode in (capi.E0_TILES, capi.E0_IMPLICIT_LDSACC):
+        ctx.set_e0_mode(mode)
+        assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-13
+        inc_b, _, _, _ = ctx.solve_pose(LAM, 0, M)
+        assert rc == 0 and rel(inc_b, inc_a) < 1e-12
     # S = B - E0 is positive definite: x^T B x > x^T E0 x with B^-1 from the library
     binv = ctx.get_buffer(capi.BUF_B_INV).reshape(p.n_cams, 12, 12)
     xb = x.reshape(p.n_cams, 12)
@@ -260,10 +261,11 @@ def test_venice_size_properties():
     assert np.array_equal(ctx.right_mul_e0_pose(x), ex)
     inc_a, it, st, rc = ctx.solve_pose(LAM, 0, M)
     assert rc == 0 and it == M
-    ctx.set_e0_mode(capi.E0_TILES)
-    assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-12
-    inc_b, _, _, _ = ctx.solve_pose(LAM, 0, M)
-    assert rel(inc_b, inc_a) < 1e-11
+    for mode in (capi.E0_TILES, capi.E0_IMPLICIT_LDSACC):
+        ctx.set_e0_mode(mode)
+        assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-12
+        inc_b, _, _, _ = ctx.solve_pose(LAM, 0, M)
+        assert rel(inc_b, inc_a) < 1e-11
     # accepted-step property of the model: apply, then the cost must be finite and the state moves
     ctx.set_e0_mode(capi.E0_IMPLICIT)
     ctx.backup_pose()
