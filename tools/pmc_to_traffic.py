@@ -32,7 +32,7 @@ def main():
     if os.path.exists(out):
         data = json.load(open(out))
     problem, mode, world = key.split(":")
-    lm = [k for k in e0 if ("e0_lm_cached" in k if mode == "implicit" else "OpE0Tiles" in k)]
+    lm = [k for k in e0 if ("e0_lm_cached" in k if mode != "tiles" else "OpE0Tiles" in k)]
     cm = [k for k in e0 if "cm_scatter" in k]
     data[key] = sum(table[k]["hbm_bytes"] for k in lm + cm)
     data.setdefault("_per_kernel", {})[key] = {k: table[k] for k in lm + cm}
