@@ -180,6 +180,17 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
         L.meta[s] = seg_first[i] | (seg_last[i] << 8) | META_REAL;
       }
     }
+  // per bin: number of doubling steps the segmented scans need = ceil(log2(longest landmark))
+  for (int b = 0; b < L.n_bins; ++b) {
+    int mx = 1;
+    for (int l = 0; l < WAVE; ++l) {
+      const int m = L.meta[(size_t)b * WAVE + l];
+      if ((m & META_REAL) && !(m & META_LONG)) mx = std::max(mx, ((m >> 8) & 255) - (m & 255) + 1);
+    }
+    int steps = 0;
+    while ((1 << steps) < mx) ++steps;
+    for (int l = 0; l < WAVE; ++l) L.meta[(size_t)b * WAVE + l] |= steps << META_STEPS_SHIFT;
+  }
   // pass 2: camera-major inverse index, ascending slot order inside a camera, cut into work
   // items of at most CM_ITEM_MAX observations of one camera.
   std::vector<int64_t> cnt(n_cams + 1, 0);

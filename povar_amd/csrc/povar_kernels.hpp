@@ -42,7 +42,9 @@ constexpr int TILE_PAIRS = 32;  // double2 pairs per observation in the blocked 
 // a long (>64 obs) landmark, bits 18-31 = 1 + rank of the camera in the LDS camera cache (0: not cached)
 constexpr int META_REAL = 1 << 16;
 constexpr int META_LONG = 1 << 17;
-constexpr int META_HOT_SHIFT = 18;
+constexpr int META_HOT_SHIFT = 18;     // 10 bits
+constexpr int META_HOT_MASK = 1023;
+constexpr int META_STEPS_SHIFT = 28;   // 3 bits: ceil(log2(longest landmark of the bin)), same in every lane of a bin
 constexpr int HOT_ACC_MAX = 590;    // cameras cached AND accumulated in LDS: 590 * (176 + 96) B = 156.7 KiB
 constexpr int HOT_MAX = 912;        // cameras cached per workgroup: 912 * 176 B = 156.75 KiB of the 160 KiB LDS
 constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :3] (4.5) + pad
@@ -253,6 +255,23 @@ __device__ inline void seg_reduce(double (&v)[N], int lane, int seg_first, int s
   for (int k = 0; k < N; ++k) v[k] = shfl_d(v[k], seg_last);
 }
 
+// same, with the number of doubling steps bounded by the longest segment of the wavefront
+// (wave-uniform): landmarks average 4-6 observations, so 3-4 steps instead of 6
+template <int N>
+__device__ inline void seg_reduce_steps(double (&v)[N], int lane, int seg_first, int seg_last, int steps) {
+  for (int s = 0; s < steps; ++s) {
+    const int dlt = 1 << s;
+    const bool take = lane - dlt >= seg_first;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double o = shfl_up_d(v[k], dlt);
+      if (take) v[k] += o;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = shfl_d(v[k], seg_last);
+}
+
 template <int N>
 __device__ inline void wave_sum(double (&v)[N]) {
 #pragma unroll
@@ -313,7 +332,9 @@ __global__ __launch_bounds__(LM_BLOCK) void lm_regular(Dp d, Op op, double* part
 #pragma unroll
   for (int k = 0; k < (Op::NRED > 0 ? Op::NRED : 1); ++k) red[k] = 0;
   if (valid) op.phase1(d, slot, cam, lm, uv, L, red);
-  if constexpr (Op::NRED > 0) seg_reduce<Op::NRED>(red, lane, seg_first, seg_last);
+  if constexpr (Op::NRED > 0)
+    seg_reduce_steps<Op::NRED>(red, lane, seg_first, seg_last,
+                               __builtin_amdgcn_readfirstlane((meta >> META_STEPS_SHIFT) & 7));
   double sc[Op::NSC > 0 ? Op::NSC : 1];
 #pragma unroll
   for (int k = 0; k < (Op::NSC > 0 ? Op::NSC : 1); ++k) sc[k] = 0;
@@ -699,15 +720,22 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
     const int s = (bin0 + wave) * WAVE + lane;
     n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
   }
+  // ... and the landmark record of the next bin is requested in the middle of the current bin
+  // (after the forward products, when the next slot data has arrived)
+  double4 n_rec0, n_rec1, n_rec2;
+  {
+    const bool v0 = (n_meta & META_REAL) && !(n_meta & META_LONG);
+    const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 3 * (size_t)(v0 ? n_lm : 0);
+    n_rec0 = rec[0]; n_rec1 = rec[1]; n_rec2 = rec[2];
+  }
   for (int bin = bin0 + wave; bin < bin1; bin += STRIDE) {
     const int slot = bin * WAVE + lane;
     const int meta = n_meta, cam = n_cam, lm = n_lm;
     const double2 uv = n_uv;
     const bool valid = (meta & META_REAL) && !(meta & META_LONG);
     const int seg_first = meta & 255, seg_last = (meta >> 8) & 255;
-    // record of the current bin first (its address is known), then the next bin's slot data
-    const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 3 * (size_t)(valid ? lm : 0);
-    const double4 rec0 = rec[0], rec1 = rec[1], rec2 = rec[2];
+    const double4 rec0 = n_rec0, rec1 = n_rec1, rec2 = n_rec2;
+    (void)lm;
     if (bin + STRIDE < bin1) {
       const int s = slot + STRIDE * WAVE;
       n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
@@ -716,7 +744,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
     E0Core core;
     if (valid) {
       double P3[9], zz[12];
-      const int hr = (meta >> META_HOT_SHIFT);
+      const int hr = ((meta >> META_HOT_SHIFT) & META_HOT_MASK);
       if (hr > 0 && hr <= n_hot) {
         const double2* h = hot + (hr - 1) * HOT_REC;
 #pragma unroll
@@ -737,19 +765,25 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
       }
       core.forward(d, P3, zz, rec0, rec1, uv, d.robust ? d.sw[slot] : 1.0, red);
     }
-    seg_reduce<3>(red, lane, seg_first, seg_last);
+    if (bin + STRIDE < bin1) {
+      const bool vn = (n_meta & META_REAL) && !(n_meta & META_LONG);
+      const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 3 * (size_t)(vn ? n_lm : 0);
+      n_rec0 = rec[0]; n_rec1 = rec[1]; n_rec2 = rec[2];
+    }
+    seg_reduce_steps<3>(red, lane, seg_first, seg_last,
+                        __builtin_amdgcn_readfirstlane((meta >> META_STEPS_SHIFT) & 7));
     if (valid) {
       const double4 q = core.backward(d, rec1, rec2, uv, red);
-      const int hr = (meta >> META_HOT_SHIFT);
+      const int hr = ((meta >> META_HOT_SHIFT) & META_HOT_MASK);
       if (ACC && hr > 0 && hr <= n_hot) {
         // Jp^T s of a cached camera goes straight into the workgroup's LDS accumulator
         // (ds_add_f64, order not fixed); only colder cameras go through q4 + cm_scatter
-        double* a = acc + 12 * (hr - 1);
+        double* a = acc + (hr - 1);  // acc[j][camera]: consecutive cameras on consecutive banks
         const double hx = rec0.x, hy = rec0.y, hz = rec0.z;
         const double v[12] = {hx * q.x, hy * q.x, hz * q.x, q.x, hx * q.y, hy * q.y,
                               hz * q.y, q.y, hx * q.z, hy * q.z, hz * q.z, q.z};
 #pragma unroll
-        for (int j = 0; j < 12; ++j) __hip_atomic_fetch_add(a + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int j = 0; j < 12; ++j) __hip_atomic_fetch_add(a + j * n_hot, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
         d.q4[slot] = q;
       }
@@ -758,7 +792,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
   if (ACC) {
     __syncthreads();
     double* out = hot_out + (size_t)blockIdx.x * n_hot * 12;
-    for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) out[i] = acc[i];
+    // LDS holds acc[j][camera]; the partials go out as [camera][12] so a camera's 12 sums are one 96-byte read
+    for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) out[i] = acc[(i % 12) * n_hot + i / 12];
   }
 }
 
