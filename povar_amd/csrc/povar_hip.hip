@@ -103,6 +103,7 @@ struct povar_ctx {
   int series_graph_key[6] = {0, 0, 0, 0, 0, 0};
   double series_graph_tol[2] = {0, 0};
   bool use_graph = true;
+  bool graph_with_comm = false;
 
   // profiling
   bool profile = false;
@@ -447,6 +448,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   c->lm_off.assign(lm_offsets, lm_offsets + n_lms + 1);
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
+  if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
 
   Layout L;
   build_layout(n_cams, n_lms, lm_offsets, cam_idx, obs, L);
@@ -740,7 +742,9 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (int rc = check_ctx(c)) return rc;
   if (m < 0) return fail(-1, "power_sc_iterations < 0");
   const bool norms = q_tol > 0 || r_tol > 0;
-  if (c->use_graph && !c->profile && m > 0) {
+  // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
+  // RCCL-in-capture is not something a 1-GPU box can validate); POVAR_GRAPH_COMM=1 opts in
+  if (c->use_graph && !c->profile && m > 0 && (!c->comm || c->graph_with_comm)) {
     // the whole loop (memset, B^-1, m x {E0 kernels, [all-reduce], B^-1 + AXPY, [check]}) is one graph
     // launch; it is re-captured only when a kernel argument changes
     const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode, c->comm ? 1 : 0, norms ? 1 : 0, r_tol > 0 ? 1 : 0};
