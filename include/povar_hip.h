@@ -185,6 +185,10 @@ int povar_shard_range(int32_t n_lms, const int32_t* lm_offsets, int32_t world, i
                       int32_t* lm_begin, int32_t* lm_end);
 int povar_comm_unique_id(uint8_t id[128]);
 int povar_comm_init(povar_ctx* ctx, int32_t world, int32_t rank, const uint8_t id[128]);
+/* same exchange steps through a caller-supplied host all-reduce (sum, in place) instead of RCCL:
+ * lets an MPI/gloo launcher or an in-process test stand in for the communicator */
+typedef void (*povar_allreduce_fn)(double* buf, int64_t n, void* user);
+int povar_comm_init_host(povar_ctx* ctx, int32_t world, int32_t rank, povar_allreduce_fn fn, void* user);
 
 #ifdef __cplusplus
 }

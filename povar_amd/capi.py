@@ -284,6 +284,13 @@ class Context:
     def device_bytes(self):
         return int(self.L.povar_device_bytes(self.h))
 
+    def comm_init_host(self, world, rank, fn):
+        """fn(buf: np.ndarray) sums buf in place over the ranks (host all-reduce hook)."""
+        def _cb(ptr, n, user):
+            fn(np.ctypeslib.as_array(ptr, shape=(n,)))
+        self._cb = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64, C.c_void_p)(_cb)
+        self._chk(self.L.povar_comm_init_host(self.h, C.c_int32(world), C.c_int32(rank), self._cb, None))
+
     def comm_init(self, world, rank, uid: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._chk(self.L.povar_comm_init(self.h, C.c_int32(world), C.c_int32(rank), buf))

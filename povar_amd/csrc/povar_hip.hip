@@ -95,6 +95,9 @@ struct povar_ctx {
 
   // multi-GPU
   ncclComm_t comm = nullptr;
+  povar_allreduce_fn host_fn = nullptr;  // caller-supplied exchange (povar_comm_init_host)
+  void* host_user = nullptr;
+  std::vector<double> host_stage;
   int world = 1, rank = 0;
 
   // hipGraph of the m-term series loop (launch-bound on small problems and at 8 GPUs)
@@ -299,7 +302,19 @@ void prof_mark(povar_ctx* c, int kind) {
   ++c->ev_used;
 }
 
+bool sharded(const povar_ctx* c) { return c->comm != nullptr || c->host_fn != nullptr; }
+
 int allreduce(povar_ctx* c, double* buf, size_t n) {
+  if (c->host_fn) {
+    prof_mark(c, 2);
+    c->host_stage.resize(n);
+    HIP_TRY(hipMemcpyAsync(c->host_stage.data(), buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->host_fn(c->host_stage.data(), (int64_t)n, c->host_user);
+    HIP_TRY(hipMemcpyAsync(buf, c->host_stage.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+  }
   if (!c->comm) return 0;
   prof_mark(c, 2);
   NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c->comm, c->stream));
@@ -315,6 +330,19 @@ Dp ldsacc_dp(povar_ctx* c) {
   return dt;
 }
 
+// OR of a per-rank failure flag over the ranks (is_numerically_valid, linearisation failure)
+int combine_flag(povar_ctx* c, int* flag) {
+  if (!sharded(c)) return 0;
+  double v = *flag ? 1.0 : 0.0;
+  HIP_TRY(hipMemcpyAsync(c->scal.p + 7, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = allreduce(c, c->scal.p + 7, 1)) return rc;
+  HIP_TRY(hipMemcpyAsync(&v, c->scal.p + 7, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *flag = v > 0 ? 1 : 0;
+  return 0;
+}
+
 // E0 x for the current term: implicit (LM pass, CM pass) or stored tiles.  The per-camera
 // result is consumed by cam_binv_axpy (mode 1: scatter items, mode 2: dense y).
 int launch_e0(povar_ctx* c, int* binv_mode) {
@@ -323,7 +351,7 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
     launch_lm(c, OpE0H{});
     hipLaunchKernelGGL(cm_scatter_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 1);
     *binv_mode = 1;
-    if (c->comm) {
+    if (sharded(c)) {
       hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.y, 1);
       *binv_mode = 2;
     }
@@ -343,12 +371,12 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
     const Dp dt = acc ? ldsacc_dp(c) : c->d;
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(dt.cmv.n_items, 1), 4)), dim3(256), 0, c->stream, dt, 1);
     *binv_mode = acc ? 3 : 1;
-    if (c->comm) {
+    if (sharded(c)) {
       hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, dt, c->d.y, 1);
       *binv_mode = 2;
     }
   }
-  if (c->comm) {
+  if (sharded(c)) {
     int rc = allreduce(c, c->d.y, 12 * (size_t)c->n_cams);
     if (rc) return rc;
   }
@@ -643,6 +671,7 @@ int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
   int f[4];
   HIP_TRY(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   if (int rc = read_flags(c, f)) return rc;
+  if (int rc = combine_flag(c, &f[0])) return rc;
   out->all_num_obs = (int64_t)std::llround(h[2]);
   out->all_error = h[0];
   out->all_residual_sum = h[1];
@@ -666,7 +695,7 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   if (c->n_cold > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold);
   hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
-  if (c->comm) {
+  if (sharded(c)) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
     hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)nullptr);
     if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
@@ -677,6 +706,7 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   HIP_TRY(hipGetLastError());
   int f[4];
   if (int rc = read_flags(c, f)) return rc;
+  if (int rc = combine_flag(c, &f[0])) return rc;
   c->new_linearization_point = true;
   c->linearized = true;
   c->tiles_valid = false;
@@ -744,10 +774,10 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   const bool norms = q_tol > 0 || r_tol > 0;
   // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
   // RCCL-in-capture is not something a 1-GPU box can validate); POVAR_GRAPH_COMM=1 opts in
-  if (c->use_graph && !c->profile && m > 0 && (!c->comm || c->graph_with_comm)) {
+  if (c->use_graph && !c->profile && m > 0 && !c->host_fn && (!c->comm || c->graph_with_comm)) {
     // the whole loop (memset, B^-1, m x {E0 kernels, [all-reduce], B^-1 + AXPY, [check]}) is one graph
     // launch; it is re-captured only when a kernel argument changes
-    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode, c->comm ? 1 : 0, norms ? 1 : 0, r_tol > 0 ? 1 : 0};
+    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode, sharded(c) ? 1 : 0, norms ? 1 : 0, r_tol > 0 ? 1 : 0};
     const bool same = c->series_graph && std::memcmp(key, c->series_graph_key, sizeof(key)) == 0 &&
                       std::memcmp(&c->d, &c->series_graph_d, sizeof(Dp)) == 0 &&
                       c->series_graph_tol[0] == q_tol && c->series_graph_tol[1] == r_tol;
@@ -889,6 +919,7 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
   int f[4];
   HIP_TRY(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   if (int rc = read_flags(c, f)) return rc;
+  if (int rc = combine_flag(c, &f[0])) return rc;
   out->all_error = h[0];
   out->all_residual_sum = h[1];
   out->all_num_obs = (int64_t)std::llround(h[2]);
@@ -908,13 +939,14 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   hipLaunchKernelGGL(cm_build_h4, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d);
   hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
-  if (c->comm) {
+  if (sharded(c)) {
     if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
     hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)c->d.G, c->ncw.p);
   }
   HIP_TRY(hipGetLastError());
   int f[4];
   if (int rc = read_flags(c, f)) return rc;
+  if (int rc = combine_flag(c, &f[0])) return rc;
   c->new_linearization_point = true;
   c->linearized = false;  // the step-1 linearisation is gone
   c->linearized_h = true;
@@ -1096,6 +1128,16 @@ int povar_comm_unique_id(uint8_t id[128]) {
   ncclUniqueId u;
   NCCL_TRY(ncclGetUniqueId(&u));
   std::memcpy(id, &u, 128);
+  return 0;
+}
+
+int povar_comm_init_host(povar_ctx* c, int32_t world, int32_t rank, povar_allreduce_fn fn, void* user) {
+  if (int rc = check_ctx(c)) return rc;
+  if (world < 1 || rank < 0 || rank >= world || !fn) return fail(-1, "bad communicator arguments");
+  c->host_fn = fn;
+  c->host_user = user;
+  c->world = world;
+  c->rank = rank;
   return 0;
 }
 

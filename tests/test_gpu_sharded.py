@@ -1,0 +1,136 @@
+"""The N > 1 path on ONE GPU: two landmark shards = two contexts driven by two threads, the
+exchange steps going through the host all-reduce hook (povar_comm_init_host) instead of RCCL.
+Every collective site of the library (linearise: Gram moments; prepare: b; each power-series term:
+E0 x; cost and l_diff scalars; failure flags) is exercised; the sharded results must equal the
+single-context ones to reduction-order tolerance (~1e-13)."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import rel
+
+pytestmark = pytest.mark.gpu
+ALPHA, LAM, M = 0.01, 1e-4, 20
+
+
+class HostAllReduce:
+    def __init__(self, world):
+        self.world, self.bar = world, threading.Barrier(world)
+        self.bufs = [None] * world
+
+    def fn(self, rank):
+        def f(buf):
+            self.bufs[rank] = buf.copy()
+            self.bar.wait()
+            tot = sum(self.bufs[r] for r in range(self.world))  # fixed order on every rank
+            self.bar.wait()
+            buf[:] = tot
+        return f
+
+
+@pytest.mark.parametrize("e0_mode", [0, 2])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pipeline_matches_single(world, e0_mode):
+    from povar_amd import capi, synth
+    p = synth.make_problem(60, 3000, 13000, seed=12)
+    ref = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=e0_mode)
+    ref.set_cameras(p.cams)
+    ref.init_landmarks_pose(ALPHA)
+    cost_ref = ref.error_pose(ALPHA)
+    assert ref.linearize_pose(ALPHA)
+    inc_ref, it, st, rc = ref.solve_pose(LAM, 0, M)
+    ldiff_ref = ref.apply_pose(0, ALPHA, inc_ref)
+    cost2_ref = ref.error_pose(ALPHA)
+    sigma_ref = ref.get_buffer(capi.BUF_POSE_SCALING)
+    lms_ref = ref.get_landmarks()
+    cams_ref = ref.get_cameras()
+    ref.close()
+
+    ar = HostAllReduce(world)
+    out = [None] * world
+
+    def worker(rank):
+        lb, le = capi.shard_range(p.lm_off, world, rank)
+        ob, oe = int(p.lm_off[lb]), int(p.lm_off[le])
+        ctx = capi.Context(p.n_cams, p.lm_off[lb:le + 1] - p.lm_off[lb], p.cam_idx[ob:oe], p.obs[ob:oe], e0_mode=e0_mode)
+        ctx.comm_init_host(world, rank, ar.fn(rank))
+        ctx.set_cameras(p.cams)
+        ctx.init_landmarks_pose(ALPHA)
+        cost = ctx.error_pose(ALPHA)
+        ok = ctx.linearize_pose(ALPHA)
+        inc, it, st, rc = ctx.solve_pose(LAM, 0, M)
+        ld = ctx.apply_pose(0, ALPHA, inc)
+        cost2 = ctx.error_pose(ALPHA)
+        out[rank] = dict(cost=cost, ok=ok, inc=inc, rc=rc, ld=ld, cost2=cost2, sigma=ctx.get_buffer(capi.BUF_POSE_SCALING),
+                         lms=ctx.get_landmarks(), cams=ctx.get_cameras(), range=(lb, le))
+        ctx.close()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert all(o is not None for o in out)
+    for r, o in enumerate(out):
+        assert o["ok"] and o["rc"] == 0
+        assert o["cost"].all_num_obs == p.n_obs and abs(o["cost"].all_error - cost_ref.all_error) <= 1e-12 * cost_ref.all_error
+        assert rel(o["sigma"], sigma_ref) < 1e-13
+        assert rel(o["inc"], inc_ref) < 1e-11
+        assert np.array_equal(o["inc"], out[0]["inc"])           # every rank holds the same replicated vector
+        assert abs(o["ld"] - ldiff_ref) <= 1e-10 * abs(ldiff_ref)
+        assert abs(o["cost2"].all_error - cost2_ref.all_error) <= 1e-10 * cost2_ref.all_error
+        assert rel(o["cams"], cams_ref) < 1e-12
+        lb, le = o["range"]
+        assert rel(o["lms"], lms_ref[lb:le]) < 1e-9
+
+
+def test_sharded_step2_matches_single():
+    from povar_amd import capi, synth
+    p = synth.make_problem(40, 2000, 8600, seed=13)
+    rng = np.random.default_rng(3)
+    cams = rng.normal(size=(p.n_cams, 12))
+    cams[:, 8:11] *= 0.1
+    cams[:, 11] = 5 + rng.random(p.n_cams)
+    cams /= np.linalg.norm(cams, axis=1, keepdims=True)
+    lms_h = np.concatenate([rng.normal(size=(p.n_lms, 3)), np.ones((p.n_lms, 1))], 1)
+    obs = p.obs / 500.0
+
+    def run(ctx, lb, le):
+        ctx.set_cameras(cams)
+        ctx.set_landmarks_homogeneous(lms_h[lb:le])
+        cost = ctx.error_homogeneous()
+        ok = ctx.linearize_homogeneous()
+        inc, it, st, rc = ctx.solve_joint(LAM, 10)
+        ld = ctx.apply_joint(inc)
+        ctx.normalize_joint()
+        return dict(cost=cost, ok=ok, inc=inc, rc=rc, ld=ld, cams=ctx.get_cameras(), lms=ctx.get_landmarks_homogeneous(),
+                    cost2=ctx.error_homogeneous())
+
+    ref_ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs)
+    ref = run(ref_ctx, 0, p.n_lms)
+    ref_ctx.close()
+    world = 2
+    ar = HostAllReduce(world)
+    out = [None] * world
+
+    def worker(rank):
+        lb, le = capi.shard_range(p.lm_off, world, rank)
+        ob, oe = int(p.lm_off[lb]), int(p.lm_off[le])
+        ctx = capi.Context(p.n_cams, p.lm_off[lb:le + 1] - p.lm_off[lb], p.cam_idx[ob:oe], obs[ob:oe])
+        ctx.comm_init_host(world, rank, ar.fn(rank))
+        out[rank] = run(ctx, lb, le)
+        out[rank]["range"] = (lb, le)
+        ctx.close()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    for o in out:
+        assert o is not None and o["ok"] and o["rc"] == 0
+        assert o["cost"].all_num_obs == p.n_obs and o["cost"].valid_num_obs == ref["cost"].valid_num_obs
+        assert abs(o["cost"].all_error - ref["cost"].all_error) <= 1e-12 * ref["cost"].all_error
+        assert rel(o["inc"], ref["inc"]) < 1e-10
+        assert abs(o["ld"] - ref["ld"]) <= 1e-9 * abs(ref["ld"])
+        assert rel(o["cams"], ref["cams"]) < 1e-12
+        lb, le = o["range"]
+        assert rel(o["lms"], ref["lms"][lb:le]) < 1e-9
+        assert abs(o["cost2"].all_error - ref["cost2"].all_error) <= 1e-8 * ref["cost2"].all_error
