@@ -240,7 +240,7 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
         const int s = L.cm_slot[p];
         const bool acc = rank[c] > 0 && rank[c] <= n_acc && !(L.meta[s] & META_LONG);
         if (acc) continue;
-        if (run % CM_ITEM_MAX == 0) L.cc_item_off.push_back((int)L.cc_slot.size());
+        if (run % CM_COLD_ITEM_MAX == 0) L.cc_item_off.push_back((int)L.cc_slot.size());
         L.cc_slot.push_back(s);
         L.cc_lm.push_back(L.cm_lm[p]);
         ++run;
@@ -541,6 +541,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(stage, std::max(3 * nl, 144 * nc));
 #undef ALLOC
   HIP_TRY(hipMemset(c->flags.p, 0, sizeof(int) * 4));
+  HIP_TRY(hipMemset(c->lms4.p, 0, sizeof(double4) * nl));
+  HIP_TRY(hipMemset(c->cams4.p, 0, sizeof(double4) * 3 * nc));
   HIP_TRY(hipMemset(c->y.p, 0, sizeof(double) * 12 * nc));
   HIP_TRY(hipMemset(c->q4.p, 0, sizeof(double4) * ns));
   HIP_TRY(hipMemset(c->sw.p, 0, sizeof(double) * ns));

@@ -36,6 +36,7 @@ namespace povar {
 constexpr int WAVE = 64;
 constexpr int LM_BLOCK = 256;   // 4 wave bins per workgroup
 constexpr int CM_ITEM_MAX = 512; // observations of one camera per CM work item
+constexpr int CM_COLD_ITEM_MAX = 128;  // same for the small "cold" view of the LDSACC mode (more, shorter waves)
 constexpr int TILE_PAIRS = 32;  // double2 pairs per observation in the blocked tile layout
 
 // meta[slot]: bits 0-7 seg_first lane, 8-15 seg_last lane, 16 = real observation, 17 = slot of
