@@ -540,13 +540,16 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(part, n_part * 2); ALLOC(scal, 8);
   ALLOC(stage, std::max(3 * nl, 144 * nc));
 #undef ALLOC
-  HIP_TRY(hipMemset(c->flags.p, 0, sizeof(int) * 4));
-  HIP_TRY(hipMemset(c->lms4.p, 0, sizeof(double4) * nl));
-  HIP_TRY(hipMemset(c->cams4.p, 0, sizeof(double4) * 3 * nc));
-  HIP_TRY(hipMemset(c->y.p, 0, sizeof(double) * 12 * nc));
-  HIP_TRY(hipMemset(c->q4.p, 0, sizeof(double4) * ns));
-  HIP_TRY(hipMemset(c->sw.p, 0, sizeof(double) * ns));
-  HIP_TRY(hipMemset(c->rres.p, 0, sizeof(double4) * ns));
+  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, c->stream));
+  HIP_TRY(hipMemsetAsync(c->lms4.p, 0, sizeof(double4) * nl, c->stream));
+  HIP_TRY(hipMemsetAsync(c->cams4.p, 0, sizeof(double4) * 3 * nc, c->stream));
+  HIP_TRY(hipMemsetAsync(c->y.p, 0, sizeof(double) * 12 * nc, c->stream));
+  HIP_TRY(hipMemsetAsync(c->q4.p, 0, sizeof(double4) * ns, c->stream));
+  HIP_TRY(hipMemsetAsync(c->sw.p, 0, sizeof(double) * ns, c->stream));
+  HIP_TRY(hipMemsetAsync(c->rres.p, 0, sizeof(double4) * ns, c->stream));
+  // every initialisation above (uploads on the null stream, memsets on the context's non-blocking
+  // stream) is complete before the context is handed out
+  HIP_TRY(hipDeviceSynchronize());
 
   Dp& d = c->d;
   d.n_cams = n_cams; d.n_lms = n_lms; d.n_bins = c->n_bins; d.n_items = c->n_items;
