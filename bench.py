@@ -58,8 +58,18 @@ def cpu_baseline(prob, alpha, lam, m, target_obs=400_000):
     st, diag2, jls, sigma, ok = orc.stage1_pose(alpha, prob.cams, lms)
     orc.scale_jp_cols_pose(st, sigma)
     hll, b, binv = orc.prepare_hb_pose(st, lam)
-    cores = os.cpu_count() or 1
-    orc.solve_pose(st, hll, binv, b, 2, n_threads=cores)  # warm-up
+    # the per-camera mutex makes the reference's scheme contention-bound on hub cameras: time a few
+    # thread counts on two terms and keep the fastest (the count used is reported as "cores")
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nt in sorted({ncpu, max(ncpu // 4, 1), min(16, ncpu), min(4, ncpu)}, reverse=True):
+        orc.solve_pose(st, hll, binv, b, 1, n_threads=nt)
+        t0 = time.perf_counter()
+        orc.solve_pose(st, hll, binv, b, 2, n_threads=nt)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+    cores = best[1]
     t0 = time.perf_counter()
     reps = 0
     while True:
@@ -76,6 +86,7 @@ def cpu_baseline(prob, alpha, lam, m, target_obs=400_000):
         "unit": "terms/s",
         "cores": cores,
         "kind": "port",
+        "host_cpus": ncpu,
         "sample": f"first {n_l} landmarks / {n_o} observations of the workload (all {prob.n_cams} cameras), "
                   f"{reps} solves x {m} terms in {dt:.1f} s = {terms_per_s_sample:.1f} terms/s on the sample, "
                   f"scaled by n_obs ratio {n_o}/{prob.n_obs}",

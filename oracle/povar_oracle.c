@@ -8,6 +8,7 @@
  *   LVP = sc/linearization_varproj.hpp              LPV = sc/linearization_power_varproj.hpp
  *   LZR = solver/linearizor_power_varproj.cpp       BBA = solver/bal_bundle_adjustment.cpp
  */
+#define _GNU_SOURCE /* pthread_barrier_t under -std=c11 */
 #include "povar_oracle.h"
 
 #include <math.h>
@@ -474,12 +475,60 @@ static void* e0_worker(void* arg) {
   return NULL;
 }
 
+/* persistent worker pool (the reference runs on TBB's pool: thread creation is not part of its
+ * per-term cost).  Workers park on a barrier pair; one pool per thread count, never torn down. */
+typedef struct {
+  int n;
+  pthread_t* th;
+  e0_job* jobs;
+  pthread_barrier_t start, done;
+} e0_pool;
+
+typedef struct {
+  e0_pool* pool;
+  int idx;
+} e0_pool_arg;
+
+static void* e0_pool_worker(void* arg) {
+  e0_pool_arg* a = (e0_pool_arg*)arg;
+  for (;;) {
+    pthread_barrier_wait(&a->pool->start);
+    e0_worker(&a->pool->jobs[a->idx]);
+    pthread_barrier_wait(&a->pool->done);
+  }
+  return NULL;
+}
+
+static e0_pool* get_pool(int n_threads) {
+  static e0_pool* pools[8];
+  static int n_pools = 0;
+  for (int i = 0; i < n_pools; ++i)
+    if (pools[i]->n == n_threads) return pools[i];
+  if (n_pools == 8) return NULL;
+  e0_pool* p = (e0_pool*)calloc(1, sizeof(e0_pool));
+  p->n = n_threads;
+  p->th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+  p->jobs = (e0_job*)calloc((size_t)n_threads, sizeof(e0_job));
+  pthread_barrier_init(&p->start, NULL, (unsigned)n_threads + 1);
+  pthread_barrier_init(&p->done, NULL, (unsigned)n_threads + 1);
+  for (int t = 0; t < n_threads; ++t) {
+    e0_pool_arg* a = (e0_pool_arg*)malloc(sizeof(e0_pool_arg));
+    a->pool = p;
+    a->idx = t;
+    pthread_create(&p->th[t], NULL, e0_pool_worker, a);
+  }
+  pools[n_pools++] = p;
+  return p;
+}
+
 /* right_mul_e0_pOSE with the reference's parallel structure: tbb::parallel_for over
  * landmark ranges (LPV:402-403) restated as contiguous ranges balanced by observation
- * count on n_threads pthreads; std::scoped_lock(pose_mutex_[c]) per observation (LPV:393-397). */
+ * count on n_threads pooled pthreads; std::scoped_lock(pose_mutex_[c]) per observation
+ * (LPV:393-397). */
 void orc_right_mul_e0_pose_mt(const orc_problem* p, const double* storage, const double* hll_inv,
                               const double* x, double* y, int32_t n_threads) {
-  if (n_threads <= 1) {
+  e0_pool* pool = n_threads > 1 ? get_pool(n_threads) : NULL;
+  if (!pool) {
     orc_right_mul_e0_pose(p, storage, hll_inv, x, y);
     return;
   }
@@ -491,21 +540,17 @@ void orc_right_mul_e0_pose_mt(const orc_problem* p, const double* storage, const
     for (int c = n_locks; c < p->n_cams; ++c) pthread_mutex_init(&locks[c], NULL);
     n_locks = p->n_cams;
   }
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
-  e0_job* jobs = (e0_job*)malloc(sizeof(e0_job) * (size_t)n_threads);
   int l = 0;
   for (int t = 0; t < n_threads; ++t) {
     const int64_t target = p->n_obs * (int64_t)(t + 1) / n_threads;
     int l1 = l;
     while (l1 < p->n_lms && p->lm_off[l1 + 1] <= target) ++l1;
     if (t == n_threads - 1) l1 = p->n_lms;
-    jobs[t] = (e0_job){p, storage, hll_inv, x, y, l, l1, locks};
+    pool->jobs[t] = (e0_job){p, storage, hll_inv, x, y, l, l1, locks};
     l = l1;
-    pthread_create(&th[t], NULL, e0_worker, &jobs[t]);
   }
-  for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
-  free(th);
-  free(jobs);
+  pthread_barrier_wait(&pool->start);
+  pthread_barrier_wait(&pool->done);
 }
 
 static double norm2(const double* v, size_t n) {

@@ -275,3 +275,36 @@ def test_venice_size_properties():
     ctx.restore_pose()
     assert abs(ctx.error_pose(ALPHA).all_error - ri.all_error) == 0
     ctx.close()
+
+
+def test_unobserved_cameras_and_two_view_landmarks():
+    """Edge cases of the layout: cameras that no landmark observes (empty camera-major segments,
+    sigma = 1/eps, B = lambda I) and a problem made of 2-observation landmarks only."""
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    rng = np.random.default_rng(9)
+    n_c, n_l = 12, 200
+    used = np.array([0, 2, 3, 5, 7, 8, 11])                      # cameras 1, 4, 6, 9, 10 are never observed
+    cam_idx = np.concatenate([np.sort(rng.choice(used, 2, replace=False)) for _ in range(n_l)]).astype(np.int32)
+    lm_off = (2 * np.arange(n_l + 1)).astype(np.int32)
+    obs = rng.normal(scale=50.0, size=(2 * n_l, 2))
+    cams = np.zeros((n_c, 12))
+    cams[:, :8] = rng.normal(size=(n_c, 8))
+    cams[:, 11] = 1.0
+    orc = O.Oracle(n_c, lm_off, cam_idx, obs)
+    for mode in (0, 1, 2):
+        ctx = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=mode)
+        ctx.set_cameras(cams)
+        ctx.init_landmarks_pose(ALPHA)
+        lms = orc.init_landmarks_pose(ALPHA, cams)
+        assert rel(ctx.get_landmarks(), lms) < 1e-7
+        ctx.set_landmarks(lms)
+        assert ctx.linearize_pose(ALPHA)
+        st, diag2, jls, sigma, hll, b, binv = _oracle_stage(orc, cams, lms, LAM)
+        ref, _, _, _ = orc.solve_pose(st, hll, binv, b, 10)
+        inc, it, stt, rc = ctx.solve_pose(LAM, 0, 10)
+        assert rc == 0 and rel(inc, ref) < 1e-10
+        assert rel(ctx.get_buffer(capi.BUF_POSE_SCALING), sigma) < 1e-13
+        unused = np.setdiff1d(np.arange(n_c), used)
+        assert np.all(inc.reshape(n_c, 12)[unused] == 0)         # b = 0 there, so the increment is exactly 0
+        ctx.close()
