@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--huber", type=float, default=1.0)
     ap.add_argument("--step", type=int, default=1, choices=[1, 2],
                     help="1: solve_pOSE (headline); 2: solve_joint of the projective refinement (secondary)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "gloo"],
+                    help="exchange steps of the sharded path: RCCL inside the library (default) or a host "
+                         "all-reduce over torch.distributed gloo (debug / boxes without a working fabric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the stored-tile comparison leg")
     args = ap.parse_args()
@@ -130,28 +133,61 @@ def main():
     prob = synth.make_bal_problem(args.problem)
     n_c, n_l, n_o = prob.n_cams, prob.n_lms, prob.n_obs
 
+    n_dev = capi.lib().povar_device_count()
+    if n_dev <= 0:
+        sys.exit("bench.py needs a HIP device")
+    # one rank per GPU; ranks share devices only when there are fewer GPUs than ranks (1-GPU test boxes)
+    device = local_rank % n_dev
     lb, le = capi.shard_range(prob.lm_off, world, rank)
     ob, oe = int(prob.lm_off[lb]), int(prob.lm_off[le])
     mode = {"implicit": capi.E0_IMPLICIT, "tiles": capi.E0_TILES, "ldsacc": capi.E0_IMPLICIT_LDSACC}[args.e0_mode]
     ctx = capi.Context(n_c, prob.lm_off[lb : le + 1] - prob.lm_off[lb], prob.cam_idx[ob:oe],
-                       prob.obs[ob:oe], device=local_rank, e0_mode=mode, robust_norm=args.robust_norm,
+                       prob.obs[ob:oe], device=device, e0_mode=mode, robust_norm=args.robust_norm,
                        huber=args.huber)
+    comm_used = "none"
     if world > 1 or os.environ.get("POVAR_FORCE_COMM"):
         # POVAR_FORCE_COMM=1 exercises the RCCL path with a 1-rank communicator (1-GPU boxes)
-        uid = [capi.comm_unique_id() if rank == 0 else None]
+        rccl_ok = args.comm == "rccl"
+        if rccl_ok:
+            try:
+                uid = [capi.comm_unique_id() if rank == 0 else None]
+                if dist is not None:
+                    dist.broadcast_object_list(uid, src=0)
+                # RCCL prints a version banner on stdout at communicator creation: keep stdout for the JSON line
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    ctx.comm_init(world, rank, uid[0])
+                finally:
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)  # the banner sits in C stdio's buffer: flush it to stderr now
+                    os.dup2(saved, 1)
+                    os.close(saved)
+            except capi.PovarError as e:  # pragma: no cover - needs a broken fabric
+                print(f"[bench] rank {rank}: RCCL communicator failed: {e}", file=sys.stderr)
+                rccl_ok = False
         if dist is not None:
-            dist.broadcast_object_list(uid, src=0)
-        # RCCL prints a version banner on stdout at communicator creation: keep stdout for the JSON line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            ctx.comm_init(world, rank, uid[0])
-        finally:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)  # the banner sits in C stdio's buffer: flush it to stderr now
-            os.dup2(saved, 1)
-            os.close(saved)
+            import torch
+            flag = torch.tensor([1 if rccl_ok else 0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            rccl_ok = bool(flag.item())
+        if rccl_ok:
+            comm_used = "rccl"
+        else:
+            # exchange steps through torch.distributed(gloo) on host buffers: same sharded algorithm, the
+            # collective is no longer RCCL -- reported in config.comm, never silent
+            import torch
+
+            def host_allreduce(buf):
+                t = torch.from_numpy(buf)
+                if dist is not None:
+                    dist.all_reduce(t)
+
+            ctx.comm_init_host(world, rank, host_allreduce)
+            comm_used = "gloo-host"
+            if rank == 0:
+                print("[bench] WARNING: exchange steps run over gloo on host buffers, not RCCL", file=sys.stderr)
 
     ctx.set_cameras(prob.cams)
     ctx.init_landmarks_pose(alpha)
@@ -236,8 +272,9 @@ def main():
             "workload": f"BAL {args.problem} shape ({n_c} cams / {n_l} landmarks / {n_o} obs), seeded synthetic, "
                         f"solve_pOSE with power_sc_iterations={m}, eta=0, lambda={lam}, alpha={alpha}",
             "e0_mode": args.e0_mode,
-            "parallelism": f"landmark shards x{world}, one RCCL all-reduce (12*n_cams f64) per term" if world > 1
+            "parallelism": f"landmark shards x{world}, one all-reduce (12*n_cams f64) per term" if world > 1
                            else "single GPU",
+            "comm": comm_used,
         },
         "spmv_effective_GBps": algorithmic_bytes_term(n_c, n_l, n_o) * value / 1e9,
         "kernel_ms": {"e0": e0_ms, "binv_axpy": binv_ms, "allreduce": comm_ms,

@@ -76,6 +76,8 @@ typedef struct {
 } povar_profile_info;
 
 const char* povar_last_error(void);
+/* number of visible HIP devices (0 without a GPU; < 0 on a runtime error) */
+int povar_device_count(void);
 
 /* LinearizorPowerVarproj ctor (linearizor_power_varproj.cpp:21-38) + LinearizationVarProj ctor /
  * allocate_landmark (linearization_varproj.hpp:42-61, landmark_block.hpp:101-133).

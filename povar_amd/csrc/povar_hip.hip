@@ -431,6 +431,12 @@ extern "C" {
 
 const char* povar_last_error(void) { return g_err.c_str(); }
 
+int povar_device_count(void) {
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  return n;
+}
+
 int povar_shard_range(int32_t n_lms, const int32_t* lm_offsets, int32_t world, int32_t rank,
                       int32_t* lm_begin, int32_t* lm_end) {
   if (!lm_offsets || world < 1 || rank < 0 || rank >= world) return fail(-1, "bad shard arguments");
