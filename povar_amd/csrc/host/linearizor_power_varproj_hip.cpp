@@ -50,7 +50,8 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
     // get_effective_jacobi_scaling_epsilon, linearizor_base.cpp:94-100 (Sophus epsilonSqrt<double> = 1e-5)
     o.jacobi_scaling_eps = options.jacobi_scaling_epsilon > 0 ? options.jacobi_scaling_epsilon : 1e-5;
     o.device = options.device;
-    o.e0_mode = options.e0_mode == "tiles" ? POVAR_E0_TILES : POVAR_E0_IMPLICIT;
+    o.e0_mode = options.e0_mode == "tiles" ? POVAR_E0_TILES
+                : options.e0_mode == "implicit" ? POVAR_E0_IMPLICIT : POVAR_E0_IMPLICIT_LDSACC;
     check(povar_create(&ctx_, bal_problem.num_cameras(), bal_problem.num_landmarks(), (int64_t)cam_idx.size(),
                        lm_off.data(), cam_idx.data(), obs.data(), &o), "povar_create");
     push_state();

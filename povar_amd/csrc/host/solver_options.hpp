@@ -49,7 +49,7 @@ struct SolverOptions {
   double initial_vee = 2.0;
   double vee_factor = 2.0;
   // MI355X build: which E0 operator form the device uses (not a reference option)
-  std::string e0_mode = "implicit";
+  std::string e0_mode = "ldsacc";  // "ldsacc" (fastest), "implicit" (bit-reproducible), "tiles" (stored tiles)
   int device = 0;
 
   // solver_options.cpp:41-51

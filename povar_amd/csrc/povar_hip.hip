@@ -348,11 +348,21 @@ int combine_flag(povar_ctx* c, int* flag) {
 int launch_e0(povar_ctx* c, int* binv_mode) {
   prof_mark(c, 0);
   if (c->joint) {
-    launch_lm(c, OpE0H{});
-    hipLaunchKernelGGL(cm_scatter_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 1);
-    *binv_mode = 1;
+    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+    if (acc) {
+      hipLaunchKernelGGL(e0_lm_cached_h, dim3(c->e0c_grid), dim3(E0C_BLOCK),
+                         (size_t)c->n_hot_acc * (HOT_REC_H * sizeof(double2) + 96), c->stream, c->d,
+                         c->e0c_bins_per_wg, c->hot_part.p);
+      if (c->n_long > 0)
+        hipLaunchKernelGGL((lm_long<OpE0H>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0H{}, c->part.p);
+    } else {
+      launch_lm(c, OpE0H{});
+    }
+    const Dp dt = acc ? ldsacc_dp(c) : c->d;
+    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(dt.cmv.n_items, 1), 4)), dim3(256), 0, c->stream, dt, 1, 1);
+    *binv_mode = acc ? 3 : 1;
     if (sharded(c)) {
-      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.y, 1);
+      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, dt, c->d.y, 1);
       *binv_mode = 2;
     }
   } else {
@@ -369,7 +379,7 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
       hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0{}, c->part.p);
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
     const Dp dt = acc ? ldsacc_dp(c) : c->d;
-    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(dt.cmv.n_items, 1), 4)), dim3(256), 0, c->stream, dt, 1);
+    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(dt.cmv.n_items, 1), 4)), dim3(256), 0, c->stream, dt, 1, 0);
     *binv_mode = acc ? 3 : 1;
     if (sharded(c)) {
       hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, dt, c->d.y, 1);
@@ -385,9 +395,11 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
 
 void launch_binv(povar_ctx* c, int mode, int want_norms) {
   prof_mark(c, 1);
-  if (c->joint)
-    hipLaunchKernelGGL(cam_binv_axpy_h, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, c->d, mode,
+  if (c->joint) {
+    const Dp dt = mode == 3 ? ldsacc_dp(c) : c->d;
+    hipLaunchKernelGGL(cam_binv_axpy_h, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, dt, mode == 3 ? 1 : mode,
                        want_norms, (const double*)c->ncw.p);
+  }
   else {
     const Dp dt = mode == 3 ? ldsacc_dp(c) : c->d;  // 3: item sums over the cold view + LDS partials
     hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, dt, mode == 3 ? 1 : mode,
@@ -503,6 +515,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     c->n_hot = (int)L.hot_cams.size();
     HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_MAX * HOT_REC * (int)sizeof(double2)));
+    HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached_h, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HOT_ACC_MAX * (HOT_REC_H * (int)sizeof(double2) + 96)));
     HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_ACC_MAX * (HOT_REC * (int)sizeof(double2) + 96)));
   }
@@ -531,7 +545,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   } while (0)
   ALLOC(cams4, 3 * nc); ALLOC(cams_lin4, 3 * nc); ALLOC(cams_bak4, 3 * nc);
   ALLOC(lms4, nl); ALLOC(lms_lin4, nl); ALLOC(lms_bak4, nl); ALLOC(jl_scale4, nl);
-  ALLOC(hll_inv, 9 * nl); ALLOC(lmrec, 12 * nl);
+  ALLOC(hll_inv, 9 * nl); ALLOC(lmrec, 16 * nl);
   ALLOC(sw, ns); ALLOC(rres, ns); ALLOC(q4, ns);
   ALLOC(sigma, 12 * nc); ALLOC(diag2, 12 * nc); ALLOC(G, 40 * nc); ALLOC(binv, 144 * nc);
   ALLOC(b, 12 * nc); ALLOC(tmp, 12 * nc); ALLOC(accum, 12 * nc); ALLOC(z, 12 * nc); ALLOC(y, 12 * nc);
@@ -540,7 +554,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   c->n_cold = (int64_t)L.cc_slot.size();
   c->n_cold_items = (int)L.cc_item_off.size() - 1;
   c->n_hot_acc = std::min(n_cams, HOT_ACC_MAX);
-  ALLOC(cc_h, 3 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
+  ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
   ALLOC(norm_part, 2 * (size_t)c->n_cam_blocks); ALLOC(norms, 4); ALLOC(flags, 4);
   ALLOC(part, n_part * 2); ALLOC(scal, 8);
@@ -702,9 +716,9 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   launch_lm(c, OpLinearize{});
-  hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cm_lm.p, c->cm_h.p, c->n_obs);
+  hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cm_lm.p, c->cm_h.p, c->n_obs, 0);
   if (c->n_cold > 0)
-    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold);
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, 0);
   hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   if (sharded(c)) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
@@ -734,7 +748,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   c->new_linearization_point = false;
   c->d.lambda_lm = solver_type == POVAR_POWER_SCHUR_COMPLEMENT ? lambda : 0.0;  // cpp:197-200
   launch_lm(c, OpPrepare{});
-  hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0);
+  hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 0);
   hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b, 1);
   if (int rc = allreduce(c, c->d.b, 12 * (size_t)c->n_cams)) return rc;
   hipLaunchKernelGGL(cam_build_binv, dim3(grid_for(c->n_cams, K8_THREADS)), dim3(K8_THREADS), 0, c->stream,
@@ -947,7 +961,9 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   launch_lm(c, OpLinearizeH{});
-  hipLaunchKernelGGL(cm_build_h4, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d);
+  hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cm_lm.p, c->cm_h.p, c->n_obs, 1);
+  if (c->n_cold > 0)
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, 1);
   hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
   if (sharded(c)) {
@@ -972,7 +988,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
   c->new_linearization_point = false;
   c->d.lambda_lm = lambda;  // set_landmark_damping_joint, linearizor_power_varproj.cpp:136
   launch_lm(c, OpPrepareH{});
-  hipLaunchKernelGGL(cm_scatter_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0);
+  hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 1);
   hipLaunchKernelGGL(cam_sum_items_h, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b,
                      (const double*)c->ncw.p);
   if (int rc = allreduce(c, c->d.b, 11 * (size_t)c->n_cams)) return rc;

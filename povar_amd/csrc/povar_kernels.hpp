@@ -46,7 +46,8 @@ constexpr int META_LONG = 1 << 17;
 constexpr int META_HOT_SHIFT = 18;     // 10 bits
 constexpr int META_HOT_MASK = 1023;
 constexpr int META_STEPS_SHIFT = 28;   // 3 bits: ceil(log2(longest landmark of the bin)), same in every lane of a bin
-constexpr int HOT_ACC_MAX = 590;    // cameras cached AND accumulated in LDS: 590 * (176 + 96) B = 156.7 KiB
+constexpr int HOT_ACC_MAX = 568;    // cameras cached AND accumulated in LDS: step 1 568 * (176 + 96) B = 151 KiB,
+                                    // step 2 568 * (192 + 96) B = 159.75 KiB of the 160 KiB
 constexpr int HOT_MAX = 912;        // cameras cached per workgroup: 912 * 176 B = 156.75 KiB of the 160 KiB LDS
 constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :3] (4.5) + pad
 constexpr int E0C_BLOCK = 1024;     // one workgroup per CU
@@ -1040,7 +1041,7 @@ __global__ __launch_bounds__(LM_BLOCK) void materialize_tiles(Dp d) {
 
 // Second half of every Jp^T(.) product: item_part[item] = sum over the item's observations of
 // ( h q0 ; h q1 ; h q2 ).  One wavefront per item, fixed order.
-__global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
+__global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done, int hom) {
   if (check_done && d.flags[1]) return;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
   constexpr int U = 4;
   for (int p0 = b + lane; p0 < e; p0 += U * WAVE) {
     int sl[U];
-    double hx[U], hy[U], hz[U];
+    double hx[U], hy[U], hz[U], hw[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int p = p0 + u * WAVE;
@@ -1063,15 +1064,16 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
       hx[u] = d.cmv.h[pc];
       hy[u] = d.cmv.h[d.cmv.n + pc];
       hz[u] = d.cmv.h[2 * d.cmv.n + pc];
+      hw[u] = hom ? d.cmv.h[3 * d.cmv.n + pc] : 1.0;  // step 2: homogeneous landmark (X0..X3)
     }
     double4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) q[u] = sl[u] >= 0 ? d.q4[sl[u]] : make_double4(0, 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      acc[0] += hx[u] * q[u].x; acc[1] += hy[u] * q[u].x; acc[2] += hz[u] * q[u].x; acc[3] += q[u].x;
-      acc[4] += hx[u] * q[u].y; acc[5] += hy[u] * q[u].y; acc[6] += hz[u] * q[u].y; acc[7] += q[u].y;
-      acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += q[u].z;
+      acc[0] += hx[u] * q[u].x; acc[1] += hy[u] * q[u].x; acc[2] += hz[u] * q[u].x; acc[3] += hw[u] * q[u].x;
+      acc[4] += hx[u] * q[u].y; acc[5] += hy[u] * q[u].y; acc[6] += hz[u] * q[u].y; acc[7] += hw[u] * q[u].y;
+      acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += hw[u] * q[u].z;
     }
   }
   wave_sum<12>(acc);
@@ -1083,13 +1085,14 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done) {
 
 // landmark coordinates at the linearisation point, copied into camera-major order once per
 // linearisation so the per-term camera-major pass streams them instead of gathering
-__global__ __launch_bounds__(256) void cm_build_h(Dp d, const int* lm_of, double* out, int64_t n) {
+__global__ __launch_bounds__(256) void cm_build_h(Dp d, const int* lm_of, double* out, int64_t n, int hom) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   const double4 h = d.lms_lin4[lm_of[p]];
   out[p] = h.x;
   out[n + p] = h.y;
   out[2 * n + p] = h.z;
+  if (hom) out[3 * n + p] = h.w;
 }
 
 // Camera-block Gram sums of the unscaled weighted Jp: Jp^T Jp = w * (C (x) h h^T) with

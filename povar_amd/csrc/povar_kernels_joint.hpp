@@ -179,6 +179,12 @@ struct OpPrepareH {
     hinv_damped(tot, d.lambda_lm, Hi);
 #pragma unroll
     for (int k = 0; k < 9; ++k) d.hll_inv[9 * (size_t)lm + k] = Hi[k];
+    // packed 128-byte landmark record of the per-term kernel: X | s | Hll^-1 (symmetric)
+    double4* rec = reinterpret_cast<double4*>(d.lmrec) + 4 * (size_t)lm;
+    rec[0] = d.lms_lin4[lm];
+    rec[1] = d.jl_scale4[lm];
+    rec[2] = make_double4(Hi[0], Hi[1], Hi[2], Hi[4]);
+    rec[3] = make_double4(Hi[5], Hi[8], 0, 0);
   }
 };
 
@@ -259,38 +265,107 @@ struct OpBackJoint {
   }
 };
 
-// camera-major pass of step 2: item_part[item] = sum ( X q0 ; X q1 ; X q2 ) with 4-component X
-__global__ __launch_bounds__(256) void cm_scatter_h(Dp d, int check_done) {
-  if (check_done && d.flags[1]) return;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (item >= d.n_items) return;
-  const int b = d.item_off[item], e = d.item_off[item + 1];
-  double acc[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) acc[k] = 0;
-  for (int p = b + lane; p < e; p += WAVE) {
-    const double4 q = d.q4[d.cm_slot[p]];
-    const double4 h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], d.cm_h[3 * d.n_obs + p]);
-    acc[0] += h.x * q.x; acc[1] += h.y * q.x; acc[2] += h.z * q.x; acc[3] += h.w * q.x;
-    acc[4] += h.x * q.y; acc[5] += h.y * q.y; acc[6] += h.z * q.y; acc[7] += h.w * q.y;
-    acc[8] += h.x * q.z; acc[9] += h.y * q.z; acc[10] += h.z * q.z; acc[11] += h.w * q.z;
+// Per-term landmark-major kernel of step 2 with the LDS camera cache + LDS accumulation of the hot
+// cameras: the step-2 twin of e0_lm_cached<true> (same pipeline, 2-row tiles, camera record = z_c (12)
+// + full P_c (12) = 192 B, landmark record = X | s | Hll^-1 = 128 B).
+constexpr int HOT_REC_H = 12;
+__global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_wg, double* hot_out) {
+  if (d.flags[1]) return;
+  extern __shared__ double2 hot[];  // [n_hot][HOT_REC_H] records, then acc[12][n_hot]
+  const int n_hot = d.n_hot_acc;
+  double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC_H);
+  for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) acc[i] = 0;
+  {
+    const double2* z2 = reinterpret_cast<const double2*>(d.z);
+    const double2* c2 = reinterpret_cast<const double2*>(d.cams_lin4);
+    for (int i = threadIdx.x; i < n_hot * HOT_REC_H; i += E0C_BLOCK) {
+      const int r = i / HOT_REC_H, jj = i - r * HOT_REC_H;
+      const int c = d.hot_cams[r];
+      hot[i] = jj < 6 ? z2[6 * (size_t)c + jj] : c2[6 * (size_t)c + (jj - 6)];
+    }
   }
-  wave_sum<12>(acc);
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) d.item_part[12 * (size_t)item + k] = acc[k];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bin0 = blockIdx.x * bins_per_wg;
+  const int bin1 = min(bin0 + bins_per_wg, d.n_bins);
+  constexpr int STRIDE = E0C_BLOCK / WAVE;
+  int n_meta = lane | (lane << 8), n_cam = 0, n_lm = 0;
+  double2 n_uv = make_double2(0, 0);
+  if (bin0 + wave < bin1) {
+    const int s = (bin0 + wave) * WAVE + lane;
+    n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
   }
-}
-
-__global__ __launch_bounds__(256) void cm_build_h4(Dp d) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= d.n_obs) return;
-  const double4 h = d.lms_lin4[d.cm_lm[p]];
-  d.cm_h[p] = h.x;
-  d.cm_h[d.n_obs + p] = h.y;
-  d.cm_h[2 * d.n_obs + p] = h.z;
-  d.cm_h[3 * d.n_obs + p] = h.w;
+  for (int bin = bin0 + wave; bin < bin1; bin += STRIDE) {
+    const int slot = bin * WAVE + lane;
+    const int meta = n_meta, cam = n_cam, lm = n_lm;
+    const double2 uv = n_uv;
+    const bool valid = (meta & META_REAL) && !(meta & META_LONG);
+    const int seg_first = meta & 255, seg_last = (meta >> 8) & 255;
+    const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 4 * (size_t)(valid ? lm : 0);
+    const double4 X = rec[0], s4 = rec[1], h0 = rec[2], h1 = rec[3];
+    if (bin + STRIDE < bin1) {
+      const int s = slot + STRIDE * WAVE;
+      n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
+    }
+    double red[3] = {0, 0, 0};
+    double jl3[6];
+    Hom h;
+    double sw = 1.0;
+    const int hr = ((meta >> META_HOT_SHIFT) & META_HOT_MASK);
+    const bool is_hot = hr > 0 && hr <= n_hot;
+    if (valid) {
+      Cam P;
+      double4 zz[3];
+      if (is_hot) {
+        const double2* hp = hot + (hr - 1) * HOT_REC_H;
+        const double2 a0 = hp[0], a1 = hp[1], a2 = hp[2], a3 = hp[3], a4 = hp[4], a5 = hp[5];
+        zz[0] = make_double4(a0.x, a0.y, a1.x, a1.y);
+        zz[1] = make_double4(a2.x, a2.y, a3.x, a3.y);
+        zz[2] = make_double4(a4.x, a4.y, a5.x, a5.y);
+        const double2 b0 = hp[6], b1 = hp[7], b2 = hp[8], b3 = hp[9], b4 = hp[10], b5 = hp[11];
+        P.r0 = make_double4(b0.x, b0.y, b1.x, b1.y);
+        P.r1 = make_double4(b2.x, b2.y, b3.x, b3.y);
+        P.r2 = make_double4(b4.x, b4.y, b5.x, b5.y);
+      } else {
+        P = load_cam(d.cams_lin4, cam);
+        const double4* zc = reinterpret_cast<const double4*>(d.z) + 3 * cam;
+        zz[0] = zc[0]; zz[1] = zc[1]; zz[2] = zc[2];
+      }
+      sw = d.robust ? d.sw[slot] : 1.0;
+      h = hom_project(P, X, uv.x, uv.y);
+      double jl4[8], w[4], beta;
+      hom_jl4(P, h, sw, s4, jl4);
+      house4(X, w, beta);
+      jl3_of_jl4(jl4, w, beta, jl3);
+      double t[2];
+      hom_jp_x(h, X, sw, zz, t);
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) red[jj] += jl3[jj] * t[0] + jl3[3 + jj] * t[1];
+    }
+    seg_reduce_steps<3>(red, lane, seg_first, seg_last,
+                        __builtin_amdgcn_readfirstlane((meta >> META_STEPS_SHIFT) & 7));
+    if (valid) {
+      const double v0 = h0.x * red[0] + h0.y * red[1] + h0.z * red[2];
+      const double v1 = h0.y * red[0] + h0.w * red[1] + h1.x * red[2];
+      const double v2 = h0.z * red[0] + h1.x * red[1] + h1.y * red[2];
+      const double s0 = jl3[0] * v0 + jl3[1] * v1 + jl3[2] * v2;
+      const double s1 = jl3[3] * v0 + jl3[4] * v1 + jl3[5] * v2;
+      const double4 q = hom_q(h, sw, s0, s1);
+      if (is_hot) {
+        double* a = acc + (hr - 1);
+        const double v[12] = {X.x * q.x, X.y * q.x, X.z * q.x, X.w * q.x, X.x * q.y, X.y * q.y,
+                              X.z * q.y, X.w * q.y, X.x * q.z, X.y * q.z, X.z * q.z, X.w * q.z};
+#pragma unroll
+        for (int jj = 0; jj < 12; ++jj)
+          __hip_atomic_fetch_add(a + jj * n_hot, v[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        d.q4[slot] = q;
+      }
+    }
+  }
+  __syncthreads();
+  double* out = hot_out + (size_t)blockIdx.x * n_hot * 12;
+  for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) out[i] = acc[(i % 12) * n_hot + i / 12];
 }
 
 // Gram moments of the unscaled weighted Jp12: Jp12^T Jp12 = w * (C (x) X X^T),
@@ -450,14 +525,7 @@ __global__ __launch_bounds__(256) void cam_sum_items_h(Dp d, double* out11, cons
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.n_cams) return;
   double y[12];
-#pragma unroll
-  for (int j = 0; j < 12; ++j) y[j] = 0;
-  for (int it = d.cam_item_off[c] + lane; it < d.cam_item_off[c + 1]; it += WAVE) {
-    const double* ip = d.item_part + 12 * (size_t)it;
-#pragma unroll
-    for (int j = 0; j < 12; ++j) y[j] += ip[j];
-  }
-  wave_sum<12>(y);
+  camera_item_sum(d, c, lane, y);
 #pragma unroll
   for (int j = 0; j < 12; ++j) y[j] *= d.sigma[12 * (size_t)c + j];
   double o[11];
@@ -493,12 +561,7 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy_h(Dp d, int mode, 
 #pragma unroll
       for (int j = 0; j < 12; ++j) y[j] = 0;
       if (mode == 1) {
-        for (int it = d.cam_item_off[c] + lane; it < d.cam_item_off[c + 1]; it += WAVE) {
-          const double* ip = d.item_part + 12 * (size_t)it;
-#pragma unroll
-          for (int j = 0; j < 12; ++j) y[j] += ip[j];
-        }
-        wave_sum<12>(y);
+        camera_item_sum(d, c, lane, y);
 #pragma unroll
         for (int j = 0; j < 12; ++j) y[j] *= d.sigma[12 * (size_t)c + j];
       } else {

@@ -22,6 +22,7 @@ def _run(binary, path, log, extra):
 
 @pytest.mark.parametrize("extra", [
     ["--max-num-iterations-step-1", "8", "--max-num-iterations-step-2", "6", "--power-sc-iterations", "20"],
+    ["--max-num-iterations-step-1", "8", "--max-num-iterations-step-2", "6", "--power-sc-iterations", "20", "--e0-mode", "implicit"],
     ["--solver-type-step-1", "POWER_SCHUR_COMPLEMENT", "--max-num-iterations-step-1", "6",
      "--max-num-iterations-step-2", "3", "--power-sc-iterations", "10", "--eta", "0"],
     ["--residual-robust-norm", "HUBER", "--residual-huber-parameter", "5", "--max-num-iterations-step-1", "5",

@@ -83,7 +83,8 @@ def test_sharded_pipeline_matches_single(world, e0_mode):
         assert rel(o["lms"], lms_ref[lb:le]) < 1e-9
 
 
-def test_sharded_step2_matches_single():
+@pytest.mark.parametrize("e0_mode", [0, 2])
+def test_sharded_step2_matches_single(e0_mode):
     from povar_amd import capi, synth
     p = synth.make_problem(40, 2000, 8600, seed=13)
     rng = np.random.default_rng(3)
@@ -105,7 +106,7 @@ def test_sharded_step2_matches_single():
         return dict(cost=cost, ok=ok, inc=inc, rc=rc, ld=ld, cams=ctx.get_cameras(), lms=ctx.get_landmarks_homogeneous(),
                     cost2=ctx.error_homogeneous())
 
-    ref_ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs)
+    ref_ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs, e0_mode=e0_mode)
     ref = run(ref_ctx, 0, p.n_lms)
     ref_ctx.close()
     world = 2
@@ -115,7 +116,7 @@ def test_sharded_step2_matches_single():
     def worker(rank):
         lb, le = capi.shard_range(p.lm_off, world, rank)
         ob, oe = int(p.lm_off[lb]), int(p.lm_off[le])
-        ctx = capi.Context(p.n_cams, p.lm_off[lb:le + 1] - p.lm_off[lb], p.cam_idx[ob:oe], obs[ob:oe])
+        ctx = capi.Context(p.n_cams, p.lm_off[lb:le + 1] - p.lm_off[lb], p.cam_idx[ob:oe], obs[ob:oe], e0_mode=e0_mode)
         ctx.comm_init_host(world, rank, ar.fn(rank))
         out[rank] = run(ctx, lb, le)
         out[rank]["range"] = (lb, le)

@@ -23,14 +23,15 @@ def _state(p, seed=11):
     return cams, lms_h, p.obs / 500.0
 
 
+@pytest.mark.parametrize("e0_mode", [0, 2])
 @pytest.mark.parametrize("which,norm", [("small", "NONE"), ("medium", "NONE"), ("small", "HUBER")])
-def test_step2_against_oracle(which, norm, small_problem, medium_problem):
+def test_step2_against_oracle(which, norm, e0_mode, small_problem, medium_problem):
     from povar_amd import capi
     from oracle import povar_oracle as O
     p = small_problem if which == "small" else medium_problem
     cams, lms_h, obs = _state(p)
     orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, obs, robust_norm=norm, huber=0.5)
-    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs, robust_norm=norm, huber=0.5)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs, robust_norm=norm, huber=0.5, e0_mode=e0_mode)
     ctx.set_cameras(cams)
     ctx.set_landmarks_homogeneous(lms_h)
     ri, ro = ctx.error_homogeneous(), orc.error_homogeneous(cams, lms_h)
