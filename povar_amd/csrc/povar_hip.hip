@@ -679,6 +679,7 @@ int povar_init_landmarks_pose(povar_ctx* c, double alpha) {
   if (int rc = check_ctx(c)) return rc;
   set_alpha(c, alpha);
   launch_lm(c, OpInit{});
+  launch_lm(c, OpInitRefine{});
   HIP_TRY(hipGetLastError());
   return 0;
 }

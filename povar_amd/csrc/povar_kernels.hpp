@@ -426,7 +426,8 @@ struct NoLocal {};
 
 // K1: initialize_varproj_lm_pOSE (bal_bundle_adjustment_helper.cpp:76-99, 221-241).
 // x_l = argmin |G x - z|: the reference solves it with bdcSvd; here the 3x3 normal equations
-// (G^T G) x = G^T z are accumulated and solved with the closed-form inverse.
+// (G^T G) x = G^T z are accumulated and solved with the closed-form inverse, followed by one
+// refinement step (OpInitRefine).
 struct OpInit {
   static constexpr int NRED = 9, NSC = 0;
   static constexpr bool CHECK_DONE = false;
@@ -461,6 +462,49 @@ struct OpInit {
     x.y = Hi[3] * tot[6] + Hi[4] * tot[7] + Hi[5] * tot[8];
     x.z = Hi[6] * tot[6] + Hi[7] * tot[7] + Hi[8] * tot[8];
     x.w = 1.0;
+    d.lms4[lm] = x;
+  }
+};
+
+// One step of iterative refinement for K1: x += (G^T G)^-1 G^T (z - G x) with the residual taken
+// per observation at the current x.  The normal equations square the condition number of G; the
+// refinement step brings the result back to the accuracy of the reference's SVD solve for the
+// moderately ill-conditioned two- and three-view landmarks (error ~ (kappa^2 u)^2 instead of kappa^2 u).
+struct OpInitRefine {
+  static constexpr int NRED = 9, NSC = 0;
+  static constexpr bool CHECK_DONE = false;
+  using Local = NoLocal;
+  __device__ void phase1(const Dp& d, int, int cam, int lm, double2 uv, Local&, double* red) const {
+    const Cam P = load_cam(d.cams4, cam);
+    const double4 one = make_double4(1, 1, 1, 1);
+    double g[12];
+    pose_jl(d, P, uv.x, uv.y, 1.0, one, g);
+    const double4 x = d.lms4[lm];
+    const double z[4] = {d.sb * (P.r2.w * uv.x - P.r0.w), d.sb * (P.r2.w * uv.y - P.r1.w),
+                         d.sa * (uv.x - P.r0.w), d.sa * (uv.y - P.r1.w)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double res = z[r] - (g[3 * r] * x.x + g[3 * r + 1] * x.y + g[3 * r + 2] * x.z);
+      red[0] += g[3 * r] * g[3 * r];
+      red[1] += g[3 * r] * g[3 * r + 1];
+      red[2] += g[3 * r] * g[3 * r + 2];
+      red[3] += g[3 * r + 1] * g[3 * r + 1];
+      red[4] += g[3 * r + 1] * g[3 * r + 2];
+      red[5] += g[3 * r + 2] * g[3 * r + 2];
+      red[6] += g[3 * r] * res;
+      red[7] += g[3 * r + 1] * res;
+      red[8] += g[3 * r + 2] * res;
+    }
+  }
+  __device__ void phase2(const Dp&, int, int, int, double2, Local&, const double*, double*) const {}
+  __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    double H[9], Hi[9];
+    sym3(tot, H);
+    inv3(H, Hi);
+    double4 x = d.lms4[lm];
+    x.x += Hi[0] * tot[6] + Hi[1] * tot[7] + Hi[2] * tot[8];
+    x.y += Hi[3] * tot[6] + Hi[4] * tot[7] + Hi[5] * tot[8];
+    x.z += Hi[6] * tot[6] + Hi[7] * tot[7] + Hi[8] * tot[8];
     d.lms4[lm] = x;
   }
 };

@@ -36,7 +36,7 @@ def test_init_and_error(which, small_problem, medium_problem):
     ctx.set_cameras(p.cams)
     ctx.init_landmarks_pose(ALPHA)
     lms = orc.init_landmarks_pose(ALPHA, p.cams)
-    assert rel(ctx.get_landmarks(), lms) < 1e-8
+    assert rel(ctx.get_landmarks(), lms) < 1e-11
     # identical landmarks from here on
     ctx.set_landmarks(lms)
     ri, ro = ctx.error_pose(ALPHA), orc.error_pose(ALPHA, p.cams, lms)
@@ -158,7 +158,7 @@ def test_long_landmarks():
         lms = orc.init_landmarks_pose(ALPHA, base.cams)
         ctx.set_cameras(base.cams)
         ctx.init_landmarks_pose(ALPHA)
-        assert rel(ctx.get_landmarks(), lms) < 1e-8
+        assert rel(ctx.get_landmarks(), lms) < 1e-11
         ctx.set_landmarks(lms)
         ctx.linearize_pose(ALPHA)
         st, diag2, jls, sigma, hll, b, binv = _oracle_stage(orc, base.cams, lms, LAM)
@@ -184,7 +184,7 @@ def test_against_golden_fixtures(name, norm):
     alpha, lam, m = float(g["alpha"]), float(g["lam"]), int(g["m"])
     ctx.set_cameras(g["cams"])
     ctx.init_landmarks_pose(alpha)
-    assert rel(ctx.get_landmarks(), g["lms"]) < 1e-8
+    assert rel(ctx.get_landmarks(), g["lms"]) < 1e-11
     ctx.set_landmarks(g["lms"])
     ri = ctx.error_pose(alpha)
     assert abs(ri.all_error - float(g["cost"])) <= 1e-12 * float(g["cost"])
@@ -297,7 +297,7 @@ def test_unobserved_cameras_and_two_view_landmarks():
         ctx.set_cameras(cams)
         ctx.init_landmarks_pose(ALPHA)
         lms = orc.init_landmarks_pose(ALPHA, cams)
-        assert rel(ctx.get_landmarks(), lms) < 1e-7
+        assert rel(ctx.get_landmarks(), lms) < 1e-10
         ctx.set_landmarks(lms)
         assert ctx.linearize_pose(ALPHA)
         st, diag2, jls, sigma, hll, b, binv = _oracle_stage(orc, cams, lms, LAM)
