@@ -115,3 +115,30 @@ def test_step2_against_golden_ambient():
     ctx.normalize_joint()
     assert rel(ctx.get_cameras(), g["cams_norm"]) < 1e-11 and rel(ctx.get_landmarks_homogeneous(), g["lms_norm"]) < 1e-10
     ctx.close()
+
+
+@pytest.mark.parametrize("q_tol,r_tol,m", [(1e-2, -1.0, 40), (0.0, 0.3, 40), (0.0, -1.0, 0)])
+def test_step2_early_exit_and_m0(q_tol, r_tol, m, small_problem):
+    """Convergence tests of solve_joint (linearization_power_varproj.hpp:255-280) and m = 0."""
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    p = small_problem
+    cams, lms_h, obs = _state(p)
+    lam = 5.0
+    orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, obs)
+    st_h, ok = orc.linearize_homogeneous(cams, lms_h)
+    diag2 = orc.jp_diag2_homogeneous(st_h)
+    orc.scale_jl_cols_homogeneous(st_h)
+    orc.scale_jp_cols_joint(st_h, 1.0 / (1e-5 + np.sqrt(diag2)))
+    st_n = orc.linearize_nullspace(cams, lms_h, st_h)
+    hll, b, binv = orc.prepare_hb_joint(st_h, st_n, lam)
+    ref, it, status, _ = orc.solve_joint(st_n, hll, binv, b, m, q_tol=q_tol, r_tol=r_tol)
+    for mode in (0, 2):
+        ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs, e0_mode=mode)
+        ctx.set_cameras(cams)
+        ctx.set_landmarks_homogeneous(lms_h)
+        assert ctx.linearize_homogeneous()
+        inc, it2, st2, rc = ctx.solve_joint(lam, m, q_tol, r_tol)
+        assert rc == 0 and (it2, st2) == (it, status)
+        assert rel(inc, ref) < 1e-10
+        ctx.close()
