@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--problem", default="venice-1778", choices=sorted(synth.BAL_SHAPES))
-    ap.add_argument("--e0-mode", default="ldsacc", choices=["ldsacc", "implicit", "tiles"],
+    ap.add_argument("--e0-mode", default="ldsacc", choices=["ldsacc", "implicit", "tiles", "tiles-ldsacc"],
                     help="E0 operator form: implicit tiles + LDS accumulation of hot cameras (default, fastest), "
                          "implicit deterministic, or stored tiles")
     ap.add_argument("--m", type=int, default=20, help="--power-sc-iterations")
@@ -140,7 +140,8 @@ def main():
     device = local_rank % n_dev
     lb, le = capi.shard_range(prob.lm_off, world, rank)
     ob, oe = int(prob.lm_off[lb]), int(prob.lm_off[le])
-    mode = {"implicit": capi.E0_IMPLICIT, "tiles": capi.E0_TILES, "ldsacc": capi.E0_IMPLICIT_LDSACC}[args.e0_mode]
+    mode = {"implicit": capi.E0_IMPLICIT, "tiles": capi.E0_TILES, "ldsacc": capi.E0_IMPLICIT_LDSACC,
+            "tiles-ldsacc": capi.E0_TILES_LDSACC}[args.e0_mode]
     ctx = capi.Context(n_c, prob.lm_off[lb : le + 1] - prob.lm_off[lb], prob.cam_idx[ob:oe],
                        prob.obs[ob:oe], device=device, e0_mode=mode, robust_norm=args.robust_norm,
                        huber=args.huber)
@@ -283,7 +284,7 @@ def main():
         "device_bytes": ctx.device_bytes(),
         "roofline": {
             "bound": "hbm",
-            "kernel": "E0 x (e0_lm_cached + cm_scatter)" if mode != capi.E0_TILES
+            "kernel": "E0 x (e0_lm_cached + cm_scatter)" if mode not in (capi.E0_TILES, capi.E0_TILES_LDSACC)
                       else "E0 x (lm_regular<OpE0Tiles> + cm_scatter)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
@@ -302,7 +303,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary and args.step == 1:
         # secondary leg: the other E0 variant on the same state (also a full-size parity property:
         # both variants must give the same increment)
-        other = capi.E0_TILES if mode != capi.E0_TILES else capi.E0_IMPLICIT
+        tiles_modes = (capi.E0_TILES, capi.E0_TILES_LDSACC)
+        other = capi.E0_TILES_LDSACC if mode not in tiles_modes else capi.E0_IMPLICIT_LDSACC
         ctx.set_e0_mode(other)
         run_steps(1)
         ctx.synchronize()
@@ -317,7 +319,7 @@ def main():
         e0_2 = p2.e0_ms / max(p2.e0_launches, 1)
         ach2 = bytes_e0 / (e0_2 * 1e-3) / 1e9
         out["secondary"] = {
-            "e0_mode": "tiles" if other == capi.E0_TILES else "implicit",
+            "e0_mode": "tiles-ldsacc" if other == capi.E0_TILES_LDSACC else "ldsacc",
             "value": max(args.steps // 4, 2) * m / dt2,
             "unit": "terms/s",
             "e0_ms": e0_2,

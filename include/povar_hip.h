@@ -42,8 +42,10 @@ enum { POVAR_LINEAR_SOLVER_NO_CONVERGENCE = 0, POVAR_LINEAR_SOLVER_SUCCESS = 1,
  * deterministic two-pass scatter), 1 = stored tiles (the reference's [Jp|Jl] blocks kept in HBM
  * and streamed once per term, same deterministic scatter), 2 = implicit with the Jp^T s contributions
  * of the ~590 most observed cameras accumulated in LDS (fp64 LDS atomics: fastest, summation order
- * and therefore the last bits not reproducible run to run -- like the reference's mutex order) */
-enum { POVAR_E0_IMPLICIT = 0, POVAR_E0_TILES = 1, POVAR_E0_IMPLICIT_LDSACC = 2 };
+ * and therefore the last bits not reproducible run to run -- like the reference's mutex order),
+ * 3 = stored tiles with the same LDS accumulation (Jp^T s taken from the stored Jp).  Step 2 has the
+ * implicit forms only: modes 1 and 3 run its deterministic implicit path. */
+enum { POVAR_E0_IMPLICIT = 0, POVAR_E0_TILES = 1, POVAR_E0_IMPLICIT_LDSACC = 2, POVAR_E0_TILES_LDSACC = 3 };
 
 /* LandmarkBlockSC::Options (sc/landmark_block.hpp:61-75) + device selection */
 typedef struct {

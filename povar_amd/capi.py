@@ -17,7 +17,7 @@ HEADER = os.path.join(os.path.dirname(_PKG), "include", "povar_hip.h")
 
 NORM = {"NONE": 0, "HUBER": 1, "CAUCHY": 2}
 POWER_VARPROJ, POWER_SCHUR_COMPLEMENT = 0, 1
-E0_IMPLICIT, E0_TILES, E0_IMPLICIT_LDSACC = 0, 1, 2
+E0_IMPLICIT, E0_TILES, E0_IMPLICIT_LDSACC, E0_TILES_LDSACC = 0, 1, 2, 3
 NO_CONVERGENCE, SUCCESS, FAILURE = 0, 1, 2
 NUMERIC_FAILURE = 1
 (BUF_DIAG2, BUF_POSE_SCALING, BUF_JL_COL_SCALE, BUF_HLL_INV, BUF_B, BUF_B_INV, BUF_STORAGE,

@@ -367,6 +367,13 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
     }
   } else {
     if (c->opt.e0_mode == POVAR_E0_TILES) launch_lm(c, OpE0Tiles{});
+    else if (c->opt.e0_mode == POVAR_E0_TILES_LDSACC) {
+      hipLaunchKernelGGL(e0_tiles_cached, dim3(c->e0c_grid), dim3(E0T_BLOCK),
+                         (size_t)c->n_hot_acc * (HOT_REC_T * sizeof(double2) + 96), c->stream, c->d,
+                         c->e0c_bins_per_wg, c->hot_part.p);
+      if (c->n_long > 0)
+        hipLaunchKernelGGL((lm_long<OpE0Tiles>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0Tiles{}, c->part.p);
+    }
     else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)
       hipLaunchKernelGGL(e0_lm_cached<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
                          (size_t)c->n_hot_acc * (HOT_REC * sizeof(double2) + 96), c->stream, c->d,
@@ -375,9 +382,9 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
       hipLaunchKernelGGL(e0_lm_cached<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
                          (size_t)c->n_hot * HOT_REC * sizeof(double2), c->stream, c->d, c->e0c_bins_per_wg,
                          (double*)nullptr);
-    if (c->opt.e0_mode != POVAR_E0_TILES && c->n_long > 0)
+    if ((c->opt.e0_mode == POVAR_E0_IMPLICIT || c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) && c->n_long > 0)
       hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0{}, c->part.p);
-    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
     const Dp dt = acc ? ldsacc_dp(c) : c->d;
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(dt.cmv.n_items, 1), 4)), dim3(256), 0, c->stream, dt, 1, 0);
     *binv_mode = acc ? 3 : 1;
@@ -408,7 +415,7 @@ void launch_binv(povar_ctx* c, int mode, int want_norms) {
 }
 
 int ensure_tiles(povar_ctx* c) {
-  if (c->opt.e0_mode != POVAR_E0_TILES) return 0;
+  if (c->opt.e0_mode != POVAR_E0_TILES && c->opt.e0_mode != POVAR_E0_TILES_LDSACC) return 0;
   if (!c->tiles.p) {
     HIP_TRY(c->tiles.alloc((size_t)c->n_bins * TILE_PAIRS * WAVE, &c->bytes));
     c->d.tiles = c->tiles.p;
@@ -515,6 +522,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     c->n_hot = (int)L.hot_cams.size();
     HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_MAX * HOT_REC * (int)sizeof(double2)));
+    HIP_TRY(hipFuncSetAttribute((const void*)e0_tiles_cached, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HOT_ACC_MAX * (HOT_REC_T * (int)sizeof(double2) + 96)));
     HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached_h, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_ACC_MAX * (HOT_REC_H * (int)sizeof(double2) + 96)));
     HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1036,7 +1045,8 @@ int povar_normalize_joint(povar_ctx* c) {
 
 int povar_set_e0_mode(povar_ctx* c, int32_t mode) {
   if (int rc = check_ctx(c)) return rc;
-  if (mode != POVAR_E0_IMPLICIT && mode != POVAR_E0_TILES && mode != POVAR_E0_IMPLICIT_LDSACC) return fail(-1, "bad e0 mode");
+  if (mode != POVAR_E0_IMPLICIT && mode != POVAR_E0_TILES && mode != POVAR_E0_IMPLICIT_LDSACC &&
+      mode != POVAR_E0_TILES_LDSACC) return fail(-1, "bad e0 mode");
   c->opt.e0_mode = mode;
   if (c->linearized) return ensure_tiles(c);
   return 0;

@@ -901,6 +901,117 @@ struct OpE0Tiles {
   __device__ void finish_lm(const Dp&, int, const double*) const {}
 };
 
+// Stored-tile E0 with the LDS treatment of e0_lm_cached<true> (POVAR_E0_TILES_LDSACC): one 768-thread
+// workgroup per CU streams its bins' tiles (480 B per observation, every byte once); x_c of the hot
+// cameras comes from LDS and their Jp^T s -- computed from the STORED Jp, all 48 values -- is
+// accumulated in LDS (ds_add_f64) instead of going through q4 + cm_scatter.  Colder cameras and
+// >64-observation landmarks keep the q4 path of OpE0Tiles.
+constexpr int E0T_BLOCK = 768;
+constexpr int HOT_REC_T = 6;  // double2 per cached camera: x_c (12 doubles)
+__global__ __launch_bounds__(E0T_BLOCK) void e0_tiles_cached(Dp d, int bins_per_wg, double* hot_out) {
+  if (d.flags[1]) return;
+  extern __shared__ double2 hot[];  // [n_hot][HOT_REC_T] then acc[12][n_hot]
+  const int n_hot = d.n_hot_acc;
+  double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC_T);
+  for (int i = threadIdx.x; i < n_hot * 12; i += E0T_BLOCK) acc[i] = 0;
+  {
+    const double2* x2 = reinterpret_cast<const double2*>(d.tmp);
+    for (int i = threadIdx.x; i < n_hot * HOT_REC_T; i += E0T_BLOCK) {
+      const int r = i / HOT_REC_T, j = i - r * HOT_REC_T;
+      hot[i] = x2[6 * (size_t)d.hot_cams[r] + j];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bin0 = blockIdx.x * bins_per_wg;
+  const int bin1 = min(bin0 + bins_per_wg, d.n_bins);
+  for (int bin = bin0 + wave; bin < bin1; bin += E0T_BLOCK / WAVE) {
+    const int slot = bin * WAVE + lane;
+    const int meta = d.meta[slot];
+    const bool valid = (meta & META_REAL) && !(meta & META_LONG);
+    const int seg_first = meta & 255, seg_last = (meta >> 8) & 255;
+    const int hr = ((meta >> META_HOT_SHIFT) & META_HOT_MASK);
+    const bool is_hot = hr > 0 && hr <= n_hot;
+    double jp[48], jl[12];
+    double red[3] = {0, 0, 0};
+    int cam = 0, lm = 0;
+    if (valid) {
+      cam = d.cam[slot];
+      lm = d.lm[slot];
+      const double2* t = d.tiles + ((size_t)bin * TILE_PAIRS) * WAVE + lane;
+#pragma unroll
+      for (int p = 0; p < 24; ++p) {
+        const double2 a = t[p * WAVE];
+        jp[2 * p] = a.x;
+        jp[2 * p + 1] = a.y;
+      }
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const double2 a = t[(24 + p) * WAVE];
+        jl[2 * p] = a.x;
+        jl[2 * p + 1] = a.y;
+      }
+      double xc[12];
+      if (is_hot) {
+        const double2* h = hot + (hr - 1) * HOT_REC_T;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double2 v = h[j];
+          xc[2 * j] = v.x;
+          xc[2 * j + 1] = v.y;
+        }
+      } else {
+        const double2* x2 = reinterpret_cast<const double2*>(d.tmp) + 6 * (size_t)cam;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double2 v = x2[j];
+          xc[2 * j] = v.x;
+          xc[2 * j + 1] = v.y;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double tr = 0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) tr += jp[12 * r + j] * xc[j];
+        red[0] += jl[3 * r] * tr;
+        red[1] += jl[3 * r + 1] * tr;
+        red[2] += jl[3 * r + 2] * tr;
+      }
+    }
+    seg_reduce_steps<3>(red, lane, seg_first, seg_last,
+                        __builtin_amdgcn_readfirstlane((meta >> META_STEPS_SHIFT) & 7));
+    if (valid) {
+      const double* Hi = d.hll_inv + 9 * (size_t)lm;
+      const double v0 = Hi[0] * red[0] + Hi[1] * red[1] + Hi[2] * red[2];
+      const double v1 = Hi[3] * red[0] + Hi[4] * red[1] + Hi[5] * red[2];
+      const double v2 = Hi[6] * red[0] + Hi[7] * red[1] + Hi[8] * red[2];
+      double s[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] = jl[3 * r] * v0 + jl[3 * r + 1] * v1 + jl[3 * r + 2] * v2;
+      if (is_hot) {
+        double* a = acc + (hr - 1);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          const double o = jp[j] * s[0] + jp[12 + j] * s[1] + jp[24 + j] * s[2] + jp[36 + j] * s[3];
+          __hip_atomic_fetch_add(a + j * n_hot, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        const double2 uv = d.uv[slot];
+        d.q4[slot] = pose_q(d, uv.x, uv.y, d.robust ? d.sw[slot] : 1.0, s);
+      }
+    }
+  }
+  __syncthreads();
+  // the stored Jp carries the pose scaling sigma; the partials leave in the unscaled convention of
+  // the scatter items (cam_binv_axpy multiplies by sigma once for both)
+  double* out = hot_out + (size_t)blockIdx.x * n_hot * 12;
+  for (int i = threadIdx.x; i < n_hot * 12; i += E0T_BLOCK) {
+    const int cam_r = i / 12, j = i % 12;
+    out[i] = acc[j * n_hot + cam_r] / d.sigma[12 * (size_t)d.hot_cams[cam_r] + j];
+  }
+}
+
 // K12: back_substitute_pOSE (landmark_block.hpp:670-707), POWER_VARPROJ.  Fresh unweighted,
 // unscaled res/Jl at the UPDATED cameras, exact landmark re-solve, and the reference's model
 // cost change with its mixture of scaled and unscaled quantities.

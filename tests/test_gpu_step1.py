@@ -68,7 +68,7 @@ def test_linearize_prepare_buffers(norm, small_problem):
     ctx.close()
 
 
-@pytest.mark.parametrize("e0_mode", [0, 1, 2])
+@pytest.mark.parametrize("e0_mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("which", ["small", "medium"])
 def test_power_series_term_by_term(which, e0_mode, small_problem, medium_problem):
     p = small_problem if which == "small" else medium_problem
@@ -152,7 +152,7 @@ def test_long_landmarks():
     obs = rng.normal(scale=100.0, size=(cam_idx.shape[0], 2))
     from povar_amd import capi
     from oracle import povar_oracle as O
-    for e0_mode in (0, 1, 2):
+    for e0_mode in (0, 1, 2, 3):
         orc = O.Oracle(n_c, lm_off, cam_idx, obs)
         ctx = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=e0_mode)
         lms = orc.init_landmarks_pose(ALPHA, base.cams)
@@ -228,7 +228,7 @@ def test_full_size_properties():
     assert x @ ex > 0
     assert np.array_equal(ctx.right_mul_e0_pose(x), ex)  # deterministic (no atomics on the path)
     inc_a, it, st, rc = ctx.solve_pose(LAM, 0, M)
-    for mode in (capi.E0_TILES, capi.E0_IMPLICIT_LDSACC):
+    for mode in (capi.E0_TILES, capi.E0_IMPLICIT_LDSACC, capi.E0_TILES_LDSACC):
         ctx.set_e0_mode(mode)
         assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-13
         inc_b, _, _, _ = ctx.solve_pose(LAM, 0, M)
@@ -261,7 +261,7 @@ def test_venice_size_properties():
     assert np.array_equal(ctx.right_mul_e0_pose(x), ex)
     inc_a, it, st, rc = ctx.solve_pose(LAM, 0, M)
     assert rc == 0 and it == M
-    for mode in (capi.E0_TILES, capi.E0_IMPLICIT_LDSACC):
+    for mode in (capi.E0_TILES, capi.E0_IMPLICIT_LDSACC, capi.E0_TILES_LDSACC):
         ctx.set_e0_mode(mode)
         assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-12
         inc_b, _, _, _ = ctx.solve_pose(LAM, 0, M)
@@ -292,7 +292,7 @@ def test_unobserved_cameras_and_two_view_landmarks():
     cams[:, :8] = rng.normal(size=(n_c, 8))
     cams[:, 11] = 1.0
     orc = O.Oracle(n_c, lm_off, cam_idx, obs)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         ctx = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=mode)
         ctx.set_cameras(cams)
         ctx.init_landmarks_pose(ALPHA)
