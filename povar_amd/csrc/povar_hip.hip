@@ -83,7 +83,7 @@ struct povar_ctx {
   // state
   DevBuf<double4> cams4, cams_lin4, cams_bak4, lms4, lms_lin4, lms_bak4, jl_scale4, rres, q4;
   DevBuf<double> hll_inv, sw, sigma, diag2, G, binv, b, tmp, accum, z, y, inc, item_part,
-      item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec, ncw, cc_h, cc_part, hot_part;
+      item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec, ncw, cc_h, cc_part, hot_part, hot_rec;
 
   Dp d{};
   bool new_linearization_point = false;  // linearizor_power_varproj.cpp:75, 192, 240
@@ -565,6 +565,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   c->n_hot_acc = std::min(n_cams, HOT_ACC_MAX);
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
+  ALLOC(hot_rec, (size_t)HOT_MAX * HOT_REC_STRIDE);
   ALLOC(norm_part, 2 * (size_t)c->n_cam_blocks); ALLOC(norms, 4); ALLOC(flags, 4);
   ALLOC(part, n_part * 2); ALLOC(scal, 8);
   ALLOC(stage, std::max(3 * nl, 144 * nc));
@@ -591,6 +592,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.jl_scale4 = c->jl_scale4.p; d.hll_inv = c->hll_inv.p; d.lmrec = c->lmrec.p;
   d.cmv = CmView{c->cm_slot.p, c->cm_h.p, n_obs, c->item_off.p, c->cam_item_off.p, c->item_part.p, c->n_items};
   d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
+  d.hot_rec = c->hot_rec.p;
   d.hot_cams = c->hot_cams.p; d.n_hot = (int)L.hot_cams.size();
   d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.tiles = nullptr;
   d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
@@ -619,7 +621,7 @@ void povar_destroy(povar_ctx* c) {
   c->hll_inv.release(); c->sw.release(); c->sigma.release(); c->diag2.release(); c->G.release();
   c->binv.release(); c->b.release(); c->tmp.release(); c->accum.release(); c->z.release(); c->y.release();
   c->inc.release(); c->item_part.release(); c->item_partG.release(); c->norm_part.release();
-  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->ncw.release(); c->cc_h.release(); c->cc_part.release(); c->hot_part.release();
+  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->ncw.release(); c->cc_h.release(); c->cc_part.release(); c->hot_part.release(); c->hot_rec.release();
   c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -757,6 +759,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   // the scaling is part of the implicit tile; only stored tiles need (re)materialising.
   c->new_linearization_point = false;
   c->d.lambda_lm = solver_type == POVAR_POWER_SCHUR_COMPLEMENT ? lambda : 0.0;  // cpp:197-200
+  hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_hot * 12, 256)), dim3(256), 0, c->stream, c->d, 0);
   launch_lm(c, OpPrepare{});
   hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 0);
   hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b, 1);
@@ -997,6 +1000,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
   c->joint = true;
   c->new_linearization_point = false;
   c->d.lambda_lm = lambda;  // set_landmark_damping_joint, linearizor_power_varproj.cpp:136
+  hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_hot * 12, 256)), dim3(256), 0, c->stream, c->d, 1);
   launch_lm(c, OpPrepareH{});
   hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 1);
   hipLaunchKernelGGL(cam_sum_items_h, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b,

@@ -43,6 +43,7 @@ constexpr int TILE_PAIRS = 32;  // double2 pairs per observation in the blocked 
 // a long (>64 obs) landmark, bits 18-31 = 1 + rank of the camera in the LDS camera cache (0: not cached)
 constexpr int META_REAL = 1 << 16;
 constexpr int META_LONG = 1 << 17;
+constexpr int HOT_REC_STRIDE = 24;  // doubles per camera in Dp::hot_rec
 constexpr int META_HOT_SHIFT = 18;     // 10 bits
 constexpr int META_HOT_MASK = 1023;
 constexpr int META_STEPS_SHIFT = 28;   // 3 bits: ceil(log2(longest landmark of the bin)), same in every lane of a bin
@@ -71,6 +72,8 @@ struct Dp {
   const int* lm;
   const int* meta;
   const int* hot_cams;  // cameras cached in LDS by e0_lm_cached, most observed first
+  double* hot_rec;      // [HOT_MAX][24] contiguous LDS image of the hot cameras' records: z_c (12, rewritten by
+                        // every B^-1 kernel) then the static camera part (step 1: P[:, :3] (9), step 2: P (12))
   int n_hot;
   const int* long_lm;
   const int* long_first;
@@ -735,20 +738,11 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
   if (ACC)
     for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) acc[i] = 0;
   {
-    const double2* z2 = reinterpret_cast<const double2*>(d.z);
-    const double* cl = reinterpret_cast<const double*>(d.cams_lin4);
+    // coalesced copy of the record image (first HOT_REC double2 of each HOT_REC_STRIDE-double record)
+    const double2* src = reinterpret_cast<const double2*>(d.hot_rec);
     for (int i = threadIdx.x; i < n_hot * HOT_REC; i += E0C_BLOCK) {
       const int r = i / HOT_REC, j = i - r * HOT_REC;
-      const int c = d.hot_cams[r];
-      double2 v;
-      if (j < 6) {
-        v = z2[6 * (size_t)c + j];
-      } else {
-        const int e = 2 * (j - 6);  // flat index into P3 (row-major 3x3)
-        v.x = cl[12 * (size_t)c + (e / 3) * 4 + (e % 3)];
-        v.y = e + 1 < 9 ? cl[12 * (size_t)c + ((e + 1) / 3) * 4 + ((e + 1) % 3)] : 0.0;
-      }
-      hot[i] = v;
+      hot[i] = src[r * (HOT_REC_STRIDE / 2) + j];
     }
   }
   __syncthreads();
@@ -760,14 +754,17 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
   // profiles/r01_c_sq_counters.txt): a bin needs two dependent memory round trips (slot data, then
   // the landmark record it points to).  The slot data of the NEXT bin is therefore requested
   // before the current bin's record is consumed.
-  int n_meta = lane | (lane << 8), n_cam = 0, n_lm = 0;
-  double2 n_uv = make_double2(0, 0);
+  // slot data two bins ahead (m_*), one bin ahead (n_*); landmark record one bin ahead (n_rec*)
+  int n_meta = lane | (lane << 8), n_cam = 0, n_lm = 0, m_meta = n_meta, m_cam = 0, m_lm = 0;
+  double2 n_uv = make_double2(0, 0), m_uv = n_uv;
   if (bin0 + wave < bin1) {
     const int s = (bin0 + wave) * WAVE + lane;
     n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
   }
-  // ... and the landmark record of the next bin is requested in the middle of the current bin
-  // (after the forward products, when the next slot data has arrived)
+  if (bin0 + wave + STRIDE < bin1) {
+    const int s = (bin0 + wave + STRIDE) * WAVE + lane;
+    m_meta = d.meta[s]; m_cam = d.cam[s]; m_lm = d.lm[s]; m_uv = d.uv[s];
+  }
   double4 n_rec0, n_rec1, n_rec2;
   {
     const bool v0 = (n_meta & META_REAL) && !(n_meta & META_LONG);
@@ -782,9 +779,13 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
     const int seg_first = meta & 255, seg_last = (meta >> 8) & 255;
     const double4 rec0 = n_rec0, rec1 = n_rec1, rec2 = n_rec2;
     (void)lm;
-    if (bin + STRIDE < bin1) {
-      const int s = slot + STRIDE * WAVE;
-      n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
+    // rotate the slot pipeline and request the slot data two bins ahead
+    n_meta = m_meta; n_cam = m_cam; n_lm = m_lm; n_uv = m_uv;
+    if (bin + 2 * STRIDE < bin1) {
+      const int s = slot + 2 * STRIDE * WAVE;
+      m_meta = d.meta[s]; m_cam = d.cam[s]; m_lm = d.lm[s]; m_uv = d.uv[s];
+    } else {
+      m_meta = lane | (lane << 8);
     }
     double red[3] = {0, 0, 0};
     E0Core core;
@@ -1383,6 +1384,27 @@ __global__ __launch_bounds__(K8_THREADS) void cam_build_binv(Dp d, double lambda
 #undef X_
 }
 
+// z_c = sigma * x_c goes to the dense vector and, for a cached camera, into the contiguous record
+// image the E0 kernels copy into LDS (so their prologue is a coalesced copy, not a gather)
+__device__ inline void store_z(const Dp& d, int c, int j, double v) {
+  d.z[12 * (size_t)c + j] = v;
+  const int r = d.cam_hot[c];
+  if (r > 0) d.hot_rec[(size_t)(r - 1) * HOT_REC_STRIDE + j] = v;
+}
+
+// static part of the hot camera records (per linearisation): P[:, :3] row-major (step 1, hom = 0)
+// or the full P (step 2, hom = 1) after the 12 z values
+__global__ __launch_bounds__(256) void build_hot_rec(Dp d, int hom) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= d.n_hot * 12) return;
+  const int r = i / 12, e = i % 12;
+  const double* P = reinterpret_cast<const double*>(d.cams_lin4) + 12 * (size_t)d.hot_cams[r];
+  double v = 0;
+  if (hom) v = P[e];
+  else if (e < 9) v = P[(e / 3) * 4 + (e % 3)];
+  d.hot_rec[(size_t)r * HOT_REC_STRIDE + 12 + e] = v;
+}
+
 // fixed-order sum of a camera's scatter items (+ the LDS-accumulated workgroup partials of a cached
 // camera): lanes stride over the parts, then a butterfly; every lane ends with the 12 sums
 __device__ inline void camera_item_sum(const Dp& d, int c, int lane, double (&y)[12]) {
@@ -1459,7 +1481,7 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, in
     const double acc = mode == 0 ? s : d.accum[idx] + s;
     d.tmp[idx] = s;
     d.accum[idx] = acc;
-    d.z[idx] = s * d.sigma[idx];
+    store_z(d, c, lane, s * d.sigma[idx]);
     if (mode == 2) d.y[idx] = 0;
     nrm[0] = s * s;
     nrm[1] = acc * acc;
@@ -1515,7 +1537,7 @@ __global__ __launch_bounds__(256) void cam_apply_inc(Dp d, int mode) {
     cams[i] += s;
     d.inc[i] = s * (1.0 / sg);
   } else if (mode == 1) {
-    d.z[i] = s;
+    store_z(d, i / 12, i % 12, s);
   } else {
     cams[i] += s;
   }

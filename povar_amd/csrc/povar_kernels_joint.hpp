@@ -276,13 +276,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_w
   double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC_H);
   for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) acc[i] = 0;
   {
-    const double2* z2 = reinterpret_cast<const double2*>(d.z);
-    const double2* c2 = reinterpret_cast<const double2*>(d.cams_lin4);
-    for (int i = threadIdx.x; i < n_hot * HOT_REC_H; i += E0C_BLOCK) {
-      const int r = i / HOT_REC_H, jj = i - r * HOT_REC_H;
-      const int c = d.hot_cams[r];
-      hot[i] = jj < 6 ? z2[6 * (size_t)c + jj] : c2[6 * (size_t)c + (jj - 6)];
-    }
+    const double2* src = reinterpret_cast<const double2*>(d.hot_rec);  // [rank][12 double2]: z, P
+    for (int i = threadIdx.x; i < n_hot * HOT_REC_H; i += E0C_BLOCK) hot[i] = src[i];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -591,7 +586,7 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy_h(Dp d, int mode, 
   const double prev = shfl_up_d(s, 1);
   if (in && lane < 12) {
     const double p = (lane == 0 ? 0.0 : prev) - beta * w[lane] * wt;
-    d.z[12 * (size_t)c + lane] = p * d.sigma[12 * (size_t)c + lane];
+    store_z(d, c, lane, p * d.sigma[12 * (size_t)c + lane]);
     if (mode == 2) d.y[12 * (size_t)c + lane] = 0;
   }
   if (want_norms) {
@@ -617,7 +612,7 @@ __global__ __launch_bounds__(256) void cam_apply_inc_h(Dp d, int mode, const dou
   for (int i = 0; i < 12; ++i) {
     const double p = (i == 0 ? 0.0 : x[i - 1]) - beta * w[i] * wt;
     const double v = p * d.sigma[12 * (size_t)c + i];
-    if (mode == 1) d.z[12 * (size_t)c + i] = v;
+    if (mode == 1) store_z(d, c, i, v);
     else cams[i] += v;
   }
 }
