@@ -89,7 +89,7 @@ struct Dp {
   const int* cam_item_off;
   CmView cmv;            // what cm_scatter and the per-camera item sums walk
   // LDS-accumulated partial sums of the hottest cameras (POVAR_E0_IMPLICIT_LDSACC), else nullptr
-  const double* hot_part;  // [n_hot_wg][n_hot_acc][12]
+  const double* hot_part;  // [n_hot_acc][n_hot_wg][12]
   const int* cam_hot;      // [n_cams] 1 + rank in the LDS cache, 0 = not cached
   int n_hot_acc, n_hot_wg;
   // state
@@ -838,9 +838,10 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
   }
   if (ACC) {
     __syncthreads();
-    double* out = hot_out + (size_t)blockIdx.x * n_hot * 12;
-    // LDS holds acc[j][camera]; the partials go out as [camera][12] so a camera's 12 sums are one 96-byte read
-    for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) out[i] = acc[(i % 12) * n_hot + i / 12];
+    // LDS holds acc[j][camera]; the partials go out as [camera][workgroup][12]: the per-camera sum of
+    // cam_binv_axpy then reads one contiguous run of 96-byte records
+    for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK)
+      hot_out[((size_t)(i / 12) * gridDim.x + blockIdx.x) * 12 + i % 12] = acc[(i % 12) * n_hot + i / 12];
   }
 }
 
@@ -1006,10 +1007,10 @@ __global__ __launch_bounds__(E0T_BLOCK) void e0_tiles_cached(Dp d, int bins_per_
   __syncthreads();
   // the stored Jp carries the pose scaling sigma; the partials leave in the unscaled convention of
   // the scatter items (cam_binv_axpy multiplies by sigma once for both)
-  double* out = hot_out + (size_t)blockIdx.x * n_hot * 12;
   for (int i = threadIdx.x; i < n_hot * 12; i += E0T_BLOCK) {
     const int cam_r = i / 12, j = i % 12;
-    out[i] = acc[j * n_hot + cam_r] / d.sigma[12 * (size_t)d.hot_cams[cam_r] + j];
+    hot_out[((size_t)cam_r * gridDim.x + blockIdx.x) * 12 + j] =
+        acc[j * n_hot + cam_r] / d.sigma[12 * (size_t)d.hot_cams[cam_r] + j];
   }
 }
 
@@ -1419,7 +1420,7 @@ __device__ inline void camera_item_sum(const Dp& d, int c, int lane, double (&y)
     const int r = d.cam_hot[c];
     if (r > 0 && r <= d.n_hot_acc) {
       for (int w = lane; w < d.n_hot_wg; w += WAVE) {
-        const double* ip = d.hot_part + ((size_t)w * d.n_hot_acc + (r - 1)) * 12;
+        const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + w) * 12;
 #pragma unroll
         for (int j = 0; j < 12; ++j) y[j] += ip[j];
       }

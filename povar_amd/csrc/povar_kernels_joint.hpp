@@ -359,8 +359,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_w
     }
   }
   __syncthreads();
-  double* out = hot_out + (size_t)blockIdx.x * n_hot * 12;
-  for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) out[i] = acc[(i % 12) * n_hot + i / 12];
+  for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK)
+    hot_out[((size_t)(i / 12) * gridDim.x + blockIdx.x) * 12 + i % 12] = acc[(i % 12) * n_hot + i / 12];
 }
 
 // Gram moments of the unscaled weighted Jp12: Jp12^T Jp12 = w * (C (x) X X^T),
