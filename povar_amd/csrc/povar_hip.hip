@@ -358,12 +358,16 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
     } else {
       launch_lm(c, OpE0H{});
     }
-    const Dp dt = acc ? ldsacc_dp(c) : c->d;
-    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(dt.cmv.n_items, 1), 4)), dim3(256), 0, c->stream, dt, 1, 1);
-    *binv_mode = acc ? 3 : 1;
-    if (sharded(c)) {
-      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, dt, c->d.y, 1);
-      *binv_mode = 2;
+    if (acc) {
+      hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), 1);
+      *binv_mode = 2;  // dense y (sigma applied)
+    } else {
+      hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(c->n_items, 1), 4)), dim3(256), 0, c->stream, c->d, 1, 1);
+      *binv_mode = 1;
+      if (sharded(c)) {
+        hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.y, 1);
+        *binv_mode = 2;
+      }
     }
   } else {
     if (c->opt.e0_mode == POVAR_E0_TILES) launch_lm(c, OpE0Tiles{});
@@ -385,12 +389,16 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
     if ((c->opt.e0_mode == POVAR_E0_IMPLICIT || c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) && c->n_long > 0)
       hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0{}, c->part.p);
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
-    const Dp dt = acc ? ldsacc_dp(c) : c->d;
-    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(dt.cmv.n_items, 1), 4)), dim3(256), 0, c->stream, dt, 1, 0);
-    *binv_mode = acc ? 3 : 1;
-    if (sharded(c)) {
-      hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, dt, c->d.y, 1);
-      *binv_mode = 2;
+    if (acc) {
+      hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), 0);
+      *binv_mode = 2;  // dense y (sigma applied)
+    } else {
+      hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(c->n_items, 1), 4)), dim3(256), 0, c->stream, c->d, 1, 0);
+      *binv_mode = 1;
+      if (sharded(c)) {
+        hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.y, 1);
+        *binv_mode = 2;
+      }
     }
   }
   if (sharded(c)) {

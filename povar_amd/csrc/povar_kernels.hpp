@@ -1429,6 +1429,61 @@ __device__ inline void camera_item_sum(const Dp& d, int c, int lane, double (&y)
   wave_sum<12>(y);
 }
 
+// LDSACC modes: y_c = sigma * ( sum over the camera's COLD observations of (h q0; h q1; h q2)
+//                                + sum of the workgroups' LDS-accumulated partials of a cached camera ).
+// One 256-thread workgroup per camera, fixed summation order; replaces cm_scatter + the item sums
+// (a single wavefront walking a few hundred items per camera was a serial chain of dependent loads).
+__global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
+  if (d.flags[1]) return;
+  __shared__ double sh[4 * 12];
+  const int c = blockIdx.x, t = threadIdx.x;
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0;
+  const int p0 = d.cmv.item_off[d.cmv.cam_item_off[c]], p1 = d.cmv.item_off[d.cmv.cam_item_off[c + 1]];
+  // 4 observations per thread in flight: index loads, then the dependent gathers, then the FMAs
+  constexpr int U = 4;
+  for (int pb = p0 + t; pb < p1; pb += U * 256) {
+    int sl[U];
+    double hx[U], hy[U], hz[U], hw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + u * 256;
+      const bool in = p < p1;
+      const int pc = in ? p : p0;
+      sl[u] = in ? d.cmv.slot[pc] : -1;
+      hx[u] = d.cmv.h[pc];
+      hy[u] = d.cmv.h[d.cmv.n + pc];
+      hz[u] = d.cmv.h[2 * d.cmv.n + pc];
+      hw[u] = hom ? d.cmv.h[3 * d.cmv.n + pc] : 1.0;
+    }
+    double4 q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u] = sl[u] >= 0 ? d.q4[sl[u]] : make_double4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0] += hx[u] * q[u].x; acc[1] += hy[u] * q[u].x; acc[2] += hz[u] * q[u].x; acc[3] += hw[u] * q[u].x;
+      acc[4] += hx[u] * q[u].y; acc[5] += hy[u] * q[u].y; acc[6] += hz[u] * q[u].y; acc[7] += hw[u] * q[u].y;
+      acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += hw[u] * q[u].z;
+    }
+  }
+  const int r = d.hot_part ? d.cam_hot[c] : 0;
+  if (r > 0 && r <= d.n_hot_acc) {
+    for (int w = t; w < d.n_hot_wg; w += 256) {
+      const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + w) * 12;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] += ip[k];
+    }
+  }
+  block_sum<12, 256>(acc, sh);
+  if (t < 12) {
+    double v = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v = (t == k) ? acc[k] : v;
+    d.y[12 * (size_t)c + t] = v * d.sigma[12 * (size_t)c + t];
+  }
+}
+
 // b_c = sigma * sum_items (scatter parts)   (landmark_block.hpp:529-534); one wavefront per camera
 __global__ __launch_bounds__(256) void cam_sum_items(Dp d, double* out, int apply_sigma) {
   const int lane = threadIdx.x & 63;
