@@ -524,7 +524,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     // one 1024-thread workgroup per CU for the LDS-cached E0 kernel
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, options->device));
-    const int cus = std::max(prop.multiProcessorCount, 1);
+    int cus = std::max(prop.multiProcessorCount, 1);
+    if (const char* e = std::getenv("POVAR_E0_WGS")) cus = std::max(std::atoi(e), 1);  // tuning knob: E0 workgroups
     c->e0c_bins_per_wg = std::max((c->n_bins + cus - 1) / cus, 1);
     c->e0c_grid = (c->n_bins + c->e0c_bins_per_wg - 1) / c->e0c_bins_per_wg;
     c->n_hot = (int)L.hot_cams.size();
