@@ -161,6 +161,33 @@ int povar_normalize_joint(povar_ctx* ctx);
 /* povar_power_series_pose / _begin / _step / povar_get_term / povar_get_increment act on the system
  * prepared last (povar_prepare_pose: 12 n_cams vectors, povar_prepare_joint: 11 n_cams vectors) */
 
+/* ---- explicit-Schur-complement solvers: LinearizorSC (solver/linearizor_sc.cpp), selected by
+ * --solver-type-step-1 PCG | CHOLESKY and --solver-type-step-2 RIPCG (solver/linearizor.cpp:51-53,
+ * 67-72).  The reduced camera system S x = b, S = (Hpp + lambda I) - E0, is solved without landmark
+ * damping in step 1 (linearizor_sc.cpp:85-160) and with it in step 2 (:224-303); linearisation,
+ * error evaluation and apply are the calls above (povar_apply_pose with POVAR_POWER_VARPROJ ==
+ * LinearizorSC::apply, linearizor_sc.cpp:65-83). ---- */
+enum { POVAR_SC_PCG = 0, POVAR_SC_CHOLESKY = 1 };
+/* LinearizorPowerVarproj::linearize_pOSE scales the Jl columns (linearizor_power_varproj.cpp:62-64 ->
+ * landmark_block.hpp:284-295), LinearizorSC::linearize_pOSE does not (linearizor_sc.cpp:163-191); the
+ * stored Jl enters l_diff of apply (landmark_block.hpp:703-704).  enable = 1 (default) / 0 takes effect
+ * at the next povar_linearize_pose.  Step 2 scales in both linearizors. */
+int povar_set_jl_col_scaling(povar_ctx* ctx, int32_t enable);
+/* LinearizorSC::solve (linearizor_sc.cpp:85-160).  POVAR_SC_PCG: ConjugateGradientsSolver::solve
+ * (cg/conjugate_gradient.hpp:112-290) as driven by LinearizorBase::pcg (linearizor_base.cpp:104-125:
+ * min/max_linear_solver_iterations, q_tolerance = eta, r_tolerance = -1, result negated) with the
+ * SCHUR_JACOBI preconditioner (cg/preconditioner.hpp:66-135); S is applied matrix-free with the
+ * per-term E0 kernels.  POVAR_SC_CHOLESKY: solve_direct_pOSE (sc/linearization_sc.hpp:236-245), dense
+ * Cholesky of S on the device (needs 8 * (12 n_cams)^2 bytes of HBM; num_iterations = 0).
+ * termination = POVAR_LINEAR_SOLVER_*. */
+int povar_solve_pose_sc(povar_ctx* ctx, double lambda, int32_t method, int32_t min_iterations,
+                        int32_t max_iterations, double eta, double* inc, int32_t* num_iterations,
+                        int32_t* termination);
+/* LinearizorSC::solve_joint (linearizor_sc.cpp:224-303): PCG (conjugate_gradient.hpp:292-470) on the
+ * 11 n_cams tangent system */
+int povar_solve_joint_sc(povar_ctx* ctx, double lambda, int32_t min_iterations, int32_t max_iterations,
+                         double eta, double* inc, int32_t* num_iterations, int32_t* termination);
+
 /* ---- inspection of internal state in the reference's layouts (parity tests) ---- */
 enum {
   POVAR_BUF_DIAG2 = 0,     /* get_Jp_diag2_pOSE, 12 n_cams (linearization_varproj.hpp:183-222) */
@@ -173,7 +200,10 @@ enum {
   POVAR_BUF_JL_COL_SCALE_H, /* Jl_col_scale_homogeneous, 4 n_lms (landmark_block.hpp:303-306) */
   POVAR_BUF_B_JOINT,       /* b_p of prepare_Hb_joint, 11 n_cams */
   POVAR_BUF_B_INV_JOINT,   /* b_inv_joint_, 121 n_cams */
-  POVAR_BUF_NC_HOUSEHOLDER /* per camera (w[12], beta): N_c = (I - beta w w^T)[:, 1:], 13 n_cams */
+  POVAR_BUF_NC_HOUSEHOLDER, /* per camera (w[12], beta): N_c = (I - beta w w^T)[:, 1:], 13 n_cams */
+  POVAR_BUF_SC_PRECOND,    /* Schur-Jacobi inv_blocks of the last povar_solve_*_sc (preconditioner.hpp:80-107),
+                              144 n_cams (step 1) or 121 n_cams (step 2) */
+  POVAR_BUF_SC_BLOCKDIAG   /* B_c = Hpp_c + lambda I of the last povar_solve_*_sc, same sizes */
 };
 int povar_get_buffer(povar_ctx* ctx, int32_t which, double* out, int64_t n);
 

@@ -253,3 +253,67 @@ def step2(n_cams, lm_off, cam_idx, obs, cams, lms_h, lam, m, eps=1e-5, norm="NON
                 term_norms=np.linalg.norm(terms, axis=1), ambient_terms=terms @ Nc.T,
                 ambient_inc=pinc, l_diff=l_diff, cams_new=cams_new, lms_new=lms_new,
                 cams_norm=cams_norm, lms_norm=lms_norm, cost=e.sum(), valid=valid)
+
+
+# --------------------------------------------------------------------------- explicit SC (LinearizorSC)
+
+def block_jacobi_inverse(S, dim):
+    """Schur-Jacobi preconditioner: inverse of the dim x dim diagonal blocks of S
+    (cg/preconditioner.hpp:66-118 as used by solver/linearizor_sc.cpp:129-135)."""
+    M = np.zeros_like(S)
+    for c in range(S.shape[0] // dim):
+        s = slice(dim * c, dim * c + dim)
+        M[s, s] = np.linalg.inv(S[s, s])
+    return M
+
+
+def pcg(S, b, M, min_iterations=0, max_iterations=500, eta=1e-2, reset_period=10):
+    """Ceres-style PCG of cg/conjugate_gradient.hpp:112-290 as driven by
+    solver/linearizor_base.cpp:104-125 (r_tolerance = -1, q_tolerance = eta; the result is negated).
+    Returns (inc, num_iterations, status, iterates) with status 0 no convergence / 1 success /
+    2 failure and iterates[k] = x after iteration k+1 (before the final negation)."""
+    n = b.shape[0]
+    x = np.zeros(n)
+    iterates = []
+    if np.linalg.norm(b) == 0.0:
+        return -x, 0, 1, iterates
+    r = b - S @ x
+    rho, q0 = 1.0, -float(x @ (b + r))
+    status, it = 0, 0
+    p = None
+    while True:
+        it += 1
+        z = M @ r if M is not None else r.copy()
+        last_rho, rho = rho, float(r @ z)
+        if rho == 0.0 or np.isinf(rho):
+            status = 2
+            break
+        if it == 1:
+            p = z
+        else:
+            beta = rho / last_rho
+            if beta == 0.0 or np.isinf(beta):
+                status = 2
+                break
+            p = z + beta * p
+        q = S @ p
+        pq = float(p @ q)
+        if pq <= 0 or np.isinf(pq):
+            status = 0
+            break
+        alpha = rho / pq
+        if np.isinf(alpha):
+            status = 2
+            break
+        x = x + alpha * p
+        r = b - S @ x if it % reset_period == 0 else r - alpha * q
+        iterates.append(x.copy())
+        q1 = -float(x @ (b + r))
+        zeta = it * (q1 - q0) / q1
+        if zeta < eta and it >= min_iterations:
+            status = 1
+            break
+        q0 = q1
+        if it >= max_iterations:
+            break
+    return -x, it, status, np.array(iterates)

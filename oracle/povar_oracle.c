@@ -1056,3 +1056,248 @@ void orc_normalize_joint(int32_t n_cams, int32_t n_lms, double* cams, double* lm
     for (int k = 0; k < 4; ++k) lms_h[4 * (size_t)l + k] /= w;
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* explicit Schur complement: LinearizorSC (solver/linearizor_sc.cpp) with     */
+/* --solver-type-step-1 PCG | CHOLESKY and --solver-type-step-2 RIPCG         */
+/*   LSC = sc/linearization_sc.hpp   CG = cg/conjugate_gradient.hpp            */
+/*   PRE = cg/preconditioner.hpp     BSM = cg/block_sparse_matrix.hpp          */
+/* The reference keeps S in a hash map of dim x dim blocks (BSM:66-69) and sums */
+/* them in hash/TBB order; here S is one dense row-major n x n matrix          */
+/* (n = dim * n_cams), absent blocks are zero.                                  */
+/* ------------------------------------------------------------------------- */
+
+/* shared body of add_Hb_pOSE LMB:360-412 / add_Hb_joint LMB:414-472 for one landmark.
+ * jp(i, r): row r of observation i's pose tile (dim columns), jl likewise (3 columns) */
+static void add_hb_landmark(const orc_problem* p, int l, int rows, int dim, const double* jp_base,
+                            int jp_stride, const double* jl_base, int jl_stride,
+                            const double* res_base, int res_stride, double lambda_lm, double* S,
+                            double* b) {
+  const size_t n = (size_t)dim * (size_t)p->n_cams;
+  const int b0 = p->lm_off[l], e0 = p->lm_off[l + 1];
+  double H[9] = {0}, g[3] = {0}, Hi[9], hb[3];
+  for (int64_t r = (int64_t)rows * b0; r < (int64_t)rows * e0; ++r) {
+    const double* jl = jl_base + r * jl_stride;
+    for (int a = 0; a < 3; ++a) {
+      for (int c = 0; c < 3; ++c) H[a * 3 + c] += jl[a] * jl[c]; /* LMB:370, 430 */
+      g[a] += jl[a] * res_base[r * res_stride];                   /* LMB:372, 433 */
+    }
+  }
+  H[0] += lambda_lm; H[4] += lambda_lm; H[8] += lambda_lm; /* LMB:431 (joint only): Proj^T lambda Proj == lambda I_3 */
+  inv3(H, Hi);                                              /* LMB:371, 432 */
+  for (int a = 0; a < 3; ++a) hb[a] = Hi[a * 3] * g[0] + Hi[a * 3 + 1] * g[1] + Hi[a * 3 + 2] * g[2];
+  double* jltjp = (double*)malloc(sizeof(double) * 3 * (size_t)dim); /* jl_j^T jp_j */
+  double* t = (double*)malloc(sizeof(double) * 3 * (size_t)dim);     /* H_ll_inv * (jl_j^T jp_j) */
+  double* u = (double*)malloc(sizeof(double) * (size_t)rows * (size_t)dim); /* jl_i * t */
+  for (int i = b0; i < e0; ++i) {
+    const size_t ci = (size_t)p->cam_idx[i];
+    const double* jp_i = jp_base + (size_t)rows * i * jp_stride;
+    const double* jl_i = jl_base + (size_t)rows * i * jl_stride;
+    for (int a = 0; a < dim; ++a)
+      for (int c = 0; c < dim; ++c) {
+        double s = 0;
+        for (int r = 0; r < rows; ++r) s += jp_i[r * jp_stride + a] * jp_i[r * jp_stride + c];
+        S[(ci * dim + a) * n + ci * dim + c] += s; /* LMB:381-384, 445-448 */
+      }
+    for (int j = b0; j < e0; ++j) {
+      const size_t cj = (size_t)p->cam_idx[j];
+      const double* jp_j = jp_base + (size_t)rows * j * jp_stride;
+      const double* jl_j = jl_base + (size_t)rows * j * jl_stride;
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < dim; ++c) {
+          double s = 0;
+          for (int r = 0; r < rows; ++r) s += jl_j[r * jl_stride + a] * jp_j[r * jp_stride + c];
+          jltjp[a * dim + c] = s;
+        }
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < dim; ++c)
+          t[a * dim + c] = Hi[a * 3] * jltjp[c] + Hi[a * 3 + 1] * jltjp[dim + c] + Hi[a * 3 + 2] * jltjp[2 * dim + c];
+      for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < dim; ++c)
+          u[r * dim + c] = jl_i[r * jl_stride] * t[c] + jl_i[r * jl_stride + 1] * t[dim + c] +
+                           jl_i[r * jl_stride + 2] * t[2 * dim + c];
+      for (int a = 0; a < dim; ++a)
+        for (int c = 0; c < dim; ++c) {
+          double s = 0;
+          for (int r = 0; r < rows; ++r) s += -jp_i[r * jp_stride + a] * u[r * dim + c];
+          S[(ci * dim + a) * n + cj * dim + c] += s; /* LMB:393-399, 457-463 */
+        }
+    }
+    for (int a = 0; a < dim; ++a) {
+      double s = 0;
+      for (int r = 0; r < rows; ++r) {
+        const double e = res_base[((size_t)rows * i + r) * res_stride] -
+                         (jl_i[r * jl_stride] * hb[0] + jl_i[r * jl_stride + 1] * hb[1] + jl_i[r * jl_stride + 2] * hb[2]);
+        s += jp_i[r * jp_stride + a] * e;
+      }
+      b[ci * dim + a] += s; /* LMB:405-408, 468-470 */
+    }
+  }
+  free(jltjp);
+  free(t);
+  free(u);
+}
+
+/* get_Hb_pOSE LSC:403-406 -> get_hb_f_pOSE LSC:462-482 -> add_Hb_pOSE LMB:360-412; pose damping
+ * lambda * I added to the diagonal blocks (LSC:477-481).  No landmark damping on this path. */
+void orc_get_hb_pose(const orc_problem* p, const double* storage, double lambda_pose, double* S,
+                     double* b) {
+  const size_t n = 12 * (size_t)p->n_cams;
+  memset(S, 0, sizeof(double) * n * n);
+  memset(b, 0, sizeof(double) * n); /* LSC:466 */
+  for (int l = 0; l < p->n_lms; ++l)
+    add_hb_landmark(p, l, 4, 12, storage, ST, storage + 12, ST, storage + 15, ST, 0.0, S, b);
+  if (lambda_pose > 0) /* has_pose_damping_pOSE LSC:401, 477 */
+    for (size_t k = 0; k < n; ++k) S[k * n + k] += lambda_pose;
+}
+
+/* get_Hb_joint LSC:408-411 -> get_hb_f_joint LSC:484-531 -> add_Hb_joint LMB:414-472; pose damping
+ * Proj_pose^T lambda Proj_pose == lambda I_11 (LSC:521), landmark damping lambda (LMB:431). */
+void orc_get_hb_joint(const orc_problem* p, const double* storage_h, const double* storage_n,
+                      double lambda, double* S, double* b) {
+  const size_t n = 11 * (size_t)p->n_cams;
+  memset(S, 0, sizeof(double) * n * n);
+  memset(b, 0, sizeof(double) * n);
+  for (int l = 0; l < p->n_lms; ++l)
+    add_hb_landmark(p, l, 2, 11, storage_n, SN, storage_n + 11, SN, storage_h + 16, SH, lambda, S, b);
+  for (size_t k = 0; k < n; ++k) S[k * n + k] += lambda;
+}
+
+/* BlockDiagonalPreconditioner PRE:66-118 with diagonal == nullptr (SCHUR_JACOBI on the explicit S,
+ * linearizor_sc.cpp:133-135): inverse of each dim x dim diagonal block by LLT of its upper triangle */
+void orc_block_jacobi_inverse(int32_t n_cams, int32_t dim, const double* S, double* inv_blocks) {
+  const size_t n = (size_t)dim * (size_t)n_cams;
+  for (int c = 0; c < n_cams; ++c) {
+    double* B = inv_blocks + (size_t)dim * dim * c;
+    for (int i = 0; i < dim; ++i)
+      for (int j = 0; j < dim; ++j) B[i * dim + j] = S[((size_t)c * dim + i) * n + (size_t)c * dim + j];
+    llt_inverse_upper(dim, B); /* PRE:104-107 */
+  }
+}
+
+static void dense_mul(size_t n, const double* S, const double* x, double* y) { /* BSM right_multiply */
+  for (size_t i = 0; i < n; ++i) {
+    double s = 0;
+    for (size_t j = 0; j < n; ++j) s += S[i * n + j] * x[j];
+    y[i] = s;
+  }
+}
+
+static double dotn(const double* a, const double* b, size_t n) {
+  double s = 0;
+  for (size_t i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+
+static int zero_or_inf(double x) { return x == 0.0 || isinf(x); } /* cg/utils.hpp is_zero_or_infinity */
+
+/* ConjugateGradientsSolver::solve CG:112-290 (solve_joint CG:292-470 is the same loop) driven as
+ * LinearizorBase::pcg does (linearizor_base.cpp:104-125): r_tolerance = -1, q_tolerance = eta,
+ * x starts at zero and is NEGATED on return ("we solve H(-x) = b").  Returns the termination type. */
+int orc_pcg(int32_t n_cams, int32_t dim, const double* S, const double* b, const double* inv_blocks,
+            int32_t min_iterations, int32_t max_iterations, double eta, double* x,
+            int32_t* num_iterations) {
+  const size_t n = (size_t)dim * (size_t)n_cams;
+  const int residual_reset_period = 10; /* CG:87 */
+  int status = ORC_NO_CONVERGENCE, it = 0;
+  memset(x, 0, sizeof(double) * n); /* linearizor_sc.cpp:113 */
+  const double norm_b = norm2(b, n);
+  if (norm_b == 0.0) { /* CG:131-136 */
+    *num_iterations = 0;
+    return ORC_SUCCESS;
+  }
+  double* r = (double*)malloc(sizeof(double) * n);
+  double* pp = (double*)malloc(sizeof(double) * n);
+  double* z = (double*)malloc(sizeof(double) * n);
+  double* tmp = (double*)malloc(sizeof(double) * n);
+  double* q = (double*)malloc(sizeof(double) * n);
+  const double tol_r = -1.0 * norm_b; /* CG:144 with r_tolerance = -1 */
+  dense_mul(n, S, x, tmp);
+  for (size_t i = 0; i < n; ++i) r[i] = b[i] - tmp[i]; /* CG:146-147 */
+  double norm_r = norm2(r, n);
+  if (min_iterations == 0 && norm_r <= tol_r) { /* CG:149-158 (never true for tol_r < 0) */
+    status = ORC_SUCCESS;
+    goto done;
+  }
+  double rho = 1.0;
+  double q0;
+  {
+    double s = 0;
+    for (size_t i = 0; i < n; ++i) s += x[i] * (b[i] + r[i]);
+    q0 = -1.0 * s; /* CG:163 */
+  }
+  for (it = 1;; ++it) {
+    if (inv_blocks) orc_right_mul_b_inv(n_cams, dim, inv_blocks, r, z); /* CG:168-172, PRE:120-135 */
+    else memcpy(z, r, sizeof(double) * n);
+    const double last_rho = rho;
+    rho = dotn(r, z, n); /* CG:176 */
+    if (zero_or_inf(rho)) { status = ORC_FAILURE; break; } /* CG:177-185 */
+    if (it == 1) memcpy(pp, z, sizeof(double) * n);
+    else {
+      const double beta = rho / last_rho;
+      if (zero_or_inf(beta)) { status = ORC_FAILURE; break; } /* CG:191-197 */
+      for (size_t i = 0; i < n; ++i) pp[i] = z[i] + beta * pp[i];
+    }
+    dense_mul(n, S, pp, q); /* CG:201 */
+    const double pq = dotn(pp, q, n);
+    if (pq <= 0 || isinf(pq)) { status = ORC_NO_CONVERGENCE; break; } /* CG:204-215 */
+    const double alpha = rho / pq;
+    if (isinf(alpha)) { status = ORC_FAILURE; break; } /* CG:218-223 */
+    for (size_t i = 0; i < n; ++i) x[i] = x[i] + alpha * pp[i]; /* CG:225 */
+    if (it % residual_reset_period == 0) { /* CG:234-239 */
+      dense_mul(n, S, x, tmp);
+      for (size_t i = 0; i < n; ++i) r[i] = b[i] - tmp[i];
+    } else {
+      for (size_t i = 0; i < n; ++i) r[i] = r[i] - alpha * q[i];
+    }
+    double s = 0;
+    for (size_t i = 0; i < n; ++i) s += x[i] * (b[i] + r[i]);
+    const double q1 = -1.0 * s; /* CG:243 */
+    const double zeta = it * (q1 - q0) / q1; /* CG:268 */
+    if (zeta < eta && it >= min_iterations) { status = ORC_SUCCESS; break; } /* CG:269-282 */
+    q0 = q1;
+    norm_r = norm2(r, n);
+    if (norm_r <= tol_r && it >= min_iterations) { status = ORC_SUCCESS; break; } /* CG:288-297 */
+    if (it >= max_iterations) break; /* CG:299-301 */
+  }
+done:
+  for (size_t i = 0; i < n; ++i) x[i] = -x[i]; /* linearizor_base.cpp:122 */
+  *num_iterations = it;
+  free(r); free(pp); free(z); free(tmp); free(q);
+  return status;
+}
+
+/* solve_direct_pOSE LSC:236-245: accum = SimplicialLLT(H).solve(-b).  Restated with a dense
+ * Cholesky (lower factor, no fill-reducing permutation): the exact solve up to rounding.
+ * Returns 0, or 1 when the matrix is not positive definite. */
+int orc_cholesky_solve(int32_t n_, const double* S, const double* b, double* x) {
+  const size_t n = (size_t)n_;
+  double* L = (double*)malloc(sizeof(double) * n * n);
+  int bad = 0;
+  for (size_t j = 0; j < n && !bad; ++j) {
+    double d = S[j * n + j];
+    for (size_t k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+    if (!(d > 0)) { bad = 1; break; }
+    d = sqrt(d);
+    L[j * n + j] = d;
+    for (size_t i = j + 1; i < n; ++i) {
+      double s = S[i * n + j];
+      for (size_t k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = s / d;
+    }
+  }
+  if (!bad) {
+    for (size_t i = 0; i < n; ++i) {
+      double s = -b[i];
+      for (size_t k = 0; k < i; ++k) s -= L[i * n + k] * x[k];
+      x[i] = s / L[i * n + i];
+    }
+    for (size_t i = n; i-- > 0;) {
+      double s = x[i];
+      for (size_t k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
+      x[i] = s / L[i * n + i];
+    }
+  }
+  free(L);
+  return bad;
+}

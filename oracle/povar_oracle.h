@@ -135,6 +135,17 @@ void orc_apply_cam_inc_joint(int32_t n_cams, double* cams, const double* inc11,
                              const double* scaling);
 void orc_normalize_joint(int32_t n_cams, int32_t n_lms, double* cams, double* lms_h);
 
+/* ---- explicit Schur complement (LinearizorSC: PCG / CHOLESKY / RIPCG), dense S [n][n] ---- */
+void orc_get_hb_pose(const orc_problem* p, const double* storage, double lambda_pose, double* S,
+                     double* b);
+void orc_get_hb_joint(const orc_problem* p, const double* storage_h, const double* storage_n,
+                      double lambda, double* S, double* b);
+void orc_block_jacobi_inverse(int32_t n_cams, int32_t dim, const double* S, double* inv_blocks);
+int orc_pcg(int32_t n_cams, int32_t dim, const double* S, const double* b, const double* inv_blocks,
+            int32_t min_iterations, int32_t max_iterations, double eta, double* x,
+            int32_t* num_iterations);
+int orc_cholesky_solve(int32_t n, const double* S, const double* b, double* x);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,6 +218,38 @@ class Oracle:
         self.L.orc_normalize_joint(self.n_cams, self.n_lms, _p(cams), _p(lms_h))
         return cams, lms_h
 
+    # ---- explicit Schur complement (LinearizorSC: PCG / CHOLESKY / RIPCG) ----
+    def get_hb_pose(self, st, lambda_pose):
+        n = 12 * self.n_cams
+        S, b = np.zeros((n, n)), np.zeros(n)
+        self.L.orc_get_hb_pose(C.byref(self.prob), _p(st), C.c_double(lambda_pose), _p(S), _p(b))
+        return S, b
+
+    def get_hb_joint(self, st_h, st_n, lam):
+        n = 11 * self.n_cams
+        S, b = np.zeros((n, n)), np.zeros(n)
+        self.L.orc_get_hb_joint(C.byref(self.prob), _p(st_h), _p(st_n), C.c_double(lam), _p(S), _p(b))
+        return S, b
+
+    def block_jacobi_inverse(self, S, dim=12):
+        inv = np.zeros((self.n_cams, dim * dim))
+        self.L.orc_block_jacobi_inverse(self.n_cams, dim, _p(_f64(S)), _p(inv))
+        return inv
+
+    def pcg(self, S, b, inv_blocks, dim=12, min_iterations=0, max_iterations=500, eta=1e-2):
+        x = np.zeros(dim * self.n_cams)
+        it = C.c_int32(0)
+        status = self.L.orc_pcg(self.n_cams, dim, _p(_f64(S)), _p(_f64(b)),
+                                _p(inv_blocks) if inv_blocks is not None else None,
+                                C.c_int32(min_iterations), C.c_int32(max_iterations), C.c_double(eta),
+                                _p(x), C.byref(it))
+        return x, it.value, status
+
+    def cholesky_solve(self, S, b):
+        x = np.zeros(b.shape[0])
+        bad = self.L.orc_cholesky_solve(C.c_int32(b.shape[0]), _p(_f64(S)), _p(_f64(b)), _p(x))
+        return x, bad
+
     # ---- composite drivers restating LinearizorPowerVarproj (LZR) ----
     def stage1_pose(self, alpha, cams, lms):
         """LZR:45-76: linearize, diag2, Jl scaling, pose scaling vector."""

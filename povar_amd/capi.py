@@ -21,7 +21,9 @@ E0_IMPLICIT, E0_TILES, E0_IMPLICIT_LDSACC, E0_TILES_LDSACC = 0, 1, 2, 3
 NO_CONVERGENCE, SUCCESS, FAILURE = 0, 1, 2
 NUMERIC_FAILURE = 1
 (BUF_DIAG2, BUF_POSE_SCALING, BUF_JL_COL_SCALE, BUF_HLL_INV, BUF_B, BUF_B_INV, BUF_STORAGE,
- BUF_JL_COL_SCALE_H, BUF_B_JOINT, BUF_B_INV_JOINT, BUF_NC_HOUSEHOLDER) = range(11)
+ BUF_JL_COL_SCALE_H, BUF_B_JOINT, BUF_B_INV_JOINT, BUF_NC_HOUSEHOLDER, BUF_SC_PRECOND,
+ BUF_SC_BLOCKDIAG) = range(13)
+SC_PCG, SC_CHOLESKY = 0, 1
 
 
 class Options(C.Structure):
@@ -216,6 +218,27 @@ class Context:
                        allow_numeric=True)
         return inc, it.value, st.value, rc
 
+    # explicit-Schur-complement solvers (LinearizorSC: PCG / CHOLESKY / RIPCG)
+    def set_jl_col_scaling(self, enable):
+        self._chk(self.L.povar_set_jl_col_scaling(self.h, C.c_int32(1 if enable else 0)))
+
+    def solve_pose_sc(self, lam, method=SC_PCG, min_iterations=0, max_iterations=500, eta=1e-2):
+        inc = np.zeros(12 * self.n_cams)
+        it, st = C.c_int32(), C.c_int32()
+        rc = self._chk(self.L.povar_solve_pose_sc(self.h, C.c_double(lam), C.c_int32(method),
+                                                  C.c_int32(min_iterations), C.c_int32(max_iterations),
+                                                  C.c_double(eta), _p(inc), C.byref(it), C.byref(st)),
+                       allow_numeric=True)
+        return inc, it.value, st.value, rc
+
+    def solve_joint_sc(self, lam, min_iterations=0, max_iterations=500, eta=1e-2):
+        inc = np.zeros(11 * self.n_cams)
+        it, st = C.c_int32(), C.c_int32()
+        rc = self._chk(self.L.povar_solve_joint_sc(self.h, C.c_double(lam), C.c_int32(min_iterations),
+                                                   C.c_int32(max_iterations), C.c_double(eta), _p(inc),
+                                                   C.byref(it), C.byref(st)), allow_numeric=True)
+        return inc, it.value, st.value, rc
+
     def apply_joint(self, inc):
         inc = np.ascontiguousarray(inc, dtype=np.float64)
         ld = C.c_double()
@@ -263,7 +286,12 @@ class Context:
     def synchronize(self):
         self._chk(self.L.povar_synchronize(self.h))
 
-    def get_buffer(self, which):
+    def get_buffer(self, which, joint=False):
+        if which in (BUF_SC_PRECOND, BUF_SC_BLOCKDIAG):
+            n = (121 if joint else 144) * self.n_cams
+            out = np.zeros(n)
+            self._chk(self.L.povar_get_buffer(self.h, C.c_int32(which), _p(out), C.c_int64(n)))
+            return out
         n = {BUF_DIAG2: 12 * self.n_cams, BUF_POSE_SCALING: 12 * self.n_cams,
              BUF_JL_COL_SCALE: 3 * self.n_lms, BUF_HLL_INV: 9 * self.n_lms, BUF_B: 12 * self.n_cams,
              BUF_B_INV: 144 * self.n_cams, BUF_STORAGE: 64 * self.n_obs,

@@ -16,6 +16,8 @@
 
 #include "povar_kernels.hpp"
 #include "povar_kernels_joint.hpp"
+#include "povar_kernels_sc.hpp"
+#include "povar_kernels_chol.hpp"
 
 using namespace povar;
 
@@ -84,6 +86,12 @@ struct povar_ctx {
   DevBuf<double4> cams4, cams_lin4, cams_bak4, lms4, lms_lin4, lms_bak4, jl_scale4, rres, q4;
   DevBuf<double> hll_inv, sw, sigma, diag2, G, binv, b, tmp, accum, z, y, inc, item_part,
       item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec, ncw, cc_h, cc_part, hot_part, hot_rec;
+
+  // explicit-SC solvers (PCG / CHOLESKY / RIPCG), allocated on first use
+  DevBuf<double> sc_dm_part, sc_dm, sc_bmat, sc_minv, sc_x, sc_r, sc_p, sc_q, sc_zv, sc_part, sc_s;
+  ScP sc{};
+  DevBuf<double> sc_dense, sc_xpad;      // CHOLESKY: augmented S (povar_kernels_chol.hpp) and the padded solution
+  DevBuf<int> sc_lm_slot0, sc_lm_cnt, sc_info;
 
   Dp d{};
   bool new_linearization_point = false;  // linearizor_power_varproj.cpp:75, 192, 240
@@ -609,7 +617,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.item_part = c->item_part.p; d.item_partG = c->item_partG.p; d.cm_h = c->cm_h.p; d.n_obs = n_obs;
   d.flags = c->flags.p; d.norm_part = c->norm_part.p; d.norms = c->norms.p;
   d.sa = 0; d.sb = 1; d.eps = options->jacobi_scaling_eps; d.huber = options->huber_parameter;
-  d.lambda_lm = 0; d.robust = options->robust_norm;
+  d.lambda_lm = 0; d.robust = options->robust_norm; d.scale_jl = 1;
   *out = c;
   return 0;
 }
@@ -631,6 +639,9 @@ void povar_destroy(povar_ctx* c) {
   c->binv.release(); c->b.release(); c->tmp.release(); c->accum.release(); c->z.release(); c->y.release();
   c->inc.release(); c->item_part.release(); c->item_partG.release(); c->norm_part.release();
   c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->ncw.release(); c->cc_h.release(); c->cc_part.release(); c->hot_part.release(); c->hot_rec.release();
+  c->sc_dense.release(); c->sc_xpad.release(); c->sc_lm_slot0.release(); c->sc_lm_cnt.release(); c->sc_info.release();
+  c->sc_dm_part.release(); c->sc_dm.release(); c->sc_bmat.release(); c->sc_minv.release(); c->sc_x.release();
+  c->sc_r.release(); c->sc_p.release(); c->sc_q.release(); c->sc_zv.release(); c->sc_part.release(); c->sc_s.release();
   c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1090,6 +1101,18 @@ int povar_get_buffer(povar_ctx* c, int32_t which, double* out, int64_t n) {
       return 0;
     }
     case POVAR_BUF_NC_HOUSEHOLDER: return copy(c->ncw.p, 13 * nc);
+    case POVAR_BUF_SC_PRECOND:
+    case POVAR_BUF_SC_BLOCKDIAG: {
+      const size_t dim2 = c->joint ? 121 : 144;
+      if ((size_t)n != dim2 * nc) return fail(-1, "povar_get_buffer: wrong size");
+      if (!c->sc_s.p) return fail(-1, "povar_get_buffer: no explicit-SC solve yet");
+      std::vector<double> h(144 * nc);
+      HIP_TRY(hipMemcpyAsync(h.data(), which == POVAR_BUF_SC_PRECOND ? c->sc_minv.p : c->sc_bmat.p,
+                             144 * nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      for (size_t k = 0; k < nc; ++k) std::memcpy(out + dim2 * k, h.data() + 144 * k, dim2 * sizeof(double));
+      return 0;
+    }
     case POVAR_BUF_JL_COL_SCALE_H: {
       if ((size_t)n != 4 * nl) return fail(-1, "povar_get_buffer: wrong size");
       HIP_TRY(hipMemcpyAsync(out, c->jl_scale4.p, nl * sizeof(double4), hipMemcpyDeviceToHost, c->stream));
@@ -1200,6 +1223,200 @@ int povar_comm_init(povar_ctx* c, int32_t world, int32_t rank, const uint8_t id[
   NCCL_TRY(ncclCommInitRank(&c->comm, world, u, rank));
   c->world = world;
   c->rank = rank;
+  return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// explicit-Schur-complement solvers (LinearizorSC: PCG, CHOLESKY, RIPCG)
+// ------------------------------------------------------------------------------------------
+namespace {
+
+int ensure_sc(povar_ctx* c) {
+  if (c->sc_s.p) return 0;
+  const size_t nc = c->n_cams;
+  HIP_TRY(c->sc_dm_part.alloc(60 * (size_t)std::max(c->n_items, 1), &c->bytes));
+  HIP_TRY(c->sc_dm.alloc(60 * nc, &c->bytes));
+  HIP_TRY(c->sc_bmat.alloc(144 * nc, &c->bytes));
+  HIP_TRY(c->sc_minv.alloc(144 * nc, &c->bytes));
+  HIP_TRY(c->sc_x.alloc(12 * nc, &c->bytes));
+  HIP_TRY(c->sc_r.alloc(12 * nc, &c->bytes));
+  HIP_TRY(c->sc_p.alloc(12 * nc, &c->bytes));
+  HIP_TRY(c->sc_q.alloc(12 * nc, &c->bytes));
+  HIP_TRY(c->sc_zv.alloc(12 * nc, &c->bytes));
+  HIP_TRY(c->sc_part.alloc(4 * (size_t)c->n_cam_blocks, &c->bytes));
+  HIP_TRY(c->sc_s.alloc(PS_COUNT, &c->bytes));
+  c->sc = ScP{c->sc_dm_part.p, c->sc_dm.p, c->sc_bmat.p, c->sc_minv.p, c->sc_x.p, c->sc_r.p, c->sc_p.p,
+              c->sc_q.p,       c->sc_zv.p, c->sc_part.p, c->sc_s.p,    c->ncw.p};
+  return 0;
+}
+
+// after povar_prepare_pose / povar_prepare_joint: B_c (matrix) and the Schur-Jacobi preconditioner
+// S_cc^-1 (linearizor_sc.cpp:129-135, 271-274)
+template <bool HOM>
+int build_schur_jacobi(povar_ctx* c, double lambda) {
+  hipLaunchKernelGGL((cm_gram_sc<HOM>), dim3(grid_for(std::max(c->n_items, 1), 4)), dim3(256), 0, c->stream, c->d,
+                     c->sc.dm_part);
+  hipLaunchKernelGGL(cam_sum_parts60, dim3(c->n_cams), dim3(64), 0, c->stream, c->d, (const double*)c->sc.dm_part,
+                     c->sc.dm);
+  if (int rc = allreduce(c, c->sc.dm, 60 * (size_t)c->n_cams)) return rc;
+  const dim3 g(grid_for(c->n_cams, K8_THREADS)), b(K8_THREADS);
+  hipLaunchKernelGGL((cam_build_sc<HOM>), g, b, 0, c->stream, c->d, lambda, c->sc.ncw, (const double*)nullptr,
+                     (double*)nullptr, c->sc.bmat);
+  hipLaunchKernelGGL((cam_build_sc<HOM>), g, b, 0, c->stream, c->d, lambda, c->sc.ncw, (const double*)c->sc.dm,
+                     c->sc.minv, (double*)nullptr);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// E0 * (vector last written by emit_z) into the dense ambient y
+int e0_dense(povar_ctx* c) {
+  int mode = 1;
+  if (int rc = launch_e0(c, &mode)) return rc;
+  if (mode == 1)
+    hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.y, 1);
+  return 0;
+}
+
+
+// solve_direct_pOSE (linearization_sc.hpp:236-245): accum = LLT(S).solve(-b) with the dense S,
+// factored by the kernels of povar_kernels_chol.hpp
+int run_cholesky(povar_ctx* c, int32_t* num_iterations, int32_t* termination) {
+  const int n = 12 * c->n_cams;
+  const int N = (n + CH_NB - 1) / CH_NB * CH_NB;
+  const int64_t ld = (int64_t)N + CH_NB;
+  const size_t count = (size_t)N * (size_t)ld;
+  if (!c->sc_dense.p) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (count * sizeof(double) + (1u << 30) > free_b)
+      return fail(-1, "CHOLESKY: not enough device memory for the dense reduced camera matrix (" +
+                          std::to_string(count * sizeof(double) >> 20) + " MiB)");
+    HIP_TRY(c->sc_dense.alloc(count, &c->bytes));
+    HIP_TRY(c->sc_info.alloc(1, &c->bytes));
+    std::vector<int> s0(c->n_lms), cnt(c->n_lms);
+    for (int l = 0; l < c->n_lms; ++l) {
+      cnt[l] = c->lm_off[l + 1] - c->lm_off[l];
+      s0[l] = cnt[l] > 0 ? c->slot_of_obs[c->lm_off[l]] : 0;
+    }
+    if (int rc = upload(c->sc_lm_slot0, s0, c)) return rc;
+    if (int rc = upload(c->sc_lm_cnt, cnt, c)) return rc;
+  }
+  double* M = c->sc_dense.p;
+  HIP_TRY(hipMemsetAsync(M, 0, count * sizeof(double), c->stream));
+  HIP_TRY(hipMemsetAsync(c->sc_info.p, 0, sizeof(int), c->stream));
+  // replicated parts (B_c, -b, padding identity) once over the ranks; the landmark part is sharded
+  if (c->rank == 0) {
+    hipLaunchKernelGGL(sc_dense_diag, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)c->sc.bmat, M, ld, N);
+    if (N > n) hipLaunchKernelGGL(chol_pad, dim3(1), dim3(64), 0, c->stream, M, ld, n, N);
+  }
+  if (c->n_lms > 0)
+    hipLaunchKernelGGL(sc_dense_offdiag, dim3(c->n_lms), dim3(256), 0, c->stream, c->d, (const int*)c->sc_lm_slot0.p,
+                       (const int*)c->sc_lm_cnt.p, M, ld);
+  HIP_TRY(hipGetLastError());
+  if (int rc = allreduce(c, M, count)) return rc;
+  for (int k0 = 0; k0 < N; k0 += CH_NB) {
+    const int k1 = k0 + CH_NB;
+    hipLaunchKernelGGL(chol_diag, dim3(1), dim3(256), 0, c->stream, M, ld, k0, c->sc_info.p);
+    hipLaunchKernelGGL(chol_trsm, dim3(grid_for(ld - k1, 128)), dim3(128), 0, c->stream, M, ld, k0);
+    if (k1 < N)
+      hipLaunchKernelGGL(chol_syrk, dim3((unsigned)((ld - k1) / CH_NB), (unsigned)((N - k1) / CH_NB)), dim3(256), 0,
+                         c->stream, M, ld, k0);
+  }
+  if (!c->sc_xpad.p) HIP_TRY(c->sc_xpad.alloc((size_t)N, &c->bytes));
+  double* x = c->sc_xpad.p;  // N entries, the first n are the solution
+  for (int k0 = N - CH_NB; k0 >= 0; k0 -= CH_NB)
+    hipLaunchKernelGGL(chol_back, dim3(1), dim3(1024), 0, c->stream, (const double*)M, ld, N, k0, x);
+  HIP_TRY(hipGetLastError());
+  int info = 0;
+  HIP_TRY(hipMemcpyAsync(&info, c->sc_info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (info != 0) {
+    // S not positive definite: Eigen's SimplicialLLT would hand back garbage; report a non-finite step
+    std::vector<double> nanv((size_t)n, std::nan(""));
+    HIP_TRY(hipMemcpyAsync(c->accum.p, nanv.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->accum.p, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (num_iterations) *num_iterations = 0;  // LinearizationSC::Summary default (linearization_sc.hpp:71-81)
+  if (termination) *termination = POVAR_LINEAR_SOLVER_SUCCESS;
+  return 0;
+}
+
+template <int DIM, bool HOM>
+int run_pcg(povar_ctx* c, int32_t min_it, int32_t max_it, double eta, int32_t* num_iterations, int32_t* termination) {
+  const dim3 g(c->n_cam_blocks), b(K9_CAMS * 64);
+  const int residual_reset_period = 10;  // ConjugateGradientsSolver::Options, conjugate_gradient.hpp:87
+  const double r_tol = -1.0;             // linearizor_base.cpp:113
+  HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
+  hipLaunchKernelGGL((pcg_init<DIM>), g, b, 0, c->stream, c->d, c->sc);
+  hipLaunchKernelGGL(pcg_check, dim3(1), dim3(64), 0, c->stream, c->d, c->sc, c->n_cam_blocks, 0, min_it, max_it, eta, r_tol);
+  int f[4] = {0, 0, 0, 0};
+  if (int rc = read_flags(c, f)) return rc;
+  for (int it = 1; !f[1]; ++it) {
+    hipLaunchKernelGGL((pcg_dir<DIM, HOM>), g, b, 0, c->stream, c->d, c->sc, it == 1 ? 1 : 0);
+    if (int rc = e0_dense(c)) return rc;
+    hipLaunchKernelGGL((pcg_apply<DIM, HOM>), g, b, 0, c->stream, c->d, c->sc);
+    hipLaunchKernelGGL(pcg_alpha, dim3(1), dim3(64), 0, c->stream, c->d, c->sc, c->n_cam_blocks, it);
+    if (it % residual_reset_period == 0) {
+      hipLaunchKernelGGL((pcg_update<DIM, HOM>), g, b, 0, c->stream, c->d, c->sc, 1);
+      if (int rc = e0_dense(c)) return rc;
+      hipLaunchKernelGGL((pcg_residual<DIM, HOM>), g, b, 0, c->stream, c->d, c->sc);
+    } else {
+      hipLaunchKernelGGL((pcg_update<DIM, HOM>), g, b, 0, c->stream, c->d, c->sc, 0);
+    }
+    hipLaunchKernelGGL(pcg_check, dim3(1), dim3(64), 0, c->stream, c->d, c->sc, c->n_cam_blocks, it, min_it, max_it, eta, r_tol);
+    HIP_TRY(hipGetLastError());
+    if (int rc = read_flags(c, f)) return rc;
+  }
+  hipLaunchKernelGGL(pcg_finish, dim3(grid_for((int64_t)DIM * c->n_cams, 256)), dim3(256), 0, c->stream,
+                     (const double*)c->sc.x, c->accum.p, DIM * c->n_cams);
+  HIP_TRY(hipGetLastError());
+  if (num_iterations) *num_iterations = f[2];
+  if (termination) *termination = f[3];
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int povar_set_jl_col_scaling(povar_ctx* c, int32_t enable) {
+  if (int rc = check_ctx(c)) return rc;
+  c->d.scale_jl = enable ? 1 : 0;
+  return 0;
+}
+
+int povar_solve_pose_sc(povar_ctx* c, double lambda, int32_t method, int32_t min_iterations, int32_t max_iterations,
+                        double eta, double* inc, int32_t* num_iterations, int32_t* termination) {
+  if (method != POVAR_SC_PCG && method != POVAR_SC_CHOLESKY) return fail(-1, "povar_solve_pose_sc: unknown method");
+  // LinearizorSC::solve (linearizor_sc.cpp:85-160): no landmark damping on this path
+  if (int rc = povar_prepare_pose(c, lambda, POVAR_POWER_VARPROJ)) return rc;
+  if (int rc = ensure_sc(c)) return rc;
+  if (int rc = build_schur_jacobi<false>(c, lambda)) return rc;
+  if (method == POVAR_SC_CHOLESKY) {
+    if (int rc = run_cholesky(c, num_iterations, termination)) return rc;
+  } else {
+    if (int rc = run_pcg<12, false>(c, min_iterations, max_iterations, eta, num_iterations, termination)) return rc;
+  }
+  if (int rc = povar_get_increment(c, inc)) return rc;
+  for (size_t i = 0; i < 12 * (size_t)c->n_cams; ++i)
+    if (!std::isfinite(inc[i])) return POVAR_NUMERIC_FAILURE;  // bal_bundle_adjustment.cpp:362
+  return 0;
+}
+
+int povar_solve_joint_sc(povar_ctx* c, double lambda, int32_t min_iterations, int32_t max_iterations, double eta,
+                         double* inc, int32_t* num_iterations, int32_t* termination) {
+  // LinearizorSC::solve_joint (linearizor_sc.cpp:224-303)
+  if (int rc = povar_prepare_joint(c, lambda)) return rc;
+  if (int rc = ensure_sc(c)) return rc;
+  if (int rc = build_schur_jacobi<true>(c, lambda)) return rc;
+  if (int rc = run_pcg<11, true>(c, min_iterations, max_iterations, eta, num_iterations, termination)) return rc;
+  if (int rc = povar_get_increment(c, inc)) return rc;
+  for (size_t i = 0; i < 11 * (size_t)c->n_cams; ++i)
+    if (!std::isfinite(inc[i])) return POVAR_NUMERIC_FAILURE;
   return 0;
 }
 

@@ -126,6 +126,7 @@ struct Dp {
   // scalars
   double sa, sb, eps, huber, lambda_lm;
   int robust;
+  int scale_jl;  // 1: scale_Jl_cols_pOSE after linearisation (power linearizor), 0: LinearizorSC (no scaling)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -566,8 +567,10 @@ struct OpLinearize {
   }
   __device__ void phase2(const Dp&, int, int, int, double2, Local&, const double*, double*) const {}
   __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
-    d.jl_scale4[lm] = make_double4(1.0 / (d.eps + sqrt(tot[0])), 1.0 / (d.eps + sqrt(tot[1])),
-                                   1.0 / (d.eps + sqrt(tot[2])), 0.0);
+    // LinearizorSC::linearize_pOSE leaves the Jl columns unscaled (linearizor_sc.cpp:163-191)
+    d.jl_scale4[lm] = d.scale_jl ? make_double4(1.0 / (d.eps + sqrt(tot[0])), 1.0 / (d.eps + sqrt(tot[1])),
+                                                1.0 / (d.eps + sqrt(tot[2])), 0.0)
+                                 : make_double4(1.0, 1.0, 1.0, 0.0);
   }
 };
 

@@ -1,0 +1,167 @@
+"""GPU parity of the explicit-Schur-complement solvers (LinearizorSC: --solver-type-step-1 PCG /
+CHOLESKY, --solver-type-step-2 RIPCG) against the CPU oracle, through the C ABI.
+
+The oracle forms the dense S = (Hpp + lambda I) - E0 block by block as add_Hb_pOSE does
+(landmark_block.hpp:360-472) and runs the reference's PCG loop on it; the HIP path applies S
+matrix-free (B p - E0 p with the per-term E0 kernels) and forms only its block diagonal.  Both sum
+in different orders, and CG amplifies rounding with the iteration count, so the tolerance is
+1e-9 relative for a handful of iterations (the reference's default eta = 1e-2 stops after 3-6) and
+1e-6 after tens of iterations; iteration counts and termination types must be identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel
+
+pytestmark = pytest.mark.gpu
+
+ALPHA, LAM = 0.01, 1e-4
+
+
+def _oracle_sc_pose(orc, cams, lms, lam):
+    # LinearizorSC::linearize_pOSE (linearizor_sc.cpp:163-191: no Jl column scaling) + solve (:85-160)
+    st, ok = orc.linearize_pose(ALPHA, cams, lms)
+    diag2 = orc.jp_diag2_pose(st)
+    sigma = 1.0 / (1e-5 + np.sqrt(diag2))
+    orc.scale_jp_cols_pose(st, sigma)
+    S, b = orc.get_hb_pose(st, lam)
+    return st, sigma, S, b, orc.block_jacobi_inverse(S, 12)
+
+
+@pytest.mark.parametrize("e0_mode", [0, 2])
+@pytest.mark.parametrize("which,norm", [("small", "NONE"), ("medium", "NONE"), ("small", "HUBER")])
+def test_pcg_pose(which, norm, e0_mode, small_problem, medium_problem):
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    p = small_problem if which == "small" else medium_problem
+    orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm=norm, huber=30.0)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm=norm, huber=30.0, e0_mode=e0_mode)
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    ctx.set_cameras(p.cams)
+    ctx.set_landmarks(lms)
+    ctx.set_jl_col_scaling(False)  # LinearizorSC::linearize_pOSE
+    assert ctx.linearize_pose(ALPHA)
+    assert np.all(ctx.get_buffer(capi.BUF_JL_COL_SCALE) == 1.0)
+    st, sigma, S, b, minv = _oracle_sc_pose(orc, p.cams, lms, LAM)
+    # default forcing sequence (eta = 1e-2, bal/solver_options.hpp:205-212)
+    ref, it_o, st_o = orc.pcg(S, b, minv, eta=1e-2, max_iterations=500)
+    inc, it, status, rc = ctx.solve_pose_sc(LAM, capi.SC_PCG, 0, 500, 1e-2)
+    assert rc == 0 and (it, status) == (it_o, st_o) and status == capi.SUCCESS
+    assert rel(inc, ref) < 1e-9
+    assert rel(ctx.get_buffer(capi.BUF_B), b) < 1e-12
+    assert rel(ctx.get_buffer(capi.BUF_SC_PRECOND), minv.ravel()) < 1e-8
+    bm = ctx.get_buffer(capi.BUF_SC_BLOCKDIAG).reshape(p.n_cams, 12, 12)
+    # fixed iteration counts (eta = 0 never satisfies zeta < eta): 1, 3 and across the residual reset at 10
+    for k, tol in [(1, 1e-11), (3, 1e-10), (12, 1e-7)]:
+        ref_k, it_k, st_k = orc.pcg(S, b, minv, eta=0.0, max_iterations=k)
+        inc_k, it_g, st_g, rc = ctx.solve_pose_sc(LAM, capi.SC_PCG, 0, k, 0.0)
+        assert rc == 0 and it_g == it_k == k and st_g == st_k == capi.NO_CONVERGENCE
+        assert rel(inc_k, ref_k) < tol, k
+    # min_linear_solver_iterations keeps the loop going past the zeta test
+    ref_m, it_m, st_m = orc.pcg(S, b, minv, eta=1e-2, min_iterations=it_o + 2, max_iterations=500)
+    inc_m, it_gm, st_gm, rc = ctx.solve_pose_sc(LAM, capi.SC_PCG, it_o + 2, 500, 1e-2)
+    assert (it_gm, st_gm) == (it_m, st_m) and it_m >= it_o + 2 and rel(inc_m, ref_m) < 1e-8
+    # the step the outer loop takes with it: LinearizorSC::apply == the VarPro apply
+    ld = ctx.apply_pose(capi.POWER_VARPROJ, ALPHA, ref)
+    inc_s = ref * sigma
+    cams_new = p.cams + inc_s.reshape(-1, 12)
+    ld_o, lms_new = orc.back_substitute_pose(ALPHA, st, cams_new, lms, inc_s * (1.0 / sigma))
+    assert rel(ctx.get_cameras(), cams_new) < 1e-14 and rel(ctx.get_landmarks(), lms_new) < 1e-9
+    assert abs(ld - ld_o) <= 1e-9 * abs(ld_o)
+    # block diagonal: B_c == Hpp_c + lambda I == diagonal block of S + its E0 part (symmetric, SPD)
+    assert np.abs(bm - bm.transpose(0, 2, 1)).max() <= 1e-13 * np.abs(bm).max()
+    ctx.close()
+
+
+def test_pcg_pose_converges_to_schur_solve(small_problem):
+    """With strong damping and a tight forcing sequence PCG reaches the exact S^-1(-b)."""
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    p = small_problem
+    orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=0)
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    ctx.set_cameras(p.cams)
+    ctx.set_landmarks(lms)
+    assert ctx.linearize_pose(ALPHA)
+    st, sigma, S, b, minv = _oracle_sc_pose(orc, p.cams, lms, 1.0)
+    exact = np.linalg.solve(S, -b)
+    inc, it, status, rc = ctx.solve_pose_sc(1.0, capi.SC_PCG, 0, 500, 1e-14)
+    assert rc == 0 and rel(inc, exact) < 1e-8
+    ctx.close()
+
+
+def _state2(p, seed=11):
+    rng = np.random.default_rng(seed)
+    cams = rng.normal(size=(p.n_cams, 12))
+    cams[:, 8:11] *= 0.1
+    cams[:, 11] = 5 + rng.random(p.n_cams)
+    cams /= np.linalg.norm(cams, axis=1, keepdims=True)
+    lms_h = np.concatenate([rng.normal(size=(p.n_lms, 3)), np.ones((p.n_lms, 1))], 1)
+    return cams, lms_h, p.obs / 500.0
+
+
+@pytest.mark.parametrize("e0_mode", [0, 2])
+@pytest.mark.parametrize("which,norm", [("small", "NONE"), ("medium", "NONE"), ("small", "HUBER")])
+def test_ripcg_joint(which, norm, e0_mode, small_problem, medium_problem):
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    p = small_problem if which == "small" else medium_problem
+    cams, lms_h, obs = _state2(p)
+    orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, obs, robust_norm=norm, huber=0.5)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs, robust_norm=norm, huber=0.5, e0_mode=e0_mode)
+    ctx.set_cameras(cams)
+    ctx.set_landmarks_homogeneous(lms_h)
+    assert ctx.linearize_homogeneous()
+    # LinearizorSC::linearize_projective_space_homogeneous + solve_joint (linearizor_sc.cpp:196-303)
+    st_h, ok = orc.linearize_homogeneous(cams, lms_h)
+    diag2 = orc.jp_diag2_homogeneous(st_h)
+    jls = orc.scale_jl_cols_homogeneous(st_h)
+    sigma = 1.0 / (1e-5 + np.sqrt(diag2))
+    orc.scale_jp_cols_joint(st_h, sigma)
+    st_n = orc.linearize_nullspace(cams, lms_h, st_h)
+    S, b = orc.get_hb_joint(st_h, st_n, LAM)
+    minv = orc.block_jacobi_inverse(S, 11)
+    ref, it_o, st_o = orc.pcg(S, b, minv, dim=11, eta=1e-2, max_iterations=500)
+    inc, it, status, rc = ctx.solve_joint_sc(LAM, 0, 500, 1e-2)
+    assert rc == 0 and (it, status) == (it_o, st_o)
+    assert rel(inc, ref) < 1e-8
+    assert rel(ctx.get_buffer(capi.BUF_SC_PRECOND, joint=True), minv.ravel()) < 1e-7
+    for k, tol in [(1, 1e-10), (3, 1e-9), (11, 1e-6)]:
+        ref_k, it_k, st_k = orc.pcg(S, b, minv, dim=11, eta=0.0, max_iterations=k)
+        inc_k, it_g, st_g, rc = ctx.solve_joint_sc(LAM, 0, k, 0.0)
+        assert rc == 0 and it_g == it_k == k and st_g == st_k
+        assert rel(inc_k, ref_k) < tol, k
+    # apply_joint consumes the RIPCG increment exactly as the RIPOBA one
+    ld = ctx.apply_joint(ref)
+    ld_o, lms_new = orc.back_substitute_joint(st_h, jls, LAM, cams, lms_h, ref)
+    cams_new = orc.apply_cam_inc_joint(cams, ref, sigma)
+    assert abs(ld - ld_o) <= 1e-9 * abs(ld_o)
+    assert rel(ctx.get_cameras(), cams_new) < 1e-13 and rel(ctx.get_landmarks_homogeneous(), lms_new) < 1e-10
+    ctx.close()
+
+
+@pytest.mark.parametrize("which,norm", [("small", "NONE"), ("medium", "NONE"), ("small", "HUBER")])
+def test_cholesky_pose(which, norm, small_problem, medium_problem):
+    """--solver-type-step-1 CHOLESKY: dense S assembled on the device (upper block triangle, fp64 atomics)
+    and factored by rocSOLVER vs the oracle's dense Cholesky of the same S (solve_direct_pOSE,
+    linearization_sc.hpp:236-245).  An exact solve: tolerance cond(S) * eps, stated as 1e-8."""
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    p = small_problem if which == "small" else medium_problem
+    orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm=norm, huber=30.0)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm=norm, huber=30.0)
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    ctx.set_cameras(p.cams)
+    ctx.set_landmarks(lms)
+    ctx.set_jl_col_scaling(False)
+    assert ctx.linearize_pose(ALPHA)
+    for lam in (LAM, 1.0):
+        st, sigma, S, b, minv = _oracle_sc_pose(orc, p.cams, lms, lam)
+        ref, bad = orc.cholesky_solve(S, b)
+        assert bad == 0
+        inc, it, status, rc = ctx.solve_pose_sc(lam, capi.SC_CHOLESKY)
+        assert rc == 0 and it == 0
+        assert rel(inc, ref) < 1e-8, lam
+        assert rel(S @ inc, -b) < 1e-9
+    ctx.close()
