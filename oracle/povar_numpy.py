@@ -255,6 +255,33 @@ def step2(n_cams, lm_off, cam_idx, obs, cams, lms_h, lam, m, eps=1e-5, norm="NON
                 cams_norm=cams_norm, lms_norm=lms_norm, cost=e.sum(), valid=valid)
 
 
+def step2_system(n_cams, lm_off, cam_idx, obs, cams, lms_h, lam, eps=1e-5, norm="NONE", huber=1.0):
+    """The reduced camera system of step 2 in scipy null_space tangent coordinates: B, E0, b and the
+    block-diagonal basis Nc (12 n_cams x 11 n_cams) mapping tangent to ambient vectors."""
+    n_l = lm_off.shape[0] - 1
+    Jp, Jl, r, e, w, valid = dense_homogeneous(n_cams, lm_off, cam_idx, obs, cams, lms_h, norm, huber)
+    sigma = 1.0 / (eps + np.sqrt((Jp * Jp).sum(0)))
+    jl_scale = 1.0 / (eps + np.sqrt((Jl * Jl).sum(0)))
+    Jps, Jls = Jp * sigma, Jl * jl_scale
+    Nc = np.zeros((12 * n_cams, 11 * n_cams))
+    for c in range(n_cams):
+        Nc[12 * c : 12 * c + 12, 11 * c : 11 * c + 11] = scipy.linalg.null_space(cams[c][None, :])
+    Nl = np.zeros((4 * n_l, 3 * n_l))
+    for l in range(n_l):
+        Nl[4 * l : 4 * l + 4, 3 * l : 3 * l + 3] = scipy.linalg.null_space(lms_h[l][None, :])
+    Jpt, Jlt = Jps @ Nc, Jls @ Nl
+    Hll = Jlt.T @ Jlt + lam * np.eye(3 * n_l)
+    Hll_inv = np.zeros_like(Hll)
+    for l in range(n_l):
+        s = slice(3 * l, 3 * l + 3)
+        Hll_inv[s, s] = np.linalg.inv(Hll[s, s])
+    Hpl = Jpt.T @ Jlt
+    E0 = Hpl @ Hll_inv @ Hpl.T
+    B = Jpt.T @ Jpt + lam * np.eye(11 * n_cams)
+    b = Jpt.T @ (r - Jlt @ (Hll_inv @ (Jlt.T @ r)))
+    return dict(B=B, E0=E0, b=b, Nc=Nc, sigma=sigma)
+
+
 # --------------------------------------------------------------------------- explicit SC (LinearizorSC)
 
 def block_jacobi_inverse(S, dim):

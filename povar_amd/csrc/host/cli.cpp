@@ -72,6 +72,8 @@ bool parse_bal_app_arguments(int argc, char** argv, BalAppOptions& o) {
   dbl("initial-trust-region-radius", &o.solver.initial_trust_region_radius);
   dbl("min-trust-region-radius", &o.solver.min_trust_region_radius);
   dbl("max-trust-region-radius", &o.solver.max_trust_region_radius);
+  integer("min-linear-solver-iterations", &o.solver.min_linear_solver_iterations);
+  integer("max-linear-solver-iterations", &o.solver.max_linear_solver_iterations);
   dbl("eta", &o.solver.eta);
   dbl("r-tolerance", &o.solver.r_tolerance);
   flag["jacobi-scaling"] = &o.solver.jacobi_scaling;

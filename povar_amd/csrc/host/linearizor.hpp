@@ -62,8 +62,9 @@ struct SolverSummary {
 class Linearizor {
  public:
   using VecX = std::vector<double>;
-  // factories, solver/linearizor.cpp:47-80: POWER_VARPROJ / POWER_SCHUR_COMPLEMENT / RIPOBA select
-  // the MI355X implementation; PCG, CHOLESKY and RIPCG (explicit-SC linearizor) are out of scope.
+  // factories, solver/linearizor.cpp:47-80: POWER_VARPROJ / POWER_SCHUR_COMPLEMENT / RIPOBA select the
+  // power-series linearizor (LinearizorPowerVarproj), PCG / CHOLESKY / RIPCG the explicit-Schur-complement
+  // one (LinearizorSC); both are served by the MI355X library behind include/povar_hip.h.
   static std::unique_ptr<Linearizor> create(BalProblem& bal_problem, const SolverOptions& options,
                                             SolverSummary* summary = nullptr);
   static std::unique_ptr<Linearizor> create_homogeneous(BalProblem& bal_problem, const SolverOptions& options,

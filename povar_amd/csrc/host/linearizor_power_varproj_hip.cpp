@@ -1,5 +1,7 @@
 // LinearizorPowerVarproj (solver/linearizor_power_varproj.cpp:21-308 + solver/linearizor_base.cpp:48-100)
-// on top of the C ABI of include/povar_hip.h.  The device context owns cameras and landmarks
+// and LinearizorSC (solver/linearizor_sc.cpp:50-360; PCG / CHOLESKY / RIPCG) on top of the C ABI of
+// include/povar_hip.h: the two reference classes differ in solve()/solve_joint() and in the Jl column
+// scaling of step 1 only, so one class serves both.  The device context owns cameras and landmarks
 // between calls; BalProblem forwards backup/restore/normalise through StateMirror.
 #include <chrono>
 #include <cmath>
@@ -54,6 +56,11 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
                 : options.e0_mode == "implicit" ? POVAR_E0_IMPLICIT : POVAR_E0_IMPLICIT_LDSACC;
     check(povar_create(&ctx_, bal_problem.num_cameras(), bal_problem.num_landmarks(), (int64_t)cam_idx.size(),
                        lm_off.data(), cam_idx.data(), obs.data(), &o), "povar_create");
+    using ST = SolverOptions::SolverType;
+    sc_step1_ = !homogeneous && (options.solver_type_step_1 == ST::PCG || options.solver_type_step_1 == ST::CHOLESKY);
+    sc_step2_ = homogeneous && options.solver_type_step_2 == SolverOptions::SolverTypeRiemannian::RIPCG;
+    // LinearizorSC::linearize_pOSE does not scale the landmark Jacobian columns (linearizor_sc.cpp:163-191)
+    if (sc_step1_) check(povar_set_jl_col_scaling(ctx_, 0), "povar_set_jl_col_scaling");
     push_state();
     bal_problem_.mirror = this;
   }
@@ -114,6 +121,16 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
   VecX solve(const SolverOptions& so, double lambda, double) override {
     VecX inc(12 * (size_t)bal_problem_.num_cameras());
     Timer t;
+    if (sc_step1_) {  // LinearizorSC::solve, linearizor_sc.cpp:85-160
+      const bool chol = so.solver_type_step_1 == SolverOptions::SolverType::CHOLESKY;
+      if (!chol) require_schur_jacobi();
+      int32_t iters = 0, term = 0;
+      check(povar_solve_pose_sc(ctx_, lambda, chol ? POVAR_SC_CHOLESKY : POVAR_SC_PCG, options_.min_linear_solver_iterations,
+                                options_.max_linear_solver_iterations, options_.eta, inc.data(), &iters, &term),
+            "povar_solve_pose_sc");
+      fill_sc_summary(t.elapsed(), iters, term, chol);
+      return inc;
+    }
     const int st = so.solver_type_step_1 == SolverOptions::SolverType::POWER_SCHUR_COMPLEMENT
                        ? POVAR_POWER_SCHUR_COMPLEMENT : POVAR_POWER_VARPROJ;
     check(povar_prepare_pose(ctx_, lambda, st), "povar_prepare_pose");
@@ -130,6 +147,13 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
     VecX inc(11 * (size_t)bal_problem_.num_cameras());
     Timer t;
     int32_t iters = 0, term = 0;
+    if (sc_step2_) {  // LinearizorSC::solve_joint, linearizor_sc.cpp:224-303
+      require_schur_jacobi();
+      check(povar_solve_joint_sc(ctx_, lambda, options_.min_linear_solver_iterations, options_.max_linear_solver_iterations,
+                                 options_.eta, inc.data(), &iters, &term), "povar_solve_joint_sc");
+      fill_sc_summary(t.elapsed(), iters, term, false);
+      return inc;
+    }
     check(povar_solve_joint(ctx_, lambda, options_.power_sc_iterations, options_.eta, options_.r_tolerance,
                             inc.data(), &iters, &term), "povar_solve_joint");
     fill_solver_summary(t.elapsed(), iters, term);
@@ -203,7 +227,28 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
     IF_SET(summary_)->num_linear_solves += 1;
   }
 
+  void require_schur_jacobi() const {  // CHECK of linearizor_sc.cpp:126-128, 268-270
+    if (options_.preconditioner_type != SolverOptions::PreconditionerType::SCHUR_JACOBI) {
+      std::fprintf(stderr, "FATAL: preconditioner_type: not implemented\n");
+      std::abort();
+    }
+  }
+  void fill_sc_summary(double seconds, int iters, int term, bool direct) {
+    IF_SET(it_summary_)->solve_reduced_system_time_in_seconds = seconds;
+    IF_SET(it_summary_)->linear_solver_iterations = iters;
+    // messages of conjugate_gradient.hpp:114-301 (without the numbers they embed); solve_direct_pOSE
+    // leaves the message empty (linearization_sc.hpp:239)
+    IF_SET(it_summary_)->linear_solver_message =
+        direct ? ""
+        : term == POVAR_LINEAR_SOLVER_SUCCESS ? "Iteration: " + std::to_string(iters) + " Convergence."
+        : term == POVAR_LINEAR_SOLVER_FAILURE ? "Numerical failure."
+                                              : "Maximum number of iterations reached.";
+    IF_SET(it_summary_)->linear_solver_type = "bal_sc";
+    IF_SET(summary_)->num_linear_solves += 1;
+  }
+
   SolverOptions options_;
+  bool sc_step1_ = false, sc_step2_ = false;
   BalProblem& bal_problem_;
   SolverSummary* summary_ = nullptr;
   IterationSummary* it_summary_ = nullptr;
@@ -223,23 +268,11 @@ std::unique_ptr<Linearizor> make(BalProblem& p, const SolverOptions& o, SolverSu
 void set_linearizor_factory(LinearizorFactory f) { g_factory = f; }
 
 std::unique_ptr<Linearizor> Linearizor::create(BalProblem& p, const SolverOptions& o, SolverSummary* s) {
-  switch (o.solver_type_step_1) {
-    case SolverOptions::SolverType::POWER_VARPROJ:
-    case SolverOptions::SolverType::POWER_SCHUR_COMPLEMENT:
-      return make(p, o, s, false);
-    default:
-      std::fprintf(stderr, "FATAL: solver_type_step_1 %s uses the explicit-SC LinearizorSC, which is outside "
-                           "the accelerated path (SURVEY.md 2.1)\n", to_string(o.solver_type_step_1));
-      std::abort();
-  }
+  return make(p, o, s, false);  // solver/linearizor.cpp:47-62: every SolverType has a device implementation
 }
 
 std::unique_ptr<Linearizor> Linearizor::create_homogeneous(BalProblem& p, const SolverOptions& o, SolverSummary* s) {
-  if (o.solver_type_step_2 != SolverOptions::SolverTypeRiemannian::RIPOBA) {
-    std::fprintf(stderr, "FATAL: solver_type_step_2 RIPCG uses LinearizorSC, outside the accelerated path\n");
-    std::abort();
-  }
-  return make(p, o, s, true);
+  return make(p, o, s, true);  // solver/linearizor.cpp:64-80
 }
 
 }  // namespace povar_host

@@ -39,6 +39,8 @@ struct SolverOptions {
   double initial_trust_region_radius = 1e4;
   double min_trust_region_radius = 1e-32;
   double max_trust_region_radius = 1e16;
+  int min_linear_solver_iterations = 0;    // bal/solver_options.hpp:196-200
+  int max_linear_solver_iterations = 500;  // bal/solver_options.hpp:201-203
   double eta = 1e-2;
   double r_tolerance = -1.0;
   bool jacobi_scaling = true;

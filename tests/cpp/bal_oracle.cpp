@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE: the restated `bal` host program (povar_amd/csrc/host) driven by a Linearizor
 // backed by the CPU oracle (oracle/povar_oracle.c) instead of the HIP library.  Same LM loop, same
 // loader, same CLI: the end-to-end test runs this binary and bin/bal on the same input file and
-// compares the iteration logs.  Mirrors LinearizorPowerVarproj (solver/linearizor_power_varproj.cpp).
+// compares the iteration logs.  Mirrors LinearizorPowerVarproj (solver/linearizor_power_varproj.cpp) and,
+// for --solver-type-step-1 PCG | CHOLESKY / --solver-type-step-2 RIPCG, LinearizorSC (solver/linearizor_sc.cpp).
 #include <cmath>
 #include <cstdio>
 
@@ -29,6 +30,9 @@ class LinearizorOracle : public Linearizor {
     binv_.resize(144 * (size_t)nc_);
     jls_.resize(4 * (size_t)nl_);
     sigma_.resize(12 * (size_t)nc_);
+    using ST = SolverOptions::SolverType;
+    sc1_ = !hom && (o.solver_type_step_1 == ST::PCG || o.solver_type_step_1 == ST::CHOLESKY);
+    sc2_ = hom && o.solver_type_step_2 == SolverOptions::SolverTypeRiemannian::RIPCG;
   }
   void start_iteration(IterationSummary* it) override { it_ = it; }
   void finish_iteration() override {}
@@ -55,7 +59,7 @@ class LinearizorOracle : public Linearizor {
     orc_linearize_pose(&prob_, &opts_, alpha, cams_.data(), lms_.data(), storage_.data());
     std::vector<double> d2(12 * (size_t)nc_);
     orc_jp_diag2_pose(&prob_, storage_.data(), d2.data());
-    orc_scale_jl_cols_pose(&prob_, &opts_, storage_.data(), jls_.data());
+    if (!sc1_) orc_scale_jl_cols_pose(&prob_, &opts_, storage_.data(), jls_.data());  // linearizor_sc.cpp:163-191 skips it
     for (size_t i = 0; i < d2.size(); ++i) sigma_[i] = 1.0 / (opts_.jacobi_scaling_eps + std::sqrt(d2[i]));
     new_lin_ = true;
   }
@@ -71,6 +75,7 @@ class LinearizorOracle : public Linearizor {
   VecX solve(const SolverOptions& so, double lambda, double) override {  // cpp:178-243
     if (new_lin_) orc_scale_jp_cols_pose(&prob_, storage_.data(), sigma_.data());
     new_lin_ = false;
+    if (sc1_) return solve_sc(12, so.solver_type_step_1 == SolverOptions::SolverType::CHOLESKY, lambda);  // linearizor_sc.cpp:85-160
     const bool poba = so.solver_type_step_1 == SolverOptions::SolverType::POWER_SCHUR_COMPLEMENT;
     std::vector<double> b(12 * (size_t)nc_);
     orc_prepare_hb_pose(&prob_, storage_.data(), lambda, poba ? lambda : 0.0, hll_.data(), b.data(), binv_.data());
@@ -89,6 +94,7 @@ class LinearizorOracle : public Linearizor {
       orc_linearize_nullspace(&prob_, cams_.data(), lms_.data(), storage_h_.data(), storage_n_.data());
     }
     new_lin_ = false;
+    if (sc2_) return solve_sc(11, false, lambda);  // linearizor_sc.cpp:224-303
     std::vector<double> b(11 * (size_t)nc_);
     orc_prepare_hb_joint(&prob_, storage_h_.data(), storage_n_.data(), lambda, hll_.data(), b.data(), binv_.data());
     lambda_ = lambda;
@@ -102,7 +108,7 @@ class LinearizorOracle : public Linearizor {
   double apply(const SolverOptions& so, double alpha, VecX&& inc) override {  // cpp:246-273
     pull();
     double l_diff;
-    if (so.solver_type_step_1 == SolverOptions::SolverType::POWER_VARPROJ) {
+    if (so.solver_type_step_1 != SolverOptions::SolverType::POWER_SCHUR_COMPLEMENT) {  // also LinearizorSC::apply, linearizor_sc.cpp:65-83
       for (size_t i = 0; i < inc.size(); ++i) inc[i] *= sigma_[i];
       orc_apply_cam_inc(nc_, cams_.data(), inc.data());
       for (size_t i = 0; i < inc.size(); ++i) inc[i] *= 1.0 / sigma_[i];
@@ -124,6 +130,32 @@ class LinearizorOracle : public Linearizor {
   }
 
  private:
+  VecX solve_sc(int dim, bool direct, double lambda) {
+    const size_t n = (size_t)dim * (size_t)nc_;
+    std::vector<double> S(n * n), b(n), minv((size_t)dim * dim * nc_);
+    if (dim == 12) orc_get_hb_pose(&prob_, storage_.data(), lambda, S.data(), b.data());
+    else orc_get_hb_joint(&prob_, storage_h_.data(), storage_n_.data(), lambda, S.data(), b.data());
+    lambda_ = lambda;
+    VecX inc(n);
+    int32_t iters = 0;
+    int st = ORC_SUCCESS;
+    if (direct) {
+      if (orc_cholesky_solve((int32_t)n, S.data(), b.data(), inc.data()))
+        for (double& v : inc) v = std::nan("");
+    } else {
+      orc_block_jacobi_inverse(nc_, dim, S.data(), minv.data());
+      st = orc_pcg(nc_, dim, S.data(), b.data(), minv.data(), options_.min_linear_solver_iterations,
+                   options_.max_linear_solver_iterations, options_.eta, inc.data(), &iters);
+    }
+    if (it_) {
+      it_->linear_solver_iterations = iters;
+      it_->linear_solver_message = direct ? "" : st == ORC_SUCCESS ? "Iteration: " + std::to_string(iters) + " Convergence."
+                                   : st == ORC_FAILURE ? "Numerical failure." : "Maximum number of iterations reached.";
+      it_->linear_solver_type = "bal_sc";
+    }
+    if (summary_) summary_->num_linear_solves += 1;
+    return inc;
+  }
   static ResidualInfo conv(const orc_residual_info& r) {
     ResidualInfo o;
     o.all = {(long)r.all_num_obs, r.all_error, r.all_residual_sum};
@@ -162,7 +194,7 @@ class LinearizorOracle : public Linearizor {
   BalProblem& bal_;
   SolverSummary* summary_;
   IterationSummary* it_ = nullptr;
-  bool hom_, new_lin_ = false;
+  bool hom_, new_lin_ = false, sc1_ = false, sc2_ = false;
   int nc_ = 0, nl_ = 0;
   double lambda_ = 0;
   std::vector<int> lm_off_, cam_idx_;

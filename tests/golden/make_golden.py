@@ -67,6 +67,34 @@ def step2_fixture(p):
                 cams_norm=s2["cams_norm"], lms_norm=s2["lms_norm"], cost=s2["cost"])
 
 
+def sc_fixture(p):
+    """Explicit-Schur-complement solvers (LinearizorSC): dense S = B - E0, Schur-Jacobi PCG iterates and
+    the exact solve, step 1 (12 n_cams) and step 2 (ambient coordinates: basis independent)."""
+    lms = N.init_landmarks_pose(ALPHA, p.lm_off, p.cam_idx, p.obs, p.cams)
+    s1 = N.step1(ALPHA, p.n_cams, p.lm_off, p.cam_idx, p.obs, p.cams, lms, LAM, 1, EPS)
+    S = s1["B"] - s1["E0"]
+    M = N.block_jacobi_inverse(S, 12)
+    inc, it, status, iterates = N.pcg(S, s1["b"], M, eta=1e-2)
+    inc8, it8, status8, iterates8 = N.pcg(S, s1["b"], M, eta=0.0, max_iterations=12)
+    out = dict(n_cams=p.n_cams, lm_off=p.lm_off, cam_idx=p.cam_idx, obs=p.obs, cams=p.cams, lms=lms,
+               alpha=ALPHA, lam=LAM, eps=EPS, S_diag_blocks=np.array([S[12 * c:12 * c + 12, 12 * c:12 * c + 12]
+                                                                      for c in range(p.n_cams)]),
+               S_row0=S[:12], b=s1["b"], pcg_inc=inc, pcg_iterations=it, pcg_status=status,
+               pcg_iterates_eta0=iterates8, exact=s1["exact"])
+    # step 2
+    g2 = step2_fixture(p)
+    s2 = N.step2_system(p.n_cams, p.lm_off, p.cam_idx, g2["obs"], g2["cams"], g2["lms_h"], LAM, EPS)
+    S2 = s2["B"] - s2["E0"]
+    M2 = N.block_jacobi_inverse(S2, 11)
+    inc2, it2, status2, iterates2 = N.pcg(S2, s2["b"], M2, eta=1e-2)
+    _, _, _, iterates2_eta0 = N.pcg(S2, s2["b"], M2, eta=0.0, max_iterations=6)
+    out.update(obs2=g2["obs"], cams2=g2["cams"], lms_h2=g2["lms_h"],
+               ripcg_ambient_inc=s2["Nc"] @ inc2, ripcg_iterations=it2, ripcg_status=status2,
+               ripcg_ambient_iterates_eta0=iterates2_eta0 @ s2["Nc"].T,
+               ripcg_ambient_exact=s2["Nc"] @ np.linalg.solve(S2, -s2["b"]))
+    return out
+
+
 def main():
     small = synth.make_problem(6, 40, 150, seed=3)
     medium = synth.make_problem(49, 300, 1230, seed=49)
@@ -74,6 +102,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "step1_small_huber.npz"), **step1_fixture(small, "HUBER", 30.0, False))
     np.savez_compressed(os.path.join(HERE, "step1_medium_none.npz"), **step1_fixture(medium, "NONE", 1.0, False))
     np.savez_compressed(os.path.join(HERE, "step2_small.npz"), **step2_fixture(small))
+    np.savez_compressed(os.path.join(HERE, "sc_small.npz"), **sc_fixture(small))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -80,3 +80,30 @@ def test_create_dataset_roundtrip(binaries, tmp_path):
     r2 = subprocess.run([bal_oracle, "--input", str(out), "--quiet", "--max-num-iterations-step-1", "2",
                          "--max-num-iterations-step-2", "0", "--log-log-path", str(tmp_path / "l.json")], capture_output=True, text=True)
     assert r2.returncode == 0
+
+
+@pytest.mark.parametrize("step1", ["PCG", "CHOLESKY"])
+def test_lm_loop_explicit_sc_solvers(binaries, tmp_path, step1):
+    """--solver-type-step-1 PCG | CHOLESKY (LinearizorSC) through the same LM loop: the exact solve and the
+    truncated PCG both drive the pOSE cost down, and the log names the explicit-SC linear solver."""
+    from povar_amd import synth
+    bal, bal_oracle = binaries
+    r = subprocess.run([bal, "--help"], capture_output=True, text=True)
+    assert "--max-linear-solver-iterations" in r.stdout and "--min-linear-solver-iterations" in r.stdout
+    p = synth.make_problem(8, 150, 640, seed=5)
+    f = str(tmp_path / "problem-8-150.txt")
+    synth.write_data_custom(f, p)
+    log = str(tmp_path / "ba_log.json")
+    r = subprocess.run([bal_oracle, "--input", f, "--log-log-path", log, "--quiet", "--solver-type-step-1", step1,
+                        "--solver-type-step-2", "RIPCG", "--max-num-iterations-step-1", "20",
+                        "--max-num-iterations-step-2", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.load(open(log))
+    n1 = [i for i, it in enumerate(d["iteration"]) if it == 0][1]
+    cost = np.array(d["cost"][:n1])
+    ok = np.array(d["step_is_successful"][:n1], dtype=bool)
+    acc = cost[ok]
+    assert np.all(np.diff(acc) < 0) and acc[-1] < 0.05 * acc[0]
+    its = d["linear_solver_iterations"][1:n1]
+    assert all(i == 0 for i in its) if step1 == "CHOLESKY" else all(0 < i <= 500 for i in its)
+    assert d["_static"]["solver"]["solver_type"] == ("bal_pcg" if step1 == "PCG" else "variable_projection")

@@ -121,3 +121,41 @@ def test_kernel_basis_orthonormal():
             Nn = np.zeros((n, n - 1))
             O.lib().orc_kernel_basis(n, C.c_void_p(v.ctypes.data), C.c_void_p(Nn.ctypes.data))
             assert np.abs(Nn.T @ Nn - np.eye(n - 1)).max() < 1e-14 and np.abs(Nn.T @ v).max() < 1e-14
+
+
+def test_pcg_termination_semantics(small_problem):
+    """ConjugateGradientsSolver::solve exits (conjugate_gradient.hpp:131-136, 269-301) as restated."""
+    from oracle import povar_oracle as O
+    p = small_problem
+    orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs)
+    lms = orc.init_landmarks_pose(0.01, p.cams)
+    st, ok = orc.linearize_pose(0.01, p.cams, lms)
+    sigma = 1.0 / (1e-5 + np.sqrt(orc.jp_diag2_pose(st)))
+    orc.scale_jp_cols_pose(st, sigma)
+    S, b = orc.get_hb_pose(st, 1.0)
+    minv = orc.block_jacobi_inverse(S, 12)
+    # |b| = 0: immediate success with a zero step
+    x, it, status = orc.pcg(S, np.zeros_like(b), minv)
+    assert it == 0 and status == 1 and not x.any()
+    # max_iterations reached without the zeta test firing: NO_CONVERGENCE
+    x, it, status = orc.pcg(S, b, minv, eta=0.0, max_iterations=3)
+    assert it == 3 and status == 0
+    # zeta test: i * (Q_i - Q_{i-1}) / Q_i < eta at the returned iteration and not before
+    x, it, status = orc.pcg(S, b, minv, eta=1e-3)
+    assert status == 1 and 1 < it < 100
+    Q = lambda v: v @ S @ v - 2 * b @ v  # noqa: E731
+    xs = [np.zeros_like(b)] + [-orc.pcg(S, b, minv, eta=0.0, max_iterations=k)[0] for k in range(1, it + 1)]
+    zeta = [k * (Q(xs[k]) - Q(xs[k - 1])) / Q(xs[k]) for k in range(1, it + 1)]
+    assert zeta[-1] < 1e-3 and all(z >= 1e-3 for z in zeta[:-1])
+    # min_iterations overrides the test; a tight forcing sequence reaches the exact solve
+    x2, it2, _ = orc.pcg(S, b, minv, eta=1e-3, min_iterations=it + 3)
+    assert it2 >= it + 3
+    x3, it3, st3 = orc.pcg(S, b, minv, eta=1e-14)
+    assert rel(x3, np.linalg.solve(S, -b)) < 1e-7
+    # without a preconditioner (z = r) CG still converges, more slowly
+    x4, it4, st4 = orc.pcg(S, b, None, eta=1e-14, max_iterations=2000)
+    assert rel(x4, x3) < 1e-6 and it4 > it3
+    # not positive definite: p'q <= 0 -> NO_CONVERGENCE; the direct solve reports it
+    x5, it5, st5 = orc.pcg(-S, b, None, eta=1e-14)
+    assert st5 == 0 and it5 == 1
+    assert orc.cholesky_solve(-S, b)[1] == 1
