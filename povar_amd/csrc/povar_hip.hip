@@ -1285,8 +1285,8 @@ int e0_dense(povar_ctx* c) {
 int run_cholesky(povar_ctx* c, int32_t* num_iterations, int32_t* termination) {
   const int n = 12 * c->n_cams;
   const int N = (n + CH_NB - 1) / CH_NB * CH_NB;
-  const int64_t ld = (int64_t)N + CH_NB;
-  const size_t count = (size_t)N * (size_t)ld;
+  const int64_t ld = (int64_t)N + CH_T;
+  const size_t count = (size_t)(N + CH_NB) * (size_t)ld;  // slack rows / columns for the 128 x 128 update tiles
   if (!c->sc_dense.p) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1316,18 +1316,28 @@ int run_cholesky(povar_ctx* c, int32_t* num_iterations, int32_t* termination) {
                        (const int*)c->sc_lm_cnt.p, M, ld);
   HIP_TRY(hipGetLastError());
   if (int rc = allreduce(c, M, count)) return rc;
-  for (int k0 = 0; k0 < N; k0 += CH_NB) {
-    const int k1 = k0 + CH_NB;
-    hipLaunchKernelGGL(chol_diag, dim3(1), dim3(256), 0, c->stream, M, ld, k0, c->sc_info.p);
-    hipLaunchKernelGGL(chol_trsm, dim3(grid_for(ld - k1, 128)), dim3(128), 0, c->stream, M, ld, k0);
-    if (k1 < N)
-      hipLaunchKernelGGL(chol_syrk, dim3((unsigned)((ld - k1) / CH_NB), (unsigned)((N - k1) / CH_NB)), dim3(256), 0,
-                         c->stream, M, ld, k0);
+  for (int K0 = 0; K0 < N; K0 += CH_OB) {
+    const int kdepth = std::min(CH_OB, N - K0), R0 = K0 + kdepth;
+    for (int k0 = K0; k0 < R0; k0 += CH_NB) {
+      const int k1 = k0 + CH_NB;
+      hipLaunchKernelGGL(chol_diag, dim3(1), dim3(64), 0, c->stream, M, ld, k0, c->sc_info.p);
+      hipLaunchKernelGGL(chol_trsm, dim3(grid_for((int64_t)N + 1 - k1, 128)), dim3(128), 0, c->stream, M, ld, k0);
+      if (k1 < R0)  // the block's own remaining rows, all columns to their right (through the rhs tile)
+        hipLaunchKernelGGL(chol_syrk, dim3((unsigned)((N + CH_NB - k1) / CH_NB), (unsigned)((R0 - k1) / CH_NB)), dim3(256),
+                           0, c->stream, M, ld, k0);
+    }
+    if (R0 < N)
+      hipLaunchKernelGGL(chol_syrk_outer, dim3((unsigned)((N - R0) / CH_T + 1), (unsigned)((N - R0 + CH_T - 1) / CH_T)),
+                         dim3(256), 0, c->stream, M, ld, K0, kdepth);
   }
   if (!c->sc_xpad.p) HIP_TRY(c->sc_xpad.alloc((size_t)N, &c->bytes));
   double* x = c->sc_xpad.p;  // N entries, the first n are the solution
-  for (int k0 = N - CH_NB; k0 >= 0; k0 -= CH_NB)
-    hipLaunchKernelGGL(chol_back, dim3(1), dim3(1024), 0, c->stream, (const double*)M, ld, N, k0, x);
+  hipLaunchKernelGGL(chol_copy_rhs, dim3(grid_for(N, 256)), dim3(256), 0, c->stream, (const double*)M, ld, N, x);
+  for (int k0 = N - CH_NB; k0 >= 0; k0 -= CH_NB) {
+    hipLaunchKernelGGL(chol_back_solve, dim3(1), dim3(64), 0, c->stream, (const double*)M, ld, k0, x);
+    if (k0 > 0)
+      hipLaunchKernelGGL(chol_back_update, dim3(grid_for(k0, 4)), dim3(256), 0, c->stream, (const double*)M, ld, k0, x);
+  }
   HIP_TRY(hipGetLastError());
   int info = 0;
   HIP_TRY(hipMemcpyAsync(&info, c->sc_info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
