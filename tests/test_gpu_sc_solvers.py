@@ -165,3 +165,40 @@ def test_cholesky_pose(which, norm, small_problem, medium_problem):
         assert rel(inc, ref) < 1e-8, lam
         assert rel(S @ inc, -b) < 1e-9
     ctx.close()
+
+
+@pytest.mark.parametrize("shape", ["trafalgar-257", "venice-1778"])
+def test_full_size_properties(shape):
+    """BASELINE.json sizes: the oracle's dense S is out of reach (venice-1778: 3.6 GB), so the solvers are
+    checked through size-independent properties -- the residual |S x + b| / |b| with S applied through the
+    independent povar_right_mul_e0_pose entry point, monotone decrease of that residual with the forcing
+    sequence, CHOLESKY == the limit of PCG, and the power series (same operator) moving towards it."""
+    from povar_amd import capi, synth
+    p = synth.make_bal_problem(shape)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    ctx.set_cameras(p.cams)
+    ctx.init_landmarks_pose(ALPHA)
+    ctx.set_jl_col_scaling(False)
+    assert ctx.linearize_pose(ALPHA)
+    lam = 1e-2
+
+    def residual(x):
+        bm = ctx.get_buffer(capi.BUF_SC_BLOCKDIAG).reshape(p.n_cams, 12, 12)
+        b = ctx.get_buffer(capi.BUF_B)
+        Sx = np.einsum("cij,cj->ci", bm, x.reshape(-1, 12)).ravel() - ctx.right_mul_e0_pose(x)
+        return np.linalg.norm(Sx + b) / np.linalg.norm(b)
+
+    x_c, it, st, rc = ctx.solve_pose_sc(lam, capi.SC_CHOLESKY)
+    assert rc == 0 and it == 0 and residual(x_c) < 1e-11
+    res, xs = [], []
+    for eta in (1e-1, 1e-3, 1e-6):
+        x, it, st, rc = ctx.solve_pose_sc(lam, capi.SC_PCG, 0, 500, eta)
+        assert rc == 0 and st == capi.SUCCESS and 0 < it < 500
+        res.append(residual(x))
+        xs.append(rel(x, x_c))
+    assert res[0] > res[1] > res[2] and xs[0] > xs[1] > xs[2] and res[2] < 1e-3
+    # the power series sums the same Neumann series PCG accelerates: more terms, closer to the direct solve
+    e20 = rel(ctx.solve_pose(lam, capi.POWER_VARPROJ, 20)[0], x_c)
+    e80 = rel(ctx.solve_pose(lam, capi.POWER_VARPROJ, 80)[0], x_c)
+    assert e80 < e20 < 1.0
+    ctx.close()
