@@ -135,3 +135,49 @@ def test_sharded_step2_matches_single(e0_mode):
         lb, le = o["range"]
         assert rel(o["lms"], ref["lms"][lb:le]) < 1e-9
         assert abs(o["cost2"].all_error - ref["cost2"].all_error) <= 1e-8 * ref["cost2"].all_error
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_explicit_sc_solvers_match_single(world):
+    """The explicit-SC solvers on landmark shards: the E0-diagonal moments (60 n_cams), every S p of PCG and
+    the dense S of CHOLESKY (assembled per shard, B_c / rhs / padding on rank 0 only) go through the
+    exchange hook; results equal the single-context ones."""
+    from povar_amd import capi, synth
+    p = synth.make_problem(30, 1500, 6500, seed=14)
+
+    def run(ctx):
+        ctx.set_cameras(p.cams)
+        ctx.init_landmarks_pose(ALPHA)
+        ctx.set_jl_col_scaling(False)
+        ok = ctx.linearize_pose(ALPHA)
+        pcg = ctx.solve_pose_sc(LAM, capi.SC_PCG, 0, 500, 1e-2)
+        pcg12 = ctx.solve_pose_sc(LAM, capi.SC_PCG, 0, 12, 0.0)
+        chol = ctx.solve_pose_sc(LAM, capi.SC_CHOLESKY)
+        minv = ctx.get_buffer(capi.BUF_SC_PRECOND)
+        return dict(ok=ok, pcg=pcg, pcg12=pcg12, chol=chol, minv=minv)
+
+    ref_ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=0)
+    ref = run(ref_ctx)
+    ref_ctx.close()
+    ar = HostAllReduce(world)
+    out = [None] * world
+
+    def worker(rank):
+        lb, le = capi.shard_range(p.lm_off, world, rank)
+        ob, oe = int(p.lm_off[lb]), int(p.lm_off[le])
+        ctx = capi.Context(p.n_cams, p.lm_off[lb:le + 1] - p.lm_off[lb], p.cam_idx[ob:oe], p.obs[ob:oe], e0_mode=0)
+        ctx.comm_init_host(world, rank, ar.fn(rank))
+        out[rank] = run(ctx)
+        ctx.close()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    for o in out:
+        assert o is not None and o["ok"]
+        assert rel(o["minv"], ref["minv"]) < 1e-9
+        for key, tol in (("pcg", 1e-9), ("pcg12", 1e-7), ("chol", 1e-9)):
+            inc, it, st, rc = o[key]
+            inc_r, it_r, st_r, rc_r = ref[key]
+            assert rc == 0 and (it, st) == (it_r, st_r) and rel(inc, inc_r) < tol, key
+        assert np.array_equal(o["pcg"][0], out[0]["pcg"][0])
