@@ -202,3 +202,47 @@ def test_full_size_properties(shape):
     e80 = rel(ctx.solve_pose(lam, capi.POWER_VARPROJ, 80)[0], x_c)
     assert e80 < e20 < 1.0
     ctx.close()
+
+
+def test_edge_cases_long_landmarks_and_unobserved_cameras():
+    """Layout edge cases for the explicit-SC kernels: landmarks with more than 64 observations (several
+    staging chunks per landmark in sc_dense_offdiag, the lm_long driver inside PCG's operator), cameras no
+    landmark observes (S_cc = lambda I, zero right-hand side) and two-view landmarks."""
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    rng = np.random.default_rng(17)
+    n_c = 150
+    used = np.setdiff1d(np.arange(n_c), [3, 77, 149])
+    degs = [140, 97, 65, 64] + [2] * 120 + list(rng.integers(3, 9, size=150))
+    cam_idx = np.concatenate([np.sort(rng.choice(used, k, replace=False)) for k in degs]).astype(np.int32)
+    lm_off = np.concatenate([[0], np.cumsum(degs)]).astype(np.int32)
+    n_l = len(degs)
+    cams = np.zeros((n_c, 12))
+    cams[:, :8] = rng.normal(size=(n_c, 8))
+    cams[:, 11] = 1.0
+    X = rng.normal(size=(n_l, 3))
+    lm_of = np.repeat(np.arange(n_l), degs)
+    P = cams[cam_idx].reshape(-1, 3, 4)
+    proj = np.einsum("nij,nj->ni", P[:, :2, :3], X[lm_of]) + P[:, :2, 3]
+    obs = proj + rng.normal(scale=0.05, size=proj.shape)
+    orc = O.Oracle(n_c, lm_off, cam_idx, obs)
+    lms = orc.init_landmarks_pose(ALPHA, cams)
+    st, sigma, S, b, minv = _oracle_sc_pose(orc, cams, lms, LAM)
+    ref_c, bad = orc.cholesky_solve(S, b)
+    assert bad == 0
+    for mode in (0, 2):
+        ctx = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=mode)
+        ctx.set_cameras(cams)
+        ctx.set_landmarks(lms)
+        ctx.set_jl_col_scaling(False)
+        assert ctx.linearize_pose(ALPHA)
+        for k in (2, 11):
+            ref_k, it_k, st_k = orc.pcg(S, b, minv, eta=0.0, max_iterations=k)
+            inc_k, it_g, st_g, rc = ctx.solve_pose_sc(LAM, capi.SC_PCG, 0, k, 0.0)
+            assert rc == 0 and (it_g, st_g) == (it_k, st_k) and rel(inc_k, ref_k) < 1e-7, (mode, k)
+        assert rel(ctx.get_buffer(capi.BUF_SC_PRECOND), minv.ravel()) < 1e-8
+        inc_c, it, stt, rc = ctx.solve_pose_sc(LAM, capi.SC_CHOLESKY)
+        assert rc == 0 and rel(inc_c, ref_c) < 1e-8
+        unused = np.setdiff1d(np.arange(n_c), used)
+        assert np.all(inc_c.reshape(n_c, 12)[unused] == 0) and np.all(inc_k.reshape(n_c, 12)[unused] == 0)
+        ctx.close()
