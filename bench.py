@@ -328,6 +328,25 @@ def main():
             "rel_diff_vs_primary": float(np.linalg.norm(inc_other - inc_main) / np.linalg.norm(inc_main)),
         }
         ctx.set_e0_mode(mode)
+        # the explicit-Schur-complement solvers on the same linearisation (LinearizorSC: PCG / CHOLESKY);
+        # reported beside the headline, never part of `value`
+        try:
+            ctx.solve_pose_sc(lam, capi.SC_PCG, 0, 500, 1e-6)
+            t1 = time.perf_counter()
+            _, it_pcg, st_pcg, _ = ctx.solve_pose_sc(lam, capi.SC_PCG, 0, 500, 1e-6)
+            dt_pcg = time.perf_counter() - t1
+            ctx.solve_pose_sc(lam, capi.SC_CHOLESKY)
+            t1 = time.perf_counter()
+            x_ch, _, _, rc_ch = ctx.solve_pose_sc(lam, capi.SC_CHOLESKY)
+            dt_ch = time.perf_counter() - t1
+            n_red = 12 * prob.n_cams
+            out["explicit_sc"] = {
+                "pcg_iterations_per_s": it_pcg / dt_pcg, "pcg_iterations": it_pcg, "pcg_eta": 1e-6,
+                "cholesky_ms": dt_ch * 1e3, "cholesky_dim": n_red,
+                "cholesky_tflops": n_red ** 3 / 3 / dt_ch / 1e12, "cholesky_rc": rc_ch,
+            }
+        except capi.PovarError as e:  # e.g. the dense matrix does not fit: the headline is unaffected
+            out["explicit_sc"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.step == 1:
         out["cpu_baseline"] = cpu_baseline(prob, alpha, lam, m)
