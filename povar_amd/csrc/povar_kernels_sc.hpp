@@ -251,7 +251,8 @@ __device__ inline double block_row_times(const double* M, int c, int lane, doubl
   return s;
 }
 
-// z = sigma * v (step 1) or sigma * (N_c v) (step 2) into the E0 input (dense z + hot records)
+// E0 input: z = sigma * v (step 1; plus v itself for the stored-tile forms) or sigma * (N_c v) (step 2)
+// into the dense z + hot records
 template <bool HOM>
 __device__ inline void emit_z(const Dp& d, const double* ncw, int c, int lane, bool in, double v) {
   if (HOM) {
@@ -266,7 +267,10 @@ __device__ inline void emit_z(const Dp& d, const double* ncw, int c, int lane, b
       store_z(d, c, lane, pa * d.sigma[12 * (size_t)c + lane]);
     }
   } else {
-    if (in && lane < 12) store_z(d, c, lane, v * d.sigma[12 * (size_t)c + lane]);
+    if (in && lane < 12) {
+      store_z(d, c, lane, v * d.sigma[12 * (size_t)c + lane]);
+      d.tmp[12 * (size_t)c + lane] = v;  // the stored-tile E0 forms take the unscaled vector (sigma is in the tile)
+    }
   }
 }
 

@@ -28,7 +28,7 @@ def _oracle_sc_pose(orc, cams, lms, lam):
     return st, sigma, S, b, orc.block_jacobi_inverse(S, 12)
 
 
-@pytest.mark.parametrize("e0_mode", [0, 2])
+@pytest.mark.parametrize("e0_mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("which,norm", [("small", "NONE"), ("medium", "NONE"), ("small", "HUBER")])
 def test_pcg_pose(which, norm, e0_mode, small_problem, medium_problem):
     from povar_amd import capi
