@@ -308,3 +308,40 @@ def test_unobserved_cameras_and_two_view_landmarks():
         unused = np.setdiff1d(np.arange(n_c), used)
         assert np.all(inc.reshape(n_c, 12)[unused] == 0)         # b = 0 there, so the increment is exactly 0
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_landmark_order_invariance(seed, medium_problem):
+    """the same problem with its landmarks in another order (different wave bins, different
+    camera-major item cuts, different hot/cold split inside the bins) gives the same per-camera results
+    to reduction tolerance, in every E0 mode, for the power series and for PCG."""
+    from povar_amd import capi
+    p = medium_problem
+    perm = np.random.default_rng(seed).permutation(p.n_lms)
+    k = np.diff(p.lm_off)
+    lm_off2 = np.concatenate([[0], np.cumsum(k[perm])]).astype(np.int32)
+    idx = np.concatenate([np.arange(p.lm_off[l], p.lm_off[l + 1]) for l in perm])
+
+    def run(lm_off, cam_idx, obs, mode):
+        ctx = capi.Context(p.n_cams, lm_off, cam_idx, obs, e0_mode=mode)
+        ctx.set_cameras(p.cams)
+        ctx.init_landmarks_pose(ALPHA)
+        lms = ctx.get_landmarks()
+        cost = ctx.error_pose(ALPHA).all_error
+        assert ctx.linearize_pose(ALPHA)
+        inc, it, st, rc = ctx.solve_pose(LAM, 0, M)
+        pcg, it_p, st_p, rc_p = ctx.solve_pose_sc(LAM, capi.SC_PCG, 0, 500, 1e-2)
+        ld = ctx.apply_pose(0, ALPHA, inc)
+        out = dict(lms=lms, cost=cost, inc=inc, pcg=pcg, it_p=it_p, ld=ld, lms_new=ctx.get_landmarks(),
+                   sigma=ctx.get_buffer(capi.BUF_POSE_SCALING))
+        ctx.close()
+        return out
+
+    for mode in (0, 1, 2, 3):
+        a = run(p.lm_off, p.cam_idx, p.obs, mode)
+        b = run(lm_off2, p.cam_idx[idx], p.obs[idx], mode)
+        assert np.array_equal(b["lms"], a["lms"][perm])           # per-landmark work does not see the order
+        assert abs(a["cost"] - b["cost"]) <= 1e-12 * a["cost"]
+        assert rel(b["sigma"], a["sigma"]) < 1e-13 and rel(b["inc"], a["inc"]) < 1e-10
+        assert b["it_p"] == a["it_p"] and rel(b["pcg"], a["pcg"]) < 1e-9
+        assert abs(a["ld"] - b["ld"]) <= 1e-9 * abs(a["ld"]) and rel(b["lms_new"], a["lms_new"][perm]) < 1e-9

@@ -159,3 +159,46 @@ def test_pcg_termination_semantics(small_problem):
     x5, it5, st5 = orc.pcg(-S, b, None, eta=1e-14)
     assert st5 == 0 and it5 == 1
     assert orc.cholesky_solve(-S, b)[1] == 1
+
+
+def _permute_landmarks(p, perm):
+    """The same problem with its landmarks listed in another order (observations stay grouped by landmark,
+    cameras ascending inside each)."""
+    k = np.diff(p.lm_off)
+    lm_off = np.concatenate([[0], np.cumsum(k[perm])]).astype(np.int32)
+    idx = np.concatenate([np.arange(p.lm_off[l], p.lm_off[l + 1]) for l in perm])
+    return lm_off, p.cam_idx[idx], p.obs[idx]
+
+
+def test_landmark_order_invariance_hypothesis():
+    """permuting the landmark order changes only the order of the per-camera sums, so
+    every per-camera quantity agrees to reduction tolerance and per-landmark ones are permuted copies."""
+    from hypothesis import given, settings, strategies as hst
+    from oracle import povar_oracle as O
+    from povar_amd import synth
+
+    @settings(max_examples=6, deadline=None)
+    @given(seed=hst.integers(0, 10_000), n_c=hst.integers(4, 12), n_l=hst.integers(30, 120))
+    def check(seed, n_c, n_l):
+        p = synth.make_problem(n_c, n_l, 4 * n_l, seed=seed)
+        perm = np.random.default_rng(seed).permutation(p.n_lms)
+        lm_off2, cam2, obs2 = _permute_landmarks(p, perm)
+        a = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs)
+        b = O.Oracle(p.n_cams, lm_off2, cam2, obs2)
+        lms_a = a.init_landmarks_pose(0.01, p.cams)
+        lms_b = b.init_landmarks_pose(0.01, p.cams)
+        assert np.array_equal(lms_b, lms_a[perm])
+        res = []
+        for orc, lms in ((a, lms_a), (b, lms_b)):
+            st, diag2, jls, sigma, ok = orc.stage1_pose(0.01, p.cams, lms)
+            orc.scale_jp_cols_pose(st, sigma)
+            hll, bb, binv = orc.prepare_hb_pose(st, 1e-2)
+            inc, it, status, _ = orc.solve_pose(st, hll, binv, bb, 10)
+            S, b2 = orc.get_hb_pose(st, 1e-2)
+            x_pcg, it_pcg, st_pcg = orc.pcg(S, b2, orc.block_jacobi_inverse(S, 12), eta=1e-3)
+            res.append((sigma, bb, inc, x_pcg, it_pcg, orc.error_pose(0.01, p.cams, lms).all_error))
+        for u, v in zip(res[0][:4], res[1][:4]):
+            assert rel(v, u) < 1e-9
+        assert res[0][4] == res[1][4] and abs(res[0][5] - res[1][5]) <= 1e-12 * res[0][5]
+
+    check()
