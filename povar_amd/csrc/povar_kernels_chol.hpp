@@ -67,8 +67,9 @@ __global__ __launch_bounds__(64) void chol_diag(double* M, int64_t ld, int k0, i
   for (int r = 0; r < CH_NB; ++r) blk[(int64_t)r * ld + c] = c >= r ? a[r] : 0.0;
 }
 
-// R12 = R11^-T S12 for the columns [k0 + 64, LD): forward substitution down each column,
-// R11 broadcast from LDS
+// R12 = R11^-T S12 for the columns [k0 + 64, N]: forward substitution down each column, one thread
+// per column, R11 broadcast from LDS (reading R11 with wave-uniform scalar loads instead was slower:
+// 58 vs 46 us per panel on venice-1778)
 __global__ __launch_bounds__(128) void chol_trsm(double* M, int64_t ld, int k0) {
   __shared__ double R[CH_NB][CH_NB];
   const double* blk = M + (int64_t)k0 * ld + k0;
@@ -160,17 +161,31 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_outer(double* M, int64_t ld,
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = ch_d4{0, 0, 0, 0};
-  for (int kc = 0; kc < kdepth; kc += CH_KC) {
+  // software pipeline: the global loads of chunk kc + 1 are in flight while the MFMAs of chunk kc run
+  constexpr int NLD = CH_KC * CH_T / 2 / 256;  // double2 per thread and operand
+  double2 ra[NLD], rb[NLD];
+  auto fetch = [&](int kc) {
     const double* pan = M + ((int64_t)K0 + kc) * ld;
-    __syncthreads();
-    for (int e = threadIdx.x; e < CH_KC * CH_T / 2; e += 256) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int e = threadIdx.x + 256 * u;
       const int p = e >> 6, q = (e & 63) * 2;
-      const double2 a = *reinterpret_cast<const double2*>(pan + (int64_t)p * ld + i0 + q);
-      const double2 b = *reinterpret_cast<const double2*>(pan + (int64_t)p * ld + j0 + q);
-      As[p][q] = a.x; As[p][q + 1] = a.y;
-      Bs[p][q] = b.x; Bs[p][q + 1] = b.y;
+      ra[u] = *reinterpret_cast<const double2*>(pan + (int64_t)p * ld + i0 + q);
+      rb[u] = *reinterpret_cast<const double2*>(pan + (int64_t)p * ld + j0 + q);
+    }
+  };
+  fetch(0);
+  for (int kc = 0; kc < kdepth; kc += CH_KC) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      const int p = e >> 6, q = (e & 63) * 2;
+      As[p][q] = ra[u].x; As[p][q + 1] = ra[u].y;
+      Bs[p][q] = rb[u].x; Bs[p][q + 1] = rb[u].y;
     }
     __syncthreads();
+    if (kc + CH_KC < kdepth) fetch(kc + CH_KC);
 #pragma unroll 2
     for (int kk = 0; kk < CH_KC; kk += 4) {
       double a[4], b[4];
