@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-term time of ONE rank's landmark shard of the venice-1778 shape on one GPU (the compute part of a
 strong-scaling step at world = N; the all-reduce latency is not included: POVAR_FORCE_COMM=1 adds a 1-rank
-communicator so that the kernel sequence is the sharded one).  usage: shard_term_time.py N"""
+communicator so that the kernel sequence is the sharded one).  usage: shard_term_time.py N [shape]"""
 import os
 import sys
 import time
@@ -12,7 +12,8 @@ from povar_amd import capi, synth  # noqa: E402
 
 def main():
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    p = synth.make_bal_problem("venice-1778")
+    shape = sys.argv[2] if len(sys.argv) > 2 else "venice-1778"
+    p = synth.make_bal_problem(shape)
     lb, le = capi.shard_range(p.lm_off, world, 0)
     ob, oe = int(p.lm_off[lb]), int(p.lm_off[le])
     ctx = capi.Context(p.n_cams, p.lm_off[lb:le + 1] - p.lm_off[lb], p.cam_idx[ob:oe], p.obs[ob:oe],
@@ -38,7 +39,7 @@ def main():
         ctx.power_series_pose(m, 0.0, -1.0)
     ctx.synchronize()
     pr = ctx.profile_get()
-    print(f"world={world}: shard {le - lb} landmarks / {oe - ob} obs; {dt / (k * m) * 1e6:.1f} us per term "
+    print(f"{shape} world={world}: shard {le - lb} landmarks / {oe - ob} obs; {dt / (k * m) * 1e6:.1f} us per term "
           f"({k * m / dt:.0f} terms/s); e0 {pr.e0_ms / max(pr.e0_launches, 1) * 1e3:.1f} us, "
           f"binv {pr.binv_ms / max(pr.binv_launches, 1) * 1e3:.1f} us, comm {pr.comm_ms / max(pr.comm_launches, 1) * 1e3:.1f} us")
     ctx.close()
