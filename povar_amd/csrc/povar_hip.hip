@@ -1258,7 +1258,7 @@ template <bool HOM>
 int build_schur_jacobi(povar_ctx* c, double lambda) {
   hipLaunchKernelGGL((cm_gram_sc<HOM>), dim3(grid_for(std::max(c->n_items, 1), 4)), dim3(256), 0, c->stream, c->d,
                      c->sc.dm_part);
-  hipLaunchKernelGGL(cam_sum_parts60, dim3(c->n_cams), dim3(64), 0, c->stream, c->d, (const double*)c->sc.dm_part,
+  hipLaunchKernelGGL(cam_sum_parts60, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)c->sc.dm_part,
                      c->sc.dm);
   if (int rc = allreduce(c, c->sc.dm, 60 * (size_t)c->n_cams)) return rc;
   const dim3 g(grid_for(c->n_cams, K8_THREADS)), b(K8_THREADS);
@@ -1365,6 +1365,10 @@ int run_pcg(povar_ctx* c, int32_t min_it, int32_t max_it, double eta, int32_t* n
   hipLaunchKernelGGL(pcg_check, dim3(1), dim3(64), 0, c->stream, c->d, c->sc, c->n_cam_blocks, 0, min_it, max_it, eta, r_tol);
   int f[4] = {0, 0, 0, 0};
   if (int rc = read_flags(c, f)) return rc;
+  // The termination tests run on the device (pcg_alpha / pcg_check set flags[1]; every kernel of a later
+  // iteration then returns at once), so the host only polls the flag word every few iterations: the
+  // launch pipeline stays full and at most kPoll - 1 empty iterations are enqueued past the end.
+  constexpr int kPoll = 4;
   for (int it = 1; !f[1]; ++it) {
     hipLaunchKernelGGL((pcg_dir<DIM, HOM>), g, b, 0, c->stream, c->d, c->sc, it == 1 ? 1 : 0);
     if (int rc = e0_dense(c)) return rc;
@@ -1379,7 +1383,9 @@ int run_pcg(povar_ctx* c, int32_t min_it, int32_t max_it, double eta, int32_t* n
     }
     hipLaunchKernelGGL(pcg_check, dim3(1), dim3(64), 0, c->stream, c->d, c->sc, c->n_cam_blocks, it, min_it, max_it, eta, r_tol);
     HIP_TRY(hipGetLastError());
-    if (int rc = read_flags(c, f)) return rc;
+    // with a host exchange hook every all-reduce already synchronises; poll each iteration there
+    if (it % kPoll == 0 || it >= max_it || c->host_fn)
+      if (int rc = read_flags(c, f)) return rc;
   }
   hipLaunchKernelGGL(pcg_finish, dim3(grid_for((int64_t)DIM * c->n_cams, 256)), dim3(256), 0, c->stream,
                      (const double*)c->sc.x, c->accum.p, DIM * c->n_cams);

@@ -136,13 +136,23 @@ __global__ __launch_bounds__(256) void cm_gram_sc(Dp d, double* part) {
   }
 }
 
-// dm[c] = sum of the camera's item moments, fixed order; one 64-thread workgroup per camera
-__global__ __launch_bounds__(64) void cam_sum_parts60(Dp d, const double* part, double* dm) {
-  const int c = blockIdx.x, e = threadIdx.x;
-  if (e >= 60) return;
-  double s = 0;
-  for (int it = d.cam_item_off[c]; it < d.cam_item_off[c + 1]; ++it) s += part[60 * (size_t)it + e];
-  dm[60 * (size_t)c + e] = s;
+// dm[c] = sum of the camera's item moments, fixed order: 16 wavefronts stride over the items (a hub
+// camera of venice-1778 has ~800 of them), then a fixed-order sum of the 16 partials
+__global__ __launch_bounds__(1024) void cam_sum_parts60(Dp d, const double* part, double* dm) {
+  __shared__ double sh[16][60];
+  const int c = blockIdx.x, e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  if (e < 60) {
+    double s = 0;
+    for (int it = d.cam_item_off[c] + q; it < d.cam_item_off[c + 1]; it += 16) s += part[60 * (size_t)it + e];
+    sh[q][e] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 60) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sh[k][threadIdx.x];
+    dm[60 * (size_t)c + threadIdx.x] = s;
+  }
 }
 
 // Per camera: A = sigma (Hpp-moments [- E0-diagonal moments]) sigma, projected on the tangent space

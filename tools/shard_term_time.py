@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-term time of ONE rank's landmark shard of the venice-1778 shape on one GPU (the compute part of a
 strong-scaling step at world = N; the all-reduce latency is not included: POVAR_FORCE_COMM=1 adds a 1-rank
-communicator so that the kernel sequence is the sharded one).  usage: shard_term_time.py N [shape]"""
+communicator so that the kernel sequence is the sharded one).  usage: shard_term_time.py N [shape] [e0_mode 0-3]"""
 import os
 import sys
 import time
@@ -17,7 +17,7 @@ def main():
     lb, le = capi.shard_range(p.lm_off, world, 0)
     ob, oe = int(p.lm_off[lb]), int(p.lm_off[le])
     ctx = capi.Context(p.n_cams, p.lm_off[lb:le + 1] - p.lm_off[lb], p.cam_idx[ob:oe], p.obs[ob:oe],
-                       e0_mode=capi.E0_IMPLICIT_LDSACC)
+                       e0_mode=int(sys.argv[3]) if len(sys.argv) > 3 else capi.E0_IMPLICIT_LDSACC)
     if os.environ.get("POVAR_FORCE_COMM"):
         ctx.comm_init(1, 0, capi.comm_unique_id())
     ctx.set_cameras(p.cams)
