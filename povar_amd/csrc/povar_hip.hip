@@ -115,6 +115,7 @@ struct povar_ctx {
   double series_graph_tol[2] = {0, 0};
   bool use_graph = true;
   bool graph_with_comm = false;
+  bool fuse_binv = true;   // POVAR_NO_FUSE=1: keep cam_cold_sum and cam_binv_axpy separate
 
   // profiling
   bool profile = false;
@@ -353,7 +354,9 @@ int combine_flag(povar_ctx* c, int* flag) {
 
 // E0 x for the current term: implicit (LM pass, CM pass) or stored tiles.  The per-camera
 // result is consumed by cam_binv_axpy (mode 1: scatter items, mode 2: dense y).
-int launch_e0(povar_ctx* c, int* binv_mode) {
+// fuse_norms >= 0: the caller is the term loop and takes B^-1 + AXPY next with want_norms = fuse_norms,
+// so the unsharded step-1 LDSACC path may run them inside the per-camera sum (binv_mode 4: done)
+int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
   prof_mark(c, 0);
   if (c->joint) {
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
@@ -397,7 +400,10 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
     if ((c->opt.e0_mode == POVAR_E0_IMPLICIT || c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) && c->n_long > 0)
       hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0{}, c->part.p);
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
-    if (acc) {
+    if (acc && fuse_norms >= 0 && !sharded(c) && c->fuse_binv) {
+      hipLaunchKernelGGL(cam_cold_sum_binv, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), fuse_norms);
+      *binv_mode = 4;  // B^-1, AXPY and z already done
+    } else if (acc) {
       hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), 0);
       *binv_mode = 2;  // dense y (sigma applied)
     } else {
@@ -417,6 +423,7 @@ int launch_e0(povar_ctx* c, int* binv_mode) {
 }
 
 void launch_binv(povar_ctx* c, int mode, int want_norms) {
+  if (mode == 4) return;  // fused into cam_cold_sum_binv
   prof_mark(c, 1);
   if (c->joint) {
     const Dp dt = mode == 3 ? ldsacc_dp(c) : c->d;
@@ -518,6 +525,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
+  if (const char* g = std::getenv("POVAR_NO_FUSE")) c->fuse_binv = !(g[0] == '1');
 
   Layout L;
   build_layout(n_cams, n_lms, lm_offsets, cam_idx, obs, L);
@@ -583,7 +591,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
   ALLOC(hot_rec, (size_t)HOT_MAX * HOT_REC_STRIDE);
-  ALLOC(norm_part, 2 * (size_t)c->n_cam_blocks); ALLOC(norms, 4); ALLOC(flags, 4);
+  ALLOC(norm_part, 2 * (size_t)std::max(c->n_cam_blocks, n_cams)); ALLOC(norms, 4); ALLOC(flags, 4);
   ALLOC(part, n_part * 2); ALLOC(scal, 8);
   ALLOC(stage, std::max(3 * nl, 144 * nc));
 #undef ALLOC
@@ -802,7 +810,7 @@ int povar_power_series_begin(povar_ctx* c) {
 int povar_power_series_step(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
   int mode = 1;
-  if (int rc = launch_e0(c, &mode)) return rc;
+  if (int rc = launch_e0(c, &mode, 0)) return rc;
   launch_binv(c, mode, 0);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -816,10 +824,11 @@ static int enqueue_series(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
     hipLaunchKernelGGL(series_check, dim3(1), dim3(64), 0, c->stream, c->d, c->n_cam_blocks, 0, q_tol, r_tol);
   for (int i = 1; i <= m; ++i) {
     int mode = 1;
-    if (int rc = launch_e0(c, &mode)) return rc;
+    if (int rc = launch_e0(c, &mode, norms ? 1 : 0)) return rc;
     launch_binv(c, mode, norms ? 1 : 0);
-    if (norms)
-      hipLaunchKernelGGL(series_check, dim3(1), dim3(64), 0, c->stream, c->d, c->n_cam_blocks, i, q_tol, r_tol);
+    if (norms)  // the fused kernel leaves one norm partial per camera, cam_binv_axpy one per workgroup
+      hipLaunchKernelGGL(series_check, dim3(1), dim3(64), 0, c->stream, c->d, mode == 4 ? c->n_cams : c->n_cam_blocks, i,
+                         q_tol, r_tol);
   }
   prof_mark(c, -1);
   return 0;

@@ -1488,6 +1488,75 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
   }
 }
 
+// cam_cold_sum fused with cam_binv_axpy (mode 2) for the unsharded LDSACC term loop: the workgroup that
+// has just summed camera c's E0 row applies B_c^-1, the AXPY and the sigma scaling itself, so the term
+// needs one kernel less (the dense y is never materialised).  Norm partials are per camera
+// (series_check then sums n_cams entries).
+__global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
+  if (d.flags[1]) return;
+  __shared__ double sh[4 * 12];
+  const int c = blockIdx.x, t = threadIdx.x;
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0;
+  const int p0 = d.cmv.item_off[d.cmv.cam_item_off[c]], p1 = d.cmv.item_off[d.cmv.cam_item_off[c + 1]];
+  constexpr int U = 4;
+  for (int pb = p0 + t; pb < p1; pb += U * 256) {
+    int sl[U];
+    double hx[U], hy[U], hz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + u * 256;
+      const bool in = p < p1;
+      const int pc = in ? p : p0;
+      sl[u] = in ? d.cmv.slot[pc] : -1;
+      hx[u] = d.cmv.h[pc];
+      hy[u] = d.cmv.h[d.cmv.n + pc];
+      hz[u] = d.cmv.h[2 * d.cmv.n + pc];
+    }
+    double4 q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u] = sl[u] >= 0 ? d.q4[sl[u]] : make_double4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0] += hx[u] * q[u].x; acc[1] += hy[u] * q[u].x; acc[2] += hz[u] * q[u].x; acc[3] += q[u].x;
+      acc[4] += hx[u] * q[u].y; acc[5] += hy[u] * q[u].y; acc[6] += hz[u] * q[u].y; acc[7] += q[u].y;
+      acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += q[u].z;
+    }
+  }
+  const int r = d.hot_part ? d.cam_hot[c] : 0;
+  if (r > 0 && r <= d.n_hot_acc) {
+    for (int w = t; w < d.n_hot_wg; w += 256) {
+      const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + w) * 12;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] += ip[k];
+    }
+  }
+  block_sum<12, 256>(acc, sh);  // every thread now holds the 12 sums
+  if (t >= 64) return;
+  double nrm[2] = {0, 0};
+  if (t < 12) {
+    const size_t base = 12 * (size_t)c, idx = base + t;
+    const double* Bi = d.binv + 144 * (size_t)c + 12 * t;
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s += Bi[j] * (acc[j] * d.sigma[base + j]);
+    const double a = d.accum[idx] + s;
+    d.tmp[idx] = s;
+    d.accum[idx] = a;
+    store_z(d, c, t, s * d.sigma[idx]);
+    nrm[0] = s * s;
+    nrm[1] = a * a;
+  }
+  if (want_norms) {
+    wave_sum<2>(nrm);
+    if (t == 0) {
+      d.norm_part[2 * (size_t)c] = nrm[0];
+      d.norm_part[2 * (size_t)c + 1] = nrm[1];
+    }
+  }
+}
+
 // b_c = sigma * sum_items (scatter parts)   (landmark_block.hpp:529-534); one wavefront per camera
 __global__ __launch_bounds__(256) void cam_sum_items(Dp d, double* out, int apply_sigma) {
   const int lane = threadIdx.x & 63;
