@@ -194,6 +194,14 @@ def main():
     ctx.init_landmarks_pose(alpha)
     ok = ctx.linearize_pose(alpha)
     assert ok, "numerical failure during linearization"
+    ctx.prepare_pose(lam, capi.POWER_VARPROJ)
+    ctx.synchronize()
+    # secondary figures: linearize (K3-K6) and prepare_Hb (K7+K8), second call of each
+    t_lin = time.perf_counter()
+    ok = ctx.linearize_pose(alpha)
+    ctx.synchronize()
+    t_lin = time.perf_counter() - t_lin
+    assert ok
     t_prep = time.perf_counter()
     ctx.prepare_pose(lam, capi.POWER_VARPROJ)
     ctx.synchronize()
@@ -281,11 +289,16 @@ def main():
         "kernel_ms": {"e0": e0_ms, "binv_axpy": binv_ms, "allreduce": comm_ms,
                       "e0_launches": int(prof.e0_launches)},
         "prepare_Hb_ms": t_prep * 1e3,
+        "prepare_Hb_effective_GBps": (516 * (oe - ob) + 76 * (le - lb) + 2400 * n_c) / t_prep / 1e9,
+        "linearize_ms": t_lin * 1e3,
+        "linearize_effective_GBps": 512 * (oe - ob) / t_lin / 1e9,  # the reference's streaming write of every 4x16 tile
         "device_bytes": ctx.device_bytes(),
         "roofline": {
             "bound": "hbm",
-            "kernel": "E0 x (e0_lm_cached + cm_scatter)" if mode not in (capi.E0_TILES, capi.E0_TILES_LDSACC)
-                      else "E0 x (lm_regular<OpE0Tiles> + cm_scatter)",
+            "kernel": {capi.E0_IMPLICIT: "E0 x (e0_lm_cached<false> + cm_scatter)",
+                       capi.E0_IMPLICIT_LDSACC: "E0 x (e0_lm_cached<true> + cam_cold_sum[_binv])",
+                       capi.E0_TILES: "E0 x (lm_regular<OpE0Tiles> + cm_scatter)",
+                       capi.E0_TILES_LDSACC: "E0 x (e0_tiles_cached + cam_cold_sum[_binv])"}[mode],
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
