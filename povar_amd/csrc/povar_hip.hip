@@ -80,6 +80,7 @@ struct povar_ctx {
 
   // static
   DevBuf<double2> uv, cm_uv, tiles;
+  DevBuf<int2> cc_cam_range;  // per camera: (first, end) position of its run in the cold camera-major view
   DevBuf<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
       cam_item_off, flags;
   // state
@@ -334,7 +335,7 @@ int allreduce(povar_ctx* c, double* buf, size_t n) {
 Dp ldsacc_dp(povar_ctx* c) {
   Dp dt = c->d;
   dt.cmv = CmView{c->cc_slot.p, c->cc_h.p, c->n_cold, c->cc_item_off.p, c->cc_cam_item_off.p, c->cc_part.p,
-                  c->n_cold_items};
+                  c->n_cold_items, c->cc_cam_range.p};
   dt.hot_part = c->hot_part.p;
   return dt;
 }
@@ -587,6 +588,12 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(item_part, 12 * ni); ALLOC(item_partG, 40 * ni); ALLOC(cm_h, 4 * (size_t)n_obs); ALLOC(ncw, 13 * nc);
   c->n_cold = (int64_t)L.cc_slot.size();
   c->n_cold_items = (int)L.cc_item_off.size() - 1;
+  {
+    std::vector<int2> range(n_cams);
+    for (int k = 0; k < n_cams; ++k)
+      range[k] = make_int2(L.cc_item_off[L.cc_cam_item_off[k]], L.cc_item_off[L.cc_cam_item_off[k + 1]]);
+    if (int rc = upload(c->cc_cam_range, range, c)) return rc;
+  }
   c->n_hot_acc = std::min(n_cams, HOT_ACC_MAX);
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
@@ -615,7 +622,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.item_off = c->item_off.p; d.item_cam = c->item_cam.p; d.cam_item_off = c->cam_item_off.p;
   d.cams4 = c->cams4.p; d.cams_lin4 = c->cams_lin4.p; d.lms4 = c->lms4.p; d.lms_lin4 = c->lms_lin4.p;
   d.jl_scale4 = c->jl_scale4.p; d.hll_inv = c->hll_inv.p; d.lmrec = c->lmrec.p;
-  d.cmv = CmView{c->cm_slot.p, c->cm_h.p, n_obs, c->item_off.p, c->cam_item_off.p, c->item_part.p, c->n_items};
+  d.cmv = CmView{c->cm_slot.p, c->cm_h.p, n_obs, c->item_off.p, c->cam_item_off.p, c->item_part.p, c->n_items, nullptr};
   d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
   d.hot_rec = c->hot_rec.p;
   d.hot_cams = c->hot_cams.p; d.n_hot = (int)L.hot_cams.size();
@@ -650,6 +657,7 @@ void povar_destroy(povar_ctx* c) {
   c->sc_dense.release(); c->sc_xpad.release(); c->sc_lm_slot0.release(); c->sc_lm_cnt.release(); c->sc_info.release();
   c->sc_dm_part.release(); c->sc_dm.release(); c->sc_bmat.release(); c->sc_minv.release(); c->sc_x.release();
   c->sc_r.release(); c->sc_p.release(); c->sc_q.release(); c->sc_zv.release(); c->sc_part.release(); c->sc_s.release();
+  c->cc_cam_range.release();
   c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -29,6 +29,9 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#ifndef POVAR_EXP
+#define POVAR_EXP 0  // timing-only ablation builds (tools, never shipped): see DESIGN.md experiment log
+#endif
 #include <stdint.h>
 
 namespace povar {
@@ -62,6 +65,7 @@ struct CmView {
   const int* cam_item_off; // [n_cams + 1]
   double* part;            // [n_items][12]
   int n_items;
+  const int2* cam_range;   // [n_cams] (first, end) position of each camera's run (cold view only, else nullptr)
 };
 
 struct Dp {
@@ -284,6 +288,51 @@ __device__ inline void wave_sum(double (&v)[N]) {
   for (int m = 32; m >= 1; m >>= 1) {
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] += shfl_xor_d(v[k], m);
+  }
+}
+
+// value of lane (src lane per the DPP control), 0 where the source lane does not exist (bound_ctrl)
+template <int CTRL>
+__device__ inline double dpp_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// wavefront sum through the VALU's DPP network (row_shr 1/2/4/8, row_bcast 15/31): the totals end up in
+// lane 63 only.  Six dependent v_mov_dpp + v_add_f64 steps instead of six ds_bpermute round trips through
+// the LDS crossbar -- the per-camera kernels are one latency chain, so this is their critical path.
+template <int N>
+__device__ inline void wave_total_dpp(double (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_d<0x111>(v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_d<0x112>(v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_d<0x114>(v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_d<0x118>(v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_d<0x142>(v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_d<0x143>(v[k]);
+}
+// deterministic workgroup sum like block_sum, wavefront stage on DPP
+template <int N, int BLOCK>
+__device__ inline void block_sum_dpp(double (&v)[N], double* sh /* [BLOCK/64][N] */) {
+  wave_total_dpp<N>(v);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) sh[w * N + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double s = 0;
+    for (int i = 0; i < BLOCK / 64; ++i) s += sh[i * N + k];
+    v[k] = s;
   }
 }
 
@@ -1444,7 +1493,10 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0;
-  const int p0 = d.cmv.item_off[d.cmv.cam_item_off[c]], p1 = d.cmv.item_off[d.cmv.cam_item_off[c + 1]];
+  const int2 pr = d.cmv.cam_range[c];
+  const int p0 = pr.x, p1 = pr.y;
+  const int r = d.hot_part ? d.cam_hot[c] : 0;
+  const double sg_t = t < 12 ? d.sigma[12 * (size_t)c + t] : 0.0;  // requested early, used last
   // 4 observations per thread in flight: index loads, then the dependent gathers, then the FMAs
   constexpr int U = 4;
   for (int pb = p0 + t; pb < p1; pb += U * 256) {
@@ -1471,7 +1523,6 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
       acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += hw[u] * q[u].z;
     }
   }
-  const int r = d.hot_part ? d.cam_hot[c] : 0;
   if (r > 0 && r <= d.n_hot_acc) {
     for (int w = t; w < d.n_hot_wg; w += 256) {
       const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + w) * 12;
@@ -1479,12 +1530,12 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
       for (int k = 0; k < 12; ++k) acc[k] += ip[k];
     }
   }
-  block_sum<12, 256>(acc, sh);
+  block_sum_dpp<12, 256>(acc, sh);
   if (t < 12) {
     double v = 0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) v = (t == k) ? acc[k] : v;
-    d.y[12 * (size_t)c + t] = v * d.sigma[12 * (size_t)c + t];
+    d.y[12 * (size_t)c + t] = v * sg_t;
   }
 }
 
@@ -1499,8 +1550,25 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0;
-  const int p0 = d.cmv.item_off[d.cmv.cam_item_off[c]], p1 = d.cmv.item_off[d.cmv.cam_item_off[c + 1]];
+  const int2 pr = d.cmv.cam_range[c];  // one load instead of the two-level item index
+  const int p0 = pr.x, p1 = pr.y;
+  const int r = d.hot_part ? d.cam_hot[c] : 0;
+  // everything the tail needs that depends on c only is requested now, off the critical path
+  const size_t base = 12 * (size_t)c;
+  double bi[12], sg[12], acc_old = 0;
+  if (t < 12) {
+    const double* Bi = d.binv + 144 * (size_t)c + 12 * t;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      bi[j] = Bi[j];
+      sg[j] = d.sigma[base + j];
+    }
+    acc_old = d.accum[base + t];
+  }
   constexpr int U = 4;
+#if POVAR_EXP == 22
+  if (false)
+#endif
   for (int pb = p0 + t; pb < p1; pb += U * 256) {
     int sl[U];
     double hx[U], hy[U], hz[U];
@@ -1524,7 +1592,9 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
       acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += q[u].z;
     }
   }
-  const int r = d.hot_part ? d.cam_hot[c] : 0;
+#if POVAR_EXP == 21
+  if (false)
+#endif
   if (r > 0 && r <= d.n_hot_acc) {
     for (int w = t; w < d.n_hot_wg; w += 256) {
       const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + w) * 12;
@@ -1532,19 +1602,21 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
       for (int k = 0; k < 12; ++k) acc[k] += ip[k];
     }
   }
-  block_sum<12, 256>(acc, sh);  // every thread now holds the 12 sums
+  block_sum_dpp<12, 256>(acc, sh);  // every thread now holds the 12 sums
   if (t >= 64) return;
   double nrm[2] = {0, 0};
   if (t < 12) {
-    const size_t base = 12 * (size_t)c, idx = base + t;
-    const double* Bi = d.binv + 144 * (size_t)c + 12 * t;
-    double s = 0;
+    const size_t idx = base + t;
+    double s = 0, sgt = 0;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) s += Bi[j] * (acc[j] * d.sigma[base + j]);
-    const double a = d.accum[idx] + s;
+    for (int j = 0; j < 12; ++j) {
+      s += bi[j] * (acc[j] * sg[j]);
+      sgt = (t == j) ? sg[j] : sgt;
+    }
+    const double a = acc_old + s;
     d.tmp[idx] = s;
     d.accum[idx] = a;
-    store_z(d, c, t, s * d.sigma[idx]);
+    store_z(d, c, t, s * sgt);
     nrm[0] = s * s;
     nrm[1] = a * a;
   }
