@@ -784,7 +784,9 @@ struct OpE0 {
 // from global memory.
 template <bool ACC>
 __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg, double* hot_out) {
-  if (d.flags[1]) return;
+  // the series-done flag is requested first but only tested after the LDS staging below: the staging has
+  // no global side effects, so the flag's round trip overlaps with it instead of preceding every launch
+  const int done = d.flags[1];
   extern __shared__ double2 hot[];  // [n_hot][HOT_REC] (+ [n_hot][12] doubles of accumulators if ACC)
   const int n_hot = ACC ? d.n_hot_acc : d.n_hot;
   double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC);
@@ -799,6 +801,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
     }
   }
   __syncthreads();
+  if (done) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bin0 = blockIdx.x * bins_per_wg;
   const int bin1 = min(bin0 + bins_per_wg, d.n_bins);
@@ -1487,7 +1490,7 @@ __device__ inline void camera_item_sum(const Dp& d, int c, int lane, double (&y)
 // One 256-thread workgroup per camera, fixed summation order; replaces cm_scatter + the item sums
 // (a single wavefront walking a few hundred items per camera was a serial chain of dependent loads).
 __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
-  if (d.flags[1]) return;
+  const int done = d.flags[1];  // tested after the first batch of loads is in flight
   __shared__ double sh[4 * 12];
   const int c = blockIdx.x, t = threadIdx.x;
   double acc[12];
@@ -1497,6 +1500,7 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
   const int p0 = pr.x, p1 = pr.y;
   const int r = d.hot_part ? d.cam_hot[c] : 0;
   const double sg_t = t < 12 ? d.sigma[12 * (size_t)c + t] : 0.0;  // requested early, used last
+  if (done) return;
   // 4 observations per thread in flight: index loads, then the dependent gathers, then the FMAs
   constexpr int U = 4;
   for (int pb = p0 + t; pb < p1; pb += U * 256) {
@@ -1544,7 +1548,7 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
 // needs one kernel less (the dense y is never materialised).  Norm partials are per camera
 // (series_check then sums n_cams entries).
 __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
-  if (d.flags[1]) return;
+  const int done = d.flags[1];  // tested after the first batch of loads is in flight
   __shared__ double sh[4 * 12];
   const int c = blockIdx.x, t = threadIdx.x;
   double acc[12];
@@ -1565,6 +1569,7 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
     }
     acc_old = d.accum[base + t];
   }
+  if (done) return;
   constexpr int U = 4;
 #if POVAR_EXP == 22
   if (false)
@@ -1647,10 +1652,10 @@ __global__ __launch_bounds__(256) void cam_sum_items(Dp d, double* out, int appl
 // K9 + K11: tmp = B^-1 y, accum (+)= tmp, z = sigma * tmp, optional squared-norm partials
 // (right_mul_b_inv_pOSE + the loop body of solve_pOSE, linearization_power_varproj.hpp:196-207,
 // 322-340).  mode 0: y = -b (series start); 1: y = sigma * sum of scatter items (implicit E0);
-// 2: y = dense buffer d.y (stored-tile E0, or the all-reduced vector), cleared after reading.
+// 2: y = dense buffer d.y (the per-camera sums of the LDSACC modes, or the all-reduced vector).
 constexpr int K9_CAMS = 4;  // one wavefront per camera, 4 cameras per workgroup
 __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, int want_norms) {
-  if (mode != 0 && d.flags[1]) return;
+  const int done = mode != 0 ? d.flags[1] : 0;  // tested before the first store: its round trip overlaps the loads
   __shared__ double sh[K9_CAMS * 2];
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * K9_CAMS + (threadIdx.x >> 6);
@@ -1673,17 +1678,21 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, in
     }
   }
   double nrm[2] = {0, 0};
+  double s = 0, acc = 0, sg = 0;
   if (in && lane < 12) {
     const size_t idx = 12 * (size_t)c + lane;
     const double* Bi = d.binv + 144 * (size_t)c + 12 * lane;
-    double s = 0;
 #pragma unroll
     for (int j = 0; j < 12; ++j) s += Bi[j] * y[j];
-    const double acc = mode == 0 ? s : d.accum[idx] + s;
+    acc = mode == 0 ? s : d.accum[idx] + s;
+    sg = d.sigma[idx];
+  }
+  if (done) return;
+  if (in && lane < 12) {
+    const size_t idx = 12 * (size_t)c + lane;
     d.tmp[idx] = s;
     d.accum[idx] = acc;
-    store_z(d, c, lane, s * d.sigma[idx]);
-    if (mode == 2) d.y[idx] = 0;
+    store_z(d, c, lane, s * sg);
     nrm[0] = s * s;
     nrm[1] = acc * acc;
   }
