@@ -370,7 +370,11 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
     } else {
       launch_lm(c, OpE0H{});
     }
-    if (acc) {
+    if (acc && fuse_norms >= 0 && !sharded(c) && c->fuse_binv) {
+      hipLaunchKernelGGL(cam_cold_sum_binv_h, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), fuse_norms,
+                         (const double*)c->ncw.p);
+      *binv_mode = 4;  // B^-1, AXPY and z already done
+    } else if (acc) {
       hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), 1);
       *binv_mode = 2;  // dense y (sigma applied)
     } else {

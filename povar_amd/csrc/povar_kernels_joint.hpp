@@ -598,6 +598,111 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy_h(Dp d, int mode, 
   }
 }
 
+// cam_cold_sum fused with cam_binv_axpy_h (mode 2) for the unsharded LDSACC term loop of step 2
+// (the step-2 twin of cam_cold_sum_binv): per-camera sum of the E0 row, tangent projection, B^-1 (11x11),
+// AXPY and z = sigma * (N_c tmp) in one kernel.
+__global__ __launch_bounds__(256) void cam_cold_sum_binv_h(Dp d, int want_norms, const double* ncw) {
+  const int done = d.flags[1];
+  __shared__ double sh[4 * 12];
+  const int c = blockIdx.x, t = threadIdx.x;
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0;
+  const int2 pr = d.cmv.cam_range[c];
+  const int p0 = pr.x, p1 = pr.y;
+  const int r = d.hot_part ? d.cam_hot[c] : 0;
+  const size_t base = 12 * (size_t)c;
+  double bi[11], sg[12], w[12], acc_old = 0;
+  const double beta = ncw[13 * (size_t)c + 12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    sg[j] = d.sigma[base + j];
+    w[j] = ncw[13 * (size_t)c + j];
+  }
+  if (t < 11) {
+    const double* Bi = d.binv + 144 * (size_t)c + 11 * t;
+#pragma unroll
+    for (int j = 0; j < 11; ++j) bi[j] = Bi[j];
+    acc_old = d.accum[11 * (size_t)c + t];
+  }
+  if (done) return;
+  constexpr int U = 4;
+  for (int pb = p0 + t; pb < p1; pb += U * 256) {
+    int sl[U];
+    double hx[U], hy[U], hz[U], hw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + u * 256;
+      const bool in = p < p1;
+      const int pc = in ? p : p0;
+      sl[u] = in ? d.cmv.slot[pc] : -1;
+      hx[u] = d.cmv.h[pc];
+      hy[u] = d.cmv.h[d.cmv.n + pc];
+      hz[u] = d.cmv.h[2 * d.cmv.n + pc];
+      hw[u] = d.cmv.h[3 * d.cmv.n + pc];
+    }
+    double4 q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u] = sl[u] >= 0 ? d.q4[sl[u]] : make_double4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0] += hx[u] * q[u].x; acc[1] += hy[u] * q[u].x; acc[2] += hz[u] * q[u].x; acc[3] += hw[u] * q[u].x;
+      acc[4] += hx[u] * q[u].y; acc[5] += hy[u] * q[u].y; acc[6] += hz[u] * q[u].y; acc[7] += hw[u] * q[u].y;
+      acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += hw[u] * q[u].z;
+    }
+  }
+  if (r > 0 && r <= d.n_hot_acc) {
+    for (int wg = t; wg < d.n_hot_wg; wg += 256) {
+      const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + wg) * 12;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] += ip[k];
+    }
+  }
+  block_sum_dpp<12, 256>(acc, sh);  // every thread now holds the 12 ambient sums
+  if (t >= 64) return;
+  double y[12], y11[11];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) y[j] = acc[j] * sg[j];
+  nt_apply(w, beta, y, y11);
+  double s = 0;
+  if (t < 11) {
+#pragma unroll
+    for (int j = 0; j < 11; ++j) s += bi[j] * y11[j];
+  }
+  double nrm[2] = {0, 0};
+  if (t < 11) {
+    const size_t idx = 11 * (size_t)c + t;
+    const double a = acc_old + s;
+    d.tmp[idx] = s;
+    d.accum[idx] = a;
+    nrm[0] = s * s;
+    nrm[1] = a * a;
+  }
+  // p12 = N_c tmp11: p_i = [0; tmp]_i - beta w_i (w[1:] . tmp)
+  double wsel = 0, wsel1 = 0, sgt = 0;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    wsel = (t == j) ? w[j] : wsel;
+    sgt = (t == j) ? sg[j] : sgt;
+    if (j > 0) wsel1 = (t == j - 1) ? w[j] : wsel1;
+  }
+  double wt = t < 11 ? wsel1 * s : 0.0;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) wt += shfl_xor_d(wt, m);  // lanes 0..15 hold the 11 products
+  const double prev = shfl_up_d(s, 1);
+  if (t < 12) {
+    const double pa = (t == 0 ? 0.0 : prev) - beta * wsel * wt;
+    store_z(d, c, t, pa * sgt);
+  }
+  if (want_norms) {
+    wave_sum<2>(nrm);
+    if (t == 0) {
+      d.norm_part[2 * (size_t)c] = nrm[0];
+      d.norm_part[2 * (size_t)c + 1] = nrm[1];
+    }
+  }
+}
+
 // K13' (linearizor_power_varproj.cpp:283-305) and the z = sigma * (N_c inc_c) needed by K12'.
 // mode 1: z only (before back substitution); mode 2: P_c += reshape((N_c inc_c) * sigma)
 __global__ __launch_bounds__(256) void cam_apply_inc_h(Dp d, int mode, const double* ncw) {

@@ -94,10 +94,11 @@ def test_power_series_term_by_term(which, e0_mode, small_problem, medium_problem
     ctx.close()
 
 
+@pytest.mark.parametrize("e0_mode", [0, 2, 3])  # 2, 3: norm partials come from the fused cam_cold_sum_binv
 @pytest.mark.parametrize("q_tol,r_tol", [(1e-2, -1.0), (0.0, 0.5), (0.3, 0.9)])
-def test_early_exit(q_tol, r_tol, small_problem):
+def test_early_exit(q_tol, r_tol, e0_mode, small_problem):
     p = small_problem
-    orc, ctx = _setup(p)
+    orc, ctx = _setup(p, e0_mode=e0_mode)
     lms = orc.init_landmarks_pose(ALPHA, p.cams)
     ctx.set_cameras(p.cams)
     ctx.set_landmarks(lms)
