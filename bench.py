@@ -130,7 +130,9 @@ def main():
         dist.init_process_group(backend="gloo")  # control plane only; data plane is RCCL in the library
 
     alpha, lam, m = 0.01, 1e-4, args.m
-    prob = synth.make_bal_problem(args.problem)
+    # the real BAL file when $POVAR_BAL_DIR holds it, else the seeded synthetic shape
+    bal_path = synth.find_bal_file(args.problem, os.environ.get("POVAR_BAL_DIR"))
+    prob = synth.read_bal_file(bal_path) if bal_path else synth.make_bal_problem(args.problem)
     n_c, n_l, n_o = prob.n_cams, prob.n_lms, prob.n_obs
 
     n_dev = capi.lib().povar_device_count()
@@ -276,9 +278,10 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": f"BAL file {os.path.basename(bal_path)}" if bal_path else "synthetic",
         "config": {
-            "workload": f"BAL {args.problem} shape ({n_c} cams / {n_l} landmarks / {n_o} obs), seeded synthetic, "
+            "workload": f"BAL {args.problem} shape ({n_c} cams / {n_l} landmarks / {n_o} obs), "
+                        f"{'real BAL file' if bal_path else 'seeded synthetic'}, "
                         f"solve_pOSE with power_sc_iterations={m}, eta=0, lambda={lam}, alpha={alpha}",
             "e0_mode": args.e0_mode,
             "parallelism": f"landmark shards x{world}, one all-reduce (12*n_cams f64) per term" if world > 1

@@ -182,3 +182,66 @@ def read_data_custom(path: str) -> Problem:
     lms = np.array(tok[p : p + 3 * n_l], dtype=np.float64).reshape(n_l, 3)
     return Problem(n_c, n_l, lm_off.astype(np.int32), cam.astype(np.int32),
                    np.ascontiguousarray(uv), np.ascontiguousarray(cp[:, :12]), lms)
+
+
+BAL_FILES = {  # scripts/download-bal-problems.sh:30-120 (file names on grail.cs.washington.edu)
+    "ladybug-49": "problem-49-7776-pre.txt",
+    "trafalgar-257": "problem-257-65132-pre.txt",
+    "venice-1778": "problem-1778-993923-pre.txt",
+    "final-13682": "problem-13682-4456117-pre.txt",
+}
+
+
+def read_bal_file(path: str, seed: int = 38401) -> Problem:
+    """A real BAL problem, either in the ORIGINAL format (9 parameters per camera) -- the initial cameras
+    are then drawn as ``--create-dataset`` does (rows 0-1 ~ N(0,1), row 2 = [0 0 0 1],
+    bal_problem.cpp:398-407) from a generator seeded with ``seed`` -- or in PoVar's ``data_custom`` format
+    (15 values per camera).  ``.bz2`` files are read directly.  Observations are negated in y, grouped per
+    landmark with ascending camera index, duplicates rejected, as ``load_bal_eccv`` does."""
+    import bz2
+    opener = bz2.open if path.endswith(".bz2") else open
+    with opener(path, "rt") as fh:
+        data = np.array(fh.read().split(), dtype=np.float64)
+    n_c, n_l, n_o = int(data[0]), int(data[1]), int(data[2])
+    if min(n_c, n_l, n_o) <= 0:
+        raise ValueError("invalid header")
+    body = data[3 : 3 + 4 * n_o].reshape(n_o, 4)
+    rest = data[3 + 4 * n_o :]
+    cam = body[:, 0].astype(np.int64)
+    lm = body[:, 1].astype(np.int64)
+    if cam.min() < 0 or cam.max() >= n_c or lm.min() < 0 or lm.max() >= n_l:
+        raise ValueError("index out of range")
+    uv = body[:, 2:4].copy()
+    uv[:, 1] = -uv[:, 1]
+    order = np.lexsort((cam, lm))
+    cam, lm, uv = cam[order], lm[order], uv[order]
+    if np.any((cam[1:] == cam[:-1]) & (lm[1:] == lm[:-1])):
+        raise ValueError("duplicate observation")
+    lm_off = np.zeros(n_l + 1, dtype=np.int64)
+    np.cumsum(np.bincount(lm, minlength=n_l), out=lm_off[1:])
+    if rest.shape[0] == 15 * n_c + 3 * n_l:      # data_custom
+        cams = rest[: 15 * n_c].reshape(n_c, 15)[:, :12].copy()
+        lms = rest[15 * n_c :].reshape(n_l, 3)
+    elif rest.shape[0] == 9 * n_c + 3 * n_l:     # original BAL
+        rng = np.random.default_rng(seed)
+        cams = np.zeros((n_c, 12))
+        cams[:, :8] = rng.normal(size=(n_c, 8))
+        cams[:, 11] = 1.0
+        lms = rest[9 * n_c :].reshape(n_l, 3)
+    else:
+        raise ValueError("neither an original BAL file nor a data_custom file")
+    return Problem(n_c, n_l, lm_off.astype(np.int32), cam.astype(np.int32), np.ascontiguousarray(uv),
+                   np.ascontiguousarray(cams), np.ascontiguousarray(lms))
+
+
+def find_bal_file(name: str, directory: str | None):
+    """``$POVAR_BAL_DIR`` lookup for bench.py: <dir>/[data_custom/]<file>[.bz2]."""
+    import os
+    if not directory:
+        return None
+    for sub in ("data_custom", ""):
+        for ext in ("", ".bz2"):
+            p = os.path.join(directory, sub, BAL_FILES[name] + ext)
+            if os.path.exists(p):
+                return p
+    return None

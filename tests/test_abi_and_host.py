@@ -91,3 +91,38 @@ def test_bal_shapes():
     # strictly ascending camera index inside every landmark
     same = np.repeat(np.arange(p.n_lms), k)
     assert np.all((np.diff(p.cam_idx) > 0) | (np.diff(same) > 0))
+
+
+def test_read_bal_file_original_and_custom(tmp_path):
+    """$POVAR_BAL_DIR support of bench.py: an original-format BAL file (9 camera parameters,
+    optionally .bz2) and its data_custom twin give the same observation structure; the original one gets
+    create-dataset style cameras."""
+    import bz2
+    from povar_amd import synth
+    p = synth.make_problem(7, 60, 260, seed=4)
+    lm_of = np.repeat(np.arange(p.n_lms), np.diff(p.lm_off))
+    perm = np.random.default_rng(0).permutation(p.n_obs)           # BAL files are not required to be sorted
+    lines = [f"{p.n_cams} {p.n_lms} {p.n_obs}"]
+    lines += [f"{p.cam_idx[i]} {lm_of[i]} {p.obs[i, 0]:.6f} {-p.obs[i, 1]:.6f}" for i in perm]
+    for c in range(p.n_cams):
+        lines += ["0.1", "0.2", "0.3", "0", "0", "-5", "800", "0", "0"]
+    lines += [f"{x:.6f}" for x in p.lms.ravel()]
+    d = tmp_path / "bal"
+    d.mkdir()
+    name = synth.BAL_FILES["ladybug-49"]
+    with bz2.open(d / (name + ".bz2"), "wt") as fh:
+        fh.write("\n".join(lines) + "\n")
+    found = synth.find_bal_file("ladybug-49", str(d))
+    assert found and found.endswith(".bz2") and synth.find_bal_file("venice-1778", str(d)) is None
+    q = synth.read_bal_file(found, seed=5)
+    assert (q.n_cams, q.n_lms, q.n_obs) == (p.n_cams, p.n_lms, p.n_obs)
+    assert np.array_equal(q.lm_off, p.lm_off) and np.array_equal(q.cam_idx, p.cam_idx)
+    assert np.abs(q.obs - p.obs).max() < 1e-6
+    assert np.allclose(q.cams[:, 8:], [0, 0, 0, 1]) and np.abs(q.cams[:, :8]).max() > 0.1
+    assert np.array_equal(synth.read_bal_file(found, seed=5).cams, q.cams)
+    (d / "data_custom").mkdir()
+    synth.write_data_custom(str(d / "data_custom" / name), p)
+    found2 = synth.find_bal_file("ladybug-49", str(d))
+    assert "data_custom" in found2
+    r = synth.read_bal_file(found2)
+    assert np.array_equal(r.cam_idx, p.cam_idx) and np.abs(r.cams - p.cams).max() < 1e-6
