@@ -308,6 +308,10 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_e0,
+            # the same kernel against the roofline in REAL bytes: PMC-measured HBM traffic per launch / its
+            # duration (the implicit E0 moves 6x fewer bytes than the stored-tile model it is priced against)
+            "traffic_GBps": (traffic / (e0_ms * 1e-3) / 1e9) if traffic else None,
+            "traffic_frac": (traffic / (e0_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
         },
     }
 
