@@ -108,7 +108,7 @@ struct Dp {
   // per slot, dynamic
   double* sw;          // sqrt(robust weight)
   double4* rres;       // weighted residual at the linearisation point
-  double4* q4;         // (q0, q1, q2, sw): transpose-scatter scalars per slot
+  double4* q4;         // (q0, q1, q2, -): transpose-scatter scalars per slot
   double2* tiles;      // stored-tile mode: [n_bins][TILE_PAIRS][64] double2
   // per camera
   double* sigma;       // pose_jacobian_scaling [n_cams][12]
@@ -604,7 +604,6 @@ struct OpLinearize {
     if (!isfinite(r2) || !isfinite(sw)) atomicOr(&d.flags[0], 1);
     d.sw[slot] = sw;
     d.rres[slot] = make_double4(sw * res[0], sw * res[1], sw * res[2], sw * res[3]);
-    d.q4[slot] = make_double4(0, 0, 0, sw);
     double jl[12];
     pose_jl(d, P, uv.x, uv.y, sw, make_double4(1, 1, 1, 1), jl);
 #pragma unroll
@@ -734,7 +733,7 @@ struct E0Core {
     q.x = w * (e0 - cu * e2);
     q.y = w * (e1 - cv * e2);
     q.z = w * (cuv * e2 - cu * e0 - cv * e1);
-    q.w = 0;  // (the sqrt-weight slot of q4 is only read after povar_linearize_pose, which rewrites it)
+    q.w = 0;  // (unused slot of q4)
     return q;
   }
 };
@@ -1321,7 +1320,7 @@ __global__ __launch_bounds__(256) void cm_gram(Dp d) {
 #pragma unroll
   for (int k = 0; k < 40; ++k) acc[k] = 0;
   for (int p = b + lane; p < e; p += WAVE) {
-    const double sw = d.q4[d.cm_slot[p]].w;
+    const double sw = d.robust ? d.sw[d.cm_slot[p]] : 1.0;  // no gather at all without a robust norm
     const double4 h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], 1.0);
     const double2 uv = d.cm_uv[p];
     const double w = sw * sw;

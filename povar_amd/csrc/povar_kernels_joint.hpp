@@ -116,7 +116,6 @@ struct OpLinearizeH {
     if (!isfinite(r2) || !isfinite(sw) || !isfinite(h.D02) || !isfinite(h.D12)) atomicOr(&d.flags[0], 1);
     d.sw[slot] = sw;
     d.rres[slot] = make_double4(sw * h.r0, sw * h.r1, 0, 0);
-    d.q4[slot] = make_double4(0, 0, 0, sw);
     double jl[8];
     hom_jl4(P, h, sw, make_double4(1, 1, 1, 1), jl);
 #pragma unroll
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(256) void cm_gram_h(Dp d) {
 #pragma unroll
   for (int k = 0; k < 40; ++k) acc[k] = 0;
   for (int p = b + lane; p < e; p += WAVE) {
-    const double sw = d.q4[d.cm_slot[p]].w;
+    const double sw = d.robust ? d.sw[d.cm_slot[p]] : 1.0;
     const double4 X = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], d.cm_h[3 * d.n_obs + p]);
     const double2 uv = d.cm_uv[p];
     const Hom h = hom_project(P, X, uv.x, uv.y);
