@@ -774,11 +774,11 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   if (sharded(c)) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
-    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)nullptr);
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr);
     if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
-    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)c->d.G);
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)c->d.G);
   } else {
-    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)nullptr);
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr);
   }
   HIP_TRY(hipGetLastError());
   int f[4];
@@ -1019,10 +1019,10 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   if (c->n_cold > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, 1);
   hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
-  hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
+  hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
   if (sharded(c)) {
     if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
-    hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(256), 0, c->stream, c->d, (const double*)c->d.G, c->ncw.p);
+    hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)c->d.G, c->ncw.p);
   }
   HIP_TRY(hipGetLastError());
   int f[4];

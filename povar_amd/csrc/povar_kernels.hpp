@@ -1349,24 +1349,28 @@ __device__ inline int sym10(int i, int j) {  // index of (i,j) in the packed upp
 }
 
 // per camera: G = sum of item Gram parts; diag2 and pose scaling (linearizor_power_varproj.cpp:62-70)
-__global__ __launch_bounds__(256) void cam_finish_linearize(Dp d, const double* G_in) {
+__global__ __launch_bounds__(1024) void cam_finish_linearize(Dp d, const double* G_in) {
   const int c = blockIdx.x;
-  __shared__ double part[4][40];
+  __shared__ double part[16][40];
   __shared__ double g[40];
   if (G_in) {
     if (threadIdx.x < 40) g[threadIdx.x] = G_in[40 * (size_t)c + threadIdx.x];
   } else {
-    // thread (q, e): quarter q of the camera's items, element e; fixed order
+    // thread (q, e): every 16th item of the camera starting at q, element e; fixed order
     const int e = threadIdx.x % 64, q = threadIdx.x / 64;
     if (e < 40) {
       double s = 0;
-      for (int it = d.cam_item_off[c] + q; it < d.cam_item_off[c + 1]; it += 4)
+      for (int it = d.cam_item_off[c] + q; it < d.cam_item_off[c + 1]; it += 16)
         s += d.item_partG[40 * (size_t)it + e];
       part[q][e] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 40)
-      g[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < 40) {
+      double sum = 0;  // fixed order
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sum += part[k][threadIdx.x];
+      g[threadIdx.x] = sum;
+    }
   }
   __syncthreads();
   if (threadIdx.x < 40) d.G[40 * (size_t)c + threadIdx.x] = g[threadIdx.x];
