@@ -295,7 +295,7 @@ void launch_lm(povar_ctx* c, const Op& op) {
 
 template <int N>
 void launch_reduce(povar_ctx* c, double* out) {
-  hipLaunchKernelGGL((reduce_partials<N>), dim3(1), dim3(256), 0, c->stream, c->part.p,
+  hipLaunchKernelGGL((reduce_partials<N>), dim3(1), dim3(1024), 0, c->stream, c->part.p,
                      c->n_reg_blocks + c->n_long, out);
 }
 

@@ -455,16 +455,16 @@ __global__ __launch_bounds__(LM_BLOCK) void lm_long(Dp d, Op op, double* part) {
 
 // fixed-order sum of per-workgroup partials: out[k] = sum_i part[i*N + k]
 template <int N>
-__global__ __launch_bounds__(256) void reduce_partials(const double* part, int n, double* out) {
-  __shared__ double sh[4 * N];
+__global__ __launch_bounds__(1024) void reduce_partials(const double* part, int n, double* out) {
+  __shared__ double sh[16 * N];
   double v[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) v[k] = 0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += 1024) {
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] += part[(size_t)i * N + k];
   }
-  block_sum<N, 256>(v, sh);
+  block_sum<N, 1024>(v, sh);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < N; ++k) out[k] = v[k];
