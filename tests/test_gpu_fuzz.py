@@ -1,0 +1,133 @@
+"""Seeded random sweep of the whole C ABI against the CPU oracle: problem shape (including single-camera-heavy
+graphs, two-view landmarks and >64-observation landmarks), robust norm, damping, series length, E0 mode and
+linear solver are drawn per case; every stage of one LM inner iteration is compared."""
+import numpy as np
+import pytest
+
+from conftest import rel
+
+pytestmark = pytest.mark.gpu
+ALPHA = 0.01
+
+
+def _random_problem(rng):
+    n_c = int(rng.integers(3, 90))
+    n_l = int(rng.integers(20, 400))
+    degs = np.minimum(2 + rng.geometric(rng.uniform(0.15, 0.6), size=n_l), n_c)
+    if n_c > 70 and rng.random() < 0.5:
+        degs[: int(rng.integers(1, 4))] = int(rng.integers(65, n_c))      # long landmarks (lm_long driver)
+    pop = 1.0 / (1 + np.arange(n_c)) ** rng.uniform(0.0, 1.5)
+    pop /= pop.sum()
+    cam_idx = np.concatenate([np.sort(rng.choice(n_c, int(k), replace=False, p=pop)) for k in degs]).astype(np.int32)
+    lm_off = np.concatenate([[0], np.cumsum(degs)]).astype(np.int32)
+    cams = np.zeros((n_c, 12))
+    cams[:, :8] = rng.normal(size=(n_c, 8))
+    cams[:, 11] = 1.0
+    X = rng.normal(size=(n_l, 3))
+    lm_of = np.repeat(np.arange(n_l), degs)
+    P = cams[cam_idx].reshape(-1, 3, 4)
+    obs = np.einsum("nij,nj->ni", P[:, :2, :3], X[lm_of]) + P[:, :2, 3] + rng.normal(scale=0.1, size=(len(cam_idx), 2))
+    return n_c, lm_off, cam_idx, obs, cams
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_step1_random_case(seed):
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    n_c, lm_off, cam_idx, obs, cams = _random_problem(rng)
+    norm = ["NONE", "HUBER", "CAUCHY"][int(rng.integers(0, 3))]
+    huber = float(rng.uniform(0.05, 2.0))
+    lam = float(10 ** rng.uniform(-5, 1))
+    m = int(rng.integers(0, 26))
+    mode = int(rng.integers(0, 4))
+    solver = int(rng.integers(0, 2))           # POWER_VARPROJ / POWER_SCHUR_COMPLEMENT
+    orc = O.Oracle(n_c, lm_off, cam_idx, obs, robust_norm=norm, huber=huber)
+    ctx = capi.Context(n_c, lm_off, cam_idx, obs, robust_norm=norm, huber=huber, e0_mode=mode)
+    ctx.set_cameras(cams)
+    ctx.init_landmarks_pose(ALPHA)
+    lms = orc.init_landmarks_pose(ALPHA, cams)
+    assert rel(ctx.get_landmarks(), lms) < 1e-9
+    ctx.set_landmarks(lms)
+    ri, ro = ctx.error_pose(ALPHA), orc.error_pose(ALPHA, cams, lms)
+    assert abs(ri.all_error - ro.all_error) <= 1e-11 * ro.all_error
+    assert ctx.linearize_pose(ALPHA)
+    st, diag2, jls, sigma, ok = orc.stage1_pose(ALPHA, cams, lms)
+    orc.scale_jp_cols_pose(st, sigma)
+    lam_lm = lam if solver == capi.POWER_SCHUR_COMPLEMENT else 0.0
+    hll, b, binv = orc.prepare_hb_pose(st, lam, lam_lm)
+    ref, it_o, st_o, _ = orc.solve_pose(st, hll, binv, b, m)
+    inc, it, status, rc = ctx.solve_pose(lam, solver, m)
+    assert rc == 0 and it == it_o and rel(inc, ref) < 1e-9, (norm, lam, m, mode, solver)
+    if solver == capi.POWER_VARPROJ:
+        inc_s = ref * sigma
+        cams_new = cams + inc_s.reshape(-1, 12)
+        ld_o, lms_new = orc.back_substitute_pose(ALPHA, st, cams_new, lms, inc_s * (1.0 / sigma))
+    else:
+        ld_o, lms_new = orc.back_substitute_poba(st, jls, lam, lms, ref)
+        cams_new = cams + (ref * sigma).reshape(-1, 12)
+    ld = ctx.apply_pose(solver, ALPHA, ref)
+    assert abs(ld - ld_o) <= 1e-8 * abs(ld_o) + 1e-300
+    assert rel(ctx.get_cameras(), cams_new) < 1e-13 and rel(ctx.get_landmarks(), lms_new) < 1e-8
+    # the explicit-SC solvers on the same linearisation (PCG truncated at a random count, CHOLESKY)
+    ctx.set_cameras(cams)
+    ctx.set_landmarks(lms)
+    ctx.set_jl_col_scaling(False)
+    assert ctx.linearize_pose(ALPHA)
+    st2, ok = orc.linearize_pose(ALPHA, cams, lms)
+    orc.scale_jp_cols_pose(st2, 1.0 / (1e-5 + np.sqrt(orc.jp_diag2_pose(st2))))
+    S, b2 = orc.get_hb_pose(st2, lam)
+    k = int(rng.integers(1, 9))
+    ref_k, it_k, st_k = orc.pcg(S, b2, orc.block_jacobi_inverse(S, 12), eta=0.0, max_iterations=k)
+    inc_k, it_g, st_g, rc = ctx.solve_pose_sc(lam, capi.SC_PCG, 0, k, 0.0)
+    if st_k == 0 and it_k == k:     # (a breakdown exit at the noise level may fall on either side)
+        assert rc == 0 and (it_g, st_g) == (it_k, st_k) and rel(inc_k, ref_k) < 1e-7
+    ref_c, bad = orc.cholesky_solve(S, b2)
+    inc_c, _, _, rc = ctx.solve_pose_sc(lam, capi.SC_CHOLESKY)
+    assert bad == 0 and rc == 0 and rel(inc_c, ref_c) < 1e-7
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_step2_random_case(seed):
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    rng = np.random.default_rng(2000 + seed)
+    n_c, lm_off, cam_idx, obs, _ = _random_problem(rng)
+    n_l = lm_off.shape[0] - 1
+    cams = rng.normal(size=(n_c, 12))
+    cams[:, 8:11] *= 0.1
+    cams[:, 11] = 5 + rng.random(n_c)
+    cams /= np.linalg.norm(cams, axis=1, keepdims=True)
+    lms_h = np.concatenate([rng.normal(size=(n_l, 3)), np.ones((n_l, 1))], 1)
+    obs = obs / 50.0
+    norm = ["NONE", "HUBER"][int(rng.integers(0, 2))]
+    lam = float(10 ** rng.uniform(-5, 0))
+    m = int(rng.integers(0, 16))
+    mode = [0, 2][int(rng.integers(0, 2))]
+    orc = O.Oracle(n_c, lm_off, cam_idx, obs, robust_norm=norm, huber=0.5)
+    ctx = capi.Context(n_c, lm_off, cam_idx, obs, robust_norm=norm, huber=0.5, e0_mode=mode)
+    ctx.set_cameras(cams)
+    ctx.set_landmarks_homogeneous(lms_h)
+    assert ctx.linearize_homogeneous()
+    st_h, ok = orc.linearize_homogeneous(cams, lms_h)
+    diag2 = orc.jp_diag2_homogeneous(st_h)
+    jls = orc.scale_jl_cols_homogeneous(st_h)
+    sigma = 1.0 / (1e-5 + np.sqrt(diag2))
+    orc.scale_jp_cols_joint(st_h, sigma)
+    st_n = orc.linearize_nullspace(cams, lms_h, st_h)
+    hll, b, binv = orc.prepare_hb_joint(st_h, st_n, lam)
+    ref, it_o, st_o, _ = orc.solve_joint(st_n, hll, binv, b, m)
+    inc, it, status, rc = ctx.solve_joint(lam, m)
+    assert rc == 0 and it == it_o and rel(inc, ref) < 1e-8, (norm, lam, m, mode)
+    S, b2 = orc.get_hb_joint(st_h, st_n, lam)
+    k = int(rng.integers(1, 7))
+    ref_k, it_k, st_k = orc.pcg(S, b2, orc.block_jacobi_inverse(S, 11), dim=11, eta=0.0, max_iterations=k)
+    inc_k, it_g, st_g, rc = ctx.solve_joint_sc(lam, 0, k, 0.0)
+    if st_k == 0 and it_k == k:
+        assert rc == 0 and (it_g, st_g) == (it_k, st_k) and rel(inc_k, ref_k) < 1e-6
+    ld = ctx.apply_joint(ref)
+    ld_o, lms_new = orc.back_substitute_joint(st_h, jls, lam, cams, lms_h, ref)
+    assert abs(ld - ld_o) <= 1e-8 * abs(ld_o) + 1e-300
+    assert rel(ctx.get_landmarks_homogeneous(), lms_new) < 1e-8
+    ctx.close()
