@@ -249,35 +249,47 @@ __device__ inline double shfl_up_d(double v, int delta) { return __shfl_up(v, de
 __device__ inline double shfl_d(double v, int src) { return __shfl(v, src, WAVE); }
 __device__ inline double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, WAVE); }
 
-// inclusive segmented scan inside a wavefront, then broadcast of the segment total
-template <int N>
-__device__ inline void seg_reduce(double (&v)[N], int lane, int seg_first, int seg_last) {
-#pragma unroll
-  for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
-    const bool take = lane - dlt >= seg_first;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const double o = shfl_up_d(v[k], dlt);
-      if (take) v[k] += o;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = shfl_d(v[k], seg_last);
-}
 
-// same, with the number of doubling steps bounded by the longest segment of the wavefront
-// (wave-uniform): landmarks average 4-6 observations, so 3-4 steps instead of 6
+// Per-landmark sums: inclusive segmented scan inside a wavefront, then broadcast of the segment total.
+// `steps` bounds the in-row doubling steps by the longest segment of the wavefront (wave-uniform; landmarks
+// average 4-6 observations, so 3 steps instead of 6).  The scan runs on the VALU's DPP network instead of
+// ds_bpermute round trips through the LDS crossbar: in-row Hillis-Steele steps (row_shr 1/2/4/8, out-of-row
+// sources read 0), then the carries across the three 16-lane row boundaries one row at a time
+// (row_bcast:15 under a row mask), then the broadcast of the segment totals -- the only ds_bpermute left
+// (e0_lm_cached<true>: 106.9 -> 101.0 us).  The association of a segment's sum depends on where the row
+// boundaries cut it: results are bit-reproducible for a given layout, not across landmark orders.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_dm(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 template <int N>
 __device__ inline void seg_reduce_steps(double (&v)[N], int lane, int seg_first, int seg_last, int steps) {
-  for (int s = 0; s < steps; ++s) {
-    const int dlt = 1 << s;
-    const bool take = lane - dlt >= seg_first;
+  auto mask = [](bool c) { return __hiloint2double(c ? 0x3FF00000 : 0, 0); };
+  const double m1 = mask(lane - 1 >= seg_first), m2 = mask(lane - 2 >= seg_first), m4 = mask(lane - 4 >= seg_first),
+               m8 = mask(lane - 8 >= seg_first), mc = mask(seg_first < (lane & ~15));
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const double o = shfl_up_d(v[k], dlt);
-      if (take) v[k] += o;
-    }
+  for (int k = 0; k < N; ++k) v[k] = fma(m1, dpp_dm<0x111, 0xf>(v[k]), v[k]);
+  if (steps > 1) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = fma(m2, dpp_dm<0x112, 0xf>(v[k]), v[k]);
   }
+  if (steps > 2) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = fma(m4, dpp_dm<0x114, 0xf>(v[k]), v[k]);
+  }
+  if (steps > 3) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = fma(m8, dpp_dm<0x118, 0xf>(v[k]), v[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fma(mc, dpp_dm<0x142, 0x2>(v[k]), v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fma(mc, dpp_dm<0x142, 0x4>(v[k]), v[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fma(mc, dpp_dm<0x142, 0x8>(v[k]), v[k]);
 #pragma unroll
   for (int k = 0; k < N; ++k) v[k] = shfl_d(v[k], seg_last);
 }

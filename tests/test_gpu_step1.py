@@ -341,7 +341,9 @@ def test_landmark_order_invariance(seed, medium_problem):
     for mode in (0, 1, 2, 3):
         a = run(p.lm_off, p.cam_idx, p.obs, mode)
         b = run(lm_off2, p.cam_idx[idx], p.obs[idx], mode)
-        assert np.array_equal(b["lms"], a["lms"][perm])           # per-landmark work does not see the order
+        # per-landmark work does not see the order, except for the association of the wavefront scan
+        # (it depends on where the 16-lane DPP rows cut a landmark's segment)
+        assert rel(b["lms"], a["lms"][perm]) < 1e-13
         assert abs(a["cost"] - b["cost"]) <= 1e-12 * a["cost"]
         assert rel(b["sigma"], a["sigma"]) < 1e-13 and rel(b["inc"], a["inc"]) < 1e-10
         assert b["it_p"] == a["it_p"] and rel(b["pcg"], a["pcg"]) < 1e-9
