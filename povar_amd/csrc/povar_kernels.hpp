@@ -294,15 +294,6 @@ __device__ inline void seg_reduce_steps(double (&v)[N], int lane, int seg_first,
   for (int k = 0; k < N; ++k) v[k] = shfl_d(v[k], seg_last);
 }
 
-template <int N>
-__device__ inline void wave_sum(double (&v)[N]) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) v[k] += shfl_xor_d(v[k], m);
-  }
-}
-
 // value of lane (src lane per the DPP control), 0 where the source lane does not exist (bound_ctrl)
 template <int CTRL>
 __device__ inline double dpp_d(double v) {
@@ -329,13 +320,27 @@ __device__ inline void wave_total_dpp(double (&v)[N]) {
 #pragma unroll
   for (int k = 0; k < N; ++k) v[k] += dpp_d<0x143>(v[k]);
 }
-// deterministic workgroup sum like block_sum, wavefront stage on DPP
-template <int N, int BLOCK>
-__device__ inline void block_sum_dpp(double (&v)[N], double* sh /* [BLOCK/64][N] */) {
+// value of `v` in a compile-time lane, through v_readlane (SGPR broadcast: no LDS crossbar, no VGPRs)
+__device__ inline double bcast_lane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// wavefront sum, total in every lane (DPP reduction to lane 63, then a scalar broadcast)
+template <int N>
+__device__ inline void wave_sum(double (&v)[N]) {
   wave_total_dpp<N>(v);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = bcast_lane(v[k], 63);
+}
+
+// deterministic workgroup sum of N per-thread values -> out[N] valid in every thread
+template <int N, int BLOCK>
+__device__ inline void block_sum(double (&v)[N], double* sh /* [BLOCK/64][N] */) {
+  wave_sum<N>(v);
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __syncthreads();
-  if (lane == 63) {
+  if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < N; ++k) sh[w * N + k] = v[k];
   }
@@ -348,13 +353,13 @@ __device__ inline void block_sum_dpp(double (&v)[N], double* sh /* [BLOCK/64][N]
   }
 }
 
-// deterministic workgroup sum of N per-thread values -> out[N] valid in every thread
+// deterministic workgroup sum like block_sum, wavefront stage on DPP
 template <int N, int BLOCK>
-__device__ inline void block_sum(double (&v)[N], double* sh /* [BLOCK/64][N] */) {
-  wave_sum<N>(v);
+__device__ inline void block_sum_dpp(double (&v)[N], double* sh /* [BLOCK/64][N] */) {
+  wave_total_dpp<N>(v);
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __syncthreads();
-  if (lane == 0) {
+  if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < N; ++k) sh[w * N + k] = v[k];
   }

@@ -34,13 +34,6 @@ constexpr int CH_LDS = 80;   // LDS row stride in doubles: rows 2 apart share ba
 
 typedef double ch_d4 __attribute__((ext_vector_type(4)));
 
-// value of `v` in a compile-time lane, through v_readlane (SGPR broadcast: no LDS crossbar, no VGPRs)
-__device__ inline double bcast_lane(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
 // R11 = chol(S11): upper Cholesky of the 64 x 64 diagonal block at (k0, k0); info |= 1 when a pivot
 // is not positive.  One wavefront, lane c keeps column c in registers; row j of R reaches the other
 // lanes through constant-lane broadcasts, so the 64 dependent steps need no LDS and no barriers
