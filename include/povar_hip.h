@@ -5,8 +5,10 @@
  * The reference (tum-vision/povar, C++17, CPU only) has no C ABI.  Its operator boundary for
  * this path is the abstract class Linearizor<Scalar> (src/rootba_povar/solver/linearizor.hpp:48-82)
  * as implemented by LinearizorPowerVarproj (solver/linearizor_power_varproj.cpp:21-308) on top
- * of LinearizationPowerVarproj (sc/linearization_power_varproj.hpp:28-469).  Each entry point
- * below names the reference interface it replaces.  A reference-side binding (a Linearizor
+ * of LinearizationPowerVarproj (sc/linearization_power_varproj.hpp:28-469), and -- for the explicit
+ * Schur-complement solver types PCG / CHOLESKY / RIPCG -- by LinearizorSC (solver/linearizor_sc.cpp:50-360)
+ * on top of LinearizationSC (sc/linearization_sc.hpp).  Each entry point below names the reference
+ * interface it replaces.  A reference-side binding (a Linearizor
  * subclass forwarding to these calls) is shown in INTEGRATION.md.
  *
  * Conventions: plain pointers and sizes, caller-allocated HOST buffers, fp64 values, int32
