@@ -81,6 +81,8 @@ struct povar_ctx {
   // static
   DevBuf<double2> uv, cm_uv, tiles;
   DevBuf<int2> cc_cam_range;  // per camera: (first, end) position of its run in the cold camera-major view
+  DevBuf<int> cold_pos;       // per slot: position in the cold view (-1: accumulated in LDS)
+  DevBuf<double4> q4c;        // scatter scalars of the cold observations, in cold camera-major order
   DevBuf<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
       cam_item_off, flags;
   // state
@@ -133,7 +135,7 @@ namespace {
 struct Layout {
   std::vector<double2> uv, cm_uv;
   std::vector<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off,
-      item_cam, cam_item_off, slot_of_obs;
+      item_cam, cam_item_off, slot_of_obs, cold_pos;
   int n_bins = 0;
 };
 
@@ -258,6 +260,9 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
     }
     L.cc_cam_item_off[n_cams] = (int)L.cc_item_off.size();
     L.cc_item_off.push_back((int)L.cc_slot.size());
+    // inverse of cc_slot: where a cold observation's scatter scalars go (Dp::q4c)
+    L.cold_pos.assign(n_slots, -1);
+    for (size_t p = 0; p < L.cc_slot.size(); ++p) L.cold_pos[L.cc_slot[p]] = (int)p;
   }
   L.cam_item_off.assign(n_cams + 1, 0);
   L.item_off.clear();
@@ -337,6 +342,8 @@ Dp ldsacc_dp(povar_ctx* c) {
   dt.cmv = CmView{c->cc_slot.p, c->cc_h.p, c->n_cold, c->cc_item_off.p, c->cc_cam_item_off.p, c->cc_part.p,
                   c->n_cold_items, c->cc_cam_range.p};
   dt.hot_part = c->hot_part.p;
+  dt.q4c = c->q4c.p;
+  dt.cold_pos = c->cold_pos.p;
   return dt;
 }
 
@@ -362,11 +369,12 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
   if (c->joint) {
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
     if (acc) {
+      const Dp da = ldsacc_dp(c);  // cold observations write q to their camera-major position (q4c)
       hipLaunchKernelGGL(e0_lm_cached_h, dim3(c->e0c_grid), dim3(E0C_BLOCK),
-                         (size_t)c->n_hot_acc * (HOT_REC_H * sizeof(double2) + 96), c->stream, c->d,
+                         (size_t)c->n_hot_acc * (HOT_REC_H * sizeof(double2) + 96), c->stream, da,
                          c->e0c_bins_per_wg, c->hot_part.p);
       if (c->n_long > 0)
-        hipLaunchKernelGGL((lm_long<OpE0H>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0H{}, c->part.p);
+        hipLaunchKernelGGL((lm_long<OpE0H>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpE0H{}, c->part.p);
     } else {
       launch_lm(c, OpE0H{});
     }
@@ -386,25 +394,26 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
       }
     }
   } else {
+    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
+    const Dp da = acc ? ldsacc_dp(c) : c->d;  // ACC: cold observations write q to their camera-major position (q4c)
     if (c->opt.e0_mode == POVAR_E0_TILES) launch_lm(c, OpE0Tiles{});
     else if (c->opt.e0_mode == POVAR_E0_TILES_LDSACC) {
       hipLaunchKernelGGL(e0_tiles_cached, dim3(c->e0c_grid), dim3(E0T_BLOCK),
-                         (size_t)c->n_hot_acc * (HOT_REC_T * sizeof(double2) + 96), c->stream, c->d,
+                         (size_t)c->n_hot_acc * (HOT_REC_T * sizeof(double2) + 96), c->stream, da,
                          c->e0c_bins_per_wg, c->hot_part.p);
       if (c->n_long > 0)
-        hipLaunchKernelGGL((lm_long<OpE0Tiles>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0Tiles{}, c->part.p);
+        hipLaunchKernelGGL((lm_long<OpE0Tiles>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpE0Tiles{}, c->part.p);
     }
     else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)
       hipLaunchKernelGGL(e0_lm_cached<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
-                         (size_t)c->n_hot_acc * (HOT_REC * sizeof(double2) + 96), c->stream, c->d,
+                         (size_t)c->n_hot_acc * (HOT_REC * sizeof(double2) + 96), c->stream, da,
                          c->e0c_bins_per_wg, c->hot_part.p);
     else
       hipLaunchKernelGGL(e0_lm_cached<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
                          (size_t)c->n_hot * HOT_REC * sizeof(double2), c->stream, c->d, c->e0c_bins_per_wg,
                          (double*)nullptr);
     if ((c->opt.e0_mode == POVAR_E0_IMPLICIT || c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) && c->n_long > 0)
-      hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, c->d, OpE0{}, c->part.p);
-    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
+      hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpE0{}, c->part.p);
     if (acc && fuse_norms >= 0 && !sharded(c) && c->fuse_binv) {
       hipLaunchKernelGGL(cam_cold_sum_binv, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), fuse_norms);
       *binv_mode = 4;  // B^-1, AXPY and z already done
@@ -597,6 +606,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     for (int k = 0; k < n_cams; ++k)
       range[k] = make_int2(L.cc_item_off[L.cc_cam_item_off[k]], L.cc_item_off[L.cc_cam_item_off[k + 1]]);
     if (int rc = upload(c->cc_cam_range, range, c)) return rc;
+    if (int rc = upload(c->cold_pos, L.cold_pos, c)) return rc;
+    HIP_TRY(c->q4c.alloc(std::max<size_t>(L.cc_slot.size(), 1), &c->bytes));
   }
   c->n_hot_acc = std::min(n_cams, HOT_ACC_MAX);
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
@@ -630,7 +641,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
   d.hot_rec = c->hot_rec.p;
   d.hot_cams = c->hot_cams.p; d.n_hot = (int)L.hot_cams.size();
-  d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.tiles = nullptr;
+  d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.q4c = nullptr; d.cold_pos = nullptr; d.tiles = nullptr;
   d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
   d.tmp = c->tmp.p; d.accum = c->accum.p; d.z = c->z.p; d.y = c->y.p; d.inc = c->inc.p;
   d.item_part = c->item_part.p; d.item_partG = c->item_partG.p; d.cm_h = c->cm_h.p; d.n_obs = n_obs;
@@ -661,7 +672,7 @@ void povar_destroy(povar_ctx* c) {
   c->sc_dense.release(); c->sc_xpad.release(); c->sc_lm_slot0.release(); c->sc_lm_cnt.release(); c->sc_info.release();
   c->sc_dm_part.release(); c->sc_dm.release(); c->sc_bmat.release(); c->sc_minv.release(); c->sc_x.release();
   c->sc_r.release(); c->sc_p.release(); c->sc_q.release(); c->sc_zv.release(); c->sc_part.release(); c->sc_s.release();
-  c->cc_cam_range.release();
+  c->cc_cam_range.release(); c->cold_pos.release(); c->q4c.release();
   c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -109,6 +109,10 @@ struct Dp {
   double* sw;          // sqrt(robust weight)
   double4* rres;       // weighted residual at the linearisation point
   double4* q4;         // (q0, q1, q2, -): transpose-scatter scalars per slot
+  // LDSACC modes: the scalars of the COLD observations go straight to their position in the cold
+  // camera-major view (q4c[cold_pos[slot]]), so the per-camera sums stream them instead of gathering
+  double4* q4c;        // [n_cold] or nullptr (every other mode: q4[slot])
+  const int* cold_pos; // [n_slots] position in the cold view, -1 for observations accumulated in LDS
   double2* tiles;      // stored-tile mode: [n_bins][TILE_PAIRS][64] double2
   // per camera
   double* sigma;       // pose_jacobian_scaling [n_cams][12]
@@ -243,6 +247,12 @@ __device__ inline double4 pose_q(const Dp& d, double u, double v, double scale, 
   q.z = -scale * d.sb * (u * s[0] + v * s[1]);
   q.w = scale;
   return q;
+}
+
+// where the transpose-scatter scalars of one observation go (see Dp::q4c)
+__device__ inline void store_q(const Dp& d, int slot, const double4& q) {
+  if (d.q4c) d.q4c[d.cold_pos[slot]] = q;
+  else d.q4[slot] = q;
 }
 
 __device__ inline double shfl_up_d(double v, int delta) { return __shfl_up(v, delta, WAVE); }
@@ -786,7 +796,7 @@ struct OpE0 {
   }
   __device__ void phase2(const Dp& d, int slot, int, int, double2 uv, Local& L, const double* tot,
                          double*) const {
-    d.q4[slot] = L.core.backward(d, L.rec0, L.rec1, L.rec2, tot);
+    store_q(d, slot, L.core.backward(d, L.rec0, L.rec1, L.rec2, tot));
   }
   __device__ void finish_lm(const Dp&, int, const double*) const {}
 };
@@ -828,14 +838,17 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
   // before the current bin's record is consumed.
   // slot data two bins ahead (m_*), one bin ahead (n_*); landmark record one bin ahead (n_rec*)
   int n_meta = lane | (lane << 8), n_cam = 0, n_lm = 0, m_meta = n_meta, m_cam = 0, m_lm = 0;
+  int n_cpos = 0, m_cpos = 0;  // ACC: position of the slot in the cold camera-major view (travels with the slot data)
   double2 n_uv = make_double2(0, 0), m_uv = n_uv;
   if (bin0 + wave < bin1) {
     const int s = (bin0 + wave) * WAVE + lane;
     n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
+    if (ACC) n_cpos = d.cold_pos[s];
   }
   if (bin0 + wave + STRIDE < bin1) {
     const int s = (bin0 + wave + STRIDE) * WAVE + lane;
     m_meta = d.meta[s]; m_cam = d.cam[s]; m_lm = d.lm[s]; m_uv = d.uv[s];
+    if (ACC) m_cpos = d.cold_pos[s];
   }
   double4 n_rec0, n_rec1, n_rec2;
   {
@@ -845,17 +858,18 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
   }
   for (int bin = bin0 + wave; bin < bin1; bin += STRIDE) {
     const int slot = bin * WAVE + lane;
-    const int meta = n_meta, cam = n_cam, lm = n_lm;
+    const int meta = n_meta, cam = n_cam, lm = n_lm, cpos = n_cpos;
     const double2 uv = n_uv;
     const bool valid = (meta & META_REAL) && !(meta & META_LONG);
     const int seg_first = meta & 255, seg_last = (meta >> 8) & 255;
     const double4 rec0 = n_rec0, rec1 = n_rec1, rec2 = n_rec2;
     (void)lm;
     // rotate the slot pipeline and request the slot data two bins ahead
-    n_meta = m_meta; n_cam = m_cam; n_lm = m_lm; n_uv = m_uv;
+    n_meta = m_meta; n_cam = m_cam; n_lm = m_lm; n_uv = m_uv; n_cpos = m_cpos;
     if (bin + 2 * STRIDE < bin1) {
       const int s = slot + 2 * STRIDE * WAVE;
       m_meta = d.meta[s]; m_cam = d.cam[s]; m_lm = d.lm[s]; m_uv = d.uv[s];
+      if (ACC) m_cpos = d.cold_pos[s];
     } else {
       m_meta = lane | (lane << 8);
     }
@@ -903,6 +917,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
                               hz * q.y, q.y, hx * q.z, hy * q.z, hz * q.z, q.z};
 #pragma unroll
         for (int j = 0; j < 12; ++j) __hip_atomic_fetch_add(a + j * n_hot, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (ACC) {
+        d.q4c[cpos] = q;  // cold camera: straight to its place in the cold camera-major view
       } else {
         d.q4[slot] = q;
       }
@@ -970,7 +986,7 @@ struct OpE0Tiles {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[r] = L.jl[3 * r] * v0 + L.jl[3 * r + 1] * v1 + L.jl[3 * r + 2] * v2;
     const double sw = d.robust ? d.sw[slot] : 1.0;
-    d.q4[slot] = pose_q(d, uv.x, uv.y, sw, s);
+    store_q(d, slot, pose_q(d, uv.x, uv.y, sw, s));
   }
   __device__ void finish_lm(const Dp&, int, const double*) const {}
 };
@@ -1072,7 +1088,7 @@ __global__ __launch_bounds__(E0T_BLOCK) void e0_tiles_cached(Dp d, int bins_per_
         }
       } else {
         const double2 uv = d.uv[slot];
-        d.q4[slot] = pose_q(d, uv.x, uv.y, d.robust ? d.sw[slot] : 1.0, s);
+        store_q(d, slot, pose_q(d, uv.x, uv.y, d.robust ? d.sw[slot] : 1.0, s));
       }
     }
   }
@@ -1524,22 +1540,19 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
   // 4 observations per thread in flight: index loads, then the dependent gathers, then the FMAs
   constexpr int U = 4;
   for (int pb = p0 + t; pb < p1; pb += U * 256) {
-    int sl[U];
     double hx[U], hy[U], hz[U], hw[U];
+    double4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int p = pb + u * 256;
       const bool in = p < p1;
       const int pc = in ? p : p0;
-      sl[u] = in ? d.cmv.slot[pc] : -1;
       hx[u] = d.cmv.h[pc];
       hy[u] = d.cmv.h[d.cmv.n + pc];
       hz[u] = d.cmv.h[2 * d.cmv.n + pc];
       hw[u] = hom ? d.cmv.h[3 * d.cmv.n + pc] : 1.0;
+      q[u] = in ? d.q4c[pc] : make_double4(0, 0, 0, 0);  // streamed: E0 wrote it in this order
     }
-    double4 q[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) q[u] = sl[u] >= 0 ? d.q4[sl[u]] : make_double4(0, 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       acc[0] += hx[u] * q[u].x; acc[1] += hy[u] * q[u].x; acc[2] += hz[u] * q[u].x; acc[3] += hw[u] * q[u].x;
@@ -1595,21 +1608,18 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
   if (false)
 #endif
   for (int pb = p0 + t; pb < p1; pb += U * 256) {
-    int sl[U];
     double hx[U], hy[U], hz[U];
+    double4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int p = pb + u * 256;
       const bool in = p < p1;
       const int pc = in ? p : p0;
-      sl[u] = in ? d.cmv.slot[pc] : -1;
       hx[u] = d.cmv.h[pc];
       hy[u] = d.cmv.h[d.cmv.n + pc];
       hz[u] = d.cmv.h[2 * d.cmv.n + pc];
+      q[u] = in ? d.q4c[pc] : make_double4(0, 0, 0, 0);  // streamed: E0 wrote it in this order
     }
-    double4 q[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) q[u] = sl[u] >= 0 ? d.q4[sl[u]] : make_double4(0, 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       acc[0] += hx[u] * q[u].x; acc[1] += hy[u] * q[u].x; acc[2] += hz[u] * q[u].x; acc[3] += q[u].x;

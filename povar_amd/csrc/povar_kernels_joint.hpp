@@ -208,7 +208,7 @@ struct OpE0H {
     const double v2 = Hi[6] * tot[0] + Hi[7] * tot[1] + Hi[8] * tot[2];
     const double s0 = L.o.jl3[0] * v0 + L.o.jl3[1] * v1 + L.o.jl3[2] * v2;
     const double s1 = L.o.jl3[3] * v0 + L.o.jl3[4] * v1 + L.o.jl3[5] * v2;
-    d.q4[slot] = hom_q(L.o.h, L.o.sw, s0, s1);
+    store_q(d, slot, hom_q(L.o.h, L.o.sw, s0, s1));
   }
   __device__ void finish_lm(const Dp&, int, const double*) const {}
 };
@@ -283,15 +283,15 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_w
   const int bin0 = blockIdx.x * bins_per_wg;
   const int bin1 = min(bin0 + bins_per_wg, d.n_bins);
   constexpr int STRIDE = E0C_BLOCK / WAVE;
-  int n_meta = lane | (lane << 8), n_cam = 0, n_lm = 0;
+  int n_meta = lane | (lane << 8), n_cam = 0, n_lm = 0, n_cpos = 0;
   double2 n_uv = make_double2(0, 0);
   if (bin0 + wave < bin1) {
     const int s = (bin0 + wave) * WAVE + lane;
-    n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
+    n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s]; n_cpos = d.cold_pos[s];
   }
   for (int bin = bin0 + wave; bin < bin1; bin += STRIDE) {
     const int slot = bin * WAVE + lane;
-    const int meta = n_meta, cam = n_cam, lm = n_lm;
+    const int meta = n_meta, cam = n_cam, lm = n_lm, cpos = n_cpos;
     const double2 uv = n_uv;
     const bool valid = (meta & META_REAL) && !(meta & META_LONG);
     const int seg_first = meta & 255, seg_last = (meta >> 8) & 255;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_w
     const double4 X = rec[0], s4 = rec[1], h0 = rec[2], h1 = rec[3];
     if (bin + STRIDE < bin1) {
       const int s = slot + STRIDE * WAVE;
-      n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s];
+      n_meta = d.meta[s]; n_cam = d.cam[s]; n_lm = d.lm[s]; n_uv = d.uv[s]; n_cpos = d.cold_pos[s];
     }
     double red[3] = {0, 0, 0};
     double jl3[6];
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_w
         for (int jj = 0; jj < 12; ++jj)
           __hip_atomic_fetch_add(a + jj * n_hot, v[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
-        d.q4[slot] = q;
+        d.q4c[cpos] = q;  // cold camera: straight to its place in the cold camera-major view
       }
     }
   }
@@ -631,22 +631,19 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv_h(Dp d, int want_norms,
   if (done) return;
   constexpr int U = 4;
   for (int pb = p0 + t; pb < p1; pb += U * 256) {
-    int sl[U];
     double hx[U], hy[U], hz[U], hw[U];
+    double4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int p = pb + u * 256;
       const bool in = p < p1;
       const int pc = in ? p : p0;
-      sl[u] = in ? d.cmv.slot[pc] : -1;
       hx[u] = d.cmv.h[pc];
       hy[u] = d.cmv.h[d.cmv.n + pc];
       hz[u] = d.cmv.h[2 * d.cmv.n + pc];
       hw[u] = d.cmv.h[3 * d.cmv.n + pc];
+      q[u] = in ? d.q4c[pc] : make_double4(0, 0, 0, 0);
     }
-    double4 q[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) q[u] = sl[u] >= 0 ? d.q4[sl[u]] : make_double4(0, 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       acc[0] += hx[u] * q[u].x; acc[1] += hy[u] * q[u].x; acc[2] += hz[u] * q[u].x; acc[3] += hw[u] * q[u].x;
