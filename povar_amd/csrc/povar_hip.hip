@@ -132,6 +132,13 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // layout construction (host)
 // ------------------------------------------------------------------------------------------
+// number of cameras whose Jp^T s is accumulated in LDS (POVAR_HOT_ACC=<n> lowers it: tuning knob)
+int hot_acc_cap(int n_cams) {
+  int cap = HOT_ACC_MAX;
+  if (const char* e = std::getenv("POVAR_HOT_ACC")) cap = std::max(1, std::min(HOT_ACC_MAX, std::atoi(e)));
+  return std::min(n_cams, cap);
+}
+
 struct Layout {
   std::vector<double2> uv, cm_uv;
   std::vector<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off,
@@ -243,7 +250,7 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
     // "cold" camera-major structure for POVAR_E0_IMPLICIT_LDSACC: only the observations whose
     // Jp^T s is NOT accumulated in LDS (camera outside the HOT_ACC_MAX hottest, or a long landmark,
     // which the lm_long driver handles through q4)
-    const int n_acc = std::min(n_cams, HOT_ACC_MAX);
+    const int n_acc = hot_acc_cap(n_cams);
     L.cc_cam_item_off.assign(n_cams + 1, 0);
     for (int c = 0; c < n_cams; ++c) {
       L.cc_cam_item_off[c] = (int)L.cc_item_off.size();
@@ -609,7 +616,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (int rc = upload(c->cold_pos, L.cold_pos, c)) return rc;
     HIP_TRY(c->q4c.alloc(std::max<size_t>(L.cc_slot.size(), 1), &c->bytes));
   }
-  c->n_hot_acc = std::min(n_cams, HOT_ACC_MAX);
+  c->n_hot_acc = hot_acc_cap(n_cams);
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
   ALLOC(hot_rec, (size_t)HOT_MAX * HOT_REC_STRIDE);
