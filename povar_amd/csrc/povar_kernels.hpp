@@ -446,28 +446,40 @@ __global__ __launch_bounds__(LM_BLOCK) void lm_long(Dp d, Op op, double* part) {
   double tot[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) tot[k] = 0;
-  for (int i = threadIdx.x; i < cnt; i += LM_BLOCK) {
-    const int slot = first + i;
-    typename Op::Local L;
-    double red[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) red[k] = 0;
-    op.phase1(d, slot, d.cam[slot], lm, d.uv[slot], L, red);
-#pragma unroll
-    for (int k = 0; k < NR; ++k) tot[k] += red[k];
-  }
-  if constexpr (Op::NRED > 0) block_sum<NR, LM_BLOCK>(tot, sh);
   double sc[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) sc[k] = 0;
-  for (int i = threadIdx.x; i < cnt; i += LM_BLOCK) {
-    const int slot = first + i;
+  if (cnt <= LM_BLOCK) {
+    // one observation per thread: the phase-1 state stays in registers across the landmark sum
+    const bool in = (int)threadIdx.x < cnt;
+    const int slot = first + (in ? (int)threadIdx.x : 0);
+    const int cam = d.cam[slot];
+    const double2 uv = d.uv[slot];
     typename Op::Local L;
-    double red[NR];
+    if (in) op.phase1(d, slot, cam, lm, uv, L, tot);
+    if constexpr (Op::NRED > 0) block_sum<NR, LM_BLOCK>(tot, sh);
+    if (in) op.phase2(d, slot, cam, lm, uv, L, tot, sc);
+  } else {
+    for (int i = threadIdx.x; i < cnt; i += LM_BLOCK) {
+      const int slot = first + i;
+      typename Op::Local L;
+      double red[NR];
 #pragma unroll
-    for (int k = 0; k < NR; ++k) red[k] = 0;
-    op.phase1(d, slot, d.cam[slot], lm, d.uv[slot], L, red);
-    op.phase2(d, slot, d.cam[slot], lm, d.uv[slot], L, tot, sc);
+      for (int k = 0; k < NR; ++k) red[k] = 0;
+      op.phase1(d, slot, d.cam[slot], lm, d.uv[slot], L, red);
+#pragma unroll
+      for (int k = 0; k < NR; ++k) tot[k] += red[k];
+    }
+    if constexpr (Op::NRED > 0) block_sum<NR, LM_BLOCK>(tot, sh);
+    for (int i = threadIdx.x; i < cnt; i += LM_BLOCK) {  // longer landmarks: phase 1 recomputed
+      const int slot = first + i;
+      typename Op::Local L;
+      double red[NR];
+#pragma unroll
+      for (int k = 0; k < NR; ++k) red[k] = 0;
+      op.phase1(d, slot, d.cam[slot], lm, d.uv[slot], L, red);
+      op.phase2(d, slot, d.cam[slot], lm, d.uv[slot], L, tot, sc);
+    }
   }
   __syncthreads();  // every phase1 read of per-landmark state is done before finish_lm writes it
   if (threadIdx.x == 0) op.finish_lm(d, lm, tot);
