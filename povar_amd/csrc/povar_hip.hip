@@ -82,6 +82,12 @@ struct povar_ctx {
   DevBuf<double2> uv, cm_uv, tiles;
   DevBuf<int2> cc_cam_range;  // per camera: (first, end) position of its run in the cold camera-major view
   DevBuf<int> cold_pos;       // per slot: position in the cold view (-1: accumulated in LDS)
+  // default mode with long landmarks: e0_lm_cached walks them itself (view "A" of the cold observations)
+  DevBuf<int> c2_lm, c2_pos;
+  DevBuf<int2> c2_range;
+  DevBuf<double> c2_h;
+  int64_t n_cold2 = 0;
+  bool long_in_kernel = false;
   DevBuf<double4> q4c;        // scatter scalars of the cold observations, in cold camera-major order
   DevBuf<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
       cam_item_off, flags;
@@ -143,6 +149,10 @@ struct Layout {
   std::vector<double2> uv, cm_uv;
   std::vector<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off,
       item_cam, cam_item_off, slot_of_obs, cold_pos;
+  // cold view "A" of the default mode when the problem has long landmarks: their observations of LDS-accumulated
+  // cameras are accumulated inside e0_lm_cached too, so they are not cold (empty when there is no long landmark)
+  std::vector<int> c2_lm, c2_pos;
+  std::vector<int2> c2_range;
   int n_bins = 0;
 };
 
@@ -270,6 +280,20 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
     // inverse of cc_slot: where a cold observation's scatter scalars go (Dp::q4c)
     L.cold_pos.assign(n_slots, -1);
     for (size_t p = 0; p < L.cc_slot.size(); ++p) L.cold_pos[L.cc_slot[p]] = (int)p;
+    if (!L.long_lm.empty()) {
+      L.c2_pos.assign(n_slots, -1);
+      L.c2_range.resize(n_cams);
+      for (int c = 0; c < n_cams; ++c) {
+        const int first = (int)L.c2_lm.size();
+        const bool acc = rank[c] > 0 && rank[c] <= n_acc;
+        if (!acc)
+          for (int64_t p = cnt[c]; p < cnt[c + 1]; ++p) {
+            L.c2_pos[L.cm_slot[p]] = (int)L.c2_lm.size();
+            L.c2_lm.push_back(L.cm_lm[p]);
+          }
+        L.c2_range[c] = make_int2(first, (int)L.c2_lm.size());
+      }
+    }
   }
   L.cam_item_off.assign(n_cams + 1, 0);
   L.item_off.clear();
@@ -344,13 +368,21 @@ int allreduce(povar_ctx* c, double* buf, size_t n) {
 }
 
 // Dp of the per-term kernels in POVAR_E0_IMPLICIT_LDSACC mode: cold camera-major view + hot partials
-Dp ldsacc_dp(povar_ctx* c) {
+Dp ldsacc_dp(povar_ctx* c, bool long_in_kernel = false) {
   Dp dt = c->d;
   dt.cmv = CmView{c->cc_slot.p, c->cc_h.p, c->n_cold, c->cc_item_off.p, c->cc_cam_item_off.p, c->cc_part.p,
                   c->n_cold_items, c->cc_cam_range.p};
   dt.hot_part = c->hot_part.p;
   dt.q4c = c->q4c.p;
   dt.cold_pos = c->cold_pos.p;
+  if (long_in_kernel && c->long_in_kernel) {
+    // view "A": e0_lm_cached<true> walks the long landmarks itself, their LDS-accumulated observations are not cold
+    dt.cmv.h = c->c2_h.p;
+    dt.cmv.n = c->n_cold2;
+    dt.cmv.cam_range = c->c2_range.p;
+    dt.cold_pos = c->c2_pos.p;
+    dt.long_in_kernel = 1;
+  }
   return dt;
 }
 
@@ -402,7 +434,10 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
     }
   } else {
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
-    const Dp da = acc ? ldsacc_dp(c) : c->d;  // ACC: cold observations write q to their camera-major position (q4c)
+    // ACC: cold observations write q to their camera-major position (q4c); the implicit form also walks the
+    // long landmarks inside e0_lm_cached (its own cold view)
+    const bool lik = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->long_in_kernel;
+    const Dp da = acc ? ldsacc_dp(c, lik) : c->d;
     if (c->opt.e0_mode == POVAR_E0_TILES) launch_lm(c, OpE0Tiles{});
     else if (c->opt.e0_mode == POVAR_E0_TILES_LDSACC) {
       hipLaunchKernelGGL(e0_tiles_cached, dim3(c->e0c_grid), dim3(E0T_BLOCK),
@@ -419,13 +454,13 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
       hipLaunchKernelGGL(e0_lm_cached<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
                          (size_t)c->n_hot * HOT_REC * sizeof(double2), c->stream, c->d, c->e0c_bins_per_wg,
                          (double*)nullptr);
-    if ((c->opt.e0_mode == POVAR_E0_IMPLICIT || c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) && c->n_long > 0)
+    if ((c->opt.e0_mode == POVAR_E0_IMPLICIT || c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) && c->n_long > 0 && !lik)
       hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpE0{}, c->part.p);
     if (acc && fuse_norms >= 0 && !sharded(c) && c->fuse_binv) {
-      hipLaunchKernelGGL(cam_cold_sum_binv, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), fuse_norms);
+      hipLaunchKernelGGL(cam_cold_sum_binv, dim3(c->n_cams), dim3(256), 0, c->stream, da, fuse_norms);
       *binv_mode = 4;  // B^-1, AXPY and z already done
     } else if (acc) {
-      hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), 0);
+      hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 0);
       *binv_mode = 2;  // dense y (sigma applied)
     } else {
       hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(c->n_items, 1), 4)), dim3(256), 0, c->stream, c->d, 1, 0);
@@ -614,7 +649,15 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       range[k] = make_int2(L.cc_item_off[L.cc_cam_item_off[k]], L.cc_item_off[L.cc_cam_item_off[k + 1]]);
     if (int rc = upload(c->cc_cam_range, range, c)) return rc;
     if (int rc = upload(c->cold_pos, L.cold_pos, c)) return rc;
-    HIP_TRY(c->q4c.alloc(std::max<size_t>(L.cc_slot.size(), 1), &c->bytes));
+    HIP_TRY(c->q4c.alloc(std::max<size_t>(std::max(L.cc_slot.size(), L.c2_lm.size()), 1), &c->bytes));
+    if (!L.long_lm.empty()) {
+      c->n_cold2 = (int64_t)L.c2_lm.size();
+      if (int rc = upload(c->c2_lm, L.c2_lm, c)) return rc;
+      if (int rc = upload(c->c2_pos, L.c2_pos, c)) return rc;
+      if (int rc = upload(c->c2_range, L.c2_range, c)) return rc;
+      HIP_TRY(c->c2_h.alloc(4 * std::max<size_t>(L.c2_lm.size(), 1), &c->bytes));
+      c->long_in_kernel = std::getenv("POVAR_LONG_SEPARATE") == nullptr;  // knob: keep the lm_long kernel
+    }
   }
   c->n_hot_acc = hot_acc_cap(n_cams);
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
@@ -648,7 +691,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
   d.hot_rec = c->hot_rec.p;
   d.hot_cams = c->hot_cams.p; d.n_hot = (int)L.hot_cams.size();
-  d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.q4c = nullptr; d.cold_pos = nullptr; d.tiles = nullptr;
+  d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.q4c = nullptr; d.cold_pos = nullptr; d.long_in_kernel = 0; d.tiles = nullptr;
   d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
   d.tmp = c->tmp.p; d.accum = c->accum.p; d.z = c->z.p; d.y = c->y.p; d.inc = c->inc.p;
   d.item_part = c->item_part.p; d.item_partG = c->item_partG.p; d.cm_h = c->cm_h.p; d.n_obs = n_obs;
@@ -680,6 +723,7 @@ void povar_destroy(povar_ctx* c) {
   c->sc_dm_part.release(); c->sc_dm.release(); c->sc_bmat.release(); c->sc_minv.release(); c->sc_x.release();
   c->sc_r.release(); c->sc_p.release(); c->sc_q.release(); c->sc_zv.release(); c->sc_part.release(); c->sc_s.release();
   c->cc_cam_range.release(); c->cold_pos.release(); c->q4c.release();
+  c->c2_lm.release(); c->c2_pos.release(); c->c2_range.release(); c->c2_h.release();
   c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -789,6 +833,8 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cm_lm.p, c->cm_h.p, c->n_obs, 0);
   if (c->n_cold > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, 0);
+  if (c->long_in_kernel && c->n_cold2 > 0)
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold2, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c2_lm.p, c->c2_h.p, c->n_cold2, 0);
   hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   if (sharded(c)) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish

@@ -113,6 +113,7 @@ struct Dp {
   // camera-major view (q4c[cold_pos[slot]]), so the per-camera sums stream them instead of gathering
   double4* q4c;        // [n_cold] or nullptr (every other mode: q4[slot])
   const int* cold_pos; // [n_slots] position in the cold view, -1 for observations accumulated in LDS
+  int long_in_kernel;  // 1: e0_lm_cached<true> walks the long landmarks itself (dealt round-robin to its wavefronts)
   double2* tiles;      // stored-tile mode: [n_bins][TILE_PAIRS][64] double2
   // per camera
   double* sigma;       // pose_jacobian_scaling [n_cams][12]
@@ -933,6 +934,67 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
         d.q4c[cpos] = q;  // cold camera: straight to its place in the cold camera-major view
       } else {
         d.q4[slot] = q;
+      }
+    }
+  }
+  if (ACC && d.long_in_kernel) {
+    // Landmarks with more than 64 observations: one wavefront walks the landmark's slots twice (forward sums,
+    // then the backward pass) with the same LDS camera cache and accumulators as the bins above, instead of the
+    // generic lm_long kernel (cameras from L2, every observation through the cold scatter path).
+    // (dealt round-robin over all wavefronts of the grid: tracks cluster in landmark order, workgroups must not)
+    for (int j = blockIdx.x * STRIDE + wave; j < d.n_long; j += gridDim.x * STRIDE) {
+      const int lm = d.long_lm[j], first = d.long_first[j], cnt = d.long_cnt[j];
+      const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 3 * (size_t)lm;
+      const double4 rec0 = rec[0], rec1 = rec[1], rec2 = rec[2];
+      double tot[3] = {0, 0, 0};
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int i0 = 0; i0 < cnt; i0 += WAVE) {
+          const bool in = i0 + lane < cnt;
+          const int slot = first + (in ? i0 + lane : 0);
+          double red[3] = {0, 0, 0};
+          E0Core core;
+          int hr = 0;
+          if (in) {
+            const int meta = d.meta[slot];
+            hr = (meta >> META_HOT_SHIFT) & META_HOT_MASK;
+            double P3[9], zz[12];
+            if (hr > 0 && hr <= n_hot) {
+              const double2* h = hot + (hr - 1) * HOT_REC;
+#pragma unroll
+              for (int k = 0; k < 6; ++k) {
+                const double2 v = h[k];
+                zz[2 * k] = v.x;
+                zz[2 * k + 1] = v.y;
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const double2 v = h[6 + k];
+                P3[2 * k] = v.x;
+                P3[2 * k + 1] = v.y;
+              }
+              P3[8] = h[10].x;
+            } else {
+              load_cam_global(d, d.cam[slot], P3, zz);
+            }
+            core.forward(d, P3, zz, rec0, rec1, d.uv[slot], d.robust ? d.sw[slot] : 1.0, red);
+          }
+          if (pass == 0) {
+            wave_sum<3>(red);
+            tot[0] += red[0]; tot[1] += red[1]; tot[2] += red[2];
+          } else if (in) {
+            const double4 q = core.backward(d, rec0, rec1, rec2, tot);
+            if (hr > 0 && hr <= n_hot) {
+              double* a = acc + (hr - 1);
+              const double hx = rec0.x, hy = rec0.y, hz = rec0.z;
+              const double v[12] = {hx * q.x, hy * q.x, hz * q.x, q.x, hx * q.y, hy * q.y,
+                                    hz * q.y, q.y, hx * q.z, hy * q.z, hz * q.z, q.z};
+#pragma unroll
+              for (int k = 0; k < 12; ++k) __hip_atomic_fetch_add(a + k * n_hot, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              d.q4c[d.cold_pos[slot]] = q;
+            }
+          }
+        }
       }
     }
   }
