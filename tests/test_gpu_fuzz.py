@@ -131,3 +131,81 @@ def test_step2_random_case(seed):
     assert abs(ld - ld_o) <= 1e-8 * abs(ld_o) + 1e-300
     assert rel(ctx.get_landmarks_homogeneous(), lms_new) < 1e-8
     ctx.close()
+
+
+@pytest.mark.parametrize("hot_acc,long_separate", [(4, False), (4, True), (40, False), (1000, False)])
+def test_small_hot_set_with_long_landmarks(hot_acc, long_separate, monkeypatch):
+    """The LDS-accumulation modes with a hot set smaller than the camera count (POVAR_HOT_ACC) on a problem with
+    long landmarks: cold cameras, cold observations on long landmarks and LDS-accumulated observations on long
+    landmarks all occur, with the long landmarks walked inside e0_lm_cached<true> or by the lm_long kernel
+    (POVAR_LONG_SEPARATE).  Same answers as the oracle in every combination, steps 1 and 2, PCG included."""
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    monkeypatch.setenv("POVAR_HOT_ACC", str(hot_acc))
+    if long_separate:
+        monkeypatch.setenv("POVAR_LONG_SEPARATE", "1")
+    rng = np.random.default_rng(77)
+    n_c = 120
+    degs = np.array([110, 97, 65, 64, 70] + [2] * 60 + list(rng.integers(3, 12, size=220)))
+    degs = np.minimum(degs, n_c)
+    pop = 1.0 / (1 + np.arange(n_c)) ** 0.8
+    pop /= pop.sum()
+    cam_idx = np.concatenate([np.sort(rng.choice(n_c, int(k), replace=False, p=pop)) for k in degs]).astype(np.int32)
+    lm_off = np.concatenate([[0], np.cumsum(degs)]).astype(np.int32)
+    n_l = len(degs)
+    cams = np.zeros((n_c, 12))
+    cams[:, :8] = rng.normal(size=(n_c, 8))
+    cams[:, 11] = 1.0
+    X = rng.normal(size=(n_l, 3))
+    lm_of = np.repeat(np.arange(n_l), degs)
+    P = cams[cam_idx].reshape(-1, 3, 4)
+    obs = np.einsum("nij,nj->ni", P[:, :2, :3], X[lm_of]) + P[:, :2, 3] + rng.normal(scale=0.05, size=(len(cam_idx), 2))
+    orc = O.Oracle(n_c, lm_off, cam_idx, obs)
+    lms = orc.init_landmarks_pose(ALPHA, cams)
+    st, diag2, jls, sigma, ok = orc.stage1_pose(ALPHA, cams, lms)
+    orc.scale_jp_cols_pose(st, sigma)
+    lam, m = 1e-3, 12
+    hll, b, binv = orc.prepare_hb_pose(st, lam)
+    ref, _, _, terms = orc.solve_pose(st, hll, binv, b, m, want_terms=True)
+    for mode in (capi.E0_IMPLICIT_LDSACC, capi.E0_TILES_LDSACC):
+        ctx = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=mode)
+        ctx.set_cameras(cams)
+        ctx.set_landmarks(lms)
+        assert ctx.linearize_pose(ALPHA)
+        ctx.prepare_pose(lam)
+        ctx.power_series_begin()
+        for i in range(1, m + 1):
+            ctx.power_series_step()
+            assert rel(ctx.get_term(), terms[i]) < 1e-10, (mode, i)
+        inc, it, status, rc = ctx.solve_pose(lam, capi.POWER_VARPROJ, m)
+        assert rc == 0 and rel(inc, ref) < 1e-10
+        x = rng.normal(size=12 * n_c)
+        assert rel(ctx.right_mul_e0_pose(x), orc.right_mul_e0_pose(st, hll, x)) < 1e-11
+        pcg_a, it_a, st_a, _ = ctx.solve_pose_sc(lam, capi.SC_PCG, 0, 6, 0.0)
+        ctx.set_e0_mode(capi.E0_IMPLICIT)
+        pcg_b, it_b, st_b, _ = ctx.solve_pose_sc(lam, capi.SC_PCG, 0, 6, 0.0)
+        assert (it_a, st_a) == (it_b, st_b) and rel(pcg_a, pcg_b) < 1e-9
+        ctx.close()
+    # step 2 with the same structure
+    rng2 = np.random.default_rng(5)
+    cams2 = rng2.normal(size=(n_c, 12))
+    cams2[:, 8:11] *= 0.1
+    cams2[:, 11] = 5 + rng2.random(n_c)
+    cams2 /= np.linalg.norm(cams2, axis=1, keepdims=True)
+    lms_h = np.concatenate([rng2.normal(size=(n_l, 3)), np.ones((n_l, 1))], 1)
+    obs2 = obs / 50.0
+    orc2 = O.Oracle(n_c, lm_off, cam_idx, obs2)
+    st_h, ok = orc2.linearize_homogeneous(cams2, lms_h)
+    diag2 = orc2.jp_diag2_homogeneous(st_h)
+    orc2.scale_jl_cols_homogeneous(st_h)
+    orc2.scale_jp_cols_joint(st_h, 1.0 / (1e-5 + np.sqrt(diag2)))
+    st_n = orc2.linearize_nullspace(cams2, lms_h, st_h)
+    hll2, b2, binv2 = orc2.prepare_hb_joint(st_h, st_n, lam)
+    ref2, _, _, _ = orc2.solve_joint(st_n, hll2, binv2, b2, 8)
+    ctx = capi.Context(n_c, lm_off, cam_idx, obs2, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    ctx.set_cameras(cams2)
+    ctx.set_landmarks_homogeneous(lms_h)
+    assert ctx.linearize_homogeneous()
+    inc2, it2, st2, rc = ctx.solve_joint(lam, 8)
+    assert rc == 0 and rel(inc2, ref2) < 1e-8
+    ctx.close()
