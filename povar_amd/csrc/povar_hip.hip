@@ -408,21 +408,22 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
   if (c->joint) {
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
     if (acc) {
-      const Dp da = ldsacc_dp(c);  // cold observations write q to their camera-major position (q4c)
+      // cold observations write q to their camera-major position (q4c); long landmarks are walked inside the kernel
+      const Dp da = ldsacc_dp(c, true);
       hipLaunchKernelGGL(e0_lm_cached_h, dim3(c->e0c_grid), dim3(E0C_BLOCK),
                          (size_t)c->n_hot_acc * (HOT_REC_H * sizeof(double2) + 96), c->stream, da,
                          c->e0c_bins_per_wg, c->hot_part.p);
-      if (c->n_long > 0)
+      if (c->n_long > 0 && !c->long_in_kernel)
         hipLaunchKernelGGL((lm_long<OpE0H>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpE0H{}, c->part.p);
     } else {
       launch_lm(c, OpE0H{});
     }
     if (acc && fuse_norms >= 0 && !sharded(c) && c->fuse_binv) {
-      hipLaunchKernelGGL(cam_cold_sum_binv_h, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), fuse_norms,
+      hipLaunchKernelGGL(cam_cold_sum_binv_h, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c, true), fuse_norms,
                          (const double*)c->ncw.p);
       *binv_mode = 4;  // B^-1, AXPY and z already done
     } else if (acc) {
-      hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c), 1);
+      hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c, true), 1);
       *binv_mode = 2;  // dense y (sigma applied)
     } else {
       hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(c->n_items, 1), 4)), dim3(256), 0, c->stream, c->d, 1, 1);
@@ -1082,6 +1083,8 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cm_lm.p, c->cm_h.p, c->n_obs, 1);
   if (c->n_cold > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, 1);
+  if (c->long_in_kernel && c->n_cold2 > 0)
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold2, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c2_lm.p, c->c2_h.p, c->n_cold2, 1);
   hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
   if (sharded(c)) {

@@ -357,6 +357,82 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_w
       }
     }
   }
+  if (d.long_in_kernel) {
+    // landmarks with more than 64 observations: one wavefront per landmark, two passes over its slots with the
+    // LDS camera cache and accumulators (see e0_lm_cached<true>)
+    for (int j = blockIdx.x * STRIDE + wave; j < d.n_long; j += gridDim.x * STRIDE) {
+      const int lm = d.long_lm[j], first = d.long_first[j], cnt = d.long_cnt[j];
+      const double4* rec = reinterpret_cast<const double4*>(d.lmrec) + 4 * (size_t)lm;
+      const double4 X = rec[0], s4 = rec[1], h0 = rec[2], h1 = rec[3];
+      double hw[4], hbeta;
+      house4(X, hw, hbeta);
+      double tot[3] = {0, 0, 0};
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int i0 = 0; i0 < cnt; i0 += WAVE) {
+          const bool in = i0 + lane < cnt;
+          const int slot = first + (in ? i0 + lane : 0);
+          double red[3] = {0, 0, 0};
+          double jl3[6];
+          Hom h;
+          double sw = 1.0;
+          int hr = 0;
+          if (in) {
+            const int meta = d.meta[slot];
+            hr = (meta >> META_HOT_SHIFT) & META_HOT_MASK;
+            const double2 uv = d.uv[slot];
+            Cam P;
+            double4 zz[3];
+            if (hr > 0 && hr <= n_hot) {
+              const double2* hp = hot + (hr - 1) * HOT_REC_H;
+              const double2 a0 = hp[0], a1 = hp[1], a2 = hp[2], a3 = hp[3], a4 = hp[4], a5 = hp[5];
+              zz[0] = make_double4(a0.x, a0.y, a1.x, a1.y);
+              zz[1] = make_double4(a2.x, a2.y, a3.x, a3.y);
+              zz[2] = make_double4(a4.x, a4.y, a5.x, a5.y);
+              const double2 b0 = hp[6], b1 = hp[7], b2 = hp[8], b3 = hp[9], b4 = hp[10], b5 = hp[11];
+              P.r0 = make_double4(b0.x, b0.y, b1.x, b1.y);
+              P.r1 = make_double4(b2.x, b2.y, b3.x, b3.y);
+              P.r2 = make_double4(b4.x, b4.y, b5.x, b5.y);
+            } else {
+              const int cam = d.cam[slot];
+              P = load_cam(d.cams_lin4, cam);
+              const double4* zc = reinterpret_cast<const double4*>(d.z) + 3 * cam;
+              zz[0] = zc[0]; zz[1] = zc[1]; zz[2] = zc[2];
+            }
+            sw = d.robust ? d.sw[slot] : 1.0;
+            h = hom_project(P, X, uv.x, uv.y);
+            double jl4[8];
+            hom_jl4(P, h, sw, s4, jl4);
+            jl3_of_jl4(jl4, hw, hbeta, jl3);
+            double t[2];
+            hom_jp_x(h, X, sw, zz, t);
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) red[jj] += jl3[jj] * t[0] + jl3[3 + jj] * t[1];
+          }
+          if (pass == 0) {
+            wave_sum<3>(red);
+            tot[0] += red[0]; tot[1] += red[1]; tot[2] += red[2];
+          } else if (in) {
+            const double v0 = h0.x * tot[0] + h0.y * tot[1] + h0.z * tot[2];
+            const double v1 = h0.y * tot[0] + h0.w * tot[1] + h1.x * tot[2];
+            const double v2 = h0.z * tot[0] + h1.x * tot[1] + h1.y * tot[2];
+            const double s0 = jl3[0] * v0 + jl3[1] * v1 + jl3[2] * v2;
+            const double s1 = jl3[3] * v0 + jl3[4] * v1 + jl3[5] * v2;
+            const double4 q = hom_q(h, sw, s0, s1);
+            if (hr > 0 && hr <= n_hot) {
+              double* a = acc + (hr - 1);
+              const double v[12] = {X.x * q.x, X.y * q.x, X.z * q.x, X.w * q.x, X.x * q.y, X.y * q.y,
+                                    X.z * q.y, X.w * q.y, X.x * q.z, X.y * q.z, X.z * q.z, X.w * q.z};
+#pragma unroll
+              for (int jj = 0; jj < 12; ++jj)
+                __hip_atomic_fetch_add(a + jj * n_hot, v[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              d.q4c[d.cold_pos[slot]] = q;
+            }
+          }
+        }
+      }
+    }
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK)
     hot_out[((size_t)(i / 12) * gridDim.x + blockIdx.x) * 12 + i % 12] = acc[(i % 12) * n_hot + i / 12];
