@@ -14,10 +14,17 @@ For N > 1 the landmarks are sharded over the ranks (strong scaling: the problem 
 each term carries one RCCL all-reduce of the 12*n_cams vector.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     the E0 (SpMV) kernel pair: algorithmic bytes (SURVEY.md 8d stored-tile model,
-               484 n_obs + 76 n_lms + 288 n_cams per application) / HIP-event duration vs 8 TB/s
-  cpu_baseline the CPU restatement of the reference algorithm (oracle/, per-camera mutex scatter,
-               all host cores) on a bounded landmark sample of the same workload
+  roofline     the E0 (SpMV) kernel pair against the HBM roofline in REAL bytes: `achieved` = the bytes the
+               two kernels must stream by design (povar_e0_model_bytes: every array once) / their HIP-event
+               duration, `frac` = achieved / 8 TB/s (always <= 1); `traffic` = PMC-measured HBM bytes per
+               application from profiles/traffic.json when its stamp matches the kernel sources, else null.
+               The SURVEY.md 8(d) stored-tile figure (484 n_obs + 76 n_lms + 288 n_cams per application,
+               which the implicit kernels never move) is reported separately as `effective_GBps`.
+  cpu_baseline the CPU restatement of the reference algorithm (oracle/, per-camera mutex scatter) on the
+               FULL workload: 1 thread and the fastest thread count, CPU model stated
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its N ranks itself
+(child `python -m torch.distributed.run`), relays rank 0's JSON line and exits with the children's code.
 """
 import argparse
 import json
@@ -45,29 +52,60 @@ def algorithmic_bytes_term(n_cams, n_lms, n_obs):
     return 484 * n_obs + 76 * n_lms + 1440 * n_cams
 
 
-def cpu_baseline(prob, alpha, lam, m, target_obs=400_000):
-    """Oracle (reference-faithful layout + loop nest, per-camera mutex) on the first landmarks of
-    the workload covering ~target_obs observations, all cameras, all host cores."""
+def kernel_source_sha():
+    """Stamp of the device code the PMC traffic figures in profiles/traffic.json were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_hip.hip"):
+        with open(os.path.join(ROOT, "povar_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
+    """Oracle (reference-faithful [4k x 16] storage + loop nest of linearization_power_varproj.hpp:364-406,
+    per-camera mutex scatter) on the FULL workload: terms/s at 1 thread and at the fastest thread count.
+    Workloads above max_obs observations (final-13682: 15 GB of tiles) use the leading landmarks up to
+    max_obs and scale by the observation ratio -- said in `sample`."""
     from oracle import povar_oracle as O
 
-    n_l = int(np.searchsorted(prob.lm_off, target_obs))
-    n_l = max(min(n_l, prob.n_lms), 1)
-    n_o = int(prob.lm_off[n_l])
+    n_l, n_o, scale = prob.n_lms, prob.n_obs, 1.0
+    if n_o > max_obs:
+        n_l = max(int(np.searchsorted(prob.lm_off, max_obs)), 1)
+        n_o = int(prob.lm_off[n_l])
+        scale = n_o / prob.n_obs
     orc = O.Oracle(prob.n_cams, prob.lm_off[: n_l + 1], prob.cam_idx[:n_o], prob.obs[:n_o])
     lms = orc.init_landmarks_pose(alpha, prob.cams)
     st, diag2, jls, sigma, ok = orc.stage1_pose(alpha, prob.cams, lms)
     orc.scale_jp_cols_pose(st, sigma)
     hll, b, binv = orc.prepare_hb_pose(st, lam)
+    ncpu = os.cpu_count() or 1
+    # 1 thread: a few terms are enough (the term cost is constant)
+    orc.solve_pose(st, hll, binv, b, 1, n_threads=1)
+    m1 = max(1, min(m, int(2.0e7 / max(n_o, 1))))
+    t0 = time.perf_counter()
+    orc.solve_pose(st, hll, binv, b, m1, n_threads=1)
+    v1 = m1 / (time.perf_counter() - t0)
     # the per-camera mutex makes the reference's scheme contention-bound on hub cameras: time a few
     # thread counts on two terms and keep the fastest (the count used is reported as "cores")
-    ncpu = os.cpu_count() or 1
-    best = None
-    for nt in sorted({ncpu, max(ncpu // 4, 1), min(16, ncpu), min(4, ncpu)}, reverse=True):
+    best = (2.0 / v1, 1)
+    for nt in sorted({ncpu, max(ncpu // 4, 1), min(16, ncpu), min(4, ncpu)} - {1}, reverse=True):
         orc.solve_pose(st, hll, binv, b, 1, n_threads=nt)
         t0 = time.perf_counter()
         orc.solve_pose(st, hll, binv, b, 2, n_threads=nt)
         dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
+        if dt < best[0]:
             best = (dt, nt)
     cores = best[1]
     t0 = time.perf_counter()
@@ -78,19 +116,44 @@ def cpu_baseline(prob, alpha, lam, m, target_obs=400_000):
         if time.perf_counter() - t0 > 8.0 or reps >= 20:
             break
     dt = time.perf_counter() - t0
-    terms_per_s_sample = reps * m / dt
-    # scale to the full workload by observation count (the term cost is linear in n_obs)
-    value = terms_per_s_sample * n_o / prob.n_obs
+    vN = reps * m / dt
+    what = "the full workload" if scale == 1.0 else \
+        f"the first {n_l} landmarks / {n_o} observations (all cameras), scaled by {n_o}/{prob.n_obs}"
     return {
-        "value": value,
+        "value": vN * scale,
         "unit": "terms/s",
         "cores": cores,
         "kind": "port",
+        "value_1_thread": v1 * scale,
         "host_cpus": ncpu,
-        "sample": f"first {n_l} landmarks / {n_o} observations of the workload (all {prob.n_cams} cameras), "
-                  f"{reps} solves x {m} terms in {dt:.1f} s = {terms_per_s_sample:.1f} terms/s on the sample, "
-                  f"scaled by n_obs ratio {n_o}/{prob.n_obs}",
+        "cpu_model": cpu_model(),
+        "sample": f"{what}: {reps} x solve_pOSE of {m} terms with {cores} threads in {dt:.1f} s; "
+                  f"{m1} terms with 1 thread at {v1:.2f} terms/s",
     }
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` as the driver calls it: start the N ranks as fresh child processes (this
+    process has not touched the GPU), relay rank 0's JSON line, return the children's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in r.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        elif l.strip():
+            print(l, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return r.returncode if (r.returncode or line is not None) else 1
 
 
 def main():
@@ -114,13 +177,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the stored-tile comparison leg")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))  # nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
     # the HIP library first: it owns the GPU data path (HIP + RCCL); torch is only the rendezvous
     capi.lib()
@@ -246,6 +308,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     inc_main = ctx.get_increment()
+    if rank == 0 and os.environ.get("POVAR_BENCH_DUMP_INC"):  # tests: sharded == unsharded increment
+        np.save(os.environ["POVAR_BENCH_DUMP_INC"], inc_main)
 
     terms = args.steps * m
     value = terms / dt
@@ -253,16 +317,26 @@ def main():
     binv_ms = prof.binv_ms / max(prof.binv_launches, 1)
     comm_ms = prof.comm_ms / max(prof.comm_launches, 1)
 
-    # algorithmic bytes of ONE launch on THIS rank (its landmark shard)
+    # ONE E0 application on THIS rank (its landmark shard): the bytes its two kernels stream by design, and the
+    # SURVEY 8(d) stored-tile figure the implicit kernels are only "effectively" delivering
     loc_l, loc_o = le - lb, oe - ob
+    model_lm, model_cm = ctx.e0_model_bytes()
+    model_bytes = model_lm + model_cm
     bytes_e0 = algorithmic_bytes_e0(n_c, loc_l, loc_o)
-    achieved = bytes_e0 / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
-    traffic = None
+    achieved = model_bytes / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
+    effective = bytes_e0 / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
+    traffic, traffic_note = None, "no PMC figure for this workload/mode"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as fh:
-                traffic = json.load(fh).get(f"{args.problem}:{args.e0_mode}:{world}")
+                tj = json.load(fh)
+            key = f"{args.problem}:{args.e0_mode}:{world}"
+            if key in tj:
+                if tj.get("_source_sha", {}).get(key) == kernel_source_sha():
+                    traffic, traffic_note = tj[key], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/"
+                else:
+                    traffic_note = "profiles/traffic.json was measured on other kernel sources (stale): not reported"
         except Exception:
             traffic = None
 
@@ -302,18 +376,26 @@ def main():
                        capi.E0_IMPLICIT_LDSACC: "E0 x (e0_lm_cached<true> + cam_cold_sum[_binv])",
                        capi.E0_TILES: "E0 x (lm_regular<OpE0Tiles> + cm_scatter)",
                        capi.E0_TILES_LDSACC: "E0 x (e0_tiles_cached + cam_cold_sum[_binv])"}[mode],
+            # bytes the kernel pair streams by design (every array once) / HIP-event time of the pair
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
-            "algorithmic_bytes_per_launch": bytes_e0,
-            # the same kernel against the roofline in REAL bytes: PMC-measured HBM traffic per launch / its
-            # duration (the implicit E0 moves 6x fewer bytes than the stored-tile model it is priced against)
+            "traffic_note": traffic_note,
+            "model_bytes_per_launch": model_bytes,
+            "model_bytes_lm_kernel": model_lm,
+            "model_bytes_cam_kernel": model_cm,
             "traffic_GBps": (traffic / (e0_ms * 1e-3) / 1e9) if traffic else None,
             "traffic_frac": (traffic / (e0_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            # SURVEY 8(d) stored-tile model (the reference's bytes): an EFFECTIVE rate for the implicit kernels
+            "algorithmic_bytes_per_launch": bytes_e0,
+            "effective_GBps": effective,
+            "effective_x_peak": effective / HBM_PEAK_GBPS,
         },
     }
+    if comm_used != "none":
+        out["config"]["rccl_ranks"] = ctx.comm_ranks()
 
     if args.step == 2:
         out["metric"] = "power-series iterations/s (solve_joint terms per second, step 2)"
@@ -337,7 +419,7 @@ def main():
         ctx.profile_enable(False)
         inc_other = ctx.get_increment()
         e0_2 = p2.e0_ms / max(p2.e0_launches, 1)
-        ach2 = bytes_e0 / (e0_2 * 1e-3) / 1e9
+        ach2 = sum(ctx.e0_model_bytes()) / (e0_2 * 1e-3) / 1e9
         out["secondary"] = {
             "e0_mode": "tiles-ldsacc" if other == capi.E0_TILES_LDSACC else "ldsacc",
             "value": max(args.steps // 4, 2) * m / dt2,

@@ -214,6 +214,10 @@ int povar_profile_enable(povar_ctx* ctx, int32_t enable);
 int povar_profile_get(povar_ctx* ctx, povar_profile_info* out);
 /* bytes of device memory held by the context */
 int64_t povar_device_bytes(povar_ctx* ctx);
+/* Byte floor of ONE application of E0 (right_mul_e0_pOSE, linearization_power_varproj.hpp:364-406) in the
+ * context's current E0 mode: what the landmark-major kernel and the per-camera kernel must stream by design
+ * (each array once).  bench.py prices the HIP-event time of those kernels against it (roofline.achieved). */
+int povar_e0_model_bytes(povar_ctx* ctx, int64_t* lm_kernel_bytes, int64_t* cam_kernel_bytes);
 
 /* ---- multi-GPU: landmarks sharded over ranks, one RCCL all-reduce per exchange step ---- */
 /* host-only: contiguous landmark range of `rank`, balanced by observation count */
@@ -221,6 +225,8 @@ int povar_shard_range(int32_t n_lms, const int32_t* lm_offsets, int32_t world, i
                       int32_t* lm_begin, int32_t* lm_end);
 int povar_comm_unique_id(uint8_t id[128]);
 int povar_comm_init(povar_ctx* ctx, int32_t world, int32_t rank, const uint8_t id[128]);
+/* ranks of the attached communicator (ncclCommCount; the world size of a host hook), 0 = none, < 0 on error */
+int povar_comm_ranks(povar_ctx* ctx);
 /* same exchange steps through a caller-supplied host all-reduce (sum, in place) instead of RCCL:
  * lets an MPI/gloo launcher or an in-process test stand in for the communicator */
 typedef void (*povar_allreduce_fn)(double* buf, int64_t n, void* user);

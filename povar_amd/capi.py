@@ -313,6 +313,15 @@ class Context:
     def device_bytes(self):
         return int(self.L.povar_device_bytes(self.h))
 
+    def e0_model_bytes(self):
+        """(landmark-major kernel, per-camera kernel) byte floor of one E0 application in the current mode."""
+        a, b = C.c_int64(), C.c_int64()
+        self._chk(self.L.povar_e0_model_bytes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def comm_ranks(self):
+        return self._chk(self.L.povar_comm_ranks(self.h))
+
     def comm_init_host(self, world, rank, fn):
         """fn(buf: np.ndarray) sums buf in place over the ranks (host all-reduce hook)."""
         def _cb(ptr, n, user):

@@ -1285,6 +1285,55 @@ int povar_profile_get(povar_ctx* c, povar_profile_info* out) {
   return 0;
 }
 
+int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!lm_kernel || !cam_kernel) return fail(-1, "null argument");
+  // Bytes the E0 kernels of the current mode must move per application BY DESIGN (every array they stream, once;
+  // arrays that stay in L2 -- camera records, z, the LDS image -- counted once, not per gather).  This is the
+  // byte floor bench.py prices the measured kernel time against; the PMC-measured traffic is reported beside it.
+  const int64_t ns = c->n_slots, nl = c->n_lms, nc = c->n_cams, no = c->n_obs;
+  const int64_t robust = c->opt.robust_norm ? 8 : 0;
+  const int64_t cam_static = nc * (96 + 96);            // z (12 doubles) + P (12 doubles) per camera
+  const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
+  const bool lik = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->long_in_kernel;
+  const int64_t n_cold = lik ? c->n_cold2 : c->n_cold;
+  const int64_t hot_flush = acc ? (int64_t)c->e0c_grid * c->n_hot_acc * 96 : 0;
+  const int64_t tail = nc * (1152 + 96 /*sigma*/ + 3 * 96 /*accum rw, tmp*/ + 96 /*z*/);
+  int64_t lm = 0, cm = 0;
+  switch (c->opt.e0_mode) {
+    case POVAR_E0_IMPLICIT_LDSACC:
+      lm = ns * (E0_SLOT_BYTES + robust) + nl * E0_LMREC_BYTES + cam_static + n_cold * 32 + hot_flush;
+      cm = hot_flush + n_cold * (32 + 24) + tail;
+      break;
+    case POVAR_E0_IMPLICIT:
+      lm = ns * (28 + robust) + nl * 96 + cam_static + no * 32;   // uv, cam, lm, meta; q4 out
+      cm = no * (4 + 32 + 24) + tail;                                // cm_slot, q4 gather, cm_h
+      break;
+    case POVAR_E0_TILES:
+      lm = ns * (12 + 480 + robust) + nl * 72 + nc * 96 + no * 32;
+      cm = no * (4 + 32 + 24) + tail;
+      break;
+    case POVAR_E0_TILES_LDSACC:
+      lm = ns * (12 + 480 + robust) + nl * 72 + nc * 96 + n_cold * 32 + hot_flush;
+      cm = hot_flush + n_cold * (4 + 32 + 24) + tail;
+      break;
+    default:
+      return fail(-1, "bad e0 mode");
+  }
+  *lm_kernel = lm;
+  *cam_kernel = cm;
+  return 0;
+}
+
+int povar_comm_ranks(povar_ctx* c) {
+  if (!c) return fail(-1, "null context");
+  if (c->host_fn) return c->world;
+  if (!c->comm) return 0;
+  int n = 0;
+  NCCL_TRY(ncclCommCount(c->comm, &n));
+  return n;
+}
+
 int povar_comm_unique_id(uint8_t id[128]) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
   ncclUniqueId u;
@@ -1308,7 +1357,9 @@ int povar_comm_init(povar_ctx* c, int32_t world, int32_t rank, const uint8_t id[
   if (world < 1 || rank < 0 || rank >= world) return fail(-1, "bad communicator arguments");
   ncclUniqueId u;
   std::memcpy(&u, id, 128);
-  NCCL_TRY(ncclCommInitRank(&c->comm, world, u, rank));
+  ncclComm_t comm = nullptr;
+  NCCL_TRY(ncclCommInitRank(&comm, world, u, rank));  // e.g. two ranks on one device: "Duplicate GPU detected"
+  c->comm = comm;
   c->world = world;
   c->rank = rank;
   return 0;

@@ -55,6 +55,8 @@ constexpr int HOT_ACC_MAX = 568;    // cameras cached AND accumulated in LDS: st
 constexpr int HOT_MAX = 912;        // cameras cached per workgroup: 912 * 176 B = 156.75 KiB of the 160 KiB LDS
 constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :3] (4.5) + pad
 constexpr int E0C_BLOCK = 1024;     // one workgroup per CU
+constexpr int E0_SLOT_BYTES = 32;   // e0_lm_cached<true> per-slot stream: uv 16 + meta 4 + cam 4 + lm 4 + cold_pos 4
+constexpr int E0_LMREC_BYTES = 96;  // packed landmark record read by the per-term kernel
 
 // one camera-major index structure: observations sorted by camera, cut into work items
 struct CmView {

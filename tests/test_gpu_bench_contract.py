@@ -28,10 +28,53 @@ def test_bench_json_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    # the fraction is in real bytes: it can never exceed the roofline; the stored-tile figure is "effective" only
+    assert 0 < rf["frac"] <= 1.0 and rf["effective_GBps"] >= rf["achieved"] and rf["model_bytes_per_launch"] > 0
+    assert rf["traffic"] is None or rf["traffic"] >= 0.5 * rf["model_bytes_per_launch"]
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
-    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["value_1_thread"] > 0
+    assert "full workload" in cb["sample"] and cb["cpu_model"]
     # 20 terms per step: value == steps * m / time
     assert abs(d["value"] - 20 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-6 * d["value"]
     assert d["secondary"]["rel_diff_vs_primary"] < 1e-10 and d["explicit_sc"]["cholesky_rc"] == 0
+
+
+def _run_bench(extra_args, env_extra, dump):
+    path = os.path.join(ROOT, "gpurun_out", dump)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    env = dict(os.environ, POVAR_BENCH_DUMP_INC=path, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--problem", "ladybug-49", "--steps", "3",
+                        "--warmup", "1", "--no-secondary"] + extra_args, capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    import numpy as np
+    return json.loads(lines[0]), np.load(path)
+
+
+def test_bench_two_ranks_self_launch():
+    """`python bench.py --gpus 2` exactly as the driver calls it (no launcher): bench.py starts its two ranks
+    itself.  On a 1-GPU box both ranks share device 0; RCCL refuses that ("Duplicate GPU detected"), bench.py
+    then says so in config.comm and routes the exchange steps through the host hook -- the sharded algorithm,
+    the rendezvous and the max-over-ranks timing are the ones an 8-GPU node runs.  With >= 2 GPUs this is a real
+    2-rank RCCL run.  Either way the sharded increment must equal the 1-rank one."""
+    import numpy as np
+    d2, inc2 = _run_bench(["--gpus", "2"], {}, "inc_w2.npy")
+    assert d2["n_gpus"] == 2 and d2["value"] > 0 and d2["cpu_baseline"] is None and d2["scaling"] == "strong"
+    assert d2["config"]["comm"] in ("rccl", "gloo-host") and d2["config"]["rccl_ranks"] == 2
+    d1, inc1 = _run_bench(["--no-cpu-baseline"], {}, "inc_w1.npy")
+    assert np.linalg.norm(inc2 - inc1) <= 1e-11 * np.linalg.norm(inc1)
+
+
+@pytest.mark.parametrize("graph_comm", ["0", "1"])
+def test_bench_rccl_communicator_in_and_out_of_graph(graph_comm):
+    """The RCCL all-reduce of the term loop with a real communicator (1 rank: all a 1-GPU box can build), launched
+    kernel by kernel and captured inside the series hipGraph (POVAR_GRAPH_COMM=1): same increment as no communicator."""
+    import numpy as np
+    d, inc = _run_bench(["--no-cpu-baseline"], {"POVAR_FORCE_COMM": "1", "POVAR_GRAPH_COMM": graph_comm}, f"inc_c{graph_comm}.npy")
+    assert d["config"]["comm"] == "rccl" and d["config"]["rccl_ranks"] == 1
+    d1, inc1 = _run_bench(["--no-cpu-baseline"], {}, "inc_w1.npy")
+    assert np.linalg.norm(inc - inc1) <= 1e-12 * np.linalg.norm(inc1)

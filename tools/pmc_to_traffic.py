@@ -38,6 +38,10 @@ def main():
     cm = [k for k in e0 if ("cam_cold_sum" in k if "ldsacc" in mode else "cm_scatter" in k)]
     data[key] = sum(table[k]["hbm_bytes"] for k in lm + cm)
     data.setdefault("_per_kernel", {})[key] = {k: table[k] for k in lm + cm}
+    # stamp: bench.py reports the figure only while the kernel sources are the ones it was measured on
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    data.setdefault("_source_sha", {})[key] = bench.kernel_source_sha()
     json.dump(data, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps({key: data[key]}))
 
