@@ -394,8 +394,8 @@ def main():
             "effective_x_peak": effective / HBM_PEAK_GBPS,
         },
     }
-    if comm_used != "none":
-        out["config"]["rccl_ranks"] = ctx.comm_ranks()
+    if comm_used != "none":  # ncclCommCount of the attached communicator (host-hook runs: its world size)
+        out["config"]["rccl_ranks" if comm_used == "rccl" else "host_comm_ranks"] = ctx.comm_ranks()
 
     if args.step == 2:
         out["metric"] = "power-series iterations/s (solve_joint terms per second, step 2)"

@@ -320,7 +320,10 @@ class Context:
         return a.value, b.value
 
     def comm_ranks(self):
-        return self._chk(self.L.povar_comm_ranks(self.h))
+        n = self.L.povar_comm_ranks(self.h)
+        if n < 0:
+            raise PovarError(f"povar_hip rc={n}: {self.L.povar_last_error().decode()}")
+        return n
 
     def comm_init_host(self, world, rank, fn):
         """fn(buf: np.ndarray) sums buf in place over the ranks (host all-reduce hook)."""

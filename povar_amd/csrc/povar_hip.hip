@@ -88,6 +88,13 @@ struct povar_ctx {
   DevBuf<double> c2_h;
   int64_t n_cold2 = 0;
   bool long_in_kernel = false;
+  // lane-per-landmark layout of e0_lpl (struct V2)
+  DevBuf<double2> v2_uv;
+  DevBuf<int> v2_cw, v2_cpos, v2_lm_pos, v2_of_slot, v2_seg;
+  DevBuf<int4> v2_tile;
+  DevBuf<double> v2_w, v2_lmrec;
+  int64_t v2_rows = 0;
+  bool use_lpl = true;        // POVAR_E0_V1=1: keep e0_lm_cached<true> (lane per observation) for A/B runs
   DevBuf<double4> q4c;        // scatter scalars of the cold observations, in cold camera-major order
   DevBuf<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
       cam_item_off, flags;
@@ -154,6 +161,10 @@ struct Layout {
   std::vector<int> c2_lm, c2_pos;
   std::vector<int2> c2_range;
   int n_bins = 0;
+  // lane-per-landmark layout of e0_lpl (povar_kernels.hpp: struct V2)
+  std::vector<double2> v2_uv;
+  std::vector<int> v2_cw, v2_cpos, v2_lm_pos, v2_of_slot, v2_seg;
+  std::vector<int4> v2_tile;
 };
 
 void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx,
@@ -250,12 +261,14 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(),
                      [&](int a, int b) { return cnt[a + 1] - cnt[a] > cnt[b + 1] - cnt[b]; });
+    // popularity rank of EVERY camera (1-based): the record image (Dp::hot_rec) is in this order, so the first
+    // n records are the LDS image of a kernel that caches n cameras and colder cameras gather theirs by rank
     const int n_hot = std::min(n_cams, HOT_MAX);
     std::vector<int> rank(n_cams, 0);
-    L.hot_cams.assign(order.begin(), order.begin() + n_hot);
-    for (int r = 0; r < n_hot; ++r) rank[order[r]] = r + 1;
+    L.hot_cams.assign(order.begin(), order.end());
+    for (int r = 0; r < n_cams; ++r) rank[order[r]] = r + 1;
     for (size_t s = 0; s < n_slots; ++s)
-      if (L.meta[s] & META_REAL) L.meta[s] |= rank[L.cam[s]] << META_HOT_SHIFT;
+      if ((L.meta[s] & META_REAL) && rank[L.cam[s]] <= n_hot) L.meta[s] |= rank[L.cam[s]] << META_HOT_SHIFT;
     L.cam_hot = rank;
     // "cold" camera-major structure for POVAR_E0_IMPLICIT_LDSACC: only the observations whose
     // Jp^T s is NOT accumulated in LDS (camera outside the HOT_ACC_MAX hottest, or a long landmark,
@@ -307,6 +320,124 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
   }
   L.cam_item_off[n_cams] = (int)L.item_cam.size();
   L.item_off.push_back((int)n_obs);
+
+  // lane-per-landmark layout (struct V2).  "cold" = camera outside the LDS-accumulated set, whatever the
+  // landmark's length: the cold view is c2 when the problem has long landmarks, else the identical cc view.
+  {
+    const int n_acc = hot_acc_cap(n_cams);
+    int K0 = 8;  // rows per tile are capped by splitting longer landmarks over several lanes (knob)
+    if (const char* e = std::getenv("POVAR_LPL_K0")) K0 = std::max(2, std::atoi(e));
+    const std::vector<int>& cpos = L.c2_pos.empty() ? L.cold_pos : L.c2_pos;
+    std::vector<int> parts_of(n_lms, 0), psize_of(n_lms, 0), cold_of(n_lms, 0), order;
+    order.reserve(n_lms);
+    for (int l = 0; l < n_lms; ++l) {
+      const int k = lm_off[l + 1] - lm_off[l];
+      if (k == 0) continue;
+      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) cold_of[l] += L.cam_hot[cam_idx[i]] > n_acc;
+      parts_of[l] = k <= K0 ? 1 : std::min(WAVE, (k + K0 - 1) / K0);
+      psize_of[l] = (k + parts_of[l] - 1) / parts_of[l];
+      cold_of[l] = (cold_of[l] + parts_of[l] - 1) / parts_of[l];  // per lane
+      order.push_back(l);
+    }
+    // tiles of equal row count and equal hot/cold split, longest first (the workgroups grab them in this order):
+    // (rows per lane, cold rows per lane), original order inside a class
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      return psize_of[a] != psize_of[b] ? psize_of[a] > psize_of[b] : cold_of[a] > cold_of[b];
+    });
+    // pack the lane groups into tiles (a landmark's lanes stay in one tile, adjacent)
+    L.v2_lm_pos.assign(n_lms, -1);
+    L.v2_of_slot.assign(n_slots, -1);
+    int tile = 0, fill = 0;
+    for (int l : order) {
+      if (fill + parts_of[l] > WAVE) { ++tile; fill = 0; }
+      L.v2_lm_pos[l] = (tile * WAVE + fill) | ((parts_of[l] - 1) << 26);
+      fill += parts_of[l];
+    }
+    const int n_tiles = order.empty() ? 0 : tile + 1;
+    L.v2_tile.assign(n_tiles, make_int4(0, 0, 1 << 30, 0));
+    L.v2_seg.resize((size_t)n_tiles * WAVE);
+    for (size_t i = 0; i < L.v2_seg.size(); ++i) L.v2_seg[i] = (int)(i & 63) | ((int)(i & 63) << 8);
+    std::vector<int> lanes_used(n_tiles, 0);
+    for (int l : order) {
+      const int pos = L.v2_lm_pos[l] & ((1 << 26) - 1), t = pos >> 6, lane0 = pos & 63, P = parts_of[l];
+      const int k = lm_off[l + 1] - lm_off[l];
+      int hot = 0;
+      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) hot += L.cam_hot[cam_idx[i]] <= n_acc;
+      int4& ti = L.v2_tile[t];
+      ti.y = std::max(ti.y, psize_of[l]);
+      ti.z = std::min(ti.z, hot / P);  // leading rows in which every lane of the group has a hot observation
+      if (P > 1) ti.w |= 1;
+      for (int q = 0; q < P; ++q) L.v2_seg[(size_t)t * WAVE + lane0 + q] = lane0 | ((lane0 + P - 1) << 8);
+      lanes_used[t] += P;
+      (void)k;
+    }
+    int64_t rows = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+      if (lanes_used[t] < WAVE) L.v2_tile[t].z = 0;  // unused lanes: no branch-free rows
+      // at least two rows = four row steps per tile: the prefetch cursor (three rows ahead) then never needs a tile
+      // beyond the one the consumer has already taken
+      L.v2_tile[t].y = std::max(L.v2_tile[t].y, 2);
+      L.v2_tile[t].x = (int)rows;
+      rows += L.v2_tile[t].y;
+    }
+    L.v2_uv.assign((size_t)rows * WAVE, make_double2(0, 0));
+    L.v2_cw.assign((size_t)rows * WAVE, -1);
+    L.v2_cpos.assign((size_t)rows * WAVE, -1);
+    // LDS bank placement.  The kernel is bound by the LDS pipe (ds_add_f64 runs at ~4 lanes per clock, a
+    // same-bank or same-address collision inside a 32-lane half serialises it), so the ORDER of a landmark's hot
+    // observations over the rows of its tile is chosen greedily, landmark by landmark, to keep the accumulator
+    // banks ((slot mod 32), slot = lpl_acc_slot(rank, lane)) of each row half and the record quads ((rank mod 16)
+    // per ds_read_b128 lane group) distinct.  Without this, row 0 would hold every landmark's lowest-index camera.
+    auto read_group = [](int lane) {
+      const int l = lane & 31;
+      const int g = (l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 1;
+      return g + 2 * (lane >> 5);
+    };
+    const int hubs = lpl_hubs(n_acc);
+    std::vector<int> hot_idx, cold_idx;
+    std::vector<uint16_t> occA, occR;  // [row][2][32], [row][4][16] of the tile being filled
+    int cur_tile = -1;
+    for (int l : order) {
+      const int pos = L.v2_lm_pos[l] & ((1 << 26) - 1), t = pos >> 6, lane0 = pos & 63, P = parts_of[l];
+      if (t != cur_tile) {
+        cur_tile = t;
+        occA.assign((size_t)L.v2_tile[t].y * 64, 0);
+        occR.assign((size_t)L.v2_tile[t].y * 64, 0);
+      }
+      // observations of LDS-accumulated cameras first, cold ones last; dealt round-robin to the landmark's lanes
+      hot_idx.clear();
+      cold_idx.clear();
+      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
+        (L.cam_hot[cam_idx[i]] > n_acc ? cold_idx : hot_idx).push_back(i);
+      const int h = (int)hot_idx.size();
+      int best_rot = 0;
+      if (h > 1) {
+        long best = -1;
+        for (int rot = 0; rot < std::min(h, 16); ++rot) {
+          long cost = 0;
+          for (int n = 0; n < h; ++n) {
+            const int r = L.cam_hot[cam_idx[hot_idx[(n + rot) % h]]] - 1, lane = lane0 + n % P, j = n / P;
+            cost += 96 * occA[(size_t)j * 64 + (lane >> 5) * 32 + (lpl_acc_slot(r, lane, hubs) & 31)];
+            if (r >= hubs) cost += 16 * occR[(size_t)j * 64 + read_group(lane) * 16 + (r & 15)];
+          }
+          if (best < 0 || cost < best) { best = cost; best_rot = rot; }
+        }
+      }
+      for (int n = 0; n < h + (int)cold_idx.size(); ++n) {
+        const int i = n < h ? hot_idx[(n + best_rot) % h] : cold_idx[n - h];
+        const int q = n % P, j = n / P, r = L.cam_hot[cam_idx[i]], lane = lane0 + q;
+        const size_t idx = ((size_t)L.v2_tile[t].x + j) * WAVE + lane;
+        L.v2_uv[idx] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
+        L.v2_cw[idx] = r - 1;
+        L.v2_cpos[idx] = r > n_acc ? cpos[L.slot_of_obs[i]] : -1;
+        L.v2_of_slot[L.slot_of_obs[i]] = (int)idx;
+        if (n < h) {
+          occA[(size_t)j * 64 + (lane >> 5) * 32 + (lpl_acc_slot(r - 1, lane, hubs) & 31)]++;
+          if (r - 1 >= hubs) occR[(size_t)j * 64 + read_group(lane) * 16 + ((r - 1) & 15)]++;
+        }
+      }
+    }
+  }
 }
 
 template <class T>
@@ -447,6 +578,12 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
       if (c->n_long > 0)
         hipLaunchKernelGGL((lm_long<OpE0Tiles>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpE0Tiles{}, c->part.p);
     }
+    else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->use_lpl && c->opt.robust_norm)
+      hipLaunchKernelGGL(e0_lpl<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
+                         lpl_lds_bytes(c->n_hot_acc), c->stream, da, c->hot_part.p);
+    else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->use_lpl)
+      hipLaunchKernelGGL(e0_lpl<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
+                         lpl_lds_bytes(c->n_hot_acc), c->stream, da, c->hot_part.p);
     else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)
       hipLaunchKernelGGL(e0_lm_cached<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
                          (size_t)c->n_hot_acc * (HOT_REC * sizeof(double2) + 96), c->stream, da,
@@ -583,6 +720,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
   if (const char* g = std::getenv("POVAR_NO_FUSE")) c->fuse_binv = !(g[0] == '1');
+  if (const char* g = std::getenv("POVAR_E0_V1")) c->use_lpl = !(g[0] == '1');
 
   Layout L;
   build_layout(n_cams, n_lms, lm_offsets, cam_idx, obs, L);
@@ -601,7 +739,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (const char* e = std::getenv("POVAR_E0_WGS")) cus = std::max(std::atoi(e), 1);  // tuning knob: E0 workgroups
     c->e0c_bins_per_wg = std::max((c->n_bins + cus - 1) / cus, 1);
     c->e0c_grid = (c->n_bins + c->e0c_bins_per_wg - 1) / c->e0c_bins_per_wg;
-    c->n_hot = (int)L.hot_cams.size();
+    c->n_hot = std::min(n_cams, HOT_MAX);
     HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_MAX * HOT_REC * (int)sizeof(double2)));
     HIP_TRY(hipFuncSetAttribute((const void*)e0_tiles_cached, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -610,6 +748,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                                 HOT_ACC_MAX * (HOT_REC_H * (int)sizeof(double2) + 96)));
     HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_ACC_MAX * (HOT_REC * (int)sizeof(double2) + 96)));
+    HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lpl_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lpl_lds_bytes(HOT_ACC_MAX)));
   }
 
   int rc = 0;
@@ -657,13 +799,29 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       if (int rc = upload(c->c2_pos, L.c2_pos, c)) return rc;
       if (int rc = upload(c->c2_range, L.c2_range, c)) return rc;
       HIP_TRY(c->c2_h.alloc(4 * std::max<size_t>(L.c2_lm.size(), 1), &c->bytes));
-      c->long_in_kernel = std::getenv("POVAR_LONG_SEPARATE") == nullptr;  // knob: keep the lm_long kernel
+      // knob POVAR_LONG_SEPARATE: keep the lm_long kernel (old lane-per-observation kernels only; e0_lpl has no
+      // long/short distinction and always uses this cold view)
+      c->long_in_kernel = c->use_lpl || std::getenv("POVAR_LONG_SEPARATE") == nullptr;
     }
   }
   c->n_hot_acc = hot_acc_cap(n_cams);
+  {
+    // lane-per-landmark layout (tiles sorted longest first; workgroup w takes tiles w, w + grid, ... on demand)
+    const int nt = (int)L.v2_tile.size();
+    c->v2_rows = nt ? (int64_t)L.v2_tile[nt - 1].x + L.v2_tile[nt - 1].y : 0;
+    if (int rc = upload(c->v2_uv, L.v2_uv, c)) return rc;
+    if (int rc = upload(c->v2_cw, L.v2_cw, c)) return rc;
+    if (int rc = upload(c->v2_cpos, L.v2_cpos, c)) return rc;
+    if (int rc = upload(c->v2_lm_pos, L.v2_lm_pos, c)) return rc;
+    if (int rc = upload(c->v2_of_slot, L.v2_of_slot, c)) return rc;
+    if (int rc = upload(c->v2_tile, L.v2_tile, c)) return rc;
+    if (int rc = upload(c->v2_seg, L.v2_seg, c)) return rc;
+    HIP_TRY(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * 9 * WAVE, &c->bytes));
+    if (options->robust_norm) HIP_TRY(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
+  }
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
-  ALLOC(hot_rec, (size_t)HOT_MAX * HOT_REC_STRIDE);
+  ALLOC(hot_rec, (size_t)std::max(n_cams, HOT_MAX) * HOT_REC_STRIDE);  // every camera, in popularity order
   ALLOC(norm_part, 2 * (size_t)std::max(c->n_cam_blocks, n_cams)); ALLOC(norms, 4); ALLOC(flags, 4);
   ALLOC(part, n_part * 2); ALLOC(scal, 8);
   ALLOC(stage, std::max(3 * nl, 144 * nc));
@@ -691,7 +849,9 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.cmv = CmView{c->cm_slot.p, c->cm_h.p, n_obs, c->item_off.p, c->cam_item_off.p, c->item_part.p, c->n_items, nullptr};
   d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
   d.hot_rec = c->hot_rec.p;
-  d.hot_cams = c->hot_cams.p; d.n_hot = (int)L.hot_cams.size();
+  d.hot_cams = c->hot_cams.p; d.n_hot = std::min(n_cams, HOT_MAX);
+  d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
+            c->v2_lm_pos.p, c->v2_of_slot.p, (int)L.v2_tile.size()};
   d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.q4c = nullptr; d.cold_pos = nullptr; d.long_in_kernel = 0; d.tiles = nullptr;
   d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
   d.tmp = c->tmp.p; d.accum = c->accum.p; d.z = c->z.p; d.y = c->y.p; d.inc = c->inc.p;
@@ -724,6 +884,8 @@ void povar_destroy(povar_ctx* c) {
   c->sc_dm_part.release(); c->sc_dm.release(); c->sc_bmat.release(); c->sc_minv.release(); c->sc_x.release();
   c->sc_r.release(); c->sc_p.release(); c->sc_q.release(); c->sc_zv.release(); c->sc_part.release(); c->sc_s.release();
   c->cc_cam_range.release(); c->cold_pos.release(); c->q4c.release();
+  c->v2_uv.release(); c->v2_cw.release(); c->v2_cpos.release(); c->v2_lm_pos.release(); c->v2_of_slot.release();
+  c->v2_seg.release(); c->v2_tile.release(); c->v2_w.release(); c->v2_lmrec.release();
   c->c2_lm.release(); c->c2_pos.release(); c->c2_range.release(); c->c2_h.release();
   c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -864,7 +1026,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   // the scaling is part of the implicit tile; only stored tiles need (re)materialising.
   c->new_linearization_point = false;
   c->d.lambda_lm = solver_type == POVAR_POWER_SCHUR_COMPLEMENT ? lambda : 0.0;  // cpp:197-200
-  hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_hot * 12, 256)), dim3(256), 0, c->stream, c->d, 0);
+  hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_cams * 12, 256)), dim3(256), 0, c->stream, c->d, 0);
   launch_lm(c, OpPrepare{});
   hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 0);
   hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b, 1);
@@ -1108,7 +1270,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
   c->joint = true;
   c->new_linearization_point = false;
   c->d.lambda_lm = lambda;  // set_landmark_damping_joint, linearizor_power_varproj.cpp:136
-  hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_hot * 12, 256)), dim3(256), 0, c->stream, c->d, 1);
+  hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_cams * 12, 256)), dim3(256), 0, c->stream, c->d, 1);
   launch_lm(c, OpPrepareH{});
   hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 1);
   hipLaunchKernelGGL(cam_sum_items_h, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b,
@@ -1302,7 +1464,10 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
   int64_t lm = 0, cm = 0;
   switch (c->opt.e0_mode) {
     case POVAR_E0_IMPLICIT_LDSACC:
-      lm = ns * (E0_SLOT_BYTES + robust) + nl * E0_LMREC_BYTES + cam_static + n_cold * 32 + hot_flush;
+      if (c->use_lpl && !c->joint)  // e0_lpl: uv + camera rank per row slot, 72-byte records, cold: position + q out
+        lm = c->v2_rows * WAVE * (20 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * 72 + cam_static + n_cold * 36 + hot_flush;
+      else
+          lm = ns * (E0_SLOT_BYTES + robust) + nl * E0_LMREC_BYTES + cam_static + n_cold * 32 + hot_flush;
       cm = hot_flush + n_cold * (32 + 24) + tail;
       break;
     case POVAR_E0_IMPLICIT:

@@ -32,6 +32,10 @@
 #ifndef POVAR_EXP
 #define POVAR_EXP 0  // timing-only ablation builds (tools, never shipped): see DESIGN.md experiment log
 #endif
+#ifndef POVAR_LPLX
+#define POVAR_LPLX 0  // e0_lpl ablation mask (timing-only builds): 1 no LDS atomics, 2 no backward record reads,
+                      // 4 no forward record reads (branch-free rows), 8 no cold observations, 16 no tiles at all
+#endif
 #include <stdint.h>
 
 namespace povar {
@@ -70,8 +74,31 @@ struct CmView {
   const int2* cam_range;   // [n_cams] (first, end) position of each camera's run (cold view only, else nullptr)
 };
 
+// Lane-per-landmark layout of the per-term E0 kernel (e0_lpl).  Landmarks are sorted by (observation count,
+// number of cold observations) and cut into tiles of 64 landmarks: lane = landmark, the wavefront loops over
+// the observation rows of its tile.  Row r of the arrays holds observation j of every landmark of the tile
+// ([row][lane]: one contiguous 1 KiB / 256 B line group per wave instruction).  Inside a landmark the
+// observations of LDS-accumulated cameras come first, so the leading rows of a tile are branch-free.
+// A landmark with more than K0 (8) observations is dealt over several adjacent lanes of one tile (at most K0 rows
+// per tile, whatever the track length: the tiles are the unit of load balance); its partial sums are combined by
+// one segmented wavefront scan per tile.
+struct V2 {
+  const double2* uv;   // [n_rows][64] observation (u, v)
+  const int* cw;       // [n_rows][64] popularity rank of the camera (0-based, < n_hot_acc: accumulated in LDS), -1: no observation
+  const int* cpos;     // [n_rows][64] position in the cold camera-major view (-1: not cold)
+  double* w;           // [n_rows][64] robust weight (only with a robust norm)
+  const int4* tile;    // [n_tiles] (first row, rows, leading all-hot rows, bit 0: some landmark spans several lanes);
+                       // sorted longest first, workgroup w takes tiles w, w + grid, ... on demand
+  const int* seg;      // [n_tiles][64] first | last << 8 lane of the landmark a lane belongs to (read for flagged tiles)
+  double* lmrec;       // [n_tiles][9][64]: x, y, z, then G = diag(s) Hll^-1 diag(s) (00,01,02,11,12,22)
+  const int* lm_pos;   // [n_lms] tile * 64 + first lane of each landmark | (lanes - 1) << 26 (-1: no observation)
+  const int* of_slot;  // [n_slots] row * 64 + lane of each wave-bin slot (-1: padding)
+  int n_tiles;
+};
+
 struct Dp {
   int n_cams, n_lms, n_bins, n_items, n_long, n_reg_blocks;
+  V2 v2;
   // static landmark-major slot arrays
   const double2* uv;
   const int* cam;
@@ -645,6 +672,7 @@ struct OpLinearize {
     const double sw = sqrt(w);
     if (!isfinite(r2) || !isfinite(sw)) atomicOr(&d.flags[0], 1);
     d.sw[slot] = sw;
+    if (d.robust && d.v2.w) d.v2.w[d.v2.of_slot[slot]] = w;
     d.rres[slot] = make_double4(sw * res[0], sw * res[1], sw * res[2], sw * res[3]);
     double jl[12];
     pose_jl(d, P, uv.x, uv.y, sw, make_double4(1, 1, 1, 1), jl);
@@ -727,6 +755,18 @@ struct OpPrepare {
     rec[0] = make_double4(h.x, h.y, h.z, s.x);
     rec[1] = make_double4(s.y, s.z, Hi[0], Hi[1]);
     rec[2] = make_double4(Hi[2], Hi[4], Hi[5], Hi[8]);
+    if (d.v2.lmrec) {
+      // record of the lane-per-landmark kernel: the Jl column scale is folded into G = diag(s) Hll^-1 diag(s)
+      const int lp = d.v2.lm_pos[lm], pos = lp & ((1 << 26) - 1), lanes = ((lp >> 26) & 63) + 1;
+      const double G[6] = {s.x * Hi[0] * s.x, s.x * Hi[1] * s.y, s.x * Hi[2] * s.z,
+                           s.y * Hi[4] * s.y, s.y * Hi[5] * s.z, s.z * Hi[8] * s.z};
+      for (int q = 0; q < lanes; ++q) {  // one copy per lane the landmark occupies (adjacent, same tile)
+        double* r2 = d.v2.lmrec + ((size_t)(pos >> 6) * 9) * WAVE + (pos & 63) + q;
+        r2[0] = h.x; r2[WAVE] = h.y; r2[2 * WAVE] = h.z;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) r2[(3 + m) * WAVE] = G[m];
+      }
+    }
   }
 };
 
@@ -1006,6 +1046,299 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached(Dp d, int bins_per_wg,
     // cam_binv_axpy then reads one contiguous run of 96-byte records
     for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK)
       hot_out[((size_t)(i / 12) * gridDim.x + blockIdx.x) * 12 + i % 12] = acc[(i % 12) * n_hot + i / 12];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K10, lane-per-landmark form (default of POVAR_E0_IMPLICIT_LDSACC, step 1): right_mul_e0_pOSE
+// (linearization_power_varproj.hpp:364-406) with lane = landmark.  The per-landmark sum u = Jl^T t is a register
+// accumulation over the rows of the tile (no wavefront scan, no segment metadata), v = Hll^-1 u is computed
+// once per landmark instead of once per observation, and every global address is static, so the row stream is
+// prefetched without dependent loads.  Per observation: 20 B from HBM (uv, camera rank), 72 B per landmark.
+// Camera records (z_c, P_c[:, :3]) of the n_hot_acc most observed cameras live in LDS together with their
+// Jp^T s accumulators, exactly as in e0_lm_cached<true>; observations of colder cameras gather the record from
+// the rank-ordered image in L2 and leave their three scatter scalars in the cold camera-major view (q4c).
+// ------------------------------------------------------------------------------------------
+struct LplObs {
+  double w, cu, cv, cuv;
+  __device__ inline void set(const Dp& d, double2 uv, double w_) {
+    const double sb2 = d.sb * d.sb;
+    w = w_;
+    cu = sb2 * uv.x;
+    cv = sb2 * uv.y;
+    cuv = sb2 * (uv.x * uv.x + uv.y * uv.y);
+  }
+};
+
+// forward: red += P3^T (w C (Z h~))
+__device__ inline void lpl_forward(const LplObs& o, const double* zz, const double* P3, double hx, double hy, double hz,
+                                   double* red) {
+  const double d0 = hx * zz[0] + hy * zz[1] + hz * zz[2] + zz[3];
+  const double d1 = hx * zz[4] + hy * zz[5] + hz * zz[6] + zz[7];
+  const double d2 = hx * zz[8] + hy * zz[9] + hz * zz[10] + zz[11];
+  const double a0 = o.w * (d0 - o.cu * d2);
+  const double a1 = o.w * (d1 - o.cv * d2);
+  const double a2 = o.w * (o.cuv * d2 - o.cu * d0 - o.cv * d1);
+  red[0] += P3[0] * a0 + P3[3] * a1 + P3[6] * a2;
+  red[1] += P3[1] * a0 + P3[4] * a1 + P3[7] * a2;
+  red[2] += P3[2] * a0 + P3[5] * a1 + P3[8] * a2;
+}
+// backward: q = w C (P3 g)
+__device__ inline void lpl_backward(const LplObs& o, const double* P3, const double* g, double* q) {
+  const double e0 = P3[0] * g[0] + P3[1] * g[1] + P3[2] * g[2];
+  const double e1 = P3[3] * g[0] + P3[4] * g[1] + P3[5] * g[2];
+  const double e2 = P3[6] * g[0] + P3[7] * g[1] + P3[8] * g[2];
+  q[0] = o.w * (e0 - o.cu * e2);
+  q[1] = o.w * (e1 - o.cv * e2);
+  q[2] = o.w * (o.cuv * e2 - o.cu * e0 - o.cv * e1);
+}
+__device__ inline void lpl_read_zz(const double2* h, double* zz) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double2 v = h[j];
+    zz[2 * j] = v.x;
+    zz[2 * j + 1] = v.y;
+  }
+}
+__device__ inline void lpl_read_p3(const double2* h, double* P3) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double2 v = h[6 + j];
+    P3[2 * j] = v.x;
+    P3[2 * j + 1] = v.y;
+  }
+  P3[8] = h[10].x;
+}
+
+// The row stream of one wavefront is a static address sequence: tile t forward rows, tile t backward rows (the same
+// rows again, now L2 hits), tile t + 16 ...  A scalar prefetch cursor runs LPL_DEPTH rows ahead of the consumer
+// along that sequence, across the pass and tile boundaries, so the wavefront never waits for a load it has just
+// issued (s_waitcnt vmcnt retires in issue order: the e0_lm_cached loop exposed two HBM latencies per bin that way).
+// The next tile's landmark record is requested when the backward pass starts: G is dead by then (g = G u is
+// formed), so only the three coordinates need a second set of registers.
+constexpr int LPL_DEPTH = 3;
+// Accumulator slots.  ds_add_f64 collisions inside a 32-lane half serialise, and the most observed cameras collect
+// several observations per row (Zipf hub: 9 % of all observations): the LPL_HUBS hottest cameras therefore get four
+// accumulator replicas each, chosen by the lane, summed at the flush.
+constexpr int LPL_HUBS = 16;
+__host__ __device__ inline int lpl_hubs(int n_hot) { return n_hot < LPL_HUBS ? n_hot : LPL_HUBS; }
+__host__ __device__ inline int lpl_acc_slot(int rank, int lane, int hubs) {
+  return rank < hubs ? 4 * rank + (lane & 3) : rank + 3 * hubs;
+}
+__host__ __device__ inline size_t lpl_lds_bytes(int n_hot) {
+  return (size_t)n_hot * HOT_REC * sizeof(double2) + (size_t)(n_hot + 3 * lpl_hubs(n_hot)) * 96 + 16;
+}
+struct LplRow {
+  double2 uv;
+  int cw;
+  double w;
+};
+struct LplCursor {  // wave-uniform (SGPRs)
+  int t, pass, j, row0, k;
+};
+
+template <bool ROBUST>
+__global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
+  const int done = d.flags[1];  // requested first, tested after the LDS staging (no global side effects before)
+  extern __shared__ double2 hot[];  // [n_hot][HOT_REC] records, then acc[12][n_slots], then the tile counter
+  const int n_hot = d.n_hot_acc;
+  const int hubs = lpl_hubs(n_hot), n_slots = n_hot + 3 * hubs;
+  double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC);
+  int* grab_ctr = reinterpret_cast<int*>(acc + n_slots * 12);
+  for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
+  if (threadIdx.x == 0) *grab_ctr = 0;
+  {
+    const double2* src = reinterpret_cast<const double2*>(d.hot_rec);
+    for (int i = threadIdx.x; i < n_hot * HOT_REC; i += E0C_BLOCK) {
+      const int r = i / HOT_REC, j = i - r * HOT_REC;
+      hot[i] = src[r * (HOT_REC_STRIDE / 2) + j];
+    }
+  }
+  __syncthreads();
+  if (done) return;
+  const V2& v = d.v2;
+  const int lane = threadIdx.x & 63;
+  const int t_end = v.n_tiles;
+  const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
+  // Tiles are sorted longest first and workgroup w owns tiles w, w + grid, ...; its wavefronts take them on demand
+  // (one LDS counter), so a wavefront's last tile is a short one and the workgroups carry equal row totals.
+  auto grab = [&]() -> int {
+    int n = 0;
+    if (lane == 0) n = __hip_atomic_fetch_add(grab_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const long long t = (long long)blockIdx.x + (long long)n * gridDim.x;
+    return t < t_end ? (int)t : t_end;
+  };
+
+  // tile table through the scalar cache (constant address space + wave-uniform index => s_load_dwordx4): a vector
+  // load here would put a vmcnt(0) drain inside the row pipeline
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  const cint_p tiles = (cint_p)(uintptr_t)v.tile;
+  auto tile_info = [&](int t, int& row0, int& k, int& nh, int& fl) {
+    row0 = tiles[4 * t];
+    k = tiles[4 * t + 1];
+    nh = tiles[4 * t + 2];
+    fl = tiles[4 * t + 3];
+  };
+  LplCursor pc;
+#if POVAR_LPLX & 16
+  pc.t = t_end;
+#else
+  pc.t = grab();
+#endif
+  pc.pass = 0;
+  pc.j = 0;
+  pc.row0 = 0;
+  pc.k = 1;
+  int c_t = pc.t, c_row0 = 0, c_k = 0, c_nh = 0, c_fl = 0;
+  // the tile after the one being consumed, taken when the consumer enters a tile: the prefetch cursor runs at most
+  // LPL_DEPTH = 3 rows ahead and a tile has at least 4 row steps, so it never needs more than this one
+  int nx_t = t_end;
+  if (c_t < t_end) {
+    tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+    pc.row0 = c_row0;
+    pc.k = c_k;
+    nx_t = grab();
+  }
+  // request the row under the prefetch cursor and advance it
+  auto issue = [&](LplRow& r) {
+    if (pc.t < t_end) {
+      const size_t i = ((size_t)pc.row0 + pc.j) * WAVE + lane;
+      r.uv = v.uv[i];
+      r.cw = v.cw[i];
+      if (ROBUST) r.w = v.w[i];
+      if (++pc.j == pc.k) {
+        pc.j = 0;
+        if (++pc.pass == 2) {
+          pc.pass = 0;
+          pc.t = nx_t;
+          if (pc.t < t_end) {
+            int nh_, fl_;
+            tile_info(pc.t, pc.row0, pc.k, nh_, fl_);
+          }
+        }
+      }
+    }
+  };
+  LplRow n1, n2, n3;
+  n1.cw = n2.cw = n3.cw = -1;
+  n1.w = n2.w = n3.w = 1.0;
+  n1.uv = n2.uv = n3.uv = make_double2(0, 0);
+  issue(n1);
+  issue(n2);
+  issue(n3);
+  double hx = 0, hy = 0, hz = 0, G00 = 0, G01 = 0, G02 = 0, G11 = 0, G12 = 0, G22 = 0;
+  if (c_t < t_end) {
+    const double* rp = v.lmrec + ((size_t)c_t * 9) * WAVE + lane;
+    hx = rp[0]; hy = rp[WAVE]; hz = rp[2 * WAVE];
+    G00 = rp[3 * WAVE]; G01 = rp[4 * WAVE]; G02 = rp[5 * WAVE]; G11 = rp[6 * WAVE]; G12 = rp[7 * WAVE]; G22 = rp[8 * WAVE];
+  }
+  while (c_t < t_end) {
+    double red[3] = {0, 0, 0};
+    for (int j = 0; j < c_k; ++j) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      double zz[12], P3[9];
+      LplObs o;
+      o.set(d, cur.uv, ROBUST ? cur.w : 1.0);
+      if (j < c_nh) {  // wave-uniform: every lane has an observation of an LDS-resident camera in this row
+        const double2* h = hot + cur.cw * HOT_REC;
+#if POVAR_LPLX & 4
+        for (int m = 0; m < 12; ++m) zz[m] = cur.uv.x + m;
+        for (int m = 0; m < 9; ++m) P3[m] = cur.uv.y + m + (double)(size_t)h;
+#else
+        lpl_read_zz(h, zz);
+        lpl_read_p3(h, P3);
+#endif
+        lpl_forward(o, zz, P3, hx, hy, hz, red);
+#if POVAR_LPLX & 8
+      } else if (cur.cw >= 0 && cur.cw < n_hot) {
+#else
+      } else if (cur.cw >= 0) {
+#endif
+        if (cur.cw < n_hot) {
+          const double2* h = hot + cur.cw * HOT_REC;
+          lpl_read_zz(h, zz);
+          lpl_read_p3(h, P3);
+        } else {
+          const double2* h = rec_img + (size_t)cur.cw * (HOT_REC_STRIDE / 2);
+          lpl_read_zz(h, zz);
+          lpl_read_p3(h, P3);
+        }
+        lpl_forward(o, zz, P3, hx, hy, hz, red);
+      }
+    }
+    if (c_fl & 1) {  // landmarks dealt over several lanes: sum their partial u = Jl^T t (segmented wavefront scan)
+      const int sg = v.seg[(size_t)c_t * WAVE + lane];
+      seg_reduce_steps<3>(red, lane, sg & 255, (sg >> 8) & 255, 4);
+    }
+    const double g[3] = {G00 * red[0] + G01 * red[1] + G02 * red[2], G01 * red[0] + G11 * red[1] + G12 * red[2],
+                         G02 * red[0] + G12 * red[1] + G22 * red[2]};
+    // the next tile's record: G into its own (now dead) registers, the coordinates into a second set
+    const int n_t = nx_t;
+    double nhx = 0, nhy = 0, nhz = 0;
+    if (n_t < t_end) {
+      const double* rp = v.lmrec + ((size_t)n_t * 9) * WAVE + lane;
+      nhx = rp[0]; nhy = rp[WAVE]; nhz = rp[2 * WAVE];
+      G00 = rp[3 * WAVE]; G01 = rp[4 * WAVE]; G02 = rp[5 * WAVE]; G11 = rp[6 * WAVE]; G12 = rp[7 * WAVE]; G22 = rp[8 * WAVE];
+    }
+    const size_t base = (size_t)c_row0 * WAVE + lane;
+    for (int j = 0; j < c_k; ++j) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      double P3[9], q[3];
+      LplObs o;
+      o.set(d, cur.uv, ROBUST ? cur.w : 1.0);
+#if POVAR_LPLX & 8
+      if (j < c_nh) {
+#else
+      if (j < c_nh || (cur.cw >= 0 && cur.cw < n_hot)) {
+#endif
+#if POVAR_LPLX & 2
+        for (int m = 0; m < 9; ++m) P3[m] = cur.uv.y + m;
+#else
+        lpl_read_p3(hot + cur.cw * HOT_REC, P3);
+#endif
+        lpl_backward(o, P3, g, q);
+        double* a = acc + lpl_acc_slot(cur.cw, lane, hubs);  // acc[m][slot]: consecutive slots on consecutive banks
+        const double val[12] = {hx * q[0], hy * q[0], hz * q[0], q[0], hx * q[1], hy * q[1],
+                                hz * q[1], q[1], hx * q[2], hy * q[2], hz * q[2], q[2]};
+#if POVAR_LPLX & 1
+        double sacc = 0;
+        for (int m = 0; m < 12; ++m) sacc += val[m];
+        if (sacc == 1.2345e-300) a[0] = sacc;
+#else
+#pragma unroll
+        for (int m = 0; m < 12; ++m)
+          __hip_atomic_fetch_add(a + m * n_slots, val[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+#if POVAR_LPLX & 8
+      } else if (false) {
+#else
+      } else if (cur.cw >= 0) {
+#endif
+        lpl_read_p3(rec_img + (size_t)cur.cw * (HOT_REC_STRIDE / 2), P3);
+        lpl_backward(o, P3, g, q);
+        d.q4c[v.cpos[base + (size_t)j * WAVE]] = make_double4(q[0], q[1], q[2], 0);
+      }
+    }
+    c_t = n_t;
+    if (c_t < t_end) {
+      tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+      nx_t = grab();
+    }
+    hx = nhx; hy = nhy; hz = nhz;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) {
+    const int r = i / 12, m = i % 12;
+    const double* a = acc + m * n_slots;
+    const double s = r < hubs ? (a[4 * r] + a[4 * r + 1]) + (a[4 * r + 2] + a[4 * r + 3]) : a[r + 3 * hubs];
+    hot_out[((size_t)r * gridDim.x + blockIdx.x) * 12 + m] = s;
   }
 }
 
@@ -1565,7 +1898,7 @@ __device__ inline void store_z(const Dp& d, int c, int j, double v) {
 // or the full P (step 2, hom = 1) after the 12 z values
 __global__ __launch_bounds__(256) void build_hot_rec(Dp d, int hom) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= d.n_hot * 12) return;
+  if (i >= d.n_cams * 12) return;  // every camera: the image is in popularity order (Dp::hot_cams)
   const int r = i / 12, e = i % 12;
   const double* P = reinterpret_cast<const double*>(d.cams_lin4) + 12 * (size_t)d.hot_cams[r];
   double v = 0;

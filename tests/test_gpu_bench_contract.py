@@ -64,7 +64,8 @@ def test_bench_two_ranks_self_launch():
     import numpy as np
     d2, inc2 = _run_bench(["--gpus", "2"], {}, "inc_w2.npy")
     assert d2["n_gpus"] == 2 and d2["value"] > 0 and d2["cpu_baseline"] is None and d2["scaling"] == "strong"
-    assert d2["config"]["comm"] in ("rccl", "gloo-host") and d2["config"]["rccl_ranks"] == 2
+    assert d2["config"]["comm"] in ("rccl", "gloo-host")
+    assert d2["config"].get("rccl_ranks", d2["config"].get("host_comm_ranks")) == 2
     d1, inc1 = _run_bench(["--no-cpu-baseline"], {}, "inc_w1.npy")
     assert np.linalg.norm(inc2 - inc1) <= 1e-11 * np.linalg.norm(inc1)
 
