@@ -56,7 +56,7 @@ def kernel_source_sha():
     """Stamp of the device code the PMC traffic figures in profiles/traffic.json were measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_hip.hip"):
+    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_hip.hip", "lpl_layout.hpp"):
         with open(os.path.join(ROOT, "povar_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -51,7 +51,7 @@ def build(force: bool = False) -> str:
     """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_PKG, "csrc")
     srcs = [os.path.join(src_dir, f) for f in ("povar_hip.hip", "povar_kernels.hpp", "povar_kernels_joint.hpp",
-                                               "povar_kernels_sc.hpp", "povar_kernels_chol.hpp")] + [HEADER]
+                                               "povar_kernels_sc.hpp", "povar_kernels_chol.hpp", "lpl_layout.hpp")] + [HEADER]
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)

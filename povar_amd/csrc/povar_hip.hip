@@ -18,6 +18,7 @@
 #include "povar_kernels_joint.hpp"
 #include "povar_kernels_sc.hpp"
 #include "povar_kernels_chol.hpp"
+#include "lpl_layout.hpp"
 
 using namespace povar;
 
@@ -90,7 +91,11 @@ struct povar_ctx {
   bool long_in_kernel = false;
   // lane-per-landmark layout of e0_lpl (struct V2)
   DevBuf<double2> v2_uv;
-  DevBuf<int> v2_cw, v2_cpos, v2_lm_pos, v2_of_slot, v2_seg;
+  DevBuf<int> v2_cw, v2_cpos, v2_lm_pos, v2_of_slot, v2_seg, v2_wg_tile_off, v2_wg_cam_off, v2_wg_cams, v2_wg_slot_rec, c3_lm;
+  DevBuf<int2> v2_part_range, c3_range;
+  DevBuf<double> c3_h, v2_part;
+  int64_t n_cold3 = 0;
+  int v2_max_slots = 0, v2_n_global = 0, v2_n_tail = 0;
   DevBuf<int4> v2_tile;
   DevBuf<double> v2_w, v2_lmrec;
   int64_t v2_rows = 0;
@@ -161,10 +166,6 @@ struct Layout {
   std::vector<int> c2_lm, c2_pos;
   std::vector<int2> c2_range;
   int n_bins = 0;
-  // lane-per-landmark layout of e0_lpl (povar_kernels.hpp: struct V2)
-  std::vector<double2> v2_uv;
-  std::vector<int> v2_cw, v2_cpos, v2_lm_pos, v2_of_slot, v2_seg;
-  std::vector<int4> v2_tile;
 };
 
 void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx,
@@ -320,124 +321,6 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
   }
   L.cam_item_off[n_cams] = (int)L.item_cam.size();
   L.item_off.push_back((int)n_obs);
-
-  // lane-per-landmark layout (struct V2).  "cold" = camera outside the LDS-accumulated set, whatever the
-  // landmark's length: the cold view is c2 when the problem has long landmarks, else the identical cc view.
-  {
-    const int n_acc = hot_acc_cap(n_cams);
-    int K0 = 8;  // rows per tile are capped by splitting longer landmarks over several lanes (knob)
-    if (const char* e = std::getenv("POVAR_LPL_K0")) K0 = std::max(2, std::atoi(e));
-    const std::vector<int>& cpos = L.c2_pos.empty() ? L.cold_pos : L.c2_pos;
-    std::vector<int> parts_of(n_lms, 0), psize_of(n_lms, 0), cold_of(n_lms, 0), order;
-    order.reserve(n_lms);
-    for (int l = 0; l < n_lms; ++l) {
-      const int k = lm_off[l + 1] - lm_off[l];
-      if (k == 0) continue;
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) cold_of[l] += L.cam_hot[cam_idx[i]] > n_acc;
-      parts_of[l] = k <= K0 ? 1 : std::min(WAVE, (k + K0 - 1) / K0);
-      psize_of[l] = (k + parts_of[l] - 1) / parts_of[l];
-      cold_of[l] = (cold_of[l] + parts_of[l] - 1) / parts_of[l];  // per lane
-      order.push_back(l);
-    }
-    // tiles of equal row count and equal hot/cold split, longest first (the workgroups grab them in this order):
-    // (rows per lane, cold rows per lane), original order inside a class
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      return psize_of[a] != psize_of[b] ? psize_of[a] > psize_of[b] : cold_of[a] > cold_of[b];
-    });
-    // pack the lane groups into tiles (a landmark's lanes stay in one tile, adjacent)
-    L.v2_lm_pos.assign(n_lms, -1);
-    L.v2_of_slot.assign(n_slots, -1);
-    int tile = 0, fill = 0;
-    for (int l : order) {
-      if (fill + parts_of[l] > WAVE) { ++tile; fill = 0; }
-      L.v2_lm_pos[l] = (tile * WAVE + fill) | ((parts_of[l] - 1) << 26);
-      fill += parts_of[l];
-    }
-    const int n_tiles = order.empty() ? 0 : tile + 1;
-    L.v2_tile.assign(n_tiles, make_int4(0, 0, 1 << 30, 0));
-    L.v2_seg.resize((size_t)n_tiles * WAVE);
-    for (size_t i = 0; i < L.v2_seg.size(); ++i) L.v2_seg[i] = (int)(i & 63) | ((int)(i & 63) << 8);
-    std::vector<int> lanes_used(n_tiles, 0);
-    for (int l : order) {
-      const int pos = L.v2_lm_pos[l] & ((1 << 26) - 1), t = pos >> 6, lane0 = pos & 63, P = parts_of[l];
-      const int k = lm_off[l + 1] - lm_off[l];
-      int hot = 0;
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) hot += L.cam_hot[cam_idx[i]] <= n_acc;
-      int4& ti = L.v2_tile[t];
-      ti.y = std::max(ti.y, psize_of[l]);
-      ti.z = std::min(ti.z, hot / P);  // leading rows in which every lane of the group has a hot observation
-      if (P > 1) ti.w |= 1;
-      for (int q = 0; q < P; ++q) L.v2_seg[(size_t)t * WAVE + lane0 + q] = lane0 | ((lane0 + P - 1) << 8);
-      lanes_used[t] += P;
-      (void)k;
-    }
-    int64_t rows = 0;
-    for (int t = 0; t < n_tiles; ++t) {
-      if (lanes_used[t] < WAVE) L.v2_tile[t].z = 0;  // unused lanes: no branch-free rows
-      // at least two rows = four row steps per tile: the prefetch cursor (three rows ahead) then never needs a tile
-      // beyond the one the consumer has already taken
-      L.v2_tile[t].y = std::max(L.v2_tile[t].y, 2);
-      L.v2_tile[t].x = (int)rows;
-      rows += L.v2_tile[t].y;
-    }
-    L.v2_uv.assign((size_t)rows * WAVE, make_double2(0, 0));
-    L.v2_cw.assign((size_t)rows * WAVE, -1);
-    L.v2_cpos.assign((size_t)rows * WAVE, -1);
-    // LDS bank placement.  The kernel is bound by the LDS pipe (ds_add_f64 runs at ~4 lanes per clock, a
-    // same-bank or same-address collision inside a 32-lane half serialises it), so the ORDER of a landmark's hot
-    // observations over the rows of its tile is chosen greedily, landmark by landmark, to keep the accumulator
-    // banks ((slot mod 32), slot = lpl_acc_slot(rank, lane)) of each row half and the record quads ((rank mod 16)
-    // per ds_read_b128 lane group) distinct.  Without this, row 0 would hold every landmark's lowest-index camera.
-    auto read_group = [](int lane) {
-      const int l = lane & 31;
-      const int g = (l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 1;
-      return g + 2 * (lane >> 5);
-    };
-    const int hubs = lpl_hubs(n_acc);
-    std::vector<int> hot_idx, cold_idx;
-    std::vector<uint16_t> occA, occR;  // [row][2][32], [row][4][16] of the tile being filled
-    int cur_tile = -1;
-    for (int l : order) {
-      const int pos = L.v2_lm_pos[l] & ((1 << 26) - 1), t = pos >> 6, lane0 = pos & 63, P = parts_of[l];
-      if (t != cur_tile) {
-        cur_tile = t;
-        occA.assign((size_t)L.v2_tile[t].y * 64, 0);
-        occR.assign((size_t)L.v2_tile[t].y * 64, 0);
-      }
-      // observations of LDS-accumulated cameras first, cold ones last; dealt round-robin to the landmark's lanes
-      hot_idx.clear();
-      cold_idx.clear();
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
-        (L.cam_hot[cam_idx[i]] > n_acc ? cold_idx : hot_idx).push_back(i);
-      const int h = (int)hot_idx.size();
-      int best_rot = 0;
-      if (h > 1) {
-        long best = -1;
-        for (int rot = 0; rot < std::min(h, 16); ++rot) {
-          long cost = 0;
-          for (int n = 0; n < h; ++n) {
-            const int r = L.cam_hot[cam_idx[hot_idx[(n + rot) % h]]] - 1, lane = lane0 + n % P, j = n / P;
-            cost += 96 * occA[(size_t)j * 64 + (lane >> 5) * 32 + (lpl_acc_slot(r, lane, hubs) & 31)];
-            if (r >= hubs) cost += 16 * occR[(size_t)j * 64 + read_group(lane) * 16 + (r & 15)];
-          }
-          if (best < 0 || cost < best) { best = cost; best_rot = rot; }
-        }
-      }
-      for (int n = 0; n < h + (int)cold_idx.size(); ++n) {
-        const int i = n < h ? hot_idx[(n + best_rot) % h] : cold_idx[n - h];
-        const int q = n % P, j = n / P, r = L.cam_hot[cam_idx[i]], lane = lane0 + q;
-        const size_t idx = ((size_t)L.v2_tile[t].x + j) * WAVE + lane;
-        L.v2_uv[idx] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
-        L.v2_cw[idx] = r - 1;
-        L.v2_cpos[idx] = r > n_acc ? cpos[L.slot_of_obs[i]] : -1;
-        L.v2_of_slot[L.slot_of_obs[i]] = (int)idx;
-        if (n < h) {
-          occA[(size_t)j * 64 + (lane >> 5) * 32 + (lpl_acc_slot(r - 1, lane, hubs) & 31)]++;
-          if (r - 1 >= hubs) occR[(size_t)j * 64 + read_group(lane) * 16 + ((r - 1) & 15)]++;
-        }
-      }
-    }
-  }
 }
 
 template <class T>
@@ -506,6 +389,17 @@ Dp ldsacc_dp(povar_ctx* c, bool long_in_kernel = false) {
   dt.hot_part = c->hot_part.p;
   dt.q4c = c->q4c.p;
   dt.cold_pos = c->cold_pos.p;
+  if (c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
+    // e0_lpl: its own cold view (observations whose camera is not resident in their workgroup) and partial records
+    dt.cmv.h = c->c3_h.p;
+    dt.cmv.n = c->n_cold3;
+    dt.cmv.cam_range = c->c3_range.p;
+    dt.hot_part = c->v2_part.p;
+    dt.part_range = c->v2_part_range.p;
+    dt.cold_pos = nullptr;
+    dt.long_in_kernel = 1;
+    return dt;
+  }
   if (long_in_kernel && c->long_in_kernel) {
     // view "A": e0_lm_cached<true> walks the long landmarks itself, their LDS-accumulated observations are not cold
     dt.cmv.h = c->c2_h.p;
@@ -580,10 +474,10 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
     }
     else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->use_lpl && c->opt.robust_norm)
       hipLaunchKernelGGL(e0_lpl<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
-                         lpl_lds_bytes(c->n_hot_acc), c->stream, da, c->hot_part.p);
+                         lpl_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
     else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->use_lpl)
       hipLaunchKernelGGL(e0_lpl<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
-                         lpl_lds_bytes(c->n_hot_acc), c->stream, da, c->hot_part.p);
+                         lpl_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
     else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)
       hipLaunchKernelGGL(e0_lm_cached<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
                          (size_t)c->n_hot_acc * (HOT_REC * sizeof(double2) + 96), c->stream, da,
@@ -792,7 +686,6 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       range[k] = make_int2(L.cc_item_off[L.cc_cam_item_off[k]], L.cc_item_off[L.cc_cam_item_off[k + 1]]);
     if (int rc = upload(c->cc_cam_range, range, c)) return rc;
     if (int rc = upload(c->cold_pos, L.cold_pos, c)) return rc;
-    HIP_TRY(c->q4c.alloc(std::max<size_t>(std::max(L.cc_slot.size(), L.c2_lm.size()), 1), &c->bytes));
     if (!L.long_lm.empty()) {
       c->n_cold2 = (int64_t)L.c2_lm.size();
       if (int rc = upload(c->c2_lm, L.c2_lm, c)) return rc;
@@ -806,18 +699,40 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   }
   c->n_hot_acc = hot_acc_cap(n_cams);
   {
-    // lane-per-landmark layout (tiles sorted longest first; workgroup w takes tiles w, w + grid, ... on demand)
-    const int nt = (int)L.v2_tile.size();
-    c->v2_rows = nt ? (int64_t)L.v2_tile[nt - 1].x + L.v2_tile[nt - 1].y : 0;
-    if (int rc = upload(c->v2_uv, L.v2_uv, c)) return rc;
-    if (int rc = upload(c->v2_cw, L.v2_cw, c)) return rc;
-    if (int rc = upload(c->v2_cpos, L.v2_cpos, c)) return rc;
-    if (int rc = upload(c->v2_lm_pos, L.v2_lm_pos, c)) return rc;
-    if (int rc = upload(c->v2_of_slot, L.v2_of_slot, c)) return rc;
-    if (int rc = upload(c->v2_tile, L.v2_tile, c)) return rc;
-    if (int rc = upload(c->v2_seg, L.v2_seg, c)) return rc;
+    // lane-per-landmark layout of e0_lpl (lpl_layout.hpp)
+    LplLayout V;
+    build_lpl(n_cams, n_lms, lm_offsets, cam_idx, obs, L.cam_hot, L.slot_of_obs, (size_t)c->n_slots, c->e0c_grid,
+              c->n_hot_acc, V);
+    if (V.max_slots > c->n_hot_acc) { povar_destroy(c); return fail(-1, "lpl layout: workgroup camera set exceeds the LDS capacity"); }
+    c->v2_rows = V.rows;
+    c->v2_max_slots = V.max_slots;
+    c->v2_n_global = V.n_global;
+    c->v2_n_tail = V.n_tail;
+    c->n_cold3 = (int64_t)V.cold_lm.size();
+    if (int rc = upload(c->v2_uv, V.uv, c)) return rc;
+    if (int rc = upload(c->v2_cw, V.cw, c)) return rc;
+    if (int rc = upload(c->v2_cpos, V.cpos, c)) return rc;
+    if (int rc = upload(c->v2_lm_pos, V.lm_pos, c)) return rc;
+    if (int rc = upload(c->v2_of_slot, V.of_slot, c)) return rc;
+    if (int rc = upload(c->v2_tile, V.tile, c)) return rc;
+    if (int rc = upload(c->v2_seg, V.seg, c)) return rc;
+    if (int rc = upload(c->v2_wg_tile_off, V.wg_tile_off, c)) return rc;
+    if (int rc = upload(c->v2_wg_cam_off, V.wg_cam_off, c)) return rc;
+    if (int rc = upload(c->v2_wg_cams, V.wg_cams, c)) return rc;
+    if (int rc = upload(c->v2_wg_slot_rec, V.wg_slot_rec, c)) return rc;
+    if (int rc = upload(c->v2_part_range, V.part_range, c)) return rc;
+    if (int rc = upload(c->c3_lm, V.cold_lm, c)) return rc;
+    if (int rc = upload(c->c3_range, V.cold_range, c)) return rc;
+    const int nt = (int)V.tile.size();
     HIP_TRY(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * 9 * WAVE, &c->bytes));
+    HIP_TRY(c->v2_part.alloc((size_t)std::max(V.n_part_rec, 1) * 12, &c->bytes));
+    HIP_TRY(c->c3_h.alloc(4 * std::max<size_t>(V.cold_lm.size(), 1), &c->bytes));
     if (options->robust_norm) HIP_TRY(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
+    // scatter scalars of the cold observations: one buffer, sized for the largest of the cold views
+    HIP_TRY(c->q4c.alloc(std::max<size_t>(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), V.cold_lm.size()), 1), &c->bytes));
+    c->d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
+                 c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
+                 c->v2_wg_slot_rec.p, nt, lpl_hubs(V.n_global)};
   }
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
@@ -850,8 +765,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
   d.hot_rec = c->hot_rec.p;
   d.hot_cams = c->hot_cams.p; d.n_hot = std::min(n_cams, HOT_MAX);
-  d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
-            c->v2_lm_pos.p, c->v2_of_slot.p, (int)L.v2_tile.size()};
+  d.part_range = nullptr;
   d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.q4c = nullptr; d.cold_pos = nullptr; d.long_in_kernel = 0; d.tiles = nullptr;
   d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
   d.tmp = c->tmp.p; d.accum = c->accum.p; d.z = c->z.p; d.y = c->y.p; d.inc = c->inc.p;
@@ -885,7 +799,8 @@ void povar_destroy(povar_ctx* c) {
   c->sc_r.release(); c->sc_p.release(); c->sc_q.release(); c->sc_zv.release(); c->sc_part.release(); c->sc_s.release();
   c->cc_cam_range.release(); c->cold_pos.release(); c->q4c.release();
   c->v2_uv.release(); c->v2_cw.release(); c->v2_cpos.release(); c->v2_lm_pos.release(); c->v2_of_slot.release();
-  c->v2_seg.release(); c->v2_tile.release(); c->v2_w.release(); c->v2_lmrec.release();
+  c->v2_seg.release(); c->v2_tile.release(); c->v2_wg_tile_off.release(); c->v2_wg_cam_off.release(); c->v2_wg_cams.release();
+  c->v2_wg_slot_rec.release(); c->c3_lm.release(); c->v2_part_range.release(); c->c3_range.release(); c->c3_h.release(); c->v2_part.release(); c->v2_w.release(); c->v2_lmrec.release();
   c->c2_lm.release(); c->c2_pos.release(); c->c2_range.release(); c->c2_h.release();
   c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -998,6 +913,8 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, 0);
   if (c->long_in_kernel && c->n_cold2 > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold2, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c2_lm.p, c->c2_h.p, c->n_cold2, 0);
+  if (c->n_cold3 > 0)
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 0);
   hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   if (sharded(c)) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
@@ -1458,8 +1375,9 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
   const int64_t cam_static = nc * (96 + 96);            // z (12 doubles) + P (12 doubles) per camera
   const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
   const bool lik = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->long_in_kernel;
-  const int64_t n_cold = lik ? c->n_cold2 : c->n_cold;
-  const int64_t hot_flush = acc ? (int64_t)c->e0c_grid * c->n_hot_acc * 96 : 0;
+  const bool lpl = c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+  const int64_t n_cold = lpl ? c->n_cold3 : lik ? c->n_cold2 : c->n_cold;
+  const int64_t hot_flush = lpl ? (int64_t)c->v2_part.n * 8 : acc ? (int64_t)c->e0c_grid * c->n_hot_acc * 96 : 0;
   const int64_t tail = nc * (1152 + 96 /*sigma*/ + 3 * 96 /*accum rw, tmp*/ + 96 /*z*/);
   int64_t lm = 0, cm = 0;
   switch (c->opt.e0_mode) {

@@ -84,16 +84,22 @@ struct CmView {
 // one segmented wavefront scan per tile.
 struct V2 {
   const double2* uv;   // [n_rows][64] observation (u, v)
-  const int* cw;       // [n_rows][64] popularity rank of the camera (0-based, < n_hot_acc: accumulated in LDS), -1: no observation
+  const int* cw;       // [n_rows][64] >= 0: LDS slot of the camera in this workgroup; -1: no observation;
+                       // <= -2: cold observation of the camera with popularity rank -2 - cw (record gathered from L2)
   const int* cpos;     // [n_rows][64] position in the cold camera-major view (-1: not cold)
   double* w;           // [n_rows][64] robust weight (only with a robust norm)
-  const int4* tile;    // [n_tiles] (first row, rows, leading all-hot rows, bit 0: some landmark spans several lanes);
-                       // sorted longest first, workgroup w takes tiles w, w + grid, ... on demand
+  const int4* tile;    // [n_tiles] (first row, rows, leading all-hot rows, bit 0: some landmark spans several lanes)
   const int* seg;      // [n_tiles][64] first | last << 8 lane of the landmark a lane belongs to (read for flagged tiles)
   double* lmrec;       // [n_tiles][9][64]: x, y, z, then G = diag(s) Hll^-1 diag(s) (00,01,02,11,12,22)
   const int* lm_pos;   // [n_lms] tile * 64 + first lane of each landmark | (lanes - 1) << 26 (-1: no observation)
   const int* of_slot;  // [n_slots] row * 64 + lane of each wave-bin slot (-1: padding)
+  // per E0 workgroup (lpl_layout.hpp): its tiles, the cameras it keeps in LDS, where their accumulators are flushed
+  const int* wg_tile_off;  // [grid + 1] tiles of workgroup w, longest first
+  const int* wg_cam_off;   // [grid + 1] camera slots of workgroup w
+  const int* wg_cams;      // popularity rank (= index in the record image Dp::hot_rec) of the camera in each slot
+  const int* wg_slot_rec;  // partial record (12 doubles in hot_out) each slot is flushed to
   int n_tiles;
+  int hubs;                // leading slots with four accumulator replicas each (lpl_acc_slot)
 };
 
 struct Dp {
@@ -122,7 +128,8 @@ struct Dp {
   const int* cam_item_off;
   CmView cmv;            // what cm_scatter and the per-camera item sums walk
   // LDS-accumulated partial sums of the hottest cameras (POVAR_E0_IMPLICIT_LDSACC), else nullptr
-  const double* hot_part;  // [n_hot_acc][n_hot_wg][12]
+  const double* hot_part;  // [n_hot_acc][n_hot_wg][12], or partial records addressed through part_range
+  const int2* part_range;  // [n_cams] (first, end) partial record of each camera (e0_lpl), else nullptr
   const int* cam_hot;      // [n_cams] 1 + rank in the LDS cache, 0 = not cached
   int n_hot_acc, n_hot_wg;
   // state
@@ -1141,32 +1148,32 @@ template <bool ROBUST>
 __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   const int done = d.flags[1];  // requested first, tested after the LDS staging (no global side effects before)
   extern __shared__ double2 hot[];  // [n_hot][HOT_REC] records, then acc[12][n_slots], then the tile counter
-  const int n_hot = d.n_hot_acc;
-  const int hubs = lpl_hubs(n_hot), n_slots = n_hot + 3 * hubs;
+  const V2& v = d.v2;
+  // this workgroup's camera slots: the records of the cameras it keeps in LDS (lpl_layout.hpp) and their accumulators
+  const int cam0 = v.wg_cam_off[blockIdx.x];
+  const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  const int hubs = v.hubs, n_slots = n_hot + 3 * hubs;
   double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC);
   int* grab_ctr = reinterpret_cast<int*>(acc + n_slots * 12);
   for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
   if (threadIdx.x == 0) *grab_ctr = 0;
-  {
-    const double2* src = reinterpret_cast<const double2*>(d.hot_rec);
-    for (int i = threadIdx.x; i < n_hot * HOT_REC; i += E0C_BLOCK) {
-      const int r = i / HOT_REC, j = i - r * HOT_REC;
-      hot[i] = src[r * (HOT_REC_STRIDE / 2) + j];
-    }
+  const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
+  for (int i = threadIdx.x; i < n_hot * HOT_REC; i += E0C_BLOCK) {
+    const int r = i / HOT_REC, j = i - r * HOT_REC;
+    hot[i] = rec_img[(size_t)v.wg_cams[cam0 + r] * (HOT_REC_STRIDE / 2) + j];
   }
   __syncthreads();
   if (done) return;
-  const V2& v = d.v2;
   const int lane = threadIdx.x & 63;
-  const int t_end = v.n_tiles;
-  const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
-  // Tiles are sorted longest first and workgroup w owns tiles w, w + grid, ...; its wavefronts take them on demand
-  // (one LDS counter), so a wavefront's last tile is a short one and the workgroups carry equal row totals.
+  // The workgroup's tiles are sorted longest first; its wavefronts take them on demand (one LDS counter), so a
+  // wavefront's last tile is a short one.  The workgroups carry equal observation totals (lpl_layout.hpp).
+  const int t_begin = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
+  const int t_end = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
   auto grab = [&]() -> int {
     int n = 0;
     if (lane == 0) n = __hip_atomic_fetch_add(grab_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     n = __builtin_amdgcn_readfirstlane(n);
-    const long long t = (long long)blockIdx.x + (long long)n * gridDim.x;
+    const long long t = (long long)t_begin + n;
     return t < t_end ? (int)t : t_end;
   };
 
@@ -1254,16 +1261,16 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
 #endif
         lpl_forward(o, zz, P3, hx, hy, hz, red);
 #if POVAR_LPLX & 8
-      } else if (cur.cw >= 0 && cur.cw < n_hot) {
-#else
       } else if (cur.cw >= 0) {
+#else
+      } else if (cur.cw != -1) {
 #endif
-        if (cur.cw < n_hot) {
+        if (cur.cw >= 0) {
           const double2* h = hot + cur.cw * HOT_REC;
           lpl_read_zz(h, zz);
           lpl_read_p3(h, P3);
-        } else {
-          const double2* h = rec_img + (size_t)cur.cw * (HOT_REC_STRIDE / 2);
+        } else {  // cold: camera with popularity rank -2 - cw, record from the rank-ordered image (L2)
+          const double2* h = rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
           lpl_read_zz(h, zz);
           lpl_read_p3(h, P3);
         }
@@ -1296,7 +1303,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
 #if POVAR_LPLX & 8
       if (j < c_nh) {
 #else
-      if (j < c_nh || (cur.cw >= 0 && cur.cw < n_hot)) {
+      if (j < c_nh || cur.cw >= 0) {
 #endif
 #if POVAR_LPLX & 2
         for (int m = 0; m < 9; ++m) P3[m] = cur.uv.y + m;
@@ -1319,9 +1326,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
 #if POVAR_LPLX & 8
       } else if (false) {
 #else
-      } else if (cur.cw >= 0) {
+      } else if (cur.cw < -1) {
 #endif
-        lpl_read_p3(rec_img + (size_t)cur.cw * (HOT_REC_STRIDE / 2), P3);
+        lpl_read_p3(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2), P3);
         lpl_backward(o, P3, g, q);
         d.q4c[v.cpos[base + (size_t)j * WAVE]] = make_double4(q[0], q[1], q[2], 0);
       }
@@ -1334,11 +1341,12 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
     hx = nhx; hy = nhy; hz = nhz;
   }
   __syncthreads();
+  // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run)
   for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) {
     const int r = i / 12, m = i % 12;
     const double* a = acc + m * n_slots;
     const double s = r < hubs ? (a[4 * r] + a[4 * r + 1]) + (a[4 * r + 2] + a[4 * r + 3]) : a[r + 3 * hubs];
-    hot_out[((size_t)r * gridDim.x + blockIdx.x) * 12 + m] = s;
+    hot_out[(size_t)v.wg_slot_rec[cam0 + r] * 12 + m] = s;
   }
 }
 
@@ -1917,7 +1925,14 @@ __device__ inline void camera_item_sum(const Dp& d, int c, int lane, double (&y)
 #pragma unroll
     for (int j = 0; j < 12; ++j) y[j] += ip[j];
   }
-  if (d.hot_part) {
+  if (d.hot_part && d.part_range) {
+    const int2 rr = d.part_range[c];
+    for (int w = rr.x + lane; w < rr.y; w += WAVE) {
+      const double* ip = d.hot_part + (size_t)w * 12;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) y[j] += ip[j];
+    }
+  } else if (d.hot_part) {
     const int r = d.cam_hot[c];
     if (r > 0 && r <= d.n_hot_acc) {
       for (int w = lane; w < d.n_hot_wg; w += WAVE) {
@@ -1969,7 +1984,14 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
       acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += hw[u] * q[u].z;
     }
   }
-  if (r > 0 && r <= d.n_hot_acc) {
+  if (d.part_range) {  // e0_lpl: the camera's partial records are one contiguous run
+    const int2 rr = d.part_range[c];
+    for (int w = rr.x + t; w < rr.y; w += 256) {
+      const double* ip = d.hot_part + (size_t)w * 12;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] += ip[k];
+    }
+  } else if (r > 0 && r <= d.n_hot_acc) {
     for (int w = t; w < d.n_hot_wg; w += 256) {
       const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + w) * 12;
 #pragma unroll
@@ -2039,7 +2061,14 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
 #if POVAR_EXP == 21
   if (false)
 #endif
-  if (r > 0 && r <= d.n_hot_acc) {
+  if (d.part_range) {  // e0_lpl: the camera's partial records are one contiguous run
+    const int2 rr = d.part_range[c];
+    for (int w = rr.x + t; w < rr.y; w += 256) {
+      const double* ip = d.hot_part + (size_t)w * 12;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] += ip[k];
+    }
+  } else if (r > 0 && r <= d.n_hot_acc) {
     for (int w = t; w < d.n_hot_wg; w += 256) {
       const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + w) * 12;
 #pragma unroll

@@ -1,0 +1,137 @@
+// Host-only check of the lane-per-landmark layout builder (povar_amd/csrc/lpl_layout.hpp): reads a problem dumped
+// by tests/test_lpl_layout.py, builds the layout for a given grid / LDS capacity, verifies its invariants and prints
+// one JSON line of statistics.  No HIP runtime call is made (runs without a GPU).
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <vector>
+
+#include "../../povar_amd/csrc/lpl_layout.hpp"
+
+using namespace povar;
+
+template <class T>
+static std::vector<T> read_vec(const char* path) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { std::perror(path); std::exit(2); }
+  std::fseek(f, 0, SEEK_END);
+  const long n = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  std::vector<T> v(n / sizeof(T));
+  if (std::fread(v.data(), sizeof(T), v.size(), f) != v.size()) std::exit(2);
+  std::fclose(f);
+  return v;
+}
+
+#define CHECK(c)                                                      \
+  do {                                                                \
+    if (!(c)) { std::printf("FAILED %s line %d\n", #c, __LINE__); return 1; } \
+  } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 7) return 2;
+  const int n_cams = std::atoi(argv[1]), grid = std::atoi(argv[5]), n_acc = std::atoi(argv[6]);
+  const auto lm_off = read_vec<int32_t>(argv[2]);
+  const auto cam_idx = read_vec<int32_t>(argv[3]);
+  const auto obs = read_vec<double>(argv[4]);
+  const int n_lms = (int)lm_off.size() - 1;
+  const int64_t n_obs = lm_off[n_lms];
+  // popularity ranks (1-based, ties: lower index) as build_layout computes them
+  std::vector<int64_t> cnt(n_cams, 0);
+  for (int64_t i = 0; i < n_obs; ++i) cnt[cam_idx[i]]++;
+  std::vector<int> order(n_cams), rank1(n_cams);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });
+  for (int r = 0; r < n_cams; ++r) rank1[order[r]] = r + 1;
+  std::vector<int> slot_of_obs(n_obs);
+  std::iota(slot_of_obs.begin(), slot_of_obs.end(), 0);
+  LplLayout L;
+  build_lpl(n_cams, n_lms, lm_off.data(), cam_idx.data(), obs.data(), rank1, slot_of_obs, (size_t)n_obs, grid, n_acc, L);
+  // ---- invariants
+  CHECK(L.max_slots <= n_acc);
+  CHECK((int)L.wg_tile_off.size() == grid + 1 && (int)L.wg_cam_off.size() == grid + 1);
+  CHECK(L.wg_tile_off[grid] == (int)L.tile.size());
+  CHECK((int64_t)L.uv.size() == L.rows * 64 && L.cw.size() == L.uv.size() && L.cpos.size() == L.uv.size());
+  // every observation appears exactly once, with its (u, v); resident slots point at its camera; cold ones at a
+  // position of the cold view that belongs to its camera and names its landmark
+  std::vector<char> seen(n_obs, 0);
+  int64_t n_cold = 0, n_placed = 0, min_rows = 1 << 30;
+  std::vector<int64_t> wg_rows(grid, 0), wg_obs(grid, 0);
+  std::vector<int> lm_of(n_obs);
+  for (int l = 0; l < n_lms; ++l)
+    for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) lm_of[i] = l;
+  for (int w = 0; w < grid; ++w) {
+    const int c0 = L.wg_cam_off[w], nw = L.wg_cam_off[w + 1] - c0;
+    for (int t = L.wg_tile_off[w]; t < L.wg_tile_off[w + 1]; ++t) {
+      const int4 ti = L.tile[t];
+      CHECK(ti.y >= 2 && ti.z <= ti.y);
+      wg_rows[w] += ti.y;
+      min_rows = std::min<int64_t>(min_rows, ti.y);
+      if (t > L.wg_tile_off[w]) CHECK(L.tile[t - 1].y >= ti.y);  // longest first
+      for (int j = 0; j < ti.y; ++j)
+        for (int lane = 0; lane < 64; ++lane) {
+          const size_t idx = ((size_t)ti.x + j) * 64 + lane;
+          const int cw = L.cw[idx];
+          if (j < ti.z) CHECK(cw >= 0);
+          if (cw == -1) continue;
+          ++n_placed;
+          wg_obs[w]++;
+          if (cw >= 0) {
+            CHECK(cw < nw);
+          } else {
+            ++n_cold;
+            CHECK(L.cpos[idx] >= 0 && L.cpos[idx] < (int)L.cold_lm.size());
+          }
+        }
+    }
+  }
+  for (int64_t i = 0; i < n_obs; ++i) {
+    const int idx = L.of_slot[i];
+    CHECK(idx >= 0 && !seen[i]);
+    seen[i] = 1;
+    CHECK(L.uv[idx].x == obs[2 * i] && L.uv[idx].y == obs[2 * i + 1]);
+    const int cw = L.cw[idx], r0 = rank1[cam_idx[i]] - 1;
+    // which workgroup owns this row
+    const int row = idx / 64;
+    int w = 0;
+    {
+      int lo = 0, hi = grid;  // tiles are in workgroup order and rows ascend with the tile index
+      while (lo + 1 < hi) {
+        const int mid = (lo + hi) / 2;
+        (L.wg_tile_off[mid] < (int)L.tile.size() && L.tile[L.wg_tile_off[mid]].x <= row && L.wg_tile_off[mid] < L.wg_tile_off[grid] ? lo : hi) = mid;
+      }
+      w = lo;
+      while (w + 1 < grid && L.wg_tile_off[w + 1] < (int)L.tile.size() && L.tile[L.wg_tile_off[w + 1]].x <= row) ++w;
+      while (w > 0 && (L.wg_tile_off[w] >= (int)L.tile.size() || L.tile[L.wg_tile_off[w]].x > row)) --w;
+    }
+    if (cw >= 0) {
+      CHECK(L.wg_cams[L.wg_cam_off[w] + cw] == r0);
+    } else {
+      CHECK(-2 - cw == r0);
+      const int p = L.cpos[idx];
+      CHECK(p >= L.cold_range[cam_idx[i]].x && p < L.cold_range[cam_idx[i]].y && L.cold_lm[p] == lm_of[i]);
+    }
+    // the landmark's lanes
+    const int lp = L.lm_pos[lm_of[i]], pos = lp & ((1 << 26) - 1), lanes = ((lp >> 26) & 63) + 1;
+    CHECK(idx % 64 >= (pos & 63) && idx % 64 < (pos & 63) + lanes);
+  }
+  CHECK(n_placed == n_obs && n_cold == (int64_t)L.cold_lm.size());
+  // partial records: every slot of every workgroup has its own record inside its camera's run
+  std::vector<char> rec_used(L.n_part_rec, 0);
+  for (int w = 0; w < grid; ++w)
+    for (int s = L.wg_cam_off[w]; s < L.wg_cam_off[w + 1]; ++s) {
+      const int rec = L.wg_slot_rec[s], cam = order[L.wg_cams[s]];
+      CHECK(rec >= L.part_range[cam].x && rec < L.part_range[cam].y && !rec_used[rec]);
+      rec_used[rec] = 1;
+    }
+  for (int r = 0; r < L.n_part_rec; ++r) CHECK(rec_used[r]);
+  int64_t mx = 0, mn = 1LL << 60;
+  for (int w = 0; w < grid; ++w) { mx = std::max(mx, wg_rows[w]); mn = std::min(mn, wg_rows[w]); }
+  std::printf("{\"ok\": 1, \"n_global\": %d, \"n_tail\": %d, \"grid\": [%d, %d], \"max_slots\": %d, \"rows\": %lld, "
+              "\"tiles\": %zu, \"cold\": %lld, \"cold_frac\": %.5f, \"pad_frac\": %.5f, \"wg_rows_min\": %lld, "
+              "\"wg_rows_max\": %lld, \"part_recs\": %d}\n",
+              L.n_global, L.n_tail, L.grid_a, L.grid_b, L.max_slots, (long long)L.rows, L.tile.size(),
+              (long long)n_cold, (double)n_cold / n_obs, (double)L.rows * 64 / n_obs - 1.0, (long long)mn, (long long)mx,
+              L.n_part_rec);
+  return 0;
+}
