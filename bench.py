@@ -373,7 +373,9 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": {capi.E0_IMPLICIT: "E0 x (e0_lm_cached<false> + cm_scatter)",
-                       capi.E0_IMPLICIT_LDSACC: "E0 x (e0_lm_cached<true> + cam_cold_sum[_binv])",
+                       capi.E0_IMPLICIT_LDSACC: ("E0 x (e0_lm_cached<true> + cam_cold_sum[_binv])"
+                                                 if os.environ.get("POVAR_E0_V1") == "1" or args.step == 2
+                                                 else "E0 x (e0_lpl + cam_cold_sum[_binv])"),
                        capi.E0_TILES: "E0 x (lm_regular<OpE0Tiles> + cm_scatter)",
                        capi.E0_TILES_LDSACC: "E0 x (e0_tiles_cached + cam_cold_sum[_binv])"}[mode],
             # bytes the kernel pair streams by design (every array once) / HIP-event time of the pair

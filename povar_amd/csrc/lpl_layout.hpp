@@ -22,7 +22,9 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <atomic>
 #include <queue>
+#include <thread>
 #include <vector>
 
 #include "povar_kernels.hpp"
@@ -43,6 +45,44 @@ struct LplLayout {
   int64_t rows = 0;
   int n_part_rec = 0, max_slots = 0, n_global = 0, n_tail = 0, grid_a = 1, grid_b = 1;
 };
+
+// Minimum-cost assignment of h items to h positions (Hungarian algorithm, O(h^3); h is the number of resident
+// observations of one landmark: 2..8 for almost all of them).  assign[item] = position.
+inline void lpl_assign(int h, const std::vector<long>& cost, std::vector<int>& assign) {
+  const long INF = 1L << 60;
+  std::vector<long> u(h + 1, 0), v(h + 1, 0), minv(h + 1);
+  std::vector<int> p(h + 1, 0), way(h + 1, 0);
+  std::vector<char> used(h + 1);
+  for (int i = 1; i <= h; ++i) {
+    p[0] = i;
+    int j0 = 0;
+    std::fill(minv.begin(), minv.end(), INF);
+    std::fill(used.begin(), used.end(), 0);
+    do {
+      used[j0] = 1;
+      const int i0 = p[j0];
+      long delta = INF;
+      int j1 = 0;
+      for (int j = 1; j <= h; ++j)
+        if (!used[j]) {
+          const long cur = cost[(size_t)(i0 - 1) * h + (j - 1)] - u[i0] - v[j];
+          if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+          if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+        }
+      for (int j = 0; j <= h; ++j)
+        if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+        else minv[j] -= delta;
+      j0 = j1;
+    } while (p[j0] != 0);
+    do {
+      const int j1 = way[j0];
+      p[j0] = p[j1];
+      j0 = j1;
+    } while (j0);
+  }
+  assign.assign(h, 0);
+  for (int j = 1; j <= h; ++j) assign[p[j] - 1] = j - 1;
+}
 
 // rank1[c]: 1-based popularity rank of camera c; cnt_sorted[r]: observation count of the camera with rank r (0-based)
 inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx, const double* obs,
@@ -167,7 +207,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
           L.cold_lm[p] = l;
         }
   }
-  // ---- per workgroup: camera slots (global cameras in rank order, then the tail cameras its landmarks use)
+  // ---- per workgroup: camera slots (global cameras in rank order, then the tail cameras its landmarks use), tiles
   std::vector<std::vector<int>> lms_of(grid);
   for (int l = 0; l < n_lms; ++l)
     if (wg_of[l] >= 0) lms_of[wg_of[l]].push_back(l);
@@ -175,139 +215,197 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   L.wg_tile_off.assign(grid + 1, 0);
   L.lm_pos.assign(n_lms, -1);
   L.of_slot.assign(n_slots, -1);
-  std::vector<int> slot_of_rank(n_cams, -1);  // scratch, per workgroup
   std::vector<std::vector<int>> holders(n_cams);  // rank -> workgroups with a slot for it (for the partial records)
   std::vector<int> parts_of(n_lms, 0), psize_of(n_lms, 0), cold_of(n_lms, 0);
+  std::vector<std::vector<int>> order_of(grid);
+  {
+    std::vector<char> mark(n_cams, 0);
+    for (int w = 0; w < grid; ++w) {
+      const int slot0 = (int)L.wg_cams.size();
+      std::vector<int> used_tail;
+      for (int l : lms_of[w])
+        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) {
+          const int r0 = rank1[cam_idx[i]] - 1;
+          if (r0 >= G && !mark[r0] && resident(w, r0)) {
+            mark[r0] = 1;
+            used_tail.push_back(r0);
+          }
+        }
+      std::sort(used_tail.begin(), used_tail.end());
+      for (int r0 = 0; r0 < G; ++r0) L.wg_cams.push_back(r0);
+      for (int r0 : used_tail) { L.wg_cams.push_back(r0); mark[r0] = 0; }
+      const int n_w = (int)L.wg_cams.size() - slot0;
+      L.max_slots = std::max(L.max_slots, n_w);
+      for (int s = 0; s < n_w; ++s) holders[L.wg_cams[slot0 + s]].push_back(w);
+      L.wg_cam_off[w + 1] = (int)L.wg_cams.size();
+      // tiles: lanes sorted by (rows per lane, cold rows per lane), longest first
+      std::vector<int>& order = order_of[w];
+      for (int l : lms_of[w]) {
+        const int k = lm_off[l + 1] - lm_off[l];
+        int cold = 0;
+        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) cold += cold_pos_of_obs[i] >= 0;
+        parts_of[l] = k <= K0 ? 1 : std::min(WAVE, (k + K0 - 1) / K0);
+        psize_of[l] = (k + parts_of[l] - 1) / parts_of[l];
+        cold_of[l] = (cold + parts_of[l] - 1) / parts_of[l];
+        order.push_back(l);
+      }
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return psize_of[a] != psize_of[b] ? psize_of[a] > psize_of[b] : cold_of[a] > cold_of[b];
+      });
+      const int tile0 = (int)L.tile.size();
+      int tile = tile0, fill = 0;
+      for (int l : order) {
+        if (fill + parts_of[l] > WAVE) { ++tile; fill = 0; }
+        L.lm_pos[l] = (tile * WAVE + fill) | ((parts_of[l] - 1) << 26);
+        fill += parts_of[l];
+      }
+      const int n_tiles_w = order.empty() ? 0 : tile - tile0 + 1;
+      L.tile.resize(tile0 + n_tiles_w, make_int4(0, 0, 1 << 30, 0));
+      L.seg.resize((size_t)(tile0 + n_tiles_w) * WAVE);
+      for (size_t i = (size_t)tile0 * WAVE; i < L.seg.size(); ++i) L.seg[i] = (int)(i & 63) | ((int)(i & 63) << 8);
+      std::vector<int> lanes_used(n_tiles_w, 0);
+      for (int l : order) {
+        const int pos = L.lm_pos[l] & ((1 << 26) - 1), t = pos >> 6, lane0 = pos & 63, P = parts_of[l];
+        int hot = 0;
+        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) hot += cold_pos_of_obs[i] < 0;
+        int4& ti = L.tile[t];
+        ti.y = std::max(ti.y, psize_of[l]);
+        ti.z = std::min(ti.z, hot / P);  // leading rows in which every lane of the landmark has a resident camera
+        if (P > 1) ti.w |= 1;
+        for (int q = 0; q < P; ++q) L.seg[(size_t)t * WAVE + lane0 + q] = lane0 | ((lane0 + P - 1) << 8);
+        lanes_used[t - tile0] += P;
+      }
+      for (int t = tile0; t < tile0 + n_tiles_w; ++t) {
+        if (lanes_used[t - tile0] < WAVE) L.tile[t].z = 0;  // unused lanes: no branch-free rows
+        // at least two rows = four row steps per tile: the prefetch cursor (three rows ahead) then never needs a
+        // tile beyond the one the consumer has already taken
+        L.tile[t].y = std::max(L.tile[t].y, 2);
+        L.tile[t].x = (int)L.rows;
+        L.rows += L.tile[t].y;
+      }
+      L.wg_tile_off[w + 1] = (int)L.tile.size();
+    }
+  }
+  L.uv.assign((size_t)L.rows * WAVE, make_double2(0, 0));
+  L.cw.assign((size_t)L.rows * WAVE, -1);
+  L.cpos.assign((size_t)L.rows * WAVE, -1);
+  // ---- row stream with LDS bank placement, workgroups in parallel (disjoint row ranges).
+  // ds_add_f64 takes 8 LDS cycles per wavefront when the 32 lanes of each half hit 32 different bank pairs and 8
+  // more for every additional lane on a bank (tools/micro/lds_atomic_rates.hip); a ds_read_b128 takes one more
+  // cycle per lane group for every additional record on a bank quad.  With the observations in their natural order
+  // row 0 would hold every landmark's lowest-index camera.  So the assignment of a landmark's resident
+  // observations to the rows of its lanes is an assignment problem against the banks already taken in its tile
+  // (accumulator bank = lpl_acc_slot(slot, lane) mod 32 per row half, record quad = slot mod 16 per read group):
+  // solved exactly per landmark (Hungarian), landmark after landmark, then once more with the whole tile known.
   auto read_group = [](int lane) {
     const int l = lane & 31;
     const int g = (l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 1;
     return g + 2 * (lane >> 5);
   };
-  struct PendingRow { size_t idx; int i; };
-  std::vector<int> hot_idx, cold_idx, order;
-  std::vector<uint16_t> occA, occR;
-  for (int w = 0; w < grid; ++w) {
-    // slots
-    const int slot0 = (int)L.wg_cams.size();
-    std::vector<int> used_tail;
-    for (int l : lms_of[w])
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) {
-        const int r0 = rank1[cam_idx[i]] - 1;
-        if (r0 >= G && resident(w, r0) && slot_of_rank[r0] < 0) {
-          slot_of_rank[r0] = 1;
-          used_tail.push_back(r0);
-        }
-      }
-    std::sort(used_tail.begin(), used_tail.end());
-    for (int r0 = 0; r0 < G; ++r0) L.wg_cams.push_back(r0);
-    for (int r0 : used_tail) L.wg_cams.push_back(r0);
-    const int n_w = (int)L.wg_cams.size() - slot0;
-    L.max_slots = std::max(L.max_slots, n_w);
-    for (int s = 0; s < n_w; ++s) {
-      slot_of_rank[L.wg_cams[slot0 + s]] = s;
-      holders[L.wg_cams[slot0 + s]].push_back(w);
-    }
-    L.wg_cam_off[w + 1] = (int)L.wg_cams.size();
-    const int hubs = lpl_hubs(G);
-    // tiles: lanes sorted by (rows per lane, cold rows per lane), longest first
-    order.clear();
-    for (int l : lms_of[w]) {
-      const int k = lm_off[l + 1] - lm_off[l];
-      int cold = 0;
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) cold += cold_pos_of_obs[i] >= 0;
-      parts_of[l] = k <= K0 ? 1 : std::min(WAVE, (k + K0 - 1) / K0);
-      psize_of[l] = (k + parts_of[l] - 1) / parts_of[l];
-      cold_of[l] = (cold + parts_of[l] - 1) / parts_of[l];
-      order.push_back(l);
-    }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      return psize_of[a] != psize_of[b] ? psize_of[a] > psize_of[b] : cold_of[a] > cold_of[b];
-    });
-    const int tile0 = (int)L.tile.size();
-    int tile = tile0, fill = 0;
-    for (int l : order) {
-      if (fill + parts_of[l] > WAVE) { ++tile; fill = 0; }
-      L.lm_pos[l] = (tile * WAVE + fill) | ((parts_of[l] - 1) << 26);
-      fill += parts_of[l];
-    }
-    const int n_tiles_w = order.empty() ? 0 : tile - tile0 + 1;
-    L.tile.resize(tile0 + n_tiles_w, make_int4(0, 0, 1 << 30, 0));
-    L.seg.resize((size_t)(tile0 + n_tiles_w) * WAVE);
-    for (size_t i = (size_t)tile0 * WAVE; i < L.seg.size(); ++i) L.seg[i] = (int)(i & 63) | ((int)(i & 63) << 8);
-    std::vector<int> lanes_used(n_tiles_w, 0);
-    for (int l : order) {
-      const int pos = L.lm_pos[l] & ((1 << 26) - 1), t = pos >> 6, lane0 = pos & 63, P = parts_of[l];
-      int hot = 0;
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) hot += cold_pos_of_obs[i] < 0;
-      int4& ti = L.tile[t];
-      ti.y = std::max(ti.y, psize_of[l]);
-      ti.z = std::min(ti.z, hot / P);  // leading rows in which every lane of the landmark has a resident camera
-      if (P > 1) ti.w |= 1;
-      for (int q = 0; q < P; ++q) L.seg[(size_t)t * WAVE + lane0 + q] = lane0 | ((lane0 + P - 1) << 8);
-      lanes_used[t - tile0] += P;
-    }
-    for (int t = tile0; t < tile0 + n_tiles_w; ++t) {
-      if (lanes_used[t - tile0] < WAVE) L.tile[t].z = 0;  // unused lanes: no branch-free rows
-      // at least two rows = four row steps per tile: the prefetch cursor (three rows ahead) then never needs a tile
-      // beyond the one the consumer has already taken
-      L.tile[t].y = std::max(L.tile[t].y, 2);
-      L.tile[t].x = (int)L.rows;
-      L.rows += L.tile[t].y;
-    }
-    L.wg_tile_off[w + 1] = (int)L.tile.size();
-    L.uv.resize((size_t)L.rows * WAVE, make_double2(0, 0));
-    L.cw.resize((size_t)L.rows * WAVE, -1);
-    L.cpos.resize((size_t)L.rows * WAVE, -1);
-    // LDS bank placement.  ds_add_f64 runs at ~4 lanes per clock and a same-bank or same-address collision inside a
-    // 32-lane half serialises it, so the ORDER of a landmark's resident observations over the rows of its tile is
-    // chosen greedily, landmark by landmark, to keep the accumulator banks ((slot' mod 32), slot' =
-    // lpl_acc_slot(slot, lane)) of each row half and the record quads ((slot mod 16) per ds_read_b128 lane group)
-    // distinct.  Without this, row 0 would hold every landmark's lowest-index camera.
-    int cur_tile = -1;
-    for (int l : order) {
-      const int pos = L.lm_pos[l] & ((1 << 26) - 1), t = pos >> 6, lane0 = pos & 63, P = parts_of[l];
-      if (t != cur_tile) {
-        cur_tile = t;
-        occA.assign((size_t)L.tile[t].y * 64, 0);
-        occR.assign((size_t)L.tile[t].y * 64, 0);
-      }
-      hot_idx.clear();
-      cold_idx.clear();
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) (cold_pos_of_obs[i] >= 0 ? cold_idx : hot_idx).push_back(i);
-      const int h = (int)hot_idx.size();
-      int best_rot = 0;
-      if (h > 1) {
-        long best = -1;
-        for (int rot = 0; rot < std::min(h, 16); ++rot) {
-          long cost = 0;
-          for (int n = 0; n < h; ++n) {
-            const int s = slot_of_rank[rank1[cam_idx[hot_idx[(n + rot) % h]]] - 1], lane = lane0 + n % P, j = n / P;
-            cost += 96 * occA[(size_t)j * 64 + (lane >> 5) * 32 + (lpl_acc_slot(s, lane, hubs) & 31)];
-            if (s >= hubs) cost += 16 * occR[(size_t)j * 64 + read_group(lane) * 16 + (s & 15)];
+  const int hubs = lpl_hubs(G);
+  int n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
+  const bool no_place = std::getenv("POVAR_LPL_NOPLACE") != nullptr;  // measurement knob: natural order
+  std::atomic<int> next_wg{0};
+  auto worker = [&]() {
+    std::vector<int> slot_of_rank(n_cams, -1);
+    std::vector<int> hot_idx, cold_idx, assign;
+    std::vector<long> cost;
+    std::vector<uint16_t> occA, occR;
+    std::vector<std::vector<int>> placed;  // per landmark of the current tile: its hot observations in position order
+    for (;;) {
+      const int w = next_wg.fetch_add(1);
+      if (w >= grid) break;
+      const int slot0 = L.wg_cam_off[w], n_w = L.wg_cam_off[w + 1] - slot0;
+      for (int s = 0; s < n_w; ++s) slot_of_rank[L.wg_cams[slot0 + s]] = s;
+      const std::vector<int>& order = order_of[w];
+      size_t o0 = 0;
+      while (o0 < order.size()) {
+        // landmarks of one tile
+        const int t = (L.lm_pos[order[o0]] & ((1 << 26) - 1)) >> 6;
+        size_t o1 = o0;
+        while (o1 < order.size() && ((L.lm_pos[order[o1]] & ((1 << 26) - 1)) >> 6) == t) ++o1;
+        const int R = L.tile[t].y;
+        occA.assign((size_t)R * 64, 0);
+        occR.assign((size_t)R * 64, 0);
+        placed.assign(o1 - o0, {});
+        auto bankA = [&](int s, int lane, int j) { return (size_t)j * 64 + (lane >> 5) * 32 + (lpl_acc_slot(s, lane, hubs) & 31); };
+        auto bankR = [&](int s, int lane, int j) { return (size_t)j * 64 + read_group(lane) * 16 + (s & 15); };
+        for (int pass = 0; pass < 2; ++pass)
+          for (size_t o = o0; o < o1; ++o) {
+            const int l = order[o], lane0 = L.lm_pos[l] & 63, P = parts_of[l];
+            std::vector<int>& cur = placed[o - o0];
+            if (pass == 0) {
+              for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
+                if (cold_pos_of_obs[i] < 0) cur.push_back(i);
+            } else {  // take this landmark's banks out again, then place it against everything else
+              for (size_t n = 0; n < cur.size(); ++n) {
+                const int s = slot_of_rank[rank1[cam_idx[cur[n]]] - 1], lane = lane0 + (int)(n % P), j = (int)(n / P);
+                occA[bankA(s, lane, j)]--;
+                if (s >= hubs) occR[bankR(s, lane, j)]--;
+              }
+            }
+            const int h = (int)cur.size();
+            if (h > 1 && h <= 64 && !no_place) {
+              // cost[o][pos]: observation o of the landmark at position pos (row pos / P, lane lane0 + pos % P)
+              cost.assign((size_t)h * h, 0);
+              for (int a = 0; a < h; ++a) {
+                const int s = slot_of_rank[rank1[cam_idx[cur[a]]] - 1];
+                for (int pos = 0; pos < h; ++pos) {
+                  const int lane = lane0 + pos % P, j = pos / P;
+                  long c = 96L * occA[bankA(s, lane, j)];
+                  if (s >= hubs) c += 16L * occR[bankR(s, lane, j)];
+                  cost[(size_t)a * h + pos] = c;
+                }
+              }
+              lpl_assign(h, cost, assign);
+              hot_idx.assign(h, 0);
+              for (int a = 0; a < h; ++a) hot_idx[assign[a]] = cur[a];
+              cur = hot_idx;
+            }
+            for (int n = 0; n < h; ++n) {
+              const int s = slot_of_rank[rank1[cam_idx[cur[n]]] - 1], lane = lane0 + n % P, j = n / P;
+              occA[bankA(s, lane, j)]++;
+              if (s >= hubs) occR[bankR(s, lane, j)]++;
+            }
           }
-          if (best < 0 || cost < best) { best = cost; best_rot = rot; }
+        // write the tile's rows
+        for (size_t o = o0; o < o1; ++o) {
+          const int l = order[o], lane0 = L.lm_pos[l] & 63, P = parts_of[l];
+          const std::vector<int>& cur = placed[o - o0];
+          const int h = (int)cur.size();
+          cold_idx.clear();
+          for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
+            if (cold_pos_of_obs[i] >= 0) cold_idx.push_back(i);
+          for (int n = 0; n < h + (int)cold_idx.size(); ++n) {
+            const int i = n < h ? cur[n] : cold_idx[n - h];
+            const int q = n % P, j = n / P, r0 = rank1[cam_idx[i]] - 1, lane = lane0 + q;
+            const size_t idx = ((size_t)L.tile[t].x + j) * WAVE + lane;
+            L.uv[idx] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
+            L.of_slot[slot_of_obs[i]] = (int)idx;
+            if (n < h) {
+              L.cw[idx] = slot_of_rank[r0];
+            } else {
+              L.cw[idx] = -2 - r0;  // cold: the record is gathered from the rank-ordered image
+              L.cpos[idx] = cold_pos_of_obs[i];
+            }
+          }
         }
+        o0 = o1;
       }
-      for (int n = 0; n < h + (int)cold_idx.size(); ++n) {
-        const int i = n < h ? hot_idx[(n + best_rot) % h] : cold_idx[n - h];
-        const int q = n % P, j = n / P, r0 = rank1[cam_idx[i]] - 1, lane = lane0 + q;
-        const size_t idx = ((size_t)L.tile[t].x + j) * WAVE + lane;
-        L.uv[idx] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
-        L.of_slot[slot_of_obs[i]] = (int)idx;
-        if (n < h) {
-          const int s = slot_of_rank[r0];
-          L.cw[idx] = s;
-          occA[(size_t)j * 64 + (lane >> 5) * 32 + (lpl_acc_slot(s, lane, hubs) & 31)]++;
-          if (s >= hubs) occR[(size_t)j * 64 + read_group(lane) * 16 + (s & 15)]++;
-        } else {
-          L.cw[idx] = -2 - r0;  // cold: the record is gathered from the rank-ordered image
-          L.cpos[idx] = cold_pos_of_obs[i];
-        }
-      }
+      for (int s = 0; s < n_w; ++s) slot_of_rank[L.wg_cams[slot0 + s]] = -1;
     }
-    for (int s = 0; s < n_w; ++s) slot_of_rank[L.wg_cams[slot0 + s]] = -1;
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
   }
-  // ---- partial records, camera-major: camera c's slots in the workgroups that hold it
+  // ---- partial records, camera-major: camera c's slots in the workgroups that hold it form one contiguous run, so
+  // the per-camera kernel streams them.  (Workgroup-major records -- one contiguous 53 KB flush per workgroup, the
+  // per-camera kernel gathering through an index list -- were measured too: the flush is bound by the 13.5 MB it
+  // writes, not by its access pattern, and the gather cost the per-camera kernel 1.6 us.)
   L.part_range.assign(n_cams, make_int2(0, 0));
   L.wg_slot_rec.assign(L.wg_cams.size(), 0);
   {

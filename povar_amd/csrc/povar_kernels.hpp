@@ -97,7 +97,7 @@ struct V2 {
   const int* wg_tile_off;  // [grid + 1] tiles of workgroup w, longest first
   const int* wg_cam_off;   // [grid + 1] camera slots of workgroup w
   const int* wg_cams;      // popularity rank (= index in the record image Dp::hot_rec) of the camera in each slot
-  const int* wg_slot_rec;  // partial record (12 doubles in hot_out) each slot is flushed to
+  const int* wg_slot_rec;  // partial record (12 doubles in hot_out, camera-major) each slot is flushed to
   int n_tiles;
   int hubs;                // leading slots with four accumulator replicas each (lpl_acc_slot)
 };
@@ -1147,6 +1147,9 @@ struct LplCursor {  // wave-uniform (SGPRs)
 template <bool ROBUST>
 __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   const int done = d.flags[1];  // requested first, tested after the LDS staging (no global side effects before)
+#if POVAR_LPLX & 32
+  if (done >= 0) return;
+#endif
   extern __shared__ double2 hot[];  // [n_hot][HOT_REC] records, then acc[12][n_slots], then the tile counter
   const V2& v = d.v2;
   // this workgroup's camera slots: the records of the cameras it keeps in LDS (lpl_layout.hpp) and their accumulators
@@ -1158,12 +1161,33 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
   if (threadIdx.x == 0) *grab_ctr = 0;
   const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
-  for (int i = threadIdx.x; i < n_hot * HOT_REC; i += E0C_BLOCK) {
-    const int r = i / HOT_REC, j = i - r * HOT_REC;
-    hot[i] = rec_img[(size_t)v.wg_cams[cam0 + r] * (HOT_REC_STRIDE / 2) + j];
+  {
+    // staging: slot -> camera rank -> record, two dependent L2 round trips; every thread first requests all its
+    // ranks, then all its record pieces, then writes LDS (a plain loop pays the two latencies once per pass)
+    constexpr int PASSES = (HOT_ACC_MAX * HOT_REC + E0C_BLOCK - 1) / E0C_BLOCK;
+    int rk[PASSES];
+    double2 piece[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      rk[u] = i < n_hot * HOT_REC ? v.wg_cams[cam0 + i / HOT_REC] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      piece[u] = rec_img[(size_t)rk[u] * (HOT_REC_STRIDE / 2) + i % HOT_REC];
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      if (i < n_hot * HOT_REC) hot[i] = piece[u];
+    }
   }
   __syncthreads();
   if (done) return;
+#if POVAR_LPLX & 64
+  if (done >= 0) return;
+#endif
   const int lane = threadIdx.x & 63;
   // The workgroup's tiles are sorted longest first; its wavefronts take them on demand (one LDS counter), so a
   // wavefront's last tile is a short one.  The workgroups carry equal observation totals (lpl_layout.hpp).
@@ -1210,7 +1234,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   // request the row under the prefetch cursor and advance it
   auto issue = [&](LplRow& r) {
     if (pc.t < t_end) {
-      const size_t i = ((size_t)pc.row0 + pc.j) * WAVE + lane;
+      // the backward pass walks the rows in reverse: the rows read last are the ones most likely still in L2
+      const size_t i = ((size_t)pc.row0 + (pc.pass ? pc.k - 1 - pc.j : pc.j)) * WAVE + lane;
       r.uv = v.uv[i];
       r.cw = v.cw[i];
       if (ROBUST) r.w = v.w[i];
@@ -1292,7 +1317,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
       G00 = rp[3 * WAVE]; G01 = rp[4 * WAVE]; G02 = rp[5 * WAVE]; G11 = rp[6 * WAVE]; G12 = rp[7 * WAVE]; G22 = rp[8 * WAVE];
     }
     const size_t base = (size_t)c_row0 * WAVE + lane;
-    for (int j = 0; j < c_k; ++j) {
+    for (int jj = 0; jj < c_k; ++jj) {
+      const int j = c_k - 1 - jj;
       const LplRow cur = n1;
       n1 = n2;
       n2 = n3;
@@ -1342,11 +1368,34 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   }
   __syncthreads();
   // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run)
-  for (int i = threadIdx.x; i < n_hot * 12; i += E0C_BLOCK) {
-    const int r = i / 12, m = i % 12;
-    const double* a = acc + m * n_slots;
-    const double s = r < hubs ? (a[4 * r] + a[4 * r + 1]) + (a[4 * r + 2] + a[4 * r + 3]) : a[r + 3 * hubs];
-    hot_out[(size_t)v.wg_slot_rec[cam0 + r] * 12 + m] = s;
+  // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run);
+  // 16-byte stores, all record indices requested first (one L2 round trip, not one per pass)
+  {
+    constexpr int PASSES = (HOT_ACC_MAX * 6 + E0C_BLOCK - 1) / E0C_BLOCK;
+    int rec[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      rec[u] = i < n_hot * 6 ? v.wg_slot_rec[cam0 + i / 6] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      if (i < n_hot * 6) {
+        const int r = i / 6, m = 2 * (i % 6);
+        const double* a0 = acc + m * n_slots;
+        const double* a1 = a0 + n_slots;
+        double2 s;
+        if (r < hubs) {
+          s.x = (a0[4 * r] + a0[4 * r + 1]) + (a0[4 * r + 2] + a0[4 * r + 3]);
+          s.y = (a1[4 * r] + a1[4 * r + 1]) + (a1[4 * r + 2] + a1[4 * r + 3]);
+        } else {
+          s.x = a0[r + 3 * hubs];
+          s.y = a1[r + 3 * hubs];
+        }
+        reinterpret_cast<double2*>(hot_out + (size_t)rec[u] * 12)[i % 6] = s;
+      }
+    }
   }
 }
 

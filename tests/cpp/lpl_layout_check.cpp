@@ -125,13 +125,39 @@ int main(int argc, char** argv) {
       rec_used[rec] = 1;
     }
   for (int r = 0; r < L.n_part_rec; ++r) CHECK(rec_used[r]);
+  // LDS collision statistics of the placement: extra lanes per accumulator bank per row half (each costs 8 LDS
+  // cycles on each of the 12 ds_add_f64) and extra records per bank quad per ds_read_b128 lane group
+  double extra_a = 0, extra_r = 0;
+  {
+    const int hubs = lpl_hubs(L.n_global);
+    auto read_group = [](int lane) {
+      const int l = lane & 31;
+      const int g = (l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 1;
+      return g + 2 * (lane >> 5);
+    };
+    for (int64_t r = 0; r < L.rows; ++r) {
+      int ca[2][32] = {}, cr[4][16] = {}, sr[4][16];
+      for (int g = 0; g < 4; ++g) for (int b = 0; b < 16; ++b) sr[g][b] = -1;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int s = L.cw[r * 64 + lane];
+        if (s < 0) continue;
+        ca[lane >> 5][lpl_acc_slot(s, lane, hubs) & 31]++;
+        const int g = read_group(lane);
+        if (sr[g][s & 15] != s) { cr[g][s & 15]++; sr[g][s & 15] = s; }  // same record next to itself: broadcast
+      }
+      for (int hlf = 0; hlf < 2; ++hlf) { int m = 1; for (int b = 0; b < 32; ++b) m = std::max(m, ca[hlf][b]); extra_a += m - 1; }
+      for (int g = 0; g < 4; ++g) { int m = 1; for (int b = 0; b < 16; ++b) m = std::max(m, cr[g][b]); extra_r += m - 1; }
+    }
+    extra_a /= (double)L.rows * 2;
+    extra_r /= (double)L.rows * 4;
+  }
   int64_t mx = 0, mn = 1LL << 60;
   for (int w = 0; w < grid; ++w) { mx = std::max(mx, wg_rows[w]); mn = std::min(mn, wg_rows[w]); }
   std::printf("{\"ok\": 1, \"n_global\": %d, \"n_tail\": %d, \"grid\": [%d, %d], \"max_slots\": %d, \"rows\": %lld, "
               "\"tiles\": %zu, \"cold\": %lld, \"cold_frac\": %.5f, \"pad_frac\": %.5f, \"wg_rows_min\": %lld, "
-              "\"wg_rows_max\": %lld, \"part_recs\": %d}\n",
+              "\"wg_rows_max\": %lld, \"part_recs\": %d, \"extra_atomic_lanes_per_half\": %.3f, \"extra_records_per_read_group\": %.3f}\n",
               L.n_global, L.n_tail, L.grid_a, L.grid_b, L.max_slots, (long long)L.rows, L.tile.size(),
               (long long)n_cold, (double)n_cold / n_obs, (double)L.rows * 64 / n_obs - 1.0, (long long)mn, (long long)mx,
-              L.n_part_rec);
+              L.n_part_rec, extra_a, extra_r);
   return 0;
 }
