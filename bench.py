@@ -173,6 +173,11 @@ def main():
     ap.add_argument("--comm", default="rccl", choices=["rccl", "gloo"],
                     help="exchange steps of the sharded path: RCCL inside the library (default) or a host "
                          "all-reduce over torch.distributed gloo (debug / boxes without a working fabric)")
+    ap.add_argument("--popularity", default="zipf1", choices=sorted(synth.POPULARITY),
+                    help="camera popularity law of the synthetic graph: zipf1 = the SURVEY 8(d) workload (headline); "
+                         "zipf0.5 / uniform = sensitivity variants of the same shape (never the headline)")
+    ap.add_argument("--long-track-frac", type=float, default=0.0,
+                    help="sensitivity variant: fraction of the observations on landmarks of 65..400 observations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the stored-tile comparison leg")
     args = ap.parse_args()
@@ -194,7 +199,8 @@ def main():
     alpha, lam, m = 0.01, 1e-4, args.m
     # the real BAL file when $POVAR_BAL_DIR holds it, else the seeded synthetic shape
     bal_path = synth.find_bal_file(args.problem, os.environ.get("POVAR_BAL_DIR"))
-    prob = synth.read_bal_file(bal_path) if bal_path else synth.make_bal_problem(args.problem)
+    prob = synth.read_bal_file(bal_path) if bal_path else \
+        synth.make_bal_problem(args.problem, args.popularity, args.long_track_frac)
     n_c, n_l, n_o = prob.n_cams, prob.n_lms, prob.n_obs
 
     n_dev = capi.lib().povar_device_count()
@@ -396,6 +402,12 @@ def main():
             "effective_x_peak": effective / HBM_PEAK_GBPS,
         },
     }
+    li = ctx.layout_info()
+    out["config"]["e0_layout"] = {"workgroups": li.grid, "lds_camera_slots": li.lds_slots, "global_cameras": li.n_global,
+                                  "grid_cameras": li.n_tail, "rows": li.n_rows, "tiles": li.n_tiles,
+                                  "lds_resident_obs_frac": 1.0 - li.n_cold / max(li.n_obs, 1)}
+    if not bal_path and (args.popularity != "zipf1" or args.long_track_frac > 0):
+        out["config"]["workload"] += f" [SENSITIVITY VARIANT: popularity={args.popularity}, long_track_frac={args.long_track_frac}]"
     if comm_used != "none":  # ncclCommCount of the attached communicator (host-hook runs: its world size)
         out["config"]["rccl_ranks" if comm_used == "rccl" else "host_comm_ranks"] = ctx.comm_ranks()
 

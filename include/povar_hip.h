@@ -218,6 +218,17 @@ int64_t povar_device_bytes(povar_ctx* ctx);
  * context's current E0 mode: what the landmark-major kernel and the per-camera kernel must stream by design
  * (each array once).  bench.py prices the HIP-event time of those kernels against it (roofline.achieved). */
 int povar_e0_model_bytes(povar_ctx* ctx, int64_t* lm_kernel_bytes, int64_t* cam_kernel_bytes);
+/* what the layout of the per-term E0 kernel decided for this problem (measurement / DESIGN.md tables) */
+typedef struct {
+  int32_t grid;         /* E0 workgroups */
+  int32_t lds_slots;    /* camera slots (record + accumulators) of the fullest workgroup */
+  int32_t n_global;     /* cameras resident in every workgroup */
+  int32_t n_tail;       /* cameras resident in one row and one column of the workgroup grid */
+  int64_t n_tiles, n_rows;  /* 64-lane tiles and observation rows of the row stream */
+  int64_t n_cold;       /* observations whose camera is not LDS-resident in their workgroup */
+  int64_t n_obs;
+} povar_layout_info;
+int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 
 /* ---- multi-GPU: landmarks sharded over ranks, one RCCL all-reduce per exchange step ---- */
 /* host-only: contiguous landmark range of `rank`, balanced by observation count */

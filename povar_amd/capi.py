@@ -43,6 +43,11 @@ class ProfileInfo(C.Structure):
                 ("binv_launches", C.c_int64), ("comm_ms", C.c_double), ("comm_launches", C.c_int64)]
 
 
+class LayoutInfo(C.Structure):
+    _fields_ = [("grid", C.c_int32), ("lds_slots", C.c_int32), ("n_global", C.c_int32), ("n_tail", C.c_int32),
+                ("n_tiles", C.c_int64), ("n_rows", C.c_int64), ("n_cold", C.c_int64), ("n_obs", C.c_int64)]
+
+
 class PovarError(RuntimeError):
     pass
 
@@ -318,6 +323,11 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         self._chk(self.L.povar_e0_model_bytes(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def layout_info(self):
+        li = LayoutInfo()
+        self._chk(self.L.povar_get_layout_info(self.h, C.byref(li)))
+        return li
 
     def comm_ranks(self):
         n = self.L.povar_comm_ranks(self.h)

@@ -1408,6 +1408,19 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
   return 0;
 }
 
+int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
+  if (!c || !out) return fail(-1, "null argument");
+  out->grid = c->e0c_grid;
+  out->lds_slots = c->v2_max_slots;
+  out->n_global = c->v2_n_global;
+  out->n_tail = c->v2_n_tail;
+  out->n_tiles = c->d.v2.n_tiles;
+  out->n_rows = c->v2_rows;
+  out->n_cold = c->n_cold3;
+  out->n_obs = c->n_obs;
+  return 0;
+}
+
 int povar_comm_ranks(povar_ctx* c) {
   if (!c) return fail(-1, "null context");
   if (c->host_fn) return c->world;

@@ -64,12 +64,16 @@ def _degrees(rng, n_cams, n_lms, n_obs):
     return k
 
 
-def _sample_cameras(rng, n_cams, lm_off):
-    """Zipf(1.0)-weighted sampling without replacement per landmark (redraw duplicates)."""
+POPULARITY = {"zipf1": 1.0, "zipf0.5": 0.5, "uniform": 0.0}
+
+
+def _sample_cameras(rng, n_cams, lm_off, zipf_s=1.0):
+    """Zipf(s)-weighted sampling without replacement per landmark (redraw duplicates); s = 1 is the SURVEY 8(d)
+    workload, s = 0 a uniform popularity (no hub cameras at all)."""
     n_obs = int(lm_off[-1])
     n_lms = lm_off.shape[0] - 1
     perm = rng.permutation(n_cams)
-    w = 1.0 / np.arange(1, n_cams + 1)
+    w = 1.0 / np.arange(1, n_cams + 1) ** zipf_s
     cdf = np.cumsum(w / w.sum())
     cdf[-1] = 1.0
     lm_of = np.repeat(np.arange(n_lms, dtype=np.int64), np.diff(lm_off))
@@ -95,12 +99,31 @@ def _sample_cameras(rng, n_cams, lm_off):
     return cam[order].astype(np.int32)
 
 
-def make_problem(n_cams, n_lms, n_obs, seed=0, noise_px=0.5) -> Problem:
+def make_problem(n_cams, n_lms, n_obs, seed=0, noise_px=0.5, popularity="zipf1", long_track_frac=0.0) -> Problem:
+    """popularity: camera popularity law of the graph ("zipf1" = SURVEY 8(d), "zipf0.5", "uniform").
+    long_track_frac: fraction of the observations moved onto landmarks of 65..min(n_cams, 400) observations
+    (real photo collections have such tracks; the SURVEY 8(d) degree law caps them at 49 for venice)."""
     rng = np.random.default_rng(seed)
     k = _degrees(rng, n_cams, n_lms, n_obs)
+    if long_track_frac > 0:
+        # lengthen the first landmarks to 65..kmax observations and take the same number of observations away
+        # from the others (never below 2), keeping n_lms and n_obs
+        kmax = min(n_cams, 400)
+        want = int(long_track_frac * n_obs)
+        n_long = max(1, want // ((65 + kmax) // 2))
+        new_k = rng.integers(65, kmax + 1, size=n_long)
+        delta = int(new_k.sum() - k[:n_long].sum())
+        k[:n_long] = new_k
+        i = n_long
+        while delta > 0:
+            take = np.flatnonzero(k[n_long:] > 2) + n_long
+            take = rng.choice(take, size=min(delta, take.size), replace=False)
+            k[take] -= 1
+            delta -= take.size
+        rng.shuffle(k)
     lm_off = np.zeros(n_lms + 1, dtype=np.int64)
     np.cumsum(k, out=lm_off[1:])
-    cam_idx = _sample_cameras(rng, n_cams, lm_off)
+    cam_idx = _sample_cameras(rng, n_cams, lm_off, POPULARITY[popularity])
     lm_of = np.repeat(np.arange(n_lms), k)
 
     # ground truth: points in a unit cube, cameras 5-15 units away looking at it
@@ -128,10 +151,11 @@ def make_problem(n_cams, n_lms, n_obs, seed=0, noise_px=0.5) -> Problem:
     return Problem(n_cams, n_lms, lm_off.astype(np.int32), cam_idx, np.ascontiguousarray(uv), cams, lms)
 
 
-def make_bal_problem(name: str) -> Problem:
-    """Seeded synthetic problem with the exact shape of a BAL problem (BASELINE.json configs)."""
+def make_bal_problem(name: str, popularity="zipf1", long_track_frac=0.0) -> Problem:
+    """Seeded synthetic problem with the exact shape of a BAL problem (BASELINE.json configs).  The defaults are the
+    SURVEY 8(d) workload; the other popularity laws / a long-track tail are sensitivity variants of the same shape."""
     n_c, n_l, n_o = BAL_SHAPES[name]
-    return make_problem(n_c, n_l, n_o, seed=BAL_SEEDS[name])
+    return make_problem(n_c, n_l, n_o, seed=BAL_SEEDS[name], popularity=popularity, long_track_frac=long_track_frac)
 
 
 def write_data_custom(path: str, prob: Problem) -> None:
