@@ -7,6 +7,11 @@
 #include <cmath>
 #include <cstdio>
 #include <limits>
+#include <fstream>
+#include <thread>
+
+#include <sys/resource.h>
+#include <unistd.h>
 
 #include "linearizor.hpp"
 
@@ -30,8 +35,15 @@ std::string item_oneline(const ResidualItem& it) {  // residual_info.cpp:77-80
 void finish_iteration(SolverSummary& summary, IterationSummary& it) {
   it.step_solver_time_in_seconds = it.scale_landmark_jacobian_time_in_seconds + it.stage2_time_in_seconds +
                                    it.solve_reduced_system_time_in_seconds + it.back_substitution_time_in_seconds;
-  if (it.iteration > 0 && !summary.iterations.empty())
-    it.cost_change_all_error = summary.iterations.back().cost.all.error - it.cost.all.error;
+  if (it.iteration > 0 && !summary.iterations.empty()) {  // cost.compared_to(previous), residual_info.cpp:43-61
+    const ResidualInfo& prev = summary.iterations.back().cost;
+    it.cost_change_all_error = prev.all.error - it.cost.all.error;
+    it.cost_change_all = {prev.all.num_obs - it.cost.all.num_obs, prev.all.error - it.cost.all.error,
+                          prev.all.error_avg() - it.cost.all.error_avg()};
+    it.cost_change_valid = {prev.valid.num_obs - it.cost.valid.num_obs, prev.valid.error - it.cost.valid.error,
+                            prev.valid.error_avg() - it.cost.valid.error_avg()};
+  }
+  get_memory_info(it.resident_memory, it.resident_memory_peak);
   summary.iterations.push_back(it);
   std::fflush(stdout);
 }
@@ -57,6 +69,13 @@ void finish_solve(SolverSummary& summary, const SolverOptions& options) {
     summary.residual_evaluation_time_in_seconds += it.residual_evaluation_time_in_seconds;
     summary.jacobian_evaluation_time_in_seconds += it.jacobian_evaluation_time_in_seconds;
   }
+  summary.logging_time_in_seconds = 0;  // "currently this is not computed", :136
+  unsigned long long rss = 0;
+  get_memory_info(rss, summary.resident_memory_peak);
+  // the reference reports TBB's arena concurrency / its observed peak; here one host thread drives the GPU
+  summary.num_threads_available = (int)std::thread::hardware_concurrency();
+  summary.num_threads_given = options.num_threads;
+  summary.num_threads_used = 1;
 }
 
 // compute_cost_decrease, bal_bundle_adjustment.cpp:163-176
@@ -309,50 +328,228 @@ std::string error_summary_oneline(const ResidualInfo& info, bool valid_first) { 
   return warning + "error: " + item_oneline(info.all) + ", error valid: " + item_oneline(info.valid);
 }
 
-void bundle_adjust_manual(BalProblem& bal_problem, const SolverOptions& so, SolverSummary* out) {
+void bundle_adjust_manual(BalProblem& bal_problem, const SolverOptions& so, SolverSummary* out,
+                          PipelineTimingSummary* timing) {
   SolverSummary local;
   SolverSummary& summary = out ? *out : local;
   Timer timer_total;
   optimize_lm(bal_problem, so, summary, timer_total, false);   // first step: linear VarPro, :860
   create_homogeneous_landmark(bal_problem);                    // :861
   optimize_lm(bal_problem, so, summary, timer_total, true);    // second step: Riemannian manifold optimisation, :864
+  if (timing) timing->optimize_time = summary.total_time_in_seconds;  // :868-870
 }
 
-// ba_log.json: the per-iteration arrays of the reference's log (bal/ba_log.hpp:147-245,
-// ba_log.cpp:72-114), flat arrays + _static + _type
-void save_ba_log_json(const SolverSummary& s, const SolverOptions& o, const BalProblem& p) {
+bool get_memory_info(unsigned long long& resident, unsigned long long& resident_peak) {
+  std::ifstream fs("/proc/self/statm");
+  if (fs.fail()) return false;
+  unsigned long long program_size = 0, resident_size = 0;
+  fs >> program_size >> resident_size;
+  resident = resident_size * (unsigned long long)sysconf(_SC_PAGESIZE);
+  struct rusage ru;
+  getrusage(RUSAGE_SELF, &ru);
+  resident_peak = (unsigned long long)ru.ru_maxrss * 1024;
+  return true;
+}
+
+void summarize_problem(const BalProblem& p, const std::string& input_path, bool compute_sparsity, DatasetSummary& out) {
+  out.type = "bal";
+  out.input_path = input_path;
+  out.num_cameras = p.num_cameras();
+  out.num_landmarks = p.num_landmarks();
+  out.num_observations = p.num_observations();
+  if (compute_sparsity) {  // compute_rcs_sparsity, bal_problem.cpp:748-814: share of empty blocks of the reduced camera system
+    const size_t nc = (size_t)p.num_cameras();
+    std::vector<bool> mask(nc * nc, false);
+    for (const auto& lm : p.landmarks())
+      for (const auto& oi : lm.obs)
+        for (const auto& oj : lm.obs) {
+          if (oj.first < oi.first) mask[(size_t)oi.first * nc + oj.first] = true;
+          else break;  // ordered map
+        }
+    const double nnz = (double)nc + 2.0 * (double)std::count(mask.begin(), mask.end(), true);
+    out.rcs_sparsity = 1.0 - nnz / ((double)nc * (double)nc);
+  }
+  double sum = 0, mn = std::numeric_limits<double>::infinity(), mx = 0;
+  for (const auto& lm : p.landmarks()) {
+    const double k = (double)lm.obs.size();
+    sum += k;
+    mn = std::min(mn, k);
+    mx = std::max(mx, k);
+  }
+  const double n = std::max(1, p.num_landmarks()), mean = sum / n;
+  double var = 0;
+  for (const auto& lm : p.landmarks()) var += ((double)lm.obs.size() - mean) * ((double)lm.obs.size() - mean);
+  out.per_lm_obs = {mean, p.num_landmarks() ? mn : 0.0, mx, std::sqrt(var / n)};
+  out.per_host_lms = DatasetSummary::Stats();
+}
+
+namespace {
+
+std::string json_escape(const std::string& s) {
+  std::string o;
+  for (char ch : s) {
+    if (ch == '"' || ch == '\\') { o += '\\'; o += ch; }
+    else if (ch == '\n') o += "\\n";
+    else o += ch;
+  }
+  return o;
+}
+
+// one iteration of the log after log_summary(BaLog::BaIteration&, prev, IterationSummary) (ba_log_utils.cpp:99-167):
+// an unsuccessful iteration repeats the previous iteration's cost values ("for monotonic plots")
+struct LoggedIteration {
+  const IterationSummary* it;
+  long num_obs, num_obs_valid, num_obs_valid_change;
+  double cost, cost_change, cost_valid, cost_valid_change, cost_avg_valid, cost_avg_valid_change;
+  double residual_block_mean, residual_block_valid_mean, grad_max_norm, grad_norm, step_norm, relative_decrease;
+};
+
+}  // namespace
+
+void save_ba_log_json(const BalPipelineSummary& ps, const SolverOptions& o) {
   if (o.log.disable_all || o.log.log_path.empty()) return;
+  const SolverSummary& s = ps.solver;
+  std::vector<LoggedIteration> L;
+  L.reserve(s.iterations.size());
+  for (const IterationSummary& it : s.iterations) {
+    LoggedIteration l{};
+    l.it = &it;
+    if (it.step_is_successful || L.empty()) {
+      l.num_obs = it.cost.all.num_obs;
+      l.num_obs_valid = it.cost.valid.num_obs;
+      l.num_obs_valid_change = it.cost_change_valid.num_obs;
+      l.cost = it.cost.all.error;
+      l.cost_change = it.cost_change_all.error;
+      l.cost_valid = it.cost.valid.error;
+      l.cost_valid_change = it.cost_change_valid.error;
+      l.cost_avg_valid = it.cost.valid.error_avg();
+      l.cost_avg_valid_change = it.cost_change_valid.error_avg;
+      l.residual_block_mean = it.cost.all.residual_mean();
+      l.residual_block_valid_mean = it.cost.valid.residual_mean();
+      l.grad_max_norm = it.gradient_max_norm;
+      l.grad_norm = it.gradient_norm;
+      l.step_norm = it.step_norm;
+      l.relative_decrease = it.relative_decrease;
+    } else {
+      const LoggedIteration& p = L.back();
+      l.num_obs = p.num_obs;
+      l.num_obs_valid = p.num_obs_valid;
+      l.cost = p.cost;
+      l.cost_valid = p.cost_valid;
+      l.cost_avg_valid = p.cost_avg_valid;
+      l.residual_block_mean = p.residual_block_mean;
+      l.residual_block_valid_mean = p.residual_block_valid_mean;
+      l.grad_max_norm = p.grad_max_norm;
+      l.grad_norm = p.grad_norm;
+    }
+    L.push_back(l);
+  }
   FILE* f = std::fopen(o.log.log_path.c_str(), "w");
-  if (!f) return;
-  auto arr_d = [&](const char* name, auto get, bool last = false) {
-    std::fprintf(f, "  \"%s\": [", name);
-    for (size_t i = 0; i < s.iterations.size(); ++i) std::fprintf(f, "%s%.17g", i ? ", " : "", (double)get(s.iterations[i]));
-    std::fprintf(f, "]%s\n", last ? "" : ",");
+  if (!f) {
+    std::fprintf(stderr, "Could not save BA log to %s.\n", o.log.log_path.c_str());
+    return;
+  }
+  // nlohmann::json objects are ordered maps: keys come out sorted, "_static" and "_type" first
+  const DatasetSummary& d = ps.dataset;
+  auto stats = [&](const char* name, const DatasetSummary::Stats& st, const char* tail) {
+    std::fprintf(f, "            \"%s\": {\"max\": %.17g, \"mean\": %.17g, \"min\": %.17g, \"stddev\": %.17g}%s\n", name, st.max,
+                 st.mean, st.min, st.stddev, tail);
   };
-  std::fprintf(f, "{\n  \"_type\": \"rootba_povar\",\n");
-  std::fprintf(f, "  \"_static\": {\"problem_info\": {\"num_cameras\": %d, \"num_landmarks\": %d, \"num_observations\": %ld},"
-                  " \"solver\": {\"solver_type\": \"%s\", \"termination_type\": \"%s\", \"message\": \"%s\","
-                  " \"num_successful_steps\": %d, \"num_unsuccessful_steps\": %d, \"num_linear_solves\": %d,"
-                  " \"total_time_in_seconds\": %.6f}},\n",
-               p.num_cameras(), p.num_landmarks(), p.num_observations(), s.solver_type.c_str(),
-               s.termination_type == CONVERGENCE ? "CONVERGENCE" : "NO_CONVERGENCE", s.message.c_str(),
-               s.num_successful_steps, s.num_unsuccessful_steps, s.num_linear_solves, s.total_time_in_seconds);
-  arr_d("iteration", [](const IterationSummary& i) { return i.iteration; });
-  arr_d("cost", [](const IterationSummary& i) { return i.cost.all.error; });
-  arr_d("cost_valid", [](const IterationSummary& i) { return i.cost.valid.error; });
-  arr_d("step_is_successful", [](const IterationSummary& i) { return i.step_is_successful ? 1 : 0; });
-  arr_d("step_is_valid", [](const IterationSummary& i) { return i.step_is_valid ? 1 : 0; });
-  arr_d("relative_decrease", [](const IterationSummary& i) { return i.relative_decrease; });
-  arr_d("trust_region_radius", [](const IterationSummary& i) { return i.trust_region_radius; });
-  arr_d("linear_solver_iterations", [](const IterationSummary& i) { return i.linear_solver_iterations; });
-  arr_d("cumulative_time", [](const IterationSummary& i) { return i.cumulative_time_in_seconds; });
-  arr_d("iteration_time", [](const IterationSummary& i) { return i.iteration_time_in_seconds; });
-  arr_d("stage1_time", [](const IterationSummary& i) { return i.stage1_time_in_seconds; });
-  arr_d("prepare_time", [](const IterationSummary& i) { return i.prepare_time_in_seconds; });
-  arr_d("solve_reduced_system_time", [](const IterationSummary& i) { return i.solve_reduced_system_time_in_seconds; });
-  arr_d("back_substitution_time", [](const IterationSummary& i) { return i.back_substitution_time_in_seconds; }, true);
-  std::fprintf(f, "}\n");
+  std::fprintf(f, "{\n    \"_static\": {\n        \"problem_info\": {\n");
+  std::fprintf(f, "            \"input_path\": \"%s\",\n            \"num_cameras\": %d,\n            \"num_landmarks\": %d,\n"
+                  "            \"num_observations\": %ld,\n", json_escape(d.input_path).c_str(), d.num_cameras, d.num_landmarks,
+               d.num_observations);
+  stats("per_host_lms", d.per_host_lms, ",");
+  stats("per_lm_obs", d.per_lm_obs, ",");
+  std::fprintf(f, "            \"rcs_sparsity\": %.17g,\n            \"type\": \"%s\"\n        },\n", d.rcs_sparsity, d.type.c_str());
+  std::fprintf(f, "        \"solver\": {\n"
+                  "            \"fraction_grouped\": %.17g,\n            \"grouping_time_in_seconds\": %.17g,\n"
+                  "            \"jacobian_evaluation_time_in_seconds\": %.17g,\n            \"linear_solver_time_in_seconds\": %.17g,\n"
+                  "            \"logging_time_in_seconds\": %.17g,\n            \"merge_factor\": true,\n"
+                  "            \"message\": \"%s\",\n            \"minimizer_time_in_seconds\": %.17g,\n"
+                  "            \"num_jacobian_evaluations\": %d,\n            \"num_linear_solves\": %d,\n"
+                  "            \"num_residual_evaluations\": %d,\n            \"num_successful_steps\": %d,\n"
+                  "            \"num_threads_available\": %d,\n            \"num_threads_given\": %d,\n"
+                  "            \"num_threads_used\": %d,\n            \"num_unsuccessful_steps\": %d,\n"
+                  "            \"postprocessor_time_in_seconds\": %.17g,\n            \"preprocessor_time_in_seconds\": %.17g,\n"
+                  "            \"residual_evaluation_time_in_seconds\": %.17g,\n            \"resident_memory_peak\": %llu,\n"
+                  "            \"solver_type\": \"%s\",\n            \"termination_type\": \"%s\",\n"
+                  "            \"total_time_in_seconds\": %.17g\n        },\n",
+               s.fraction_grouped, s.grouping_time_in_seconds, s.jacobian_evaluation_time_in_seconds,
+               s.linear_solver_time_in_seconds, s.logging_time_in_seconds, json_escape(s.message).c_str(),
+               s.minimizer_time_in_seconds, s.num_jacobian_evaluations, s.num_linear_solves, s.num_residual_evaluations,
+               s.num_successful_steps, s.num_threads_available, s.num_threads_given, s.num_threads_used,
+               s.num_unsuccessful_steps, s.postprocessor_time_in_seconds, s.preprocessor_time_in_seconds,
+               s.residual_evaluation_time_in_seconds, s.resident_memory_peak, s.solver_type.c_str(),
+               s.termination_type == CONVERGENCE ? "CONVERGENCE" : s.termination_type == NO_CONVERGENCE ? "NO_CONVERGENCE" : "FAILURE",
+               s.total_time_in_seconds);
+  const PipelineTimingSummary& t = ps.timing;
+  std::fprintf(f, "        \"timing\": {\"load\": %.17g, \"optimize\": %.17g, \"postprocess\": %.17g, \"preprocess\": %.17g, "
+                  "\"total\": %.17g}\n    },\n    \"_type\": \"rootba_povar\"",
+               t.load_time, t.optimize_time, t.postprocess_time, t.preprocess_time,
+               t.load_time + t.preprocess_time + t.optimize_time);  // PipelineTiming::update_total, ba_log.hpp:95-100
+  auto arr = [&](const char* name, auto fmt_one) {
+    std::fprintf(f, ",\n    \"%s\": [", name);
+    for (size_t i = 0; i < L.size(); ++i) {
+      if (i) std::fprintf(f, ", ");
+      fmt_one(L[i]);
+    }
+    std::fprintf(f, "]");
+  };
+#define ARR_D(name, expr) arr(name, [&](const LoggedIteration& l) { std::fprintf(f, "%.17g", (double)(expr)); })
+#define ARR_I(name, expr) arr(name, [&](const LoggedIteration& l) { std::fprintf(f, "%lld", (long long)(expr)); })
+#define ARR_B(name, expr) arr(name, [&](const LoggedIteration& l) { std::fprintf(f, "%s", (expr) ? "true" : "false"); })
+  // BaLog::BaIteration (ba_log.hpp:147-245), alphabetical like the reference's output
+  ARR_D("back_substitution_time", l.it->back_substitution_time_in_seconds);
+  ARR_D("compute_gradient_time", l.it->compute_gradient_time_in_seconds);
+  ARR_D("compute_preconditioner_time", l.it->compute_preconditioner_time_in_seconds);
+  ARR_D("cost", l.cost);
+  ARR_D("cost_avg_valid", l.cost_avg_valid);
+  ARR_D("cost_avg_valid_change", l.cost_avg_valid_change);
+  ARR_D("cost_change", l.cost_change);
+  ARR_D("cost_valid", l.cost_valid);
+  ARR_D("cost_valid_change", l.cost_valid_change);
+  ARR_D("cumulative_time", l.it->cumulative_time_in_seconds);
+  ARR_D("grad_max_norm", l.grad_max_norm);
+  ARR_D("grad_norm", l.grad_norm);
+  ARR_D("grad_projected_max_norm", 0.0);  // never assigned by log_summary: stays at its initialiser
+  ARR_D("grad_projected_norm", 0.0);
+  ARR_I("iteration", l.it->iteration);
+  ARR_D("iteration_time", l.it->iteration_time_in_seconds);
+  ARR_D("jacobian_evaluation_time", l.it->jacobian_evaluation_time_in_seconds);
+  ARR_D("landmark_damping_time", l.it->landmark_damping_time_in_seconds);
+  ARR_I("linear_solver_iterations", l.it->linear_solver_iterations);
+  arr("linear_solver_type", [&](const LoggedIteration& l) { std::fprintf(f, "\"%s\"", json_escape(l.it->linear_solver_type).c_str()); });
+  ARR_D("logging_time", l.it->logging_time_in_seconds);
+  ARR_I("num_obs", l.num_obs);
+  ARR_I("num_obs_valid", l.num_obs_valid);
+  ARR_I("num_obs_valid_change", l.num_obs_valid_change);
+  ARR_D("perform_qr_time", l.it->perform_qr_time_in_seconds);
+  ARR_D("prepare_time", l.it->prepare_time_in_seconds);
+  ARR_D("relative_decrease", l.relative_decrease);
+  ARR_I("resident_memory", l.it->resident_memory);
+  ARR_I("resident_memory_peak", l.it->resident_memory_peak);
+  ARR_D("residual_block_mean", l.residual_block_mean);
+  ARR_D("residual_block_valid_mean", l.residual_block_valid_mean);
+  ARR_D("residual_evaluation_time", l.it->residual_evaluation_time_in_seconds);
+  ARR_D("scale_landmark_jacobian_time", l.it->scale_landmark_jacobian_time_in_seconds);
+  ARR_D("scale_pose_jacobian_time", l.it->scale_pose_jacobian_time_in_seconds);
+  ARR_D("solve_reduced_system_time", l.it->solve_reduced_system_time_in_seconds);
+  ARR_D("stage1_time", l.it->stage1_time_in_seconds);
+  ARR_D("stage2_time", l.it->stage2_time_in_seconds);
+  ARR_B("step_is_nonmonotonic", l.it->step_is_nonmonotonic);
+  ARR_B("step_is_successful", l.it->step_is_successful);
+  ARR_B("step_is_valid", l.it->step_is_valid);
+  ARR_D("step_norm", l.step_norm);
+  ARR_D("step_solver_time", l.it->step_solver_time_in_seconds);
+  ARR_D("trust_region_radius", l.it->trust_region_radius);
+  ARR_D("update_cameras_time", l.it->update_cameras_time_in_seconds);
+#undef ARR_D
+#undef ARR_I
+#undef ARR_B
+  std::fprintf(f, "\n}\n");
   std::fclose(f);
+  if (!o.log.disable_all) std::fprintf(stderr, "Saved log for %zu iterations to %s.\n", L.size(), o.log.log_path.c_str());
 }
 
 }  // namespace povar_host

@@ -1,3 +1,4 @@
+#include <chrono>
 #include "bal_problem.hpp"
 
 #include <sys/stat.h>
@@ -8,6 +9,7 @@
 #include <stdexcept>
 
 #include "solver_options.hpp"
+#include "linearizor.hpp"
 
 namespace povar_host {
 
@@ -158,7 +160,9 @@ void BalProblem::flatten(std::vector<int>& lm_off, std::vector<int>& cam_idx, st
 
 // load_normalized_bal_problem, bal_problem.cpp:874-955.  normalize/perturb/filter_obs have no
 // effect on the PoVar state and are not restated.
-BalProblem load_normalized_bal_problem(const BalDatasetOptions& options) {
+BalProblem load_normalized_bal_problem(const BalDatasetOptions& options, DatasetSummary* dataset_summary,
+                                       PipelineTimingSummary* timing_summary) {
+  const auto t0 = std::chrono::steady_clock::now();
   BalProblem p;
   p.quiet = options.quiet;
   if (options.create_dataset) {
@@ -166,6 +170,12 @@ BalProblem load_normalized_bal_problem(const BalDatasetOptions& options) {
     std::exit(0);  // bal_problem.cpp:899-903
   }
   p.load_bal_eccv(options.input);
+  const double time_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (timing_summary) {  // bal_problem.cpp:939-942 (the preprocessing steps are no-ops on this path)
+    timing_summary->load_time = time_load;
+    timing_summary->preprocess_time = 0;
+  }
+  if (dataset_summary) summarize_problem(p, options.input, true, *dataset_summary);  // :944-947
   return p;
 }
 

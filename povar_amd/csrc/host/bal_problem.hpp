@@ -62,6 +62,7 @@ class BalProblem {
   std::vector<Landmark> landmarks_;
 };
 
-BalProblem load_normalized_bal_problem(const struct BalDatasetOptions& options);
+BalProblem load_normalized_bal_problem(const struct BalDatasetOptions& options, struct DatasetSummary* dataset_summary = nullptr,
+                                       struct PipelineTimingSummary* timing_summary = nullptr);
 
 }  // namespace povar_host

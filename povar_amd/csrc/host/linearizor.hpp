@@ -24,12 +24,22 @@ struct ResidualInfo {  // residual_info.hpp:78-92
 };
 std::string error_summary_oneline(const ResidualInfo& info, bool valid_first);
 
-struct IterationSummary {  // solver_summary.hpp (fields used on this path)
+struct ResidualChangeItem {  // residual_info.hpp: "previous - this" (residual_info.cpp:43-53)
+  long num_obs = 0;
+  double error = 0, error_avg = 0;
+};
+struct IterationSummary {  // solver_summary.hpp:120-222
   int iteration = 0;
   bool step_is_valid = false;
+  bool step_is_nonmonotonic = false;
   bool step_is_successful = false;
   ResidualInfo cost;
+  ResidualChangeItem cost_change_all, cost_change_valid;
   double cost_change_all_error = 0;
+  double gradient_max_norm = 0, gradient_norm = 0, step_norm = 0;  // never set on this path (logged as 0)
+  double logging_time_in_seconds = 0, perform_qr_time_in_seconds = 0, compute_preconditioner_time_in_seconds = 0,
+         compute_gradient_time_in_seconds = 0;
+  unsigned long long resident_memory = 0, resident_memory_peak = 0;
   double relative_decrease = 0;
   double trust_region_radius = 0;
   int linear_solver_iterations = 0;
@@ -57,6 +67,26 @@ struct SolverSummary {
   double preprocessor_time_in_seconds = 0, minimizer_time_in_seconds = 0, total_time_in_seconds = 0;
   double linear_solver_time_in_seconds = 0, residual_evaluation_time_in_seconds = 0,
          jacobian_evaluation_time_in_seconds = 0;
+  double logging_time_in_seconds = 0, grouping_time_in_seconds = 0, postprocessor_time_in_seconds = 0;
+  int num_threads_given = 0, num_threads_used = 0, num_threads_available = 0;
+  unsigned long long resident_memory_peak = 0;
+  double fraction_grouped = 0;
+};
+
+// bal/bal_pipeline_summary.hpp:42-79
+struct DatasetSummary {
+  struct Stats { double mean = 0, min = 0, max = 0, stddev = 0; };
+  std::string type, input_path;
+  int num_cameras = 0, num_landmarks = 0;
+  long num_observations = 0;
+  double rcs_sparsity = 0;
+  Stats per_lm_obs, per_host_lms;
+};
+struct PipelineTimingSummary { double load_time = 0, preprocess_time = 0, optimize_time = 0, postprocess_time = 0; };
+struct BalPipelineSummary {
+  DatasetSummary dataset;
+  PipelineTimingSummary timing;
+  SolverSummary solver;
 };
 
 class Linearizor {
@@ -90,7 +120,13 @@ void set_linearizor_factory(LinearizorFactory f);
 
 // solver/bal_bundle_adjustment.cpp:848-876
 void bundle_adjust_manual(BalProblem& bal_problem, const SolverOptions& solver_options,
-                          SolverSummary* output_solver_summary);
-void save_ba_log_json(const SolverSummary& summary, const SolverOptions& options, const BalProblem& problem);
+                          SolverSummary* output_solver_summary = nullptr, PipelineTimingSummary* output_timing = nullptr);
+// BaLog::save_json (bal/ba_log.cpp:63-150) after log_summary (bal/ba_log_utils.cpp:43-186): every per-iteration
+// field of BaLog::BaIteration as a flat array, _static {problem_info, timing, solver}, _type
+void save_ba_log_json(const BalPipelineSummary& summary, const SolverOptions& options);
+// BalProblem::summarize_problem (bal/bal_problem.cpp:817-859)
+void summarize_problem(const BalProblem& problem, const std::string& input_path, bool compute_sparsity, DatasetSummary& out);
+// util/system_utils.cpp:52-95 (Linux branch)
+bool get_memory_info(unsigned long long& resident, unsigned long long& resident_peak);
 
 }  // namespace povar_host

@@ -213,9 +213,10 @@ int main(int argc, char** argv) {
   BalAppOptions options;
   if (!parse_bal_app_arguments(argc, argv, options)) return 1;
   set_linearizor_factory(make_oracle);
-  BalProblem bal_problem = load_normalized_bal_problem(options.dataset);
-  SolverSummary summary;
-  bundle_adjust_manual(bal_problem, options.solver, &summary);
-  save_ba_log_json(summary, options.solver, bal_problem);
+  // src/app/bal.cpp:83-99: load (+ dataset summary, timing) -> solve -> postprocess -> log
+  BalPipelineSummary summary;
+  BalProblem bal_problem = load_normalized_bal_problem(options.dataset, &summary.dataset, &summary.timing);
+  bundle_adjust_manual(bal_problem, options.solver, &summary.solver, &summary.timing);
+  save_ba_log_json(summary, options.solver);
   return 0;
 }
