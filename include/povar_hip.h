@@ -218,6 +218,23 @@ int64_t povar_device_bytes(povar_ctx* ctx);
  * context's current E0 mode: what the landmark-major kernel and the per-camera kernel must stream by design
  * (each array once).  bench.py prices the HIP-event time of those kernels against it (roofline.achieved). */
 int povar_e0_model_bytes(povar_ctx* ctx, int64_t* lm_kernel_bytes, int64_t* cam_kernel_bytes);
+/* Device-side stage timings (hipEvent pairs on the context's stream around the entry points), the source of the
+ * IterationSummary timing fields of solver/solver_summary.hpp:186-212 that LinearizorPowerVarproj fills from host
+ * timers (linearizor_power_varproj.cpp:61-72, 194-233, 257-258).  Accumulated since povar_timings_enable(ctx, 1). */
+typedef struct {
+  double linearize_ms;  /* linearize_pOSE / linearize_projective_space_homogeneous: stage1_time */
+  int64_t linearize_calls;
+  double prepare_ms;    /* prepare_Hb_*: prepare_time (+ scale_pose_jacobian, landmark_damping) */
+  int64_t prepare_calls;
+  double solve_ms;      /* solve_pOSE / solve_joint (power series) or PCG / CHOLESKY: solve_reduced_system_time */
+  int64_t solve_calls;
+  double apply_ms;      /* apply / apply_joint: back_substitution_time + update_cameras_time */
+  int64_t apply_calls;
+  double other_ms;      /* cost evaluations, landmark initialisation */
+  int64_t other_calls;
+} povar_timings_info;
+int povar_timings_enable(povar_ctx* ctx, int32_t enable);
+int povar_timings(povar_ctx* ctx, povar_timings_info* out);
 /* what the layout of the per-term E0 kernel decided for this problem (measurement / DESIGN.md tables) */
 typedef struct {
   int32_t grid;         /* E0 workgroups */

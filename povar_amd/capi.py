@@ -48,6 +48,13 @@ class LayoutInfo(C.Structure):
                 ("n_tiles", C.c_int64), ("n_rows", C.c_int64), ("n_cold", C.c_int64), ("n_obs", C.c_int64)]
 
 
+class TimingsInfo(C.Structure):
+    _fields_ = [("linearize_ms", C.c_double), ("linearize_calls", C.c_int64), ("prepare_ms", C.c_double),
+                ("prepare_calls", C.c_int64), ("solve_ms", C.c_double), ("solve_calls", C.c_int64),
+                ("apply_ms", C.c_double), ("apply_calls", C.c_int64), ("other_ms", C.c_double),
+                ("other_calls", C.c_int64)]
+
+
 class PovarError(RuntimeError):
     pass
 
@@ -323,6 +330,14 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         self._chk(self.L.povar_e0_model_bytes(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def timings_enable(self, on=True):
+        self._chk(self.L.povar_timings_enable(self.h, C.c_int32(1 if on else 0)))
+
+    def timings(self):
+        ti = TimingsInfo()
+        self._chk(self.L.povar_timings(self.h, C.byref(ti)))
+        return ti
 
     def layout_info(self):
         li = LayoutInfo()

@@ -61,6 +61,9 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
     sc_step2_ = homogeneous && options.solver_type_step_2 == SolverOptions::SolverTypeRiemannian::RIPCG;
     // LinearizorSC::linearize_pOSE does not scale the landmark Jacobian columns (linearizor_sc.cpp:163-191)
     if (sc_step1_) check(povar_set_jl_col_scaling(ctx_, 0), "povar_set_jl_col_scaling");
+    // IterationSummary timings come from the device (hipEvents on the library's stream, povar_timings), not from
+    // host clocks around the calls
+    check(povar_timings_enable(ctx_, 1), "povar_timings_enable");
     push_state();
     bal_problem_.mirror = this;
   }
@@ -81,7 +84,8 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
     povar_residual_info r;
     check(povar_error_pose(ctx_, options_.alpha, &r), "povar_error_pose");
     ri = to_ri(r);
-    IF_SET(it_summary_)->residual_evaluation_time_in_seconds += t.elapsed();
+    (void)t;
+    IF_SET(it_summary_)->residual_evaluation_time_in_seconds += device_seconds(4);
     IF_SET(summary_)->num_residual_evaluations += 1;
   }
   void compute_error_homogeneous(ResidualInfo& ri, bool) override {
@@ -89,7 +93,8 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
     povar_residual_info r;
     check(povar_error_homogeneous(ctx_, &r), "povar_error_homogeneous");
     ri = to_ri(r);
-    IF_SET(it_summary_)->residual_evaluation_time_in_seconds += t.elapsed();
+    (void)t;
+    IF_SET(it_summary_)->residual_evaluation_time_in_seconds += device_seconds(4);
     IF_SET(summary_)->num_residual_evaluations += 1;
   }
   void linearize_pOSE(double alpha) override {
@@ -100,7 +105,8 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
       std::fprintf(stderr, "FATAL: did not expect numerical failure during linearization\n");
       std::abort();
     }
-    const double e = t.elapsed();
+    (void)t;
+    const double e = device_seconds(0);
     IF_SET(it_summary_)->jacobian_evaluation_time_in_seconds = e;
     IF_SET(it_summary_)->stage1_time_in_seconds = e;
     IF_SET(summary_)->num_jacobian_evaluations += 1;
@@ -113,7 +119,8 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
       std::fprintf(stderr, "FATAL: did not expect numerical failure during linearization\n");
       std::abort();
     }
-    const double e = t.elapsed();
+    (void)t;
+    const double e = device_seconds(0);
     IF_SET(it_summary_)->jacobian_evaluation_time_in_seconds = e;
     IF_SET(it_summary_)->stage1_time_in_seconds = e;
     IF_SET(summary_)->num_jacobian_evaluations += 1;
@@ -128,19 +135,20 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
       check(povar_solve_pose_sc(ctx_, lambda, chol ? POVAR_SC_CHOLESKY : POVAR_SC_PCG, options_.min_linear_solver_iterations,
                                 options_.max_linear_solver_iterations, options_.eta, inc.data(), &iters, &term),
             "povar_solve_pose_sc");
-      fill_sc_summary(t.elapsed(), iters, term, chol);
+      IF_SET(it_summary_)->prepare_time_in_seconds = device_seconds(1);
+      fill_sc_summary(device_seconds(2), iters, term, chol);
       return inc;
     }
     const int st = so.solver_type_step_1 == SolverOptions::SolverType::POWER_SCHUR_COMPLEMENT
                        ? POVAR_POWER_SCHUR_COMPLEMENT : POVAR_POWER_VARPROJ;
     check(povar_prepare_pose(ctx_, lambda, st), "povar_prepare_pose");
-    check(povar_synchronize(ctx_), "povar_synchronize");
-    IF_SET(it_summary_)->prepare_time_in_seconds = t.reset();
     int32_t iters = 0, term = 0;
     check(povar_power_series_pose(ctx_, options_.power_sc_iterations, options_.eta, options_.r_tolerance, &iters, &term),
           "povar_power_series_pose");
     check(povar_get_increment(ctx_, inc.data()), "povar_get_increment");
-    fill_solver_summary(t.elapsed(), iters, term);
+    (void)t;
+    IF_SET(it_summary_)->prepare_time_in_seconds = device_seconds(1);
+    fill_solver_summary(device_seconds(2), iters, term);
     return inc;
   }
   VecX solve_joint(double lambda, double) override {
@@ -151,12 +159,15 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
       require_schur_jacobi();
       check(povar_solve_joint_sc(ctx_, lambda, options_.min_linear_solver_iterations, options_.max_linear_solver_iterations,
                                  options_.eta, inc.data(), &iters, &term), "povar_solve_joint_sc");
-      fill_sc_summary(t.elapsed(), iters, term, false);
+      IF_SET(it_summary_)->prepare_time_in_seconds = device_seconds(1);
+      fill_sc_summary(device_seconds(2), iters, term, false);
       return inc;
     }
     check(povar_solve_joint(ctx_, lambda, options_.power_sc_iterations, options_.eta, options_.r_tolerance,
                             inc.data(), &iters, &term), "povar_solve_joint");
-    fill_solver_summary(t.elapsed(), iters, term);
+    (void)t;
+    IF_SET(it_summary_)->prepare_time_in_seconds = device_seconds(1);
+    fill_solver_summary(device_seconds(2), iters, term);
     return inc;
   }
   double apply(const SolverOptions& so, double alpha, VecX&& inc) override {
@@ -165,14 +176,16 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
     const int st = so.solver_type_step_1 == SolverOptions::SolverType::POWER_SCHUR_COMPLEMENT
                        ? POVAR_POWER_SCHUR_COMPLEMENT : POVAR_POWER_VARPROJ;
     check(povar_apply_pose(ctx_, st, alpha, inc.data(), &l_diff), "povar_apply_pose");
-    IF_SET(it_summary_)->back_substitution_time_in_seconds = t.elapsed();
+    (void)t;
+    IF_SET(it_summary_)->back_substitution_time_in_seconds = device_seconds(3);
     return l_diff;
   }
   double apply_joint(VecX&& inc) override {
     Timer t;
     double l_diff = 0;
     check(povar_apply_joint(ctx_, inc.data(), &l_diff), "povar_apply_joint");
-    IF_SET(it_summary_)->back_substitution_time_in_seconds = t.elapsed();
+    (void)t;
+    IF_SET(it_summary_)->back_substitution_time_in_seconds = device_seconds(3);
     return l_diff;
   }
 
@@ -200,6 +213,17 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
   }
 
  private:
+  // seconds of device time the entry points of `kind` have taken since the previous call of this helper
+  // (0 linearize, 1 prepare, 2 solve, 3 apply, 4 other)
+  double device_seconds(int kind) {
+    povar_timings_info t;
+    check(povar_timings(ctx_, &t), "povar_timings");
+    const double now[5] = {t.linearize_ms, t.prepare_ms, t.solve_ms, t.apply_ms, t.other_ms};
+    const double d = (now[kind] - seen_[kind]) * 1e-3;
+    seen_[kind] = now[kind];
+    return d;
+  }
+  double seen_[5] = {0, 0, 0, 0, 0};
   void push_state() {
     const int nc = bal_problem_.num_cameras(), nl = bal_problem_.num_landmarks();
     std::vector<double> cams(12 * (size_t)nc), lms((homogeneous_ ? 4 : 3) * (size_t)nl);

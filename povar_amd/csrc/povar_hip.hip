@@ -101,6 +101,14 @@ struct povar_ctx {
   int64_t v2_rows = 0;
   bool use_lpl = true;        // POVAR_E0_V1=1: keep e0_lm_cached<true> (lane per observation) for A/B runs
   DevBuf<double4> q4c;        // scatter scalars of the cold observations, in cold camera-major order
+  DevBuf<int> lm_slot0, lm_cnt_dev;
+  bool k1_qr = true;          // POVAR_K1_NORMAL_EQ=1: the round-1 normal-equation kernels (A/B accuracy runs)
+  // stage timings (povar_timings): hipEvent pairs around the entry points, summed on demand
+  bool timings_on = false;
+  std::vector<hipEvent_t> tev;
+  std::vector<int> tev_kind;
+  size_t tev_used = 0;
+  povar_timings_info tsum{};
   DevBuf<int> cam, lm, meta, hot_cams, cam_hot, cc_slot, cc_lm, cc_item_off, cc_cam_item_off, long_lm, long_first, long_cnt, cm_slot, cm_lm, item_off, item_cam,
       cam_item_off, flags;
   // state
@@ -364,6 +372,31 @@ void prof_mark(povar_ctx* c, int kind) {
 
 bool sharded(const povar_ctx* c) { return c->comm != nullptr || c->host_fn != nullptr; }
 
+// povar_timings: a pair of events on the context's stream around an entry point (kinds: 0 linearize, 1 prepare,
+// 2 solve = the power series / PCG / CHOLESKY, 3 apply = camera update + back-substitution, 4 other)
+struct TimeScope {
+  povar_ctx* c;
+  bool on;
+  TimeScope(povar_ctx* c_, int kind) : c(c_), on(c_->timings_on) {
+    if (!on) return;
+    if (c->tev_used + 2 > c->tev.size()) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        c->tev.push_back(e);
+        c->tev_kind.push_back(-1);
+      }
+    }
+    c->tev_kind[c->tev_used] = kind;
+    (void)hipEventRecord(c->tev[c->tev_used], c->stream);
+  }
+  ~TimeScope() {
+    if (!on) return;
+    (void)hipEventRecord(c->tev[c->tev_used + 1], c->stream);
+    c->tev_used += 2;
+  }
+};
+
 int allreduce(povar_ctx* c, double* buf, size_t n) {
   if (c->host_fn) {
     prof_mark(c, 2);
@@ -615,6 +648,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
   if (const char* g = std::getenv("POVAR_NO_FUSE")) c->fuse_binv = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_E0_V1")) c->use_lpl = !(g[0] == '1');
+  if (const char* g = std::getenv("POVAR_K1_NORMAL_EQ")) c->k1_qr = !(g[0] == '1');
 
   Layout L;
   build_layout(n_cams, n_lms, lm_offsets, cam_idx, obs, L);
@@ -698,6 +732,17 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     }
   }
   c->n_hot_acc = hot_acc_cap(n_cams);
+  {
+    std::vector<int> s0(n_lms, 0), cnt(n_lms, 0);
+    for (int l = 0; l < n_lms; ++l) {
+      cnt[l] = lm_offsets[l + 1] - lm_offsets[l];
+      s0[l] = cnt[l] > 0 ? L.slot_of_obs[lm_offsets[l]] : 0;
+    }
+    if (int rc = upload(c->lm_slot0, s0, c)) return rc;
+    if (int rc = upload(c->lm_cnt_dev, cnt, c)) return rc;
+    c->d.lm_slot0 = c->lm_slot0.p;
+    c->d.lm_cnt = c->lm_cnt_dev.p;
+  }
   {
     // lane-per-landmark layout of e0_lpl (lpl_layout.hpp)
     LplLayout V;
@@ -784,6 +829,8 @@ void povar_destroy(povar_ctx* c) {
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
+  c->lm_slot0.release(); c->lm_cnt_dev.release();
   c->uv.release(); c->cm_uv.release(); c->tiles.release();
   c->cam.release(); c->lm.release(); c->meta.release(); c->long_lm.release(); c->long_first.release();
   c->long_cnt.release(); c->cm_slot.release(); c->cm_lm.release(); c->item_off.release();
@@ -869,8 +916,13 @@ static void set_alpha(povar_ctx* c, double alpha) {
 int povar_init_landmarks_pose(povar_ctx* c, double alpha) {
   if (int rc = check_ctx(c)) return rc;
   set_alpha(c, alpha);
-  launch_lm(c, OpInit{});
-  launch_lm(c, OpInitRefine{});
+  TimeScope ts(c, 4);
+  if (c->k1_qr) {
+    hipLaunchKernelGGL(init_landmarks_qr, dim3(grid_for(c->n_lms, 256)), dim3(256), 0, c->stream, c->d);
+  } else {
+    launch_lm(c, OpInit{});
+    launch_lm(c, OpInitRefine{});
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -878,6 +930,7 @@ int povar_init_landmarks_pose(povar_ctx* c, double alpha) {
 int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
   if (int rc = check_ctx(c)) return rc;
   if (!out) return fail(-1, "null argument");
+  TimeScope ts(c, 4);
   set_alpha(c, alpha);
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
   launch_lm(c, OpError{});
@@ -904,6 +957,7 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   c->linearized_h = false;
   set_alpha(c, alpha);
   c->alpha_lin = alpha;
+  TimeScope ts(c, 0);
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
@@ -939,6 +993,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   if (!c->linearized) return fail(-1, "povar_prepare_pose before povar_linearize_pose");
   set_alpha(c, c->alpha_lin);
   c->joint = false;
+  TimeScope ts(c, 1);
   // scale_Jp_cols_pOSE on a new linearisation point (linearizor_power_varproj.cpp:192-195):
   // the scaling is part of the implicit tile; only stored tiles need (re)materialising.
   c->new_linearization_point = false;
@@ -994,6 +1049,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
                             int32_t* termination) {
   if (int rc = check_ctx(c)) return rc;
   if (m < 0) return fail(-1, "power_sc_iterations < 0");
+  TimeScope ts(c, 2);
   const bool norms = q_tol > 0 || r_tol > 0;
   // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
   // RCCL-in-capture is not something a 1-GPU box can validate); POVAR_GRAPH_COMM=1 opts in
@@ -1089,6 +1145,7 @@ int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const doub
   if (!c->linearized) return fail(-1, "povar_apply_pose before povar_linearize_pose");
   const size_t n = 12 * (size_t)c->n_cams;
   set_alpha(c, alpha);
+  TimeScope ts(c, 3);
   HIP_TRY(hipMemcpyAsync(c->inc.p, inc, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   if (solver_type == POVAR_POWER_VARPROJ) {
     // cpp:250-256: scale, update cameras, unscale, back-substitute at the new cameras
@@ -1133,6 +1190,7 @@ int povar_restore_joint(povar_ctx* c) { return povar_restore_pose(c); }
 int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
   if (int rc = check_ctx(c)) return rc;
   if (!out) return fail(-1, "null argument");
+  TimeScope ts(c, 4);
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
   launch_lm(c, OpErrorH{});
   launch_reduce<6>(c, c->scal.p);
@@ -1155,6 +1213,7 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
 
 int povar_linearize_homogeneous(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
+  TimeScope ts(c, 0);
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
@@ -1184,6 +1243,7 @@ int povar_linearize_homogeneous(povar_ctx* c) {
 int povar_prepare_joint(povar_ctx* c, double lambda) {
   if (int rc = check_ctx(c)) return rc;
   if (!c->linearized_h) return fail(-1, "povar_prepare_joint before povar_linearize_homogeneous");
+  TimeScope ts(c, 1);
   c->joint = true;
   c->new_linearization_point = false;
   c->d.lambda_lm = lambda;  // set_landmark_damping_joint, linearizor_power_varproj.cpp:136
@@ -1212,6 +1272,7 @@ int povar_solve_joint(povar_ctx* c, double lambda, int32_t m, double q_tol, doub
 int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
   if (int rc = check_ctx(c)) return rc;
   if (!c->linearized_h) return fail(-1, "povar_apply_joint before povar_linearize_homogeneous");
+  TimeScope ts(c, 3);
   HIP_TRY(hipMemcpyAsync(c->inc.p, inc, sizeof(double) * 11 * c->n_cams, hipMemcpyHostToDevice, c->stream));
   // cpp:280: back-substitute first (old cameras), then update the cameras (cpp:283-305)
   hipLaunchKernelGGL(cam_apply_inc_h, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, 1, (const double*)c->ncw.p);
@@ -1405,6 +1466,32 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
   }
   *lm_kernel = lm;
   *cam_kernel = cm;
+  return 0;
+}
+
+int povar_timings_enable(povar_ctx* c, int32_t enable) {
+  if (int rc = check_ctx(c)) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->timings_on = enable != 0;
+  c->tev_used = 0;
+  c->tsum = povar_timings_info{};
+  return 0;
+}
+
+int povar_timings(povar_ctx* c, povar_timings_info* out) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!out) return fail(-1, "null argument");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i + 1 < c->tev_used; i += 2) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->tev[i], c->tev[i + 1]));
+    double* slot[5] = {&c->tsum.linearize_ms, &c->tsum.prepare_ms, &c->tsum.solve_ms, &c->tsum.apply_ms, &c->tsum.other_ms};
+    int64_t* cnt[5] = {&c->tsum.linearize_calls, &c->tsum.prepare_calls, &c->tsum.solve_calls, &c->tsum.apply_calls, &c->tsum.other_calls};
+    const int k = c->tev_kind[i];
+    if (k >= 0 && k < 5) { *slot[k] += ms; ++*cnt[k]; }
+  }
+  c->tev_used = 0;
+  *out = c->tsum;
   return 0;
 }
 
@@ -1647,10 +1734,13 @@ int povar_solve_pose_sc(povar_ctx* c, double lambda, int32_t method, int32_t min
   if (int rc = povar_prepare_pose(c, lambda, POVAR_POWER_VARPROJ)) return rc;
   if (int rc = ensure_sc(c)) return rc;
   if (int rc = build_schur_jacobi<false>(c, lambda)) return rc;
-  if (method == POVAR_SC_CHOLESKY) {
-    if (int rc = run_cholesky(c, num_iterations, termination)) return rc;
-  } else {
-    if (int rc = run_pcg<12, false>(c, min_iterations, max_iterations, eta, num_iterations, termination)) return rc;
+  {
+    TimeScope ts(c, 2);
+    if (method == POVAR_SC_CHOLESKY) {
+      if (int rc = run_cholesky(c, num_iterations, termination)) return rc;
+    } else {
+      if (int rc = run_pcg<12, false>(c, min_iterations, max_iterations, eta, num_iterations, termination)) return rc;
+    }
   }
   if (int rc = povar_get_increment(c, inc)) return rc;
   for (size_t i = 0; i < 12 * (size_t)c->n_cams; ++i)
@@ -1664,7 +1754,10 @@ int povar_solve_joint_sc(povar_ctx* c, double lambda, int32_t min_iterations, in
   if (int rc = povar_prepare_joint(c, lambda)) return rc;
   if (int rc = ensure_sc(c)) return rc;
   if (int rc = build_schur_jacobi<true>(c, lambda)) return rc;
-  if (int rc = run_pcg<11, true>(c, min_iterations, max_iterations, eta, num_iterations, termination)) return rc;
+  {
+    TimeScope ts(c, 2);
+    if (int rc = run_pcg<11, true>(c, min_iterations, max_iterations, eta, num_iterations, termination)) return rc;
+  }
   if (int rc = povar_get_increment(c, inc)) return rc;
   for (size_t i = 0; i < 11 * (size_t)c->n_cams; ++i)
     if (!std::isfinite(inc[i])) return POVAR_NUMERIC_FAILURE;

@@ -117,6 +117,8 @@ struct Dp {
   const int* long_lm;
   const int* long_first;
   const int* long_cnt;
+  const int* lm_slot0;  // [n_lms] first wave-bin slot of each landmark (its slots are consecutive)
+  const int* lm_cnt;    // [n_lms] number of observations
   // static camera-major arrays
   const int* cm_slot;
   const int* cm_lm;
@@ -594,6 +596,67 @@ struct OpInit {
     d.lms4[lm] = x;
   }
 };
+
+// K1 as a least-squares solve with the conditioning of the reference's bdcSvd().solve (HLP:94): one thread per
+// landmark folds the 4 rows of every observation into an upper-triangular 3x4 [R | c] with Givens rotations
+// (an incremental QR of G; the error grows with kappa(G), not with kappa(G)^2 as for the normal equations) and
+// back-substitutes.  Near-parallel two-view landmarks (kappa 1e6..1e7) keep ~1e-9; the normal-equation kernels
+// OpInit / OpInitRefine lose them (tests/test_gpu_fuzz.py::test_init_landmarks_near_degenerate).  Runs once per
+// solve (linearizor_base.cpp:61-67), so the uncoalesced per-landmark walk does not matter.
+__global__ __launch_bounds__(256) void init_landmarks_qr(Dp d) {
+  const int lm = blockIdx.x * 256 + threadIdx.x;
+  if (lm >= d.n_lms) return;
+  const int s0 = d.lm_slot0[lm], k = d.lm_cnt[lm];
+  double R[6] = {0, 0, 0, 0, 0, 0}, c[3] = {0, 0, 0};  // R = [r00 r01 r02; 0 r11 r12; 0 0 r22]
+  for (int i = 0; i < k; ++i) {
+    const int slot = s0 + i;
+    const Cam P = load_cam(d.cams4, d.cam[slot]);
+    const double2 uv = d.uv[slot];
+    double g[12];
+    pose_jl(d, P, uv.x, uv.y, 1.0, make_double4(1, 1, 1, 1), g);
+    const double z[4] = {d.sb * (P.r2.w * uv.x - P.r0.w), d.sb * (P.r2.w * uv.y - P.r1.w),
+                         d.sa * (uv.x - P.r0.w), d.sa * (uv.y - P.r1.w)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double a0 = g[3 * r], a1 = g[3 * r + 1], a2 = g[3 * r + 2], b = z[r];
+      // eliminate a0 against r00, a1 against r11, a2 against r22
+      {
+        const double rho = hypot(R[0], a0);
+        if (rho > 0) {
+          const double cs = R[0] / rho, sn = a0 / rho;
+          R[0] = rho;
+          double t = cs * R[1] + sn * a1; a1 = cs * a1 - sn * R[1]; R[1] = t;
+          t = cs * R[2] + sn * a2; a2 = cs * a2 - sn * R[2]; R[2] = t;
+          t = cs * c[0] + sn * b; b = cs * b - sn * c[0]; c[0] = t;
+        }
+      }
+      {
+        const double rho = hypot(R[3], a1);
+        if (rho > 0) {
+          const double cs = R[3] / rho, sn = a1 / rho;
+          R[3] = rho;
+          double t = cs * R[4] + sn * a2; a2 = cs * a2 - sn * R[4]; R[4] = t;
+          t = cs * c[1] + sn * b; b = cs * b - sn * c[1]; c[1] = t;
+        }
+      }
+      {
+        const double rho = hypot(R[5], a2);
+        if (rho > 0) {
+          const double cs = R[5] / rho, sn = a2 / rho;
+          R[5] = rho;
+          const double t = cs * c[2] + sn * b;
+          c[2] = t;
+        }
+      }
+    }
+  }
+  double4 x;
+  x.z = c[2] / R[5];
+  x.y = (c[1] - R[4] * x.z) / R[3];
+  x.x = (c[0] - R[1] * x.y - R[2] * x.z) / R[0];
+  x.w = 1.0;
+  if (k > 0) d.lms4[lm] = x;
+}
 
 // One step of iterative refinement for K1: x += (G^T G)^-1 G^T (z - G x) with the residual taken
 // per observation at the current x.  The normal equations square the condition number of G; the

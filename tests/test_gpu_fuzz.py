@@ -209,3 +209,131 @@ def test_small_hot_set_with_long_landmarks(hot_acc, long_separate, monkeypatch):
     inc2, it2, st2, rc = ctx.solve_joint(lam, 8)
     assert rc == 0 and rel(inc2, ref2) < 1e-8
     ctx.close()
+
+
+def test_init_landmarks_near_degenerate():
+    """K1 on two-view landmarks whose four camera rows are nearly coplanar (kappa(G) up to ~1e7): the reference
+    solves G x = z with bdcSvd (HLP:94), i.e. with an error ~ kappa u; the QR kernel (init_landmarks_qr) keeps that,
+    the round-1 normal-equation kernels (POVAR_K1_NORMAL_EQ=1: kappa^2 u, one refinement step) do not."""
+    import os
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    rng = np.random.default_rng(17)
+    n_pairs, per_pair = 60, 20
+    n_c = 2 * n_pairs
+    cams = np.zeros((n_c, 12))
+    eps = 10.0 ** rng.uniform(-7.2, -1.0, size=n_pairs)
+    for i in range(n_pairs):
+        A = rng.normal(size=(2, 4))
+        M = rng.normal(size=(2, 2))
+        B = M @ A + eps[i] * rng.normal(size=(2, 4))
+        B[:, 3] = rng.normal(size=2)              # the translation column is free
+        cams[2 * i, :8] = A.ravel()
+        cams[2 * i + 1, :8] = B.ravel()
+    cams[:, 11] = 1.0
+    n_l = n_pairs * per_pair
+    lm_off = (2 * np.arange(n_l + 1)).astype(np.int32)
+    cam_idx = np.repeat(np.arange(n_pairs), per_pair)[:, None] * 2 + np.array([0, 1])[None, :]
+    cam_idx = cam_idx.ravel().astype(np.int32)
+    obs = rng.normal(scale=30.0, size=(2 * n_l, 2))
+    alpha = 0.01
+    ref = O.Oracle(n_c, lm_off, cam_idx, obs).init_landmarks_pose(alpha, cams)
+    # condition number of every landmark's G (8 x 3)
+    sa, sb = np.sqrt(alpha), np.sqrt(1 - alpha)
+    kappa = np.zeros(n_l)
+    for l in range(n_l):
+        rows = []
+        for o in (2 * l, 2 * l + 1):
+            P = cams[cam_idx[o]].reshape(3, 4)
+            u, v = obs[o]
+            rows += [sb * (P[0, :3] - u * P[2, :3]), sb * (P[1, :3] - v * P[2, :3]), sa * P[0, :3], sa * P[1, :3]]
+        s = np.linalg.svd(np.array(rows), compute_uv=False)
+        kappa[l] = s[0] / s[-1]
+    assert kappa.max() > 1e6 and kappa.min() < 1e3
+
+    def run_x(env):
+        old = os.environ.get("POVAR_K1_NORMAL_EQ")
+        if env:
+            os.environ["POVAR_K1_NORMAL_EQ"] = "1"
+        try:
+            ctx = capi.Context(n_c, lm_off, cam_idx, obs)
+            ctx.set_cameras(cams)
+            ctx.init_landmarks_pose(alpha)
+            x = ctx.get_landmarks()
+            ctx.close()
+        finally:
+            if env:
+                if old is None:
+                    del os.environ["POVAR_K1_NORMAL_EQ"]
+                else:
+                    os.environ["POVAR_K1_NORMAL_EQ"] = old
+        return x
+
+    # Ground truth: the exact least-squares solution of the fp64 system (rational arithmetic on the normal
+    # equations).  With noisy observations the residual is not small, so the PROBLEM is conditioned like
+    # kappa + kappa^2 |r| / (|G||x|): two backward-stable solvers may differ by that much, which is why the bar is the
+    # oracle's own distance to the truth, per decade of kappa, and not a fixed number.
+    from fractions import Fraction as Fr
+    exact = np.zeros((n_l, 3))
+    for l in range(n_l):
+        rows, zz = [], []
+        for o in (2 * l, 2 * l + 1):
+            P = cams[cam_idx[o]].reshape(3, 4)
+            u, v = obs[o]
+            rows += [sb * (P[0, :3] - u * P[2, :3]), sb * (P[1, :3] - v * P[2, :3]), sa * P[0, :3], sa * P[1, :3]]
+            zz += [sb * (P[2, 3] * u - P[0, 3]), sb * (P[2, 3] * v - P[1, 3]), sa * (u - P[0, 3]), sa * (v - P[1, 3])]
+        Gq = [[Fr(float(x)) for x in r] for r in rows]
+        zq = [Fr(float(x)) for x in zz]
+        H = [[sum(Gq[r][a] * Gq[r][b] for r in range(8)) for b in range(3)] for a in range(3)]
+        g = [sum(Gq[r][a] * zq[r] for r in range(8)) for a in range(3)]
+        det = (H[0][0] * (H[1][1] * H[2][2] - H[1][2] * H[2][1]) - H[0][1] * (H[1][0] * H[2][2] - H[1][2] * H[2][0])
+               + H[0][2] * (H[1][0] * H[2][1] - H[1][1] * H[2][0]))
+
+        def col(k):
+            Mx = [[g[i] if j == k else H[i][j] for j in range(3)] for i in range(3)]
+            return (Mx[0][0] * (Mx[1][1] * Mx[2][2] - Mx[1][2] * Mx[2][1]) - Mx[0][1] * (Mx[1][0] * Mx[2][2] - Mx[1][2] * Mx[2][0])
+                    + Mx[0][2] * (Mx[1][0] * Mx[2][1] - Mx[1][1] * Mx[2][0]))
+        exact[l] = [float(col(k) / det) for k in range(3)]
+    nrm = np.linalg.norm(exact, axis=1)
+    err_orc = np.linalg.norm(ref - exact, axis=1) / nrm
+
+    def dist(x):
+        return np.linalg.norm(x - exact, axis=1) / nrm
+
+    err = dist(run_x(False))
+    err_ne = dist(run_x(True))
+    for lo in (1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7):
+        sel = (kappa >= lo) & (kappa < 10 * lo)
+        if sel.sum() < 5:
+            continue
+        # as accurate as the reference's class of solver in every decade of kappa ...
+        assert err[sel].max() <= 10 * err_orc[sel].max() + 1e-14, (lo, err[sel].max(), err_orc[sel].max())
+    # ... while the normal equations lose the ill-conditioned landmarks by orders of magnitude (the test bites)
+    bad = kappa > 1e6
+    assert np.median(err_ne[bad]) > 100 * np.median(err[bad])
+
+
+def test_device_timings():
+    """povar_timings: hipEvent stage timings per entry point (the IterationSummary timing fields)."""
+    from povar_amd import capi, synth
+    p = synth.make_problem(49, 2000, 8200, seed=7)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    ctx.set_cameras(p.cams)
+    ctx.timings_enable(True)
+    ctx.init_landmarks_pose(0.01)
+    ctx.error_pose(0.01)
+    assert ctx.linearize_pose(0.01)
+    for _ in range(3):
+        inc, it, st, rc = ctx.solve_pose(1e-4, capi.POWER_VARPROJ, 20)
+    ctx.apply_pose(capi.POWER_VARPROJ, 0.01, inc)
+    t = ctx.timings()
+    assert (t.linearize_calls, t.prepare_calls, t.solve_calls, t.apply_calls, t.other_calls) == (1, 3, 3, 1, 2)
+    for ms in (t.linearize_ms, t.prepare_ms, t.solve_ms, t.apply_ms, t.other_ms):
+        assert 0 < ms < 1000
+    assert t.solve_ms / 3 > 20 * 0.004            # 20 terms of at least two kernels each
+    t2 = ctx.timings()                             # accumulates; nothing new happened
+    assert t2.solve_ms == t.solve_ms and t2.solve_calls == 3
+    ctx.timings_enable(False)
+    ctx.solve_pose(1e-4, capi.POWER_VARPROJ, 20)
+    assert ctx.timings().solve_calls == 0
+    ctx.close()
