@@ -33,7 +33,7 @@ namespace povar {
 
 struct LplLayout {
   std::vector<double2> uv;
-  std::vector<int> cw, cpos, seg, lm_pos, of_slot;
+  std::vector<int> cw, cpos, seg, lm_pos, of_slot, lm_of;  // lm_of: [n_tiles][64] landmark of each lane (-1: none)
   std::vector<int4> tile;
   std::vector<int> wg_tile_off;  // [grid + 1]
   std::vector<int> wg_cam_off;   // [grid + 1] into wg_cams / wg_slot_rec
@@ -222,18 +222,22 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     std::vector<char> mark(n_cams, 0);
     for (int w = 0; w < grid; ++w) {
       const int slot0 = (int)L.wg_cams.size();
-      std::vector<int> used_tail;
+      // slots: the replicated hub cameras always (fixed slots 0..hubs-1), then only the resident cameras this
+      // workgroup's landmarks actually observe, in rank order (a small shard touches far fewer than G + its grid
+      // cameras: fewer records to stage, fewer partial records to flush and to sum)
+      const int hubs_w = lpl_hubs(G);
+      std::vector<int> used;
       for (int l : lms_of[w])
         for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) {
           const int r0 = rank1[cam_idx[i]] - 1;
-          if (r0 >= G && !mark[r0] && resident(w, r0)) {
+          if (r0 >= hubs_w && !mark[r0] && resident(w, r0)) {
             mark[r0] = 1;
-            used_tail.push_back(r0);
+            used.push_back(r0);
           }
         }
-      std::sort(used_tail.begin(), used_tail.end());
-      for (int r0 = 0; r0 < G; ++r0) L.wg_cams.push_back(r0);
-      for (int r0 : used_tail) { L.wg_cams.push_back(r0); mark[r0] = 0; }
+      std::sort(used.begin(), used.end());
+      for (int r0 = 0; r0 < hubs_w; ++r0) L.wg_cams.push_back(r0);
+      for (int r0 : used) { L.wg_cams.push_back(r0); mark[r0] = 0; }
       const int n_w = (int)L.wg_cams.size() - slot0;
       L.max_slots = std::max(L.max_slots, n_w);
       for (int s = 0; s < n_w; ++s) holders[L.wg_cams[slot0 + s]].push_back(w);
@@ -262,6 +266,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       const int n_tiles_w = order.empty() ? 0 : tile - tile0 + 1;
       L.tile.resize(tile0 + n_tiles_w, make_int4(0, 0, 1 << 30, 0));
       L.seg.resize((size_t)(tile0 + n_tiles_w) * WAVE);
+      L.lm_of.resize((size_t)(tile0 + n_tiles_w) * WAVE, -1);
       for (size_t i = (size_t)tile0 * WAVE; i < L.seg.size(); ++i) L.seg[i] = (int)(i & 63) | ((int)(i & 63) << 8);
       std::vector<int> lanes_used(n_tiles_w, 0);
       for (int l : order) {
@@ -272,7 +277,10 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         ti.y = std::max(ti.y, psize_of[l]);
         ti.z = std::min(ti.z, hot / P);  // leading rows in which every lane of the landmark has a resident camera
         if (P > 1) ti.w |= 1;
-        for (int q = 0; q < P; ++q) L.seg[(size_t)t * WAVE + lane0 + q] = lane0 | ((lane0 + P - 1) << 8);
+        for (int q = 0; q < P; ++q) {
+          L.seg[(size_t)t * WAVE + lane0 + q] = lane0 | ((lane0 + P - 1) << 8);
+          L.lm_of[(size_t)t * WAVE + lane0 + q] = l;
+        }
         lanes_used[t - tile0] += P;
       }
       for (int t = tile0; t < tile0 + n_tiles_w; ++t) {

@@ -91,6 +91,7 @@ struct povar_ctx {
   bool long_in_kernel = false;
   // lane-per-landmark layout of e0_lpl (struct V2)
   DevBuf<double2> v2_uv;
+  DevBuf<int> v2_lm_of;
   DevBuf<int> v2_cw, v2_cpos, v2_lm_pos, v2_of_slot, v2_seg, v2_wg_tile_off, v2_wg_cam_off, v2_wg_cams, v2_wg_slot_rec, c3_lm;
   DevBuf<int2> v2_part_range, c3_range;
   DevBuf<double> c3_h, v2_part;
@@ -100,6 +101,7 @@ struct povar_ctx {
   DevBuf<double> v2_w, v2_lmrec;
   int64_t v2_rows = 0;
   bool use_lpl = true;        // POVAR_E0_V1=1: keep e0_lm_cached<true> (lane per observation) for A/B runs
+  bool use_lpl_prepare = true;  // POVAR_PREPARE_V1=1: keep lm_regular<OpPrepare> + cm_scatter
   DevBuf<double4> q4c;        // scatter scalars of the cold observations, in cold camera-major order
   DevBuf<int> lm_slot0, lm_cnt_dev;
   bool k1_qr = true;          // POVAR_K1_NORMAL_EQ=1: the round-1 normal-equation kernels (A/B accuracy runs)
@@ -649,6 +651,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   if (const char* g = std::getenv("POVAR_NO_FUSE")) c->fuse_binv = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_E0_V1")) c->use_lpl = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_K1_NORMAL_EQ")) c->k1_qr = !(g[0] == '1');
+  if (const char* g = std::getenv("POVAR_PREPARE_V1")) c->use_lpl_prepare = !(g[0] == '1');
 
   Layout L;
   build_layout(n_cams, n_lms, lm_offsets, cam_idx, obs, L);
@@ -680,6 +683,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                                 (int)lpl_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lpl_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)prep_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)prep_lds_bytes(HOT_ACC_MAX)));
   }
 
   int rc = 0;
@@ -758,6 +765,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (int rc = upload(c->v2_cw, V.cw, c)) return rc;
     if (int rc = upload(c->v2_cpos, V.cpos, c)) return rc;
     if (int rc = upload(c->v2_lm_pos, V.lm_pos, c)) return rc;
+    if (int rc = upload(c->v2_lm_of, V.lm_of, c)) return rc;
     if (int rc = upload(c->v2_of_slot, V.of_slot, c)) return rc;
     if (int rc = upload(c->v2_tile, V.tile, c)) return rc;
     if (int rc = upload(c->v2_seg, V.seg, c)) return rc;
@@ -776,7 +784,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     // scatter scalars of the cold observations: one buffer, sized for the largest of the cold views
     HIP_TRY(c->q4c.alloc(std::max<size_t>(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), V.cold_lm.size()), 1), &c->bytes));
     c->d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
-                 c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
+                 c->v2_lm_of.p, c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
                  c->v2_wg_slot_rec.p, nt, lpl_hubs(V.n_global)};
   }
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
@@ -846,7 +854,7 @@ void povar_destroy(povar_ctx* c) {
   c->sc_r.release(); c->sc_p.release(); c->sc_q.release(); c->sc_zv.release(); c->sc_part.release(); c->sc_s.release();
   c->cc_cam_range.release(); c->cold_pos.release(); c->q4c.release();
   c->v2_uv.release(); c->v2_cw.release(); c->v2_cpos.release(); c->v2_lm_pos.release(); c->v2_of_slot.release();
-  c->v2_seg.release(); c->v2_tile.release(); c->v2_wg_tile_off.release(); c->v2_wg_cam_off.release(); c->v2_wg_cams.release();
+  c->v2_lm_of.release(); c->v2_seg.release(); c->v2_tile.release(); c->v2_wg_tile_off.release(); c->v2_wg_cam_off.release(); c->v2_wg_cams.release();
   c->v2_wg_slot_rec.release(); c->c3_lm.release(); c->v2_part_range.release(); c->c3_range.release(); c->c3_h.release(); c->v2_part.release(); c->v2_w.release(); c->v2_lmrec.release();
   c->c2_lm.release(); c->c2_pos.release(); c->c2_range.release(); c->c2_h.release();
   c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
@@ -999,9 +1007,23 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   c->new_linearization_point = false;
   c->d.lambda_lm = solver_type == POVAR_POWER_SCHUR_COMPLEMENT ? lambda : 0.0;  // cpp:197-200
   hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_cams * 12, 256)), dim3(256), 0, c->stream, c->d, 0);
-  launch_lm(c, OpPrepare{});
-  hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 0);
-  hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b, 1);
+  if (c->use_lpl && c->use_lpl_prepare && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
+    // lane-per-landmark K7: Hll^-1, landmark records and the per-camera partial sums of b in one kernel, then the
+    // per-camera sum of the partials and the cold observations (same kernel as the per-term one, output b)
+    Dp da = ldsacc_dp(c, true);
+    // cam_cold_sum honours the series-done flag of the term loop: clear what an early exit of the last solve left
+    HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
+    if (c->opt.robust_norm)
+      hipLaunchKernelGGL(prepare_lpl<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), prep_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
+    else
+      hipLaunchKernelGGL(prepare_lpl<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), prep_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
+    da.y = c->d.b;
+    hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 0);
+  } else {
+    launch_lm(c, OpPrepare{});
+    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 0);
+    hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b, 1);
+  }
   if (int rc = allreduce(c, c->d.b, 12 * (size_t)c->n_cams)) return rc;
   hipLaunchKernelGGL(cam_build_binv, dim3(grid_for(c->n_cams, K8_THREADS)), dim3(K8_THREADS), 0, c->stream,
                      c->d, lambda);

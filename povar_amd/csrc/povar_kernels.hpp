@@ -91,6 +91,7 @@ struct V2 {
   const int4* tile;    // [n_tiles] (first row, rows, leading all-hot rows, bit 0: some landmark spans several lanes)
   const int* seg;      // [n_tiles][64] first | last << 8 lane of the landmark a lane belongs to (read for flagged tiles)
   double* lmrec;       // [n_tiles][9][64]: x, y, z, then G = diag(s) Hll^-1 diag(s) (00,01,02,11,12,22)
+  const int* lm_of;    // [n_tiles][64] landmark of each lane (-1: unused lane)
   const int* lm_pos;   // [n_lms] tile * 64 + first lane of each landmark | (lanes - 1) << 26 (-1: no observation)
   const int* of_slot;  // [n_slots] row * 64 + lane of each wave-bin slot (-1: padding)
   // per E0 workgroup (lpl_layout.hpp): its tiles, the cameras it keeps in LDS, where their accumulators are flushed
@@ -1462,6 +1463,232 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// K7 on the lane-per-landmark layout: get_Hll_inv_add_Hpp_b_pOSE / _poBA (landmark_block.hpp:510-572), the
+// landmark half of prepare_Hb_pOSE.  Same structure as e0_lpl (lane = landmark, row stream with a three-row
+// prefetch cursor, camera records and per-camera accumulators in LDS, cold observations through q4c): the forward
+// pass accumulates Hll = Jl^T Jl and Jl^T r in registers, the lane then inverts Hll (+ lambda I for
+// POWER_SCHUR_COMPLEMENT), stores Hll^-1 and the per-term landmark records, and the backward pass adds
+// Jp^T (r - Jl w) into the camera accumulators.  The tile (Jl, r) is rebuilt from (P_c, x_l, u, v, sqrt(w), s_l):
+// nothing per observation is read besides the 20-byte row.  Replaces lm_regular<OpPrepare> + cm_scatter +
+// cam_sum_items (214 + 109 + 6 us on venice-1778) for the LDSACC mode.
+// ------------------------------------------------------------------------------------------
+constexpr int PREP_REC = 6;  // double2 per camera record: P[:, :3] row-major (9), then the translation column (3)
+
+struct PrepObs {
+  double jl[12], r[4];
+  // tile of one observation (bal_bundle_adjustment_helper.cpp:244-313 with the scalings of landmark_block.hpp:284-295)
+  __device__ inline void set(const Dp& d, const double* P, double2 uv, double w, double hx, double hy, double hz,
+                             double s0, double s1, double s2) {
+    const double sw = sqrt(w), cb = d.sb * sw, ca = d.sa * sw;
+    const double m0[3] = {P[0] - P[6] * uv.x, P[1] - P[7] * uv.x, P[2] - P[8] * uv.x};
+    const double m1[3] = {P[3] - P[6] * uv.y, P[4] - P[7] * uv.y, P[5] - P[8] * uv.y};
+    const double t0 = P[9] - P[11] * uv.x, t1 = P[10] - P[11] * uv.y;
+    r[0] = cb * (m0[0] * hx + m0[1] * hy + m0[2] * hz + t0);
+    r[1] = cb * (m1[0] * hx + m1[1] * hy + m1[2] * hz + t1);
+    r[2] = ca * (P[0] * hx + P[1] * hy + P[2] * hz + P[9] - uv.x);
+    r[3] = ca * (P[3] * hx + P[4] * hy + P[5] * hz + P[10] - uv.y);
+    jl[0] = cb * m0[0] * s0; jl[1] = cb * m0[1] * s1; jl[2] = cb * m0[2] * s2;
+    jl[3] = cb * m1[0] * s0; jl[4] = cb * m1[1] * s1; jl[5] = cb * m1[2] * s2;
+    jl[6] = ca * P[0] * s0; jl[7] = ca * P[1] * s1; jl[8] = ca * P[2] * s2;
+    jl[9] = ca * P[3] * s0; jl[10] = ca * P[4] * s1; jl[11] = ca * P[5] * s2;
+  }
+};
+__device__ inline void prep_read_rec(const double2* h, double* P) {
+#pragma unroll
+  for (int j = 0; j < PREP_REC; ++j) {
+    const double2 v = h[j];
+    P[2 * j] = v.x;
+    P[2 * j + 1] = v.y;
+  }
+}
+__host__ __device__ inline size_t prep_lds_bytes(int n_hot) {
+  return (size_t)n_hot * PREP_REC * sizeof(double2) + (size_t)(n_hot + 3 * lpl_hubs(n_hot)) * 96 + 16;
+}
+
+template <bool ROBUST>
+__global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) {
+  extern __shared__ double2 hot[];  // [n_hot][PREP_REC] records, then acc[12][n_slots], then the tile counter
+  const V2& v = d.v2;
+  const int cam0 = v.wg_cam_off[blockIdx.x];
+  const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  const int hubs = v.hubs, n_slots = n_hot + 3 * hubs;
+  double* acc = reinterpret_cast<double*>(hot + n_hot * PREP_REC);
+  int* grab_ctr = reinterpret_cast<int*>(acc + n_slots * 12);
+  for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
+  if (threadIdx.x == 0) *grab_ctr = 0;
+  const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
+  for (int i = threadIdx.x; i < n_hot * PREP_REC; i += E0C_BLOCK) {
+    const int r = i / PREP_REC, j = i - r * PREP_REC;
+    hot[i] = rec_img[(size_t)v.wg_cams[cam0 + r] * (HOT_REC_STRIDE / 2) + 6 + j];  // entries 12..23 of the image
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int t_begin = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
+  const int t_end = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
+  auto grab = [&]() -> int {
+    int n = 0;
+    if (lane == 0) n = __hip_atomic_fetch_add(grab_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const long long t = (long long)t_begin + n;
+    return t < t_end ? (int)t : t_end;
+  };
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  const cint_p tiles = (cint_p)(uintptr_t)v.tile;
+  auto tile_info = [&](int t, int& row0, int& k, int& nh, int& fl) {
+    row0 = tiles[4 * t];
+    k = tiles[4 * t + 1];
+    nh = tiles[4 * t + 2];
+    fl = tiles[4 * t + 3];
+  };
+  LplCursor pc;
+  pc.t = grab();
+  pc.pass = 0;
+  pc.j = 0;
+  pc.row0 = 0;
+  pc.k = 1;
+  int c_t = pc.t, c_row0 = 0, c_k = 0, c_nh = 0, c_fl = 0, nx_t = t_end;
+  if (c_t < t_end) {
+    tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+    pc.row0 = c_row0;
+    pc.k = c_k;
+    nx_t = grab();
+  }
+  auto issue = [&](LplRow& r) {
+    if (pc.t < t_end) {
+      const size_t i = ((size_t)pc.row0 + (pc.pass ? pc.k - 1 - pc.j : pc.j)) * WAVE + lane;
+      r.uv = v.uv[i];
+      r.cw = v.cw[i];
+      if (ROBUST) r.w = v.w[i];
+      if (++pc.j == pc.k) {
+        pc.j = 0;
+        if (++pc.pass == 2) {
+          pc.pass = 0;
+          pc.t = nx_t;
+          if (pc.t < t_end) {
+            int nh_, fl_;
+            tile_info(pc.t, pc.row0, pc.k, nh_, fl_);
+          }
+        }
+      }
+    }
+  };
+  LplRow n1, n2, n3;
+  n1.cw = n2.cw = n3.cw = -1;
+  n1.w = n2.w = n3.w = 1.0;
+  n1.uv = n2.uv = n3.uv = make_double2(0, 0);
+  issue(n1);
+  issue(n2);
+  issue(n3);
+  while (c_t < t_end) {
+    // the lane's landmark: coordinates and Jl column scale (gathers; once per tile)
+    const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
+    const int sg = v.seg[(size_t)c_t * WAVE + lane];
+    const double4 h4 = d.lms_lin4[lm >= 0 ? lm : 0], s4 = d.jl_scale4[lm >= 0 ? lm : 0];
+    const double hx = h4.x, hy = h4.y, hz = h4.z;
+    double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < c_k; ++j) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      double P[12];
+      if (cur.cw >= 0) prep_read_rec(hot + cur.cw * PREP_REC, P);
+      else prep_read_rec(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
+      PrepObs o;
+      o.set(d, P, cur.uv, ROBUST ? cur.w : 1.0, hx, hy, hz, s4.x, s4.y, s4.z);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[0] += o.jl[3 * r] * o.jl[3 * r];
+        red[1] += o.jl[3 * r] * o.jl[3 * r + 1];
+        red[2] += o.jl[3 * r] * o.jl[3 * r + 2];
+        red[3] += o.jl[3 * r + 1] * o.jl[3 * r + 1];
+        red[4] += o.jl[3 * r + 1] * o.jl[3 * r + 2];
+        red[5] += o.jl[3 * r + 2] * o.jl[3 * r + 2];
+        red[6] += o.jl[3 * r] * o.r[r];
+        red[7] += o.jl[3 * r + 1] * o.r[r];
+        red[8] += o.jl[3 * r + 2] * o.r[r];
+      }
+    }
+    if (c_fl & 1) seg_reduce_steps<9>(red, lane, sg & 255, (sg >> 8) & 255, 4);
+    double Hi[9], w3[3] = {0, 0, 0};
+    if (lm >= 0) {
+      double H[9];
+      sym3(red, H);
+      H[0] += d.lambda_lm;
+      H[4] += d.lambda_lm;
+      H[8] += d.lambda_lm;
+      inv3(H, Hi);
+      w3[0] = Hi[0] * red[6] + Hi[1] * red[7] + Hi[2] * red[8];
+      w3[1] = Hi[3] * red[6] + Hi[4] * red[7] + Hi[5] * red[8];
+      w3[2] = Hi[6] * red[6] + Hi[7] * red[7] + Hi[8] * red[8];
+      // per-term record of this lane (e0_lpl); Hll^-1 and the row-major record of the other kernels once per landmark
+      double* r2 = v.lmrec + ((size_t)c_t * 9) * WAVE + lane;
+      r2[0] = hx; r2[WAVE] = hy; r2[2 * WAVE] = hz;
+      r2[3 * WAVE] = s4.x * Hi[0] * s4.x; r2[4 * WAVE] = s4.x * Hi[1] * s4.y; r2[5 * WAVE] = s4.x * Hi[2] * s4.z;
+      r2[6 * WAVE] = s4.y * Hi[4] * s4.y; r2[7 * WAVE] = s4.y * Hi[5] * s4.z; r2[8 * WAVE] = s4.z * Hi[8] * s4.z;
+      if (lane == (sg & 255)) {
+#pragma unroll
+        for (int m = 0; m < 9; ++m) d.hll_inv[9 * (size_t)lm + m] = Hi[m];
+        double4* rec = reinterpret_cast<double4*>(d.lmrec) + 3 * (size_t)lm;
+        rec[0] = make_double4(hx, hy, hz, s4.x);
+        rec[1] = make_double4(s4.y, s4.z, Hi[0], Hi[1]);
+        rec[2] = make_double4(Hi[2], Hi[4], Hi[5], Hi[8]);
+      }
+    }
+    const size_t base = (size_t)c_row0 * WAVE + lane;
+    for (int jj = 0; jj < c_k; ++jj) {
+      const int j = c_k - 1 - jj;
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      double P[12];
+      if (cur.cw >= 0) prep_read_rec(hot + cur.cw * PREP_REC, P);
+      else prep_read_rec(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
+      PrepObs o;
+      const double w = ROBUST ? cur.w : 1.0;
+      o.set(d, P, cur.uv, w, hx, hy, hz, s4.x, s4.y, s4.z);
+      double e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = o.r[r] - (o.jl[3 * r] * w3[0] + o.jl[3 * r + 1] * w3[1] + o.jl[3 * r + 2] * w3[2]);
+      const double4 q = pose_q(d, cur.uv.x, cur.uv.y, sqrt(w), e);
+      if (cur.cw >= 0) {
+        double* a = acc + lpl_acc_slot(cur.cw, lane, hubs);
+        const double val[12] = {hx * q.x, hy * q.x, hz * q.x, q.x, hx * q.y, hy * q.y,
+                                hz * q.y, q.y, hx * q.z, hy * q.z, hz * q.z, q.z};
+#pragma unroll
+        for (int m = 0; m < 12; ++m)
+          __hip_atomic_fetch_add(a + m * n_slots, val[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        d.q4c[v.cpos[base + (size_t)j * WAVE]] = make_double4(q.x, q.y, q.z, 0);
+      }
+    }
+    c_t = nx_t;
+    if (c_t < t_end) {
+      tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+      nx_t = grab();
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_hot * 6; i += E0C_BLOCK) {
+    const int r = i / 6, m = 2 * (i % 6);
+    const double* a0 = acc + m * n_slots;
+    const double* a1 = a0 + n_slots;
+    double2 s;
+    if (r < hubs) {
+      s.x = (a0[4 * r] + a0[4 * r + 1]) + (a0[4 * r + 2] + a0[4 * r + 3]);
+      s.y = (a1[4 * r] + a1[4 * r + 1]) + (a1[4 * r + 2] + a1[4 * r + 3]);
+    } else {
+      s.x = a0[r + 3 * hubs];
+      s.y = a1[r + 3 * hubs];
+    }
+    reinterpret_cast<double2*>(hot_out + (size_t)v.wg_slot_rec[cam0 + r] * 12)[i % 6] = s;
+  }
+}
+
 // K10 (stored tiles): right_mul_e0_pOSE on the tiles kept in HBM, blocked layout
 // tiles[bin][pair][lane] (double2): pairs 0-23 Jp (row-major 4x12), 24-29 Jl (4x3), 30-31 r.
 // Every byte of a tile is read once per term, 16 B per lane, 1 KiB contiguous per wave
@@ -2024,6 +2251,7 @@ __global__ __launch_bounds__(256) void build_hot_rec(Dp d, int hom) {
   double v = 0;
   if (hom) v = P[e];
   else if (e < 9) v = P[(e / 3) * 4 + (e % 3)];
+  else v = P[(e - 9) * 4 + 3];  // the translation column: prepare_lpl rebuilds the residual from the full P
   d.hot_rec[(size_t)r * HOT_REC_STRIDE + 12 + e] = v;
 }
 

@@ -231,9 +231,9 @@ def test_full_size_properties():
     inc_a, it, st, rc = ctx.solve_pose(LAM, 0, M)
     for mode in (capi.E0_TILES, capi.E0_IMPLICIT_LDSACC, capi.E0_TILES_LDSACC):
         ctx.set_e0_mode(mode)
-        assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-13
+        assert rel(ctx.right_mul_e0_pose(x), ex) < 1e-12  # per-term bar (the forms differ in summation order only)
         inc_b, _, _, _ = ctx.solve_pose(LAM, 0, M)
-        assert rc == 0 and rel(inc_b, inc_a) < 1e-12
+        assert rc == 0 and rel(inc_b, inc_a) < 1e-11
     # S = B - E0 is positive definite: x^T B x > x^T E0 x with B^-1 from the library
     binv = ctx.get_buffer(capi.BUF_B_INV).reshape(p.n_cams, 12, 12)
     xb = x.reshape(p.n_cams, 12)
