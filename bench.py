@@ -178,6 +178,9 @@ def main():
                          "zipf0.5 / uniform = sensitivity variants of the same shape (never the headline)")
     ap.add_argument("--long-track-frac", type=float, default=0.0,
                     help="sensitivity variant: fraction of the observations on landmarks of 65..400 observations")
+    ap.add_argument("--p2p", action="store_true",
+                    help="per-term exchange through the peer-to-peer push/reduce kernels (povar_p2p_attach) instead of "
+                         "one all-reduce per term; the once-per-solve exchanges keep the communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the stored-tile comparison leg")
     args = ap.parse_args()
@@ -260,6 +263,16 @@ def main():
             if rank == 0:
                 print("[bench] WARNING: exchange steps run over gloo on host buffers, not RCCL", file=sys.stderr)
 
+    term_exchange = "all-reduce" if comm_used != "none" else "none"
+    if args.p2p and comm_used != "none":
+        handles = [None] * world
+        mine = ctx.p2p_export(world)
+        if dist is not None:
+            dist.all_gather_object(handles, mine)
+        else:
+            handles = [mine]
+        ctx.p2p_attach(world, rank, handles)
+        term_exchange = "p2p push + local reduce"
     ctx.set_cameras(prob.cams)
     ctx.init_landmarks_pose(alpha)
     ok = ctx.linearize_pose(alpha)
@@ -367,6 +380,7 @@ def main():
             "parallelism": f"landmark shards x{world}, one all-reduce (12*n_cams f64) per term" if world > 1
                            else "single GPU",
             "comm": comm_used,
+            "term_exchange": term_exchange,
         },
         "spmv_effective_GBps": algorithmic_bytes_term(n_c, n_l, n_o) * value / 1e9,
         "kernel_ms": {"e0": e0_ms, "binv_axpy": binv_ms, "allreduce": comm_ms,

@@ -255,6 +255,15 @@ int povar_comm_unique_id(uint8_t id[128]);
 int povar_comm_init(povar_ctx* ctx, int32_t world, int32_t rank, const uint8_t id[128]);
 /* ranks of the attached communicator (ncclCommCount; the world size of a host hook), 0 = none, < 0 on error */
 int povar_comm_ranks(povar_ctx* ctx);
+/* Peer-to-peer exchange of the per-term E0 partials, on top of a communicator attached with
+ * povar_comm_init / povar_comm_init_host (which keeps serving the once-per-solve exchanges): instead of one
+ * all-reduce of 12 n_cams doubles per power-series term, every rank's per-camera kernel pushes its partial sums
+ * into every peer's exchange buffer (stores over xGMI) and the B^-1 kernel of every rank waits for the world's slabs
+ * of its camera and sums them in rank order -- two kernels and no library call per term, deterministic for a world.
+ * Every rank calls povar_p2p_export(ctx, world, handle) (allocates its buffer, returns a 64-byte hipIpcMemHandle),
+ * the launcher gathers the handles, every rank calls povar_p2p_attach(ctx, world, rank, handles[world][64]). */
+int povar_p2p_export(povar_ctx* ctx, int32_t world, uint8_t handle[64]);
+int povar_p2p_attach(povar_ctx* ctx, int32_t world, int32_t rank, const uint8_t* handles);
 /* same exchange steps through a caller-supplied host all-reduce (sum, in place) instead of RCCL:
  * lets an MPI/gloo launcher or an in-process test stand in for the communicator */
 typedef void (*povar_allreduce_fn)(double* buf, int64_t n, void* user);

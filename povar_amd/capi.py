@@ -357,6 +357,17 @@ class Context:
         self._cb = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64, C.c_void_p)(_cb)
         self._chk(self.L.povar_comm_init_host(self.h, C.c_int32(world), C.c_int32(rank), self._cb, None))
 
+    def p2p_export(self, world) -> bytes:
+        buf = (C.c_uint8 * 64)()
+        self._chk(self.L.povar_p2p_export(self.h, C.c_int32(world), buf))
+        return bytes(buf)
+
+    def p2p_attach(self, world, rank, handles):
+        blob = b"".join(handles)
+        assert len(blob) == 64 * world
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        self._chk(self.L.povar_p2p_attach(self.h, C.c_int32(world), C.c_int32(rank), buf))
+
     def comm_init(self, world, rank, uid: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._chk(self.L.povar_comm_init(self.h, C.c_int32(world), C.c_int32(rank), buf))

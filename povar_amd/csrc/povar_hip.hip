@@ -133,6 +133,13 @@ struct povar_ctx {
   double alpha_lin = 0;
 
   // multi-GPU
+  // peer-to-peer term exchange (povar_p2p_export / povar_p2p_attach)
+  double* xbuf = nullptr;              // this rank's exchange buffer [2][world][n_cams][16]
+  size_t xbuf_count = 0;
+  std::vector<double*> peer_host;      // opened peer mappings (index = rank; own entry = xbuf)
+  DevBuf<double*> peer_dev;
+  DevBuf<unsigned long long> p2p_epoch;
+  bool p2p = false;
   ncclComm_t comm = nullptr;
   povar_allreduce_fn host_fn = nullptr;  // caller-supplied exchange (povar_comm_init_host)
   void* host_user = nullptr;
@@ -373,6 +380,7 @@ void prof_mark(povar_ctx* c, int kind) {
 }
 
 bool sharded(const povar_ctx* c) { return c->comm != nullptr || c->host_fn != nullptr; }
+// the per-term exchange runs through the peer-to-peer kernels: no library / host call inside the term loop
 
 // povar_timings: a pair of events on the context's stream around an entry point (kinds: 0 linearize, 1 prepare,
 // 2 solve = the power series / PCG / CHOLESKY, 3 apply = camera update + back-substitution, 4 other)
@@ -414,6 +422,15 @@ int allreduce(povar_ctx* c, double* buf, size_t n) {
   prof_mark(c, 2);
   NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c->comm, c->stream));
   return 0;
+}
+
+// peer-to-peer fields of the term kernels (only while the exchange is attached)
+void p2p_dp(povar_ctx* c, Dp& dt) {
+  if (!c->p2p) return;
+  dt.p2p_peer = c->peer_dev.p;
+  dt.p2p_epoch = c->p2p_epoch.p;
+  dt.p2p_world = c->world;
+  dt.p2p_rank = c->rank;
 }
 
 // Dp of the per-term kernels in POVAR_E0_IMPLICIT_LDSACC mode: cold camera-major view + hot partials
@@ -498,7 +515,11 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
     // ACC: cold observations write q to their camera-major position (q4c); the implicit form also walks the
     // long landmarks inside e0_lm_cached (its own cold view)
     const bool lik = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->long_in_kernel;
-    const Dp da = acc ? ldsacc_dp(c, lik) : c->d;
+    Dp da = acc ? ldsacc_dp(c, lik) : c->d;
+    // peer-to-peer exchange: only inside the term loop (fuse_norms >= 0) of the lane-per-landmark kernels; every other
+    // caller (right_mul_e0, PCG) wants the dense, all-reduced y
+    const bool p2p_now = c->p2p && fuse_norms >= 0 && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+    if (p2p_now) p2p_dp(c, da);
     if (c->opt.e0_mode == POVAR_E0_TILES) launch_lm(c, OpE0Tiles{});
     else if (c->opt.e0_mode == POVAR_E0_TILES_LDSACC) {
       hipLaunchKernelGGL(e0_tiles_cached, dim3(c->e0c_grid), dim3(E0T_BLOCK),
@@ -538,6 +559,10 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
       }
     }
   }
+  if (c->p2p && fuse_norms >= 0 && *binv_mode == 2 && !c->joint && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
+    *binv_mode = 5;  // cam_cold_sum pushed the partials to the peers; cam_binv_axpy waits for the world's slabs
+    return 0;
+  }
   if (sharded(c)) {
     int rc = allreduce(c, c->d.y, 12 * (size_t)c->n_cams);
     if (rc) return rc;
@@ -554,7 +579,8 @@ void launch_binv(povar_ctx* c, int mode, int want_norms) {
                        want_norms, (const double*)c->ncw.p);
   }
   else {
-    const Dp dt = mode == 3 ? ldsacc_dp(c) : c->d;  // 3: item sums over the cold view + LDS partials
+    Dp dt = mode == 3 ? ldsacc_dp(c) : c->d;  // 3: item sums over the cold view + LDS partials
+    if (mode == 5) p2p_dp(c, dt);
     hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, dt, mode == 3 ? 1 : mode,
                        want_norms);
   }
@@ -819,6 +845,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.hot_rec = c->hot_rec.p;
   d.hot_cams = c->hot_cams.p; d.n_hot = std::min(n_cams, HOT_MAX);
   d.part_range = nullptr;
+  d.p2p_peer = nullptr; d.p2p_epoch = nullptr; d.p2p_world = 1; d.p2p_rank = 0;
   d.sw = c->sw.p; d.rres = c->rres.p; d.q4 = c->q4.p; d.q4c = nullptr; d.cold_pos = nullptr; d.long_in_kernel = 0; d.tiles = nullptr;
   d.sigma = c->sigma.p; d.diag2 = c->diag2.p; d.G = c->G.p; d.binv = c->binv.p; d.b = c->b.p;
   d.tmp = c->tmp.p; d.accum = c->accum.p; d.z = c->z.p; d.y = c->y.p; d.inc = c->inc.p;
@@ -836,6 +863,10 @@ void povar_destroy(povar_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->comm) (void)ncclCommDestroy(c->comm);
+  for (size_t p = 0; p < c->peer_host.size(); ++p)
+    if (c->peer_host[p] && c->peer_host[p] != c->xbuf) (void)hipIpcCloseMemHandle(c->peer_host[p]);
+  if (c->xbuf) (void)hipFree(c->xbuf);
+  c->peer_dev.release(); c->p2p_epoch.release();
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
   c->lm_slot0.release(); c->lm_cnt_dev.release();
@@ -1018,6 +1049,8 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
     else
       hipLaunchKernelGGL(prepare_lpl<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), prep_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
     da.y = c->d.b;
+    da.p2p_peer = nullptr;  // b goes through the ordinary exchange below, not the per-term push
+    da.p2p_epoch = nullptr;
     hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 0);
   } else {
     launch_lm(c, OpPrepare{});
@@ -1075,7 +1108,8 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   const bool norms = q_tol > 0 || r_tol > 0;
   // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
   // RCCL-in-capture is not something a 1-GPU box can validate); POVAR_GRAPH_COMM=1 opts in
-  if (c->use_graph && !c->profile && m > 0 && !c->host_fn && (!c->comm || c->graph_with_comm)) {
+  const bool p2p_terms = c->p2p && !c->joint && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+  if (c->use_graph && !c->profile && m > 0 && (p2p_terms || (!c->host_fn && (!c->comm || c->graph_with_comm)))) {
     // the whole loop (memset, B^-1, m x {E0 kernels, [all-reduce], B^-1 + AXPY, [check]}) is one graph
     // launch; it is re-captured only when a kernel argument changes
     const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode, sharded(c) ? 1 : 0, norms ? 1 : 0, r_tol > 0 ? 1 : 0};
@@ -1104,6 +1138,11 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   }
   HIP_TRY(hipGetLastError());
   int iters = m, status = POVAR_LINEAR_SOLVER_NO_CONVERGENCE;
+  if (p2p_terms) {
+    int f[4];
+    if (int rc = read_flags(c, f)) return rc;
+    if (f[0] & 2) return fail(-3, "peer-to-peer exchange: a rank did not deliver its partial sums (wait timed out)");
+  }
   if (norms) {
     int f[4];
     if (int rc = read_flags(c, f)) return rc;
@@ -1537,6 +1576,52 @@ int povar_comm_ranks(povar_ctx* c) {
   int n = 0;
   NCCL_TRY(ncclCommCount(c->comm, &n));
   return n;
+}
+
+int povar_p2p_export(povar_ctx* c, int32_t world, uint8_t handle[64]) {
+  if (int rc = check_ctx(c)) return rc;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
+  if (world < 1 || !handle) return fail(-1, "bad p2p arguments");
+  if (!c->xbuf) {
+    c->xbuf_count = (size_t)2 * world * c->n_cams * 16;
+    // fine-grained device memory: peers' stores and this GPU's system-scope loads meet in memory, not in an L2
+    hipError_t e = hipExtMallocWithFlags((void**)&c->xbuf, c->xbuf_count * sizeof(double), hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_TRY(hipMalloc((void**)&c->xbuf, c->xbuf_count * sizeof(double)));
+    }
+    c->bytes += c->xbuf_count * sizeof(double);
+    HIP_TRY(hipMemset(c->xbuf, 0xff, c->xbuf_count * sizeof(double)));  // tags != any epoch
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, c->xbuf));
+  std::memcpy(handle, &h, 64);
+  return 0;
+}
+
+int povar_p2p_attach(povar_ctx* c, int32_t world, int32_t rank, const uint8_t* handles) {
+  if (int rc = check_ctx(c)) return rc;
+  if (world < 1 || rank < 0 || rank >= world || !handles || !c->xbuf) return fail(-1, "bad p2p arguments (export first)");
+  if ((size_t)2 * world * c->n_cams * 16 != c->xbuf_count) return fail(-1, "p2p world size differs from the exported buffer");
+  c->peer_host.assign(world, nullptr);
+  for (int p = 0; p < world; ++p) {
+    if (p == rank) { c->peer_host[p] = c->xbuf; continue; }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + 64 * (size_t)p, 64);
+    void* ptr = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    c->peer_host[p] = (double*)ptr;
+  }
+  HIP_TRY(c->peer_dev.alloc(world, &c->bytes));
+  HIP_TRY(hipMemcpy(c->peer_dev.p, c->peer_host.data(), world * sizeof(double*), hipMemcpyHostToDevice));
+  HIP_TRY(c->p2p_epoch.alloc(1, &c->bytes));
+  HIP_TRY(hipMemset(c->p2p_epoch.p, 0, sizeof(unsigned long long)));
+  HIP_TRY(hipDeviceSynchronize());
+  c->world = world;
+  c->rank = rank;
+  c->p2p = true;
+  return 0;
 }
 
 int povar_comm_unique_id(uint8_t id[128]) {

@@ -167,8 +167,13 @@ struct Dp {
   double* inc;         // pose increment handed to apply
   double* item_part;   // [n_items][12]
   double* item_partG;  // [n_items][40]
+  // peer-to-peer exchange of the per-term E0 partials (povar_p2p_attach): every rank pushes its
+  // per-camera sums into every peer's exchange buffer and reduces the world's slabs itself, instead of an all-reduce
+  double* const* p2p_peer;       // [world] base of each rank's exchange buffer [2][world][n_cams][16] (peer-mapped)
+  unsigned long long* p2p_epoch; // device counter, +1 per term (by e0_lpl); tags the slabs
+  int p2p_world, p2p_rank;
   // control
-  int* flags;          // [0] non-finite seen, [1] series done, [2] iterations, [3] status
+  int* flags;          // [0] non-finite seen (bit 1: p2p wait timed out), [1] series done, [2] iterations, [3] status
   double* norm_part;   // [n_cam_blocks][2]
   double* norms;       // [0] norm_0, [1] last term norm, [2] accum norm
   // scalars
@@ -1461,6 +1466,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
       }
     }
   }
+  if (d.p2p_epoch && blockIdx.x == 0 && threadIdx.x == 0) *d.p2p_epoch += 1;  // one tick per term, read by the next kernels
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2343,7 +2349,22 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
     double v = 0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) v = (t == k) ? acc[k] : v;
-    d.y[12 * (size_t)c + t] = v * sg_t;
+    v *= sg_t;
+    if (d.p2p_peer) {
+      // push this rank's partial of camera c into the slab [parity][rank] of EVERY rank's exchange buffer (system-
+      // scope stores over xGMI), then publish it: release fence, then the epoch tag in the record's 13th entry
+      const unsigned long long ep = *d.p2p_epoch;
+      const size_t off = ((((size_t)(ep & 1) * d.p2p_world + d.p2p_rank) * d.n_cams) + c) * 16;
+      for (int p = 0; p < d.p2p_world; ++p)
+        __hip_atomic_store(d.p2p_peer[p] + off + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      if (t == 0)  // lanes 0..11 are one wavefront: the fence above covers their stores (same wave, program order)
+        for (int p = 0; p < d.p2p_world; ++p)
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.p2p_peer[p] + off + 12), ep, __ATOMIC_RELEASE,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      d.y[12 * (size_t)c + t] = v;
+    }
   }
 }
 
@@ -2480,6 +2501,24 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, in
       camera_item_sum(d, c, lane, y);
 #pragma unroll
       for (int j = 0; j < 12; ++j) y[j] *= d.sigma[base + j];
+    } else if (mode == 5) {
+      // peer-to-peer exchange: wait for every rank's slab of this camera (tag == epoch), sum in rank order
+      const unsigned long long ep = *d.p2p_epoch;
+      const double* mine = d.p2p_peer[d.p2p_rank];
+      for (int p = 0; p < d.p2p_world; ++p) {
+        const double* rec = mine + ((((size_t)(ep & 1) * d.p2p_world + p) * d.n_cams) + c) * 16;
+        int spins = 0;
+        while (__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rec + 12), __ATOMIC_ACQUIRE,
+                                 __HIP_MEMORY_SCOPE_SYSTEM) != ep) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 22)) {  // a peer never arrived: flag it and go on (the host reports the failure)
+            if (lane == 0) atomicOr(&d.flags[0], 2);
+            break;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 12; ++j) y[j] += __hip_atomic_load(rec + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 12; ++j) y[j] = d.y[base + j];

@@ -79,3 +79,34 @@ def test_bench_rccl_communicator_in_and_out_of_graph(graph_comm):
     assert d["config"]["comm"] == "rccl" and d["config"]["rccl_ranks"] == 1
     d1, inc1 = _run_bench(["--no-cpu-baseline"], {}, "inc_w1.npy")
     assert np.linalg.norm(inc - inc1) <= 1e-12 * np.linalg.norm(inc1)
+
+
+@pytest.mark.parametrize("problem", ["ladybug-49", "trafalgar-257"])
+def test_bench_two_ranks_p2p_exchange(problem):
+    """The peer-to-peer term exchange (povar_p2p_attach: push the per-camera partials into every rank's buffer over
+    IPC-mapped memory, reduce locally behind epoch tags) with TWO ranks -- on a 1-GPU box both processes share device
+    0, which the kernels do not mind (RCCL does).  Same increment as one rank."""
+    import numpy as np
+    path = os.path.join(ROOT, "gpurun_out", f"inc_p2p_{problem}.npy")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    outs = {}
+    for tag, extra in (("p2p", ["--gpus", "2", "--p2p"]), ("one", ["--no-cpu-baseline"])):
+        env = dict(os.environ, POVAR_BENCH_DUMP_INC=path + tag + ".npy")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--problem", problem, "--steps", "3",
+                            "--warmup", "1", "--no-secondary"] + extra, capture_output=True, text=True, timeout=900,
+                           cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+        outs[tag] = (d, np.load(path + tag + ".npy"))
+    d, inc = outs["p2p"]
+    assert d["n_gpus"] == 2 and d["config"]["term_exchange"] == "p2p push + local reduce"
+    assert np.linalg.norm(inc - outs["one"][1]) <= 1e-11 * np.linalg.norm(inc)
+
+
+def test_bench_p2p_single_rank_in_graph():
+    """World of one: the push/reduce kernels inside the captured term loop against the plain loop."""
+    import numpy as np
+    d, inc = _run_bench(["--no-cpu-baseline", "--p2p"], {"POVAR_FORCE_COMM": "1"}, "inc_p2p1.npy")
+    assert d["config"]["term_exchange"] == "p2p push + local reduce"
+    d1, inc1 = _run_bench(["--no-cpu-baseline"], {}, "inc_w1.npy")
+    assert np.linalg.norm(inc - inc1) <= 1e-12 * np.linalg.norm(inc1)

@@ -7,4 +7,6 @@ for n in 1 2 4 8; do
     echo -n "POVAR_GRAPH_COMM=$g: "
     POVAR_FORCE_COMM=1 POVAR_GRAPH_COMM=$g python3 tools/shard_term_time.py $n ${1:-venice-1778} 2>&1 | grep "world="
   done
+  echo -n "p2p push/reduce (in graph): "
+  POVAR_FORCE_COMM=1 POVAR_P2P=1 python3 tools/shard_term_time.py $n ${1:-venice-1778} 2>&1 | grep "world="
 done

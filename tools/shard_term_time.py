@@ -20,6 +20,8 @@ def main():
                        e0_mode=int(sys.argv[3]) if len(sys.argv) > 3 else capi.E0_IMPLICIT_LDSACC)
     if os.environ.get("POVAR_FORCE_COMM"):
         ctx.comm_init(1, 0, capi.comm_unique_id())
+        if os.environ.get("POVAR_P2P"):  # per-term exchange through the push/reduce kernels (world of one)
+            ctx.p2p_attach(1, 0, [ctx.p2p_export(1)])
     ctx.set_cameras(p.cams)
     ctx.init_landmarks_pose(0.01)
     assert ctx.linearize_pose(0.01)
