@@ -2351,16 +2351,19 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
     for (int k = 0; k < 12; ++k) v = (t == k) ? acc[k] : v;
     v *= sg_t;
     if (d.p2p_peer) {
-      // push this rank's partial of camera c into the slab [parity][rank] of EVERY rank's exchange buffer (system-
-      // scope stores over xGMI), then publish it: release fence, then the epoch tag in the record's 13th entry
+      // push this rank's partial of camera c into the slab [parity][rank] of EVERY rank's exchange buffer, then
+      // publish it with the epoch tag in the record's 13th entry.  Every store and every load of these bytes is a
+      // system-scope (sc0 sc1, write-through / cache-bypassing) access and the storing wavefront drains its stores
+      // (s_waitcnt vmcnt(0)) before the tag: no release fence -- a system-scope fence writes the whole L2 back,
+      // 44 us per term with one per camera (MI355X_MICROARCH.md, "Valid forms").  Lanes 0..11 are one wavefront.
       const unsigned long long ep = *d.p2p_epoch;
       const size_t off = ((((size_t)(ep & 1) * d.p2p_world + d.p2p_rank) * d.n_cams) + c) * 16;
       for (int p = 0; p < d.p2p_world; ++p)
         __hip_atomic_store(d.p2p_peer[p] + off + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      if (t == 0)  // lanes 0..11 are one wavefront: the fence above covers their stores (same wave, program order)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (t == 0)
         for (int p = 0; p < d.p2p_world; ++p)
-          __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.p2p_peer[p] + off + 12), ep, __ATOMIC_RELEASE,
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.p2p_peer[p] + off + 12), ep, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
       d.y[12 * (size_t)c + t] = v;
@@ -2508,8 +2511,8 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, in
       for (int p = 0; p < d.p2p_world; ++p) {
         const double* rec = mine + ((((size_t)(ep & 1) * d.p2p_world + p) * d.n_cams) + c) * 16;
         int spins = 0;
-        while (__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rec + 12), __ATOMIC_ACQUIRE,
-                                 __HIP_MEMORY_SCOPE_SYSTEM) != ep) {
+        while (__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rec + 12), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM) != ep) {  // relaxed poll; the data loads below bypass the caches too
           __builtin_amdgcn_s_sleep(8);
           if (++spins > (1 << 22)) {  // a peer never arrived: flag it and go on (the host reports the failure)
             if (lane == 0) atomicOr(&d.flags[0], 2);
