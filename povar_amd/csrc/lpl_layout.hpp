@@ -88,9 +88,16 @@ inline void lpl_assign(int h, const std::vector<long>& cost, std::vector<int>& a
 inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx, const double* obs,
                       const std::vector<int>& rank1, const std::vector<int>& slot_of_obs, size_t n_slots, int grid,
                       int n_acc, LplLayout& L) {
-  int K0 = 8;  // rows per tile are capped by dealing longer landmarks over several lanes (knob)
-  if (const char* e = std::getenv("POVAR_LPL_K0")) K0 = std::max(2, std::atoi(e));
+  // Rows per tile are capped by dealing longer landmarks over several lanes (K0 rows: at most 2 K0 row steps per
+  // tile, the unit of load balance).  A wavefront walks its tile's rows one after the other, so on a problem too small
+  // to give every wavefront a tile the cap sets the latency of the launch: 2 rows there (ladybug-49 76 k -> 106 k
+  // terms/s, trafalgar-257 61 k -> 67 k), 8 otherwise (shorter tiles cost venice shards 2-3 us: more lanes, more
+  // landmark records).
   grid = std::max(grid, 1);
+  int n_with_obs = 0;
+  for (int l = 0; l < n_lms; ++l) n_with_obs += lm_off[l + 1] > lm_off[l];
+  int K0 = n_with_obs / WAVE < grid * 16 / 2 ? 2 : 8;
+  if (const char* e = std::getenv("POVAR_LPL_K0")) K0 = std::max(2, std::atoi(e));
   // ---- grid factorisation and the (G, Tn) choice
   int B = 1;
   for (int b = 1; (int64_t)b * b <= grid; ++b)

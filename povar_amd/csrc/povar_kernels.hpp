@@ -1423,9 +1423,11 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
 #else
       } else if (cur.cw < -1) {
 #endif
+        // the position of q in the cold view is requested together with the record: one round trip, not two
+        const int cold_at = v.cpos[base + (size_t)j * WAVE];
         lpl_read_p3(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2), P3);
         lpl_backward(o, P3, g, q);
-        d.q4c[v.cpos[base + (size_t)j * WAVE]] = make_double4(q[0], q[1], q[2], 0);
+        d.q4c[cold_at] = make_double4(q[0], q[1], q[2], 0);
       }
     }
     c_t = n_t;
