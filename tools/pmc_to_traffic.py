@@ -25,17 +25,19 @@ def per_kernel(path):
 def main():
     fetch, write, key = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic.json")
-    e0 = [k for k in fetch if "e0_lm_cached" in k or "OpE0Tiles" in k or "cm_scatter" in k or "cam_cold_sum" in k]
+    e0 = [k for k in fetch if "e0_lpl" in k or "e0_lm_cached" in k or "OpE0Tiles" in k or "cm_scatter" in k or "cam_cold_sum" in k]
     table = {k: {"fetch_raw_bytes": fetch[k], "write_bytes": write.get(k, 0.0),
                  "hbm_bytes": 2 * fetch[k] + write.get(k, 0.0)} for k in sorted(fetch)}
     data = {}
     if os.path.exists(out):
         data = json.load(open(out))
     problem, mode, world = key.split(":")
-    lm = [k for k in e0 if ("e0_lm_cached" in k if mode != "tiles" else "OpE0Tiles" in k)]
+    lm = [k for k in e0 if (("e0_lpl" in k or "e0_lm_cached" in k) if mode != "tiles" else "OpE0Tiles" in k)]
     # camera-major half of E0: cm_scatter (deterministic modes) or cam_cold_sum[_binv] (LDSACC modes; the fused
     # kernel also carries the 2 MB of B^-1 reads of the AXPY)
     cm = [k for k in e0 if ("cam_cold_sum" in k if "ldsacc" in mode else "cm_scatter" in k)]
+    if any("cam_cold_sum_binv" in k for k in cm):  # the term loop's fused kernel; plain cam_cold_sum is prepare_Hb's
+        cm = [k for k in cm if "cam_cold_sum_binv" in k]
     data[key] = sum(table[k]["hbm_bytes"] for k in lm + cm)
     data.setdefault("_per_kernel", {})[key] = {k: table[k] for k in lm + cm}
     # stamp: bench.py reports the figure only while the kernel sources are the ones it was measured on
