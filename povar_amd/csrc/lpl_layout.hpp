@@ -244,7 +244,36 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         }
       std::sort(used.begin(), used.end());
       for (int r0 = 0; r0 < hubs_w; ++r0) L.wg_cams.push_back(r0);
-      for (int r0 : used) { L.wg_cams.push_back(r0); mark[r0] = 0; }
+      // Which slot a camera gets decides its LDS bank (accumulators: (slot + 3 hubs) mod 32, records: slot mod 16).
+      // In rank order the popular cameras pile up on the low banks and force collisions no row placement can avoid
+      // (a bank hit by more observations than the tile has rows must repeat inside a row).  So the cameras are dealt
+      // to the banks heaviest first, each to the least loaded bank that still has a free slot (weights = this
+      // workgroup's observations per camera; the hubs' four replicas are pre-loaded with a quarter each).
+      {
+        const int n_rest = (int)used.size(), n_w_ = hubs_w + n_rest;
+        std::vector<long> wcnt(n_cams, 0);
+        for (int l : lms_of[w])
+          for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) wcnt[rank1[cam_idx[i]] - 1]++;
+        std::vector<double> load(32, 0.0);
+        for (int r0 = 0; r0 < hubs_w; ++r0)
+          for (int q = 0; q < 4; ++q) load[(4 * r0 + q) & 31] += 0.25 * (double)wcnt[r0];
+        std::vector<std::vector<int>> free_slots(32);  // by accumulator bank, ascending
+        for (int sl = n_w_ - 1; sl >= hubs_w; --sl) free_slots[(sl + 3 * hubs_w) & 31].push_back(sl);
+        std::vector<int> by_weight(used);
+        std::stable_sort(by_weight.begin(), by_weight.end(), [&](int a, int b) { return wcnt[a] > wcnt[b]; });
+        std::vector<int> cam_of_slot(n_w_, -1);
+        for (int r0 : by_weight) {
+          int best = -1;
+          for (int b = 0; b < 32; ++b)
+            if (!free_slots[b].empty() && (best < 0 || load[b] < load[best])) best = b;
+          const int sl = free_slots[best].back();
+          free_slots[best].pop_back();
+          cam_of_slot[sl] = r0;
+          load[best] += (double)wcnt[r0];
+        }
+        for (int sl = hubs_w; sl < n_w_; ++sl) L.wg_cams.push_back(cam_of_slot[sl]);
+        for (int r0 : used) mark[r0] = 0;
+      }
       const int n_w = (int)L.wg_cams.size() - slot0;
       L.max_slots = std::max(L.max_slots, n_w);
       for (int s = 0; s < n_w; ++s) holders[L.wg_cams[slot0 + s]].push_back(w);
@@ -324,7 +353,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   std::atomic<int> next_wg{0};
   auto worker = [&]() {
     std::vector<int> slot_of_rank(n_cams, -1);
-    std::vector<int> hot_idx, cold_idx, assign;
+    std::vector<int> hot_idx, cold_idx, assign, assign2, lane_of;
     std::vector<long> cost;
     std::vector<uint16_t> occA, occR;
     std::vector<std::vector<int>> placed;  // per landmark of the current tile: its hot observations in position order
@@ -346,9 +375,38 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         placed.assign(o1 - o0, {});
         auto bankA = [&](int s, int lane, int j) { return (size_t)j * 64 + (lane >> 5) * 32 + (lpl_acc_slot(s, lane, hubs) & 31); };
         auto bankR = [&](int s, int lane, int j) { return (size_t)j * 64 + read_group(lane) * 16 + (s & 15); };
+        // single-lane landmarks may also take any of the tile's single lanes: which half, which ds_read_b128 lane
+        // group and which hub replica (lane & 3) a landmark sits in decide its collisions, so every class of free
+        // lanes is tried (16 classes) and the cheapest kept
+        auto lane_class = [&](int lane) { return (lane >> 5) * 8 + (read_group(lane) & 1) * 4 + (lane & 3); };
+        lane_of.assign(o1 - o0, 0);
+        unsigned long long free_mask = 0;
+        for (size_t o = o0; o < o1; ++o) {
+          lane_of[o - o0] = L.lm_pos[order[o]] & 63;
+          if (parts_of[order[o]] == 1) free_mask |= 1ull << lane_of[o - o0];
+        }
+        auto place_cost = [&](const std::vector<int>& cur, int lane0, int P, std::vector<int>& out_assign) -> long {
+          const int h = (int)cur.size();
+          if (h == 0) return 0;
+          cost.assign((size_t)h * h, 0);
+          for (int a = 0; a < h; ++a) {
+            const int s = slot_of_rank[rank1[cam_idx[cur[a]]] - 1];
+            for (int pos = 0; pos < h; ++pos) {
+              const int lane = lane0 + pos % P, j = pos / P;
+              long c = 96L * occA[bankA(s, lane, j)];
+              if (s >= hubs) c += 16L * occR[bankR(s, lane, j)];
+              cost[(size_t)a * h + pos] = c;
+            }
+          }
+          lpl_assign(h, cost, out_assign);
+          long tot = 0;
+          for (int a = 0; a < h; ++a) tot += cost[(size_t)a * h + out_assign[a]];
+          return tot;
+        };
         for (int pass = 0; pass < 2; ++pass)
           for (size_t o = o0; o < o1; ++o) {
-            const int l = order[o], lane0 = L.lm_pos[l] & 63, P = parts_of[l];
+            const int l = order[o], P = parts_of[l];
+            int lane0 = lane_of[o - o0];
             std::vector<int>& cur = placed[o - o0];
             if (pass == 0) {
               for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
@@ -361,22 +419,32 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
               }
             }
             const int h = (int)cur.size();
-            if (h > 1 && h <= 64 && !no_place) {
-              // cost[o][pos]: observation o of the landmark at position pos (row pos / P, lane lane0 + pos % P)
-              cost.assign((size_t)h * h, 0);
-              for (int a = 0; a < h; ++a) {
-                const int s = slot_of_rank[rank1[cam_idx[cur[a]]] - 1];
-                for (int pos = 0; pos < h; ++pos) {
-                  const int lane = lane0 + pos % P, j = pos / P;
-                  long c = 96L * occA[bankA(s, lane, j)];
-                  if (s >= hubs) c += 16L * occR[bankR(s, lane, j)];
-                  cost[(size_t)a * h + pos] = c;
+            if (h <= 64 && !no_place) {
+              if (pass == 0 && P == 1) {
+                long best = -1;
+                int best_lane = -1;
+                unsigned seen = 0;
+                for (unsigned long long m = free_mask; m; m &= m - 1) {
+                  const int lane = __builtin_ctzll(m), cls = lane_class(lane);
+                  if (seen & (1u << cls)) continue;
+                  seen |= 1u << cls;
+                  const long c = place_cost(cur, lane, 1, assign2);
+                  if (best < 0 || c < best) { best = c; best_lane = lane; assign = assign2; }
+                  if (best == 0) break;
                 }
+                lane0 = best_lane;
+                free_mask &= ~(1ull << lane0);
+                lane_of[o - o0] = lane0;
+              } else {
+                place_cost(cur, lane0, P, assign);
               }
-              lpl_assign(h, cost, assign);
-              hot_idx.assign(h, 0);
-              for (int a = 0; a < h; ++a) hot_idx[assign[a]] = cur[a];
-              cur = hot_idx;
+              if (h > 1) {
+                hot_idx.assign(h, 0);
+                for (int a = 0; a < h; ++a) hot_idx[assign[a]] = cur[a];
+                cur = hot_idx;
+              }
+            } else if (pass == 0 && P == 1) {
+              free_mask &= ~(1ull << lane0);
             }
             for (int n = 0; n < h; ++n) {
               const int s = slot_of_rank[rank1[cam_idx[cur[n]]] - 1], lane = lane0 + n % P, j = n / P;
@@ -384,6 +452,12 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
               if (s >= hubs) occR[bankR(s, lane, j)]++;
             }
           }
+        for (size_t o = o0; o < o1; ++o) {  // the lanes the single-lane landmarks ended up in
+          const int l = order[o];
+          if (parts_of[l] != 1) continue;
+          L.lm_pos[l] = t * WAVE + lane_of[o - o0];
+          L.lm_of[(size_t)t * WAVE + lane_of[o - o0]] = l;
+        }
         // write the tile's rows
         for (size_t o = o0; o < o1; ++o) {
           const int l = order[o], lane0 = L.lm_pos[l] & 63, P = parts_of[l];

@@ -150,6 +150,25 @@ int main(int argc, char** argv) {
     }
     extra_a /= (double)L.rows * 2;
     extra_r /= (double)L.rows * 4;
+    // lower bound of extra_a for the given tile membership and lane halves: a bank hit by deg observations in a
+    // half-tile of R rows repeats at least ceil(deg / R) - 1 times in some row (printed to stderr)
+    double bound = 0;
+    for (size_t t = 0; t < L.tile.size(); ++t) {
+      const int R = L.tile[t].y;
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        int deg[32] = {};
+        for (int j = 0; j < R; ++j)
+          for (int lane = hlf * 32; lane < hlf * 32 + 32; ++lane) {
+            const int sl = L.cw[((size_t)L.tile[t].x + j) * 64 + lane];
+            if (sl >= 0) deg[lpl_acc_slot(sl, lane, hubs) & 31]++;
+          }
+        int mx = 0;
+        for (int b = 0; b < 32; ++b) mx = std::max(mx, deg[b]);
+        // the best any placement can do: the heaviest bank spread evenly; averaged over the rows
+        bound += (double)std::max(0, (mx + R - 1) / R - 1) ;
+      }
+    }
+    std::fprintf(stderr, "lower bound of the worst row per half-tile (max over rows, not the mean): %.3f\n", bound / (L.tile.size() * 2));
   }
   int64_t mx = 0, mn = 1LL << 60;
   for (int w = 0; w < grid; ++w) { mx = std::max(mx, wg_rows[w]); mn = std::min(mn, wg_rows[w]); }
