@@ -340,7 +340,8 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   // row 0 would hold every landmark's lowest-index camera.  So the assignment of a landmark's resident
   // observations to the rows of its lanes is an assignment problem against the banks already taken in its tile
   // (accumulator bank = lpl_acc_slot(slot, lane) mod 32 per row half, record quad = slot mod 16 per read group):
-  // solved exactly per landmark (Hungarian), landmark after landmark, then once more with the whole tile known.
+  // solved exactly per landmark (Hungarian), landmark after landmark, then once more with everything placed.  The
+  // single-lane landmarks of one class are interchangeable, so the greedy also picks the tile and the lane.
   auto read_group = [](int lane) {
     const int l = lane & 31;
     const int g = (l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 1;
@@ -353,134 +354,199 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   std::atomic<int> next_wg{0};
   auto worker = [&]() {
     std::vector<int> slot_of_rank(n_cams, -1);
-    std::vector<int> hot_idx, cold_idx, assign, assign2, lane_of;
+    std::vector<int> hot_idx, cold_idx, assign, assign2;
+    std::vector<char> rep_tmp;
     std::vector<long> cost;
-    std::vector<uint16_t> occA, occR;
-    std::vector<std::vector<int>> placed;  // per landmark of the current tile: its hot observations in position order
     for (;;) {
       const int w = next_wg.fetch_add(1);
       if (w >= grid) break;
       const int slot0 = L.wg_cam_off[w], n_w = L.wg_cam_off[w + 1] - slot0;
       for (int s = 0; s < n_w; ++s) slot_of_rank[L.wg_cams[slot0 + s]] = s;
       const std::vector<int>& order = order_of[w];
-      size_t o0 = 0;
-      while (o0 < order.size()) {
-        // landmarks of one tile
-        const int t = (L.lm_pos[order[o0]] & ((1 << 26) - 1)) >> 6;
-        size_t o1 = o0;
-        while (o1 < order.size() && ((L.lm_pos[order[o1]] & ((1 << 26) - 1)) >> 6) == t) ++o1;
-        const int R = L.tile[t].y;
-        occA.assign((size_t)R * 64, 0);
-        occR.assign((size_t)R * 64, 0);
-        placed.assign(o1 - o0, {});
-        auto bankA = [&](int s, int lane, int j) { return (size_t)j * 64 + (lane >> 5) * 32 + (lpl_acc_slot(s, lane, hubs) & 31); };
-        auto bankR = [&](int s, int lane, int j) { return (size_t)j * 64 + read_group(lane) * 16 + (s & 15); };
-        // single-lane landmarks may also take any of the tile's single lanes: which half, which ds_read_b128 lane
-        // group and which hub replica (lane & 3) a landmark sits in decide its collisions, so every class of free
-        // lanes is tried (16 classes) and the cheapest kept
-        auto lane_class = [&](int lane) { return (lane >> 5) * 8 + (read_group(lane) & 1) * 4 + (lane & 3); };
-        lane_of.assign(o1 - o0, 0);
-        unsigned long long free_mask = 0;
-        for (size_t o = o0; o < o1; ++o) {
-          lane_of[o - o0] = L.lm_pos[order[o]] & 63;
-          if (parts_of[order[o]] == 1) free_mask |= 1ull << lane_of[o - o0];
+      const int t0w = L.wg_tile_off[w], ntw = L.wg_tile_off[w + 1] - t0w;
+      // bank occupancy of every tile of the workgroup: [tile][row][2 halves x 32 | 4 groups x 16]
+      std::vector<size_t> occ_off(ntw + 1, 0);
+      for (int t = 0; t < ntw; ++t) occ_off[t + 1] = occ_off[t] + (size_t)L.tile[t0w + t].y * 64;
+      std::vector<uint16_t> occA(occ_off[ntw], 0), occR(occ_off[ntw], 0);
+      auto idxA = [&](int t, int lane, int j, int acc_slot) { return occ_off[t - t0w] + (size_t)j * 64 + (lane >> 5) * 32 + (acc_slot & 31); };
+      auto idxR = [&](int t, int sl, int lane, int j) { return occ_off[t - t0w] + (size_t)j * 64 + read_group(lane) * 16 + (sl & 15); };
+      // What a collision costs is the WORST multiplicity of its row (per half for ds_add_f64, per lane group for
+      // ds_read_b128): a second collision in a row that already has one is free.  So the cost of putting an
+      // observation on a bank is the increase of that maximum (ties: the bank's occupancy), which makes the greedy
+      // gather the unavoidable collisions in few rows instead of spreading one into every row.
+      std::vector<uint16_t> mxA(occ_off[ntw] / 32, 1), mxR(occ_off[ntw] / 16, 1);  // per (tile, row, half) / (tile, row, group)
+      auto mxA_at = [&](int t, int lane, int j) -> uint16_t& { return mxA[(occ_off[t - t0w] + (size_t)j * 64) / 32 + (lane >> 5)]; };
+      auto mxR_at = [&](int t, int lane, int j) -> uint16_t& { return mxR[(occ_off[t - t0w] + (size_t)j * 64) / 16 + read_group(lane)]; };
+      // cost of an observation of slot sl at (t, lane, row j); hubs pick their best replica
+      auto occ_of = [&](int t, int sl, int lane, int j, int& rep) -> long {
+        const int m = mxA_at(t, lane, j);
+        if (sl >= hubs) {
+          rep = 0;
+          const int v = occA[idxA(t, lane, j, sl + 3 * hubs)];
+          return 1000L * std::max(0, v + 1 - m) + v;
         }
-        auto place_cost = [&](const std::vector<int>& cur, int lane0, int P, std::vector<int>& out_assign) -> long {
-          const int h = (int)cur.size();
-          if (h == 0) return 0;
-          cost.assign((size_t)h * h, 0);
-          for (int a = 0; a < h; ++a) {
-            const int s = slot_of_rank[rank1[cam_idx[cur[a]]] - 1];
-            for (int pos = 0; pos < h; ++pos) {
-              const int lane = lane0 + pos % P, j = pos / P;
-              long c = 96L * occA[bankA(s, lane, j)];
-              if (s >= hubs) c += 16L * occR[bankR(s, lane, j)];
-              cost[(size_t)a * h + pos] = c;
-            }
-          }
-          lpl_assign(h, cost, out_assign);
-          long tot = 0;
-          for (int a = 0; a < h; ++a) tot += cost[(size_t)a * h + out_assign[a]];
-          return tot;
-        };
-        for (int pass = 0; pass < 2; ++pass)
-          for (size_t o = o0; o < o1; ++o) {
-            const int l = order[o], P = parts_of[l];
-            int lane0 = lane_of[o - o0];
-            std::vector<int>& cur = placed[o - o0];
-            if (pass == 0) {
-              for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
-                if (cold_pos_of_obs[i] < 0) cur.push_back(i);
-            } else {  // take this landmark's banks out again, then place it against everything else
-              for (size_t n = 0; n < cur.size(); ++n) {
-                const int s = slot_of_rank[rank1[cam_idx[cur[n]]] - 1], lane = lane0 + (int)(n % P), j = (int)(n / P);
-                occA[bankA(s, lane, j)]--;
-                if (s >= hubs) occR[bankR(s, lane, j)]--;
-              }
-            }
-            const int h = (int)cur.size();
-            if (h <= 64 && !no_place) {
-              if (pass == 0 && P == 1) {
-                long best = -1;
-                int best_lane = -1;
-                unsigned seen = 0;
-                for (unsigned long long m = free_mask; m; m &= m - 1) {
-                  const int lane = __builtin_ctzll(m), cls = lane_class(lane);
-                  if (seen & (1u << cls)) continue;
-                  seen |= 1u << cls;
-                  const long c = place_cost(cur, lane, 1, assign2);
-                  if (best < 0 || c < best) { best = c; best_lane = lane; assign = assign2; }
-                  if (best == 0) break;
-                }
-                lane0 = best_lane;
-                free_mask &= ~(1ull << lane0);
-                lane_of[o - o0] = lane0;
-              } else {
-                place_cost(cur, lane0, P, assign);
-              }
-              if (h > 1) {
-                hot_idx.assign(h, 0);
-                for (int a = 0; a < h; ++a) hot_idx[assign[a]] = cur[a];
-                cur = hot_idx;
-              }
-            } else if (pass == 0 && P == 1) {
-              free_mask &= ~(1ull << lane0);
-            }
-            for (int n = 0; n < h; ++n) {
-              const int s = slot_of_rank[rank1[cam_idx[cur[n]]] - 1], lane = lane0 + n % P, j = n / P;
-              occA[bankA(s, lane, j)]++;
-              if (s >= hubs) occR[bankR(s, lane, j)]++;
-            }
-          }
-        for (size_t o = o0; o < o1; ++o) {  // the lanes the single-lane landmarks ended up in
-          const int l = order[o];
-          if (parts_of[l] != 1) continue;
-          L.lm_pos[l] = t * WAVE + lane_of[o - o0];
-          L.lm_of[(size_t)t * WAVE + lane_of[o - o0]] = l;
+        long best = 1L << 40;
+        for (int q = 0; q < 4; ++q) {
+          const int v = occA[idxA(t, lane, j, 4 * sl + q)];
+          const long c = 1000L * std::max(0, v + 1 - m) + v;
+          if (c < best) { best = c; rep = q; }
         }
-        // write the tile's rows
-        for (size_t o = o0; o < o1; ++o) {
-          const int l = order[o], lane0 = L.lm_pos[l] & 63, P = parts_of[l];
-          const std::vector<int>& cur = placed[o - o0];
-          const int h = (int)cur.size();
-          cold_idx.clear();
-          for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
-            if (cold_pos_of_obs[i] >= 0) cold_idx.push_back(i);
-          for (int n = 0; n < h + (int)cold_idx.size(); ++n) {
-            const int i = n < h ? cur[n] : cold_idx[n - h];
-            const int q = n % P, j = n / P, r0 = rank1[cam_idx[i]] - 1, lane = lane0 + q;
-            const size_t idx = ((size_t)L.tile[t].x + j) * WAVE + lane;
-            L.uv[idx] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
-            L.of_slot[slot_of_obs[i]] = (int)idx;
-            if (n < h) {
-              L.cw[idx] = slot_of_rank[r0];
-            } else {
-              L.cw[idx] = -2 - r0;  // cold: the record is gathered from the rank-ordered image
-              L.cpos[idx] = cold_pos_of_obs[i];
+        return best;
+      };
+      auto read_cost = [&](int t, int sl, int lane, int j) -> long {
+        const int v = occR[idxR(t, sl, lane, j)];
+        return 1000L * std::max(0, v + 1 - (int)mxR_at(t, lane, j)) + v;
+      };
+      const size_t n_o = order.size();
+      std::vector<std::vector<int>> placed(n_o);   // per landmark: its resident observations in position order
+      std::vector<std::vector<char>> reps(n_o);    // and the accumulator replica of each (hubs)
+      std::vector<int> tile_of(n_o), lane_of(n_o);
+      for (size_t o = 0; o < n_o; ++o) {
+        const int pos = L.lm_pos[order[o]] & ((1 << 26) - 1);
+        tile_of[o] = pos >> 6;
+        lane_of[o] = pos & 63;
+        for (int i = lm_off[order[o]]; i < lm_off[order[o] + 1]; ++i)
+          if (cold_pos_of_obs[i] < 0) placed[o].push_back(i);
+        reps[o].assign(placed[o].size(), 0);
+      }
+      auto slot_of_obs_ = [&](int i) { return slot_of_rank[rank1[cam_idx[i]] - 1]; };
+      // cheapest assignment of the landmark's resident observations to the rows of lanes [lane0, lane0 + P) of tile t
+      auto place_cost = [&](const std::vector<int>& cur, int t, int lane0, int P, std::vector<int>& out_assign) -> long {
+        const int h = (int)cur.size();
+        if (h == 0) return 0;
+        cost.assign((size_t)h * h, 0);
+        for (int a = 0; a < h; ++a) {
+          const int sl = slot_of_obs_(cur[a]);
+          for (int pos = 0; pos < h; ++pos) {
+            const int lane = lane0 + pos % P, j = pos / P;
+            int rp;
+            long c = 6L * occ_of(t, sl, lane, j, rp);  // 12 atomics x 8 cycles against 16 reads x 1 cycle per extra lane
+            if (sl >= hubs) c += read_cost(t, sl, lane, j);
+            cost[(size_t)a * h + pos] = c;
+          }
+        }
+        lpl_assign(h, cost, out_assign);
+        long tot = 0;
+        for (int a = 0; a < h; ++a) tot += cost[(size_t)a * h + out_assign[a]];
+        return tot;
+      };
+      auto commit = [&](size_t o, int sign, bool choose_rep) {
+        const std::vector<int>& cur = placed[o];
+        const int P = parts_of[order[o]];
+        for (size_t n = 0; n < cur.size(); ++n) {
+          const int sl = slot_of_obs_(cur[n]), lane = lane_of[o] + (int)(n % P), j = (int)(n / P), t = tile_of[o];
+          int acc_slot = sl + 3 * hubs;
+          if (sl < hubs) {
+            int rp = reps[o][n];
+            if (choose_rep) { occ_of(t, sl, lane, j, rp); reps[o][n] = (char)rp; }
+            acc_slot = 4 * sl + rp;
+          }
+          uint16_t& ca = occA[idxA(t, lane, j, acc_slot)];
+          ca += sign;
+          if (sign > 0) mxA_at(t, lane, j) = std::max(mxA_at(t, lane, j), ca);
+          else {  // removal: the row's maximum may drop
+            uint16_t m = 1;
+            const size_t base = occ_off[t - t0w] + (size_t)j * 64 + (lane >> 5) * 32;
+            for (int q = 0; q < 32; ++q) m = std::max(m, occA[base + q]);
+            mxA_at(t, lane, j) = m;
+          }
+          if (sl >= hubs) {
+            uint16_t& cr = occR[idxR(t, sl, lane, j)];
+            cr += sign;
+            if (sign > 0) mxR_at(t, lane, j) = std::max(mxR_at(t, lane, j), cr);
+            else {
+              uint16_t m = 1;
+              const size_t base = occ_off[t - t0w] + (size_t)j * 64 + read_group(lane) * 16;
+              for (int q = 0; q < 16; ++q) m = std::max(m, occR[base + q]);
+              mxR_at(t, lane, j) = m;
             }
           }
         }
-        o0 = o1;
+      };
+      auto reorder = [&](size_t o) {
+        std::vector<int>& cur = placed[o];
+        const int h = (int)cur.size();
+        if (h <= 1) return;
+        hot_idx.assign(h, 0);
+        for (int a = 0; a < h; ++a) hot_idx[assign[a]] = cur[a];
+        cur = hot_idx;
+      };
+      if (!no_place) {
+        // (1) landmarks dealt over several lanes keep their lanes: rows only
+        for (size_t o = 0; o < n_o; ++o)
+          if (parts_of[order[o]] > 1) {
+            if (placed[o].size() <= 64) { place_cost(placed[o], tile_of[o], lane_of[o], parts_of[order[o]], assign); reorder(o); }
+            commit(o, +1, true);
+          }
+        // (2) single-lane landmarks of one class (same rows per lane, same cold rows) are interchangeable.
+        size_t a = 0;
+        while (a < n_o) {
+          if (parts_of[order[a]] > 1) { ++a; continue; }
+          size_t b = a;
+          while (b < n_o && parts_of[order[b]] == 1 && psize_of[order[b]] == psize_of[order[a]] &&
+                 cold_of[order[b]] == cold_of[order[a]]) ++b;
+          const int ta = tile_of[a], tb = tile_of[b - 1];
+          std::vector<unsigned long long> free_mask(tb - ta + 1, 0);
+          for (size_t o = a; o < b; ++o) free_mask[tile_of[o] - ta] |= 1ull << lane_of[o];
+          // each takes the cheapest free position of the class, one landmark after the other: any tile of the class,
+          // any class of lanes (half, ds_read_b128 lane group), rows by the assignment problem
+          for (size_t o = a; o < b; ++o) {
+            long best = -1;
+            int best_t = -1, best_lane = -1;
+            for (int t = ta; t <= tb && best != 0; ++t) {
+              unsigned seen = 0;
+              for (unsigned long long m = free_mask[t - ta]; m && best != 0; m &= m - 1) {
+                const int lane = __builtin_ctzll(m), cls = (lane >> 5) * 2 + (read_group(lane) & 1);
+                if (seen & (1u << cls)) continue;
+                seen |= 1u << cls;
+                const long c = place_cost(placed[o], t, lane, 1, assign2);
+                if (best < 0 || c < best) { best = c; best_t = t; best_lane = lane; assign = assign2; }
+              }
+            }
+            tile_of[o] = best_t;
+            lane_of[o] = best_lane;
+            free_mask[best_t - ta] &= ~(1ull << best_lane);
+            reorder(o);
+            commit(o, +1, true);
+          }
+          a = b;
+        }
+        // (3) once more with everything placed: rows only (not the exactly placed ones)
+        for (size_t o = 0; o < n_o; ++o) {
+          if (placed[o].size() < 2 || placed[o].size() > 64) continue;
+          commit(o, -1, false);
+          place_cost(placed[o], tile_of[o], lane_of[o], parts_of[order[o]], assign);
+          reorder(o);
+          commit(o, +1, true);
+        }
+      } else {
+        for (size_t o = 0; o < n_o; ++o) commit(o, +1, true);
+      }
+      // write the rows
+      for (size_t o = 0; o < n_o; ++o) {
+        const int l = order[o], t = tile_of[o], lane0 = lane_of[o], P = parts_of[l];
+        if (P == 1) {
+          L.lm_pos[l] = t * WAVE + lane0;
+          L.lm_of[(size_t)t * WAVE + lane0] = l;
+        }
+        const std::vector<int>& cur = placed[o];
+        const int h = (int)cur.size();
+        cold_idx.clear();
+        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
+          if (cold_pos_of_obs[i] >= 0) cold_idx.push_back(i);
+        for (int n = 0; n < h + (int)cold_idx.size(); ++n) {
+          const int i = n < h ? cur[n] : cold_idx[n - h];
+          const int q = n % P, j = n / P, r0 = rank1[cam_idx[i]] - 1, lane = lane0 + q;
+          const size_t idx = ((size_t)L.tile[t].x + j) * WAVE + lane;
+          L.uv[idx] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
+          L.of_slot[slot_of_obs[i]] = (int)idx;
+          if (n < h) {
+            L.cw[idx] = slot_of_rank[r0] | ((int)reps[o][n] << 16);
+          } else {
+            L.cw[idx] = -2 - r0;  // cold: the record is gathered from the rank-ordered image
+            L.cpos[idx] = cold_pos_of_obs[i];
+          }
+        }
       }
       for (int s = 0; s < n_w; ++s) slot_of_rank[L.wg_cams[slot0 + s]] = -1;
     }

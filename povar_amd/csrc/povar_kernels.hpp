@@ -1195,11 +1195,14 @@ __device__ inline void lpl_read_p3(const double2* h, double* P3) {
 constexpr int LPL_DEPTH = 3;
 // Accumulator slots.  ds_add_f64 collisions inside a 32-lane half serialise, and the most observed cameras collect
 // several observations per row (Zipf hub: 9 % of all observations): the LPL_HUBS hottest cameras therefore get four
-// accumulator replicas each, chosen by the lane, summed at the flush.
+// accumulator replicas each, chosen per observation by the layout (lpl_layout.hpp), summed at the flush.
 constexpr int LPL_HUBS = 16;
 __host__ __device__ inline int lpl_hubs(int n_hot) { return n_hot < LPL_HUBS ? n_hot : LPL_HUBS; }
-__host__ __device__ inline int lpl_acc_slot(int rank, int lane, int hubs) {
-  return rank < hubs ? 4 * rank + (lane & 3) : rank + 3 * hubs;
+// cw >= 0 packs the LDS slot (low 16 bits) and, for a hub, the accumulator replica the host chose (bits 16-17)
+__host__ __device__ inline int lpl_cw_slot(int cw) { return cw & 0xffff; }
+__host__ __device__ inline int lpl_acc_slot(int cw, int hubs) {
+  const int slot = cw & 0xffff;
+  return slot < hubs ? 4 * slot + ((cw >> 16) & 3) : slot + 3 * hubs;
 }
 __host__ __device__ inline size_t lpl_lds_bytes(int n_hot) {
   return (size_t)n_hot * HOT_REC * sizeof(double2) + (size_t)(n_hot + 3 * lpl_hubs(n_hot)) * 96 + 16;
@@ -1345,7 +1348,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
       LplObs o;
       o.set(d, cur.uv, ROBUST ? cur.w : 1.0);
       if (j < c_nh) {  // wave-uniform: every lane has an observation of an LDS-resident camera in this row
-        const double2* h = hot + cur.cw * HOT_REC;
+        const double2* h = hot + lpl_cw_slot(cur.cw) * HOT_REC;
 #if POVAR_LPLX & 4
         for (int m = 0; m < 12; ++m) zz[m] = cur.uv.x + m;
         for (int m = 0; m < 9; ++m) P3[m] = cur.uv.y + m + (double)(size_t)h;
@@ -1360,7 +1363,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
       } else if (cur.cw != -1) {
 #endif
         if (cur.cw >= 0) {
-          const double2* h = hot + cur.cw * HOT_REC;
+          const double2* h = hot + lpl_cw_slot(cur.cw) * HOT_REC;
           lpl_read_zz(h, zz);
           lpl_read_p3(h, P3);
         } else {  // cold: camera with popularity rank -2 - cw, record from the rank-ordered image (L2)
@@ -1403,10 +1406,10 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
 #if POVAR_LPLX & 2
         for (int m = 0; m < 9; ++m) P3[m] = cur.uv.y + m;
 #else
-        lpl_read_p3(hot + cur.cw * HOT_REC, P3);
+        lpl_read_p3(hot + lpl_cw_slot(cur.cw) * HOT_REC, P3);
 #endif
         lpl_backward(o, P3, g, q);
-        double* a = acc + lpl_acc_slot(cur.cw, lane, hubs);  // acc[m][slot]: consecutive slots on consecutive banks
+        double* a = acc + lpl_acc_slot(cur.cw, hubs);  // acc[m][slot]: consecutive slots on consecutive banks
         const double val[12] = {hx * q[0], hy * q[0], hz * q[0], q[0], hx * q[1], hy * q[1],
                                 hz * q[1], q[1], hx * q[2], hy * q[2], hz * q[2], q[2]};
 #if POVAR_LPLX & 1
@@ -1602,7 +1605,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
       issue(n3);
       if (cur.cw == -1) continue;
       double P[12];
-      if (cur.cw >= 0) prep_read_rec(hot + cur.cw * PREP_REC, P);
+      if (cur.cw >= 0) prep_read_rec(hot + lpl_cw_slot(cur.cw) * PREP_REC, P);
       else prep_read_rec(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
       PrepObs o;
       o.set(d, P, cur.uv, ROBUST ? cur.w : 1.0, hx, hy, hz, s4.x, s4.y, s4.z);
@@ -1654,7 +1657,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
       issue(n3);
       if (cur.cw == -1) continue;
       double P[12];
-      if (cur.cw >= 0) prep_read_rec(hot + cur.cw * PREP_REC, P);
+      if (cur.cw >= 0) prep_read_rec(hot + lpl_cw_slot(cur.cw) * PREP_REC, P);
       else prep_read_rec(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
       PrepObs o;
       const double w = ROBUST ? cur.w : 1.0;
@@ -1664,7 +1667,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
       for (int r = 0; r < 4; ++r) e[r] = o.r[r] - (o.jl[3 * r] * w3[0] + o.jl[3 * r + 1] * w3[1] + o.jl[3 * r + 2] * w3[2]);
       const double4 q = pose_q(d, cur.uv.x, cur.uv.y, sqrt(w), e);
       if (cur.cw >= 0) {
-        double* a = acc + lpl_acc_slot(cur.cw, lane, hubs);
+        double* a = acc + lpl_acc_slot(cur.cw, hubs);
         const double val[12] = {hx * q.x, hy * q.x, hz * q.x, q.x, hx * q.y, hy * q.y,
                                 hz * q.y, q.y, hx * q.z, hy * q.z, hz * q.z, q.z};
 #pragma unroll

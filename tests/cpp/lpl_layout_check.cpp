@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
           ++n_placed;
           wg_obs[w]++;
           if (cw >= 0) {
-            CHECK(cw < nw);
+            CHECK(lpl_cw_slot(cw) < nw && (cw >> 16) < 4);
           } else {
             ++n_cold;
             CHECK(L.cpos[idx] >= 0 && L.cpos[idx] < (int)L.cold_lm.size());
@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
       while (w > 0 && (L.wg_tile_off[w] >= (int)L.tile.size() || L.tile[L.wg_tile_off[w]].x > row)) --w;
     }
     if (cw >= 0) {
-      CHECK(L.wg_cams[L.wg_cam_off[w] + cw] == r0);
+      CHECK(L.wg_cams[L.wg_cam_off[w] + lpl_cw_slot(cw)] == r0);
     } else {
       CHECK(-2 - cw == r0);
       const int p = L.cpos[idx];
@@ -141,12 +141,37 @@ int main(int argc, char** argv) {
       for (int lane = 0; lane < 64; ++lane) {
         const int s = L.cw[r * 64 + lane];
         if (s < 0) continue;
-        ca[lane >> 5][lpl_acc_slot(s, lane, hubs) & 31]++;
+        ca[lane >> 5][lpl_acc_slot(s, hubs) & 31]++;
         const int g = read_group(lane);
-        if (sr[g][s & 15] != s) { cr[g][s & 15]++; sr[g][s & 15] = s; }  // same record next to itself: broadcast
+        const int ss = lpl_cw_slot(s);
+        if (sr[g][ss & 15] != ss) { cr[g][ss & 15]++; sr[g][ss & 15] = ss; }  // same record next to itself: broadcast
       }
       for (int hlf = 0; hlf < 2; ++hlf) { int m = 1; for (int b = 0; b < 32; ++b) m = std::max(m, ca[hlf][b]); extra_a += m - 1; }
       for (int g = 0; g < 4; ++g) { int m = 1; for (int b = 0; b < 16; ++b) m = std::max(m, cr[g][b]); extra_r += m - 1; }
+    }
+    {  // by tile height (stderr): where the collisions sit
+      double ea[16] = {}, er[16] = {}, nrow[16] = {};
+      for (size_t t = 0; t < L.tile.size(); ++t) {
+        const int R = std::min(L.tile[t].y, 15);
+        for (int j = 0; j < L.tile[t].y; ++j) {
+          const int64_t r = (int64_t)L.tile[t].x + j;
+          int ca[2][32] = {}, cr[4][16] = {}, sr[4][16];
+          for (int g = 0; g < 4; ++g) for (int b = 0; b < 16; ++b) sr[g][b] = -1;
+          for (int lane = 0; lane < 64; ++lane) {
+            const int sl = L.cw[r * 64 + lane];
+            if (sl < 0) continue;
+            ca[lane >> 5][lpl_acc_slot(sl, hubs) & 31]++;
+            const int g = read_group(lane);
+            const int ss = lpl_cw_slot(sl);
+            if (sr[g][ss & 15] != ss) { cr[g][ss & 15]++; sr[g][ss & 15] = ss; }
+          }
+          for (int hlf = 0; hlf < 2; ++hlf) { int m = 1; for (int b = 0; b < 32; ++b) m = std::max(m, ca[hlf][b]); ea[R] += m - 1; }
+          for (int g = 0; g < 4; ++g) { int m = 1; for (int b = 0; b < 16; ++b) m = std::max(m, cr[g][b]); er[R] += m - 1; }
+          nrow[R] += 1;
+        }
+      }
+      for (int R = 2; R < 16; ++R)
+        if (nrow[R] > 0) std::fprintf(stderr, "tiles of %d rows: %.0f rows, extra atomics %.3f, extra reads %.3f\n", R, nrow[R], ea[R] / nrow[R] / 2, er[R] / nrow[R] / 4);
     }
     extra_a /= (double)L.rows * 2;
     extra_r /= (double)L.rows * 4;
@@ -160,7 +185,7 @@ int main(int argc, char** argv) {
         for (int j = 0; j < R; ++j)
           for (int lane = hlf * 32; lane < hlf * 32 + 32; ++lane) {
             const int sl = L.cw[((size_t)L.tile[t].x + j) * 64 + lane];
-            if (sl >= 0) deg[lpl_acc_slot(sl, lane, hubs) & 31]++;
+            if (sl >= 0) deg[lpl_acc_slot(sl, hubs) & 31]++;
           }
         int mx = 0;
         for (int b = 0; b < 32; ++b) mx = std::max(mx, deg[b]);
