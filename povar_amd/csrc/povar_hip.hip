@@ -441,7 +441,7 @@ Dp ldsacc_dp(povar_ctx* c, bool long_in_kernel = false) {
   dt.hot_part = c->hot_part.p;
   dt.q4c = c->q4c.p;
   dt.cold_pos = c->cold_pos.p;
-  if (c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
+  if (c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
     // e0_lpl: its own cold view (observations whose camera is not resident in their workgroup) and partial records
     dt.cmv.h = c->c3_h.p;
     dt.cmv.n = c->n_cold3;
@@ -484,7 +484,13 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
   prof_mark(c, 0);
   if (c->joint) {
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
-    if (acc) {
+    if (acc && c->use_lpl) {
+      Dp da = ldsacc_dp(c, true);
+      if (c->opt.robust_norm)
+        hipLaunchKernelGGL(e0_lpl_h<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes_h(c->v2_max_slots), c->stream, da, c->v2_part.p);
+      else
+        hipLaunchKernelGGL(e0_lpl_h<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes_h(c->v2_max_slots), c->stream, da, c->v2_part.p);
+    } else if (acc) {
       // cold observations write q to their camera-major position (q4c); long landmarks are walked inside the kernel
       const Dp da = ldsacc_dp(c, true);
       hipLaunchKernelGGL(e0_lm_cached_h, dim3(c->e0c_grid), dim3(E0C_BLOCK),
@@ -709,6 +715,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                                 (int)lpl_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lpl_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lpl_lds_bytes_h(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lpl_lds_bytes_h(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -803,7 +813,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (int rc = upload(c->c3_lm, V.cold_lm, c)) return rc;
     if (int rc = upload(c->c3_range, V.cold_range, c)) return rc;
     const int nt = (int)V.tile.size();
-    HIP_TRY(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * 9 * WAVE, &c->bytes));
+    HIP_TRY(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * LPL_REC_H * WAVE, &c->bytes));  // 9 entries used by step 1
     HIP_TRY(c->v2_part.alloc((size_t)std::max(V.n_part_rec, 1) * 12, &c->bytes));
     HIP_TRY(c->c3_h.alloc(4 * std::max<size_t>(V.cold_lm.size(), 1), &c->bytes));
     if (options->robust_norm) HIP_TRY(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
@@ -1284,6 +1294,8 @@ int povar_linearize_homogeneous(povar_ctx* c) {
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, 1);
   if (c->long_in_kernel && c->n_cold2 > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold2, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c2_lm.p, c->c2_h.p, c->n_cold2, 1);
+  if (c->n_cold3 > 0)
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 1);
   hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
   hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
   if (sharded(c)) {
@@ -1497,15 +1509,15 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
   const int64_t cam_static = nc * (96 + 96);            // z (12 doubles) + P (12 doubles) per camera
   const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
   const bool lik = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->long_in_kernel;
-  const bool lpl = c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+  const bool lpl = c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
   const int64_t n_cold = lpl ? c->n_cold3 : lik ? c->n_cold2 : c->n_cold;
   const int64_t hot_flush = lpl ? (int64_t)c->v2_part.n * 8 : acc ? (int64_t)c->e0c_grid * c->n_hot_acc * 96 : 0;
   const int64_t tail = nc * (1152 + 96 /*sigma*/ + 3 * 96 /*accum rw, tmp*/ + 96 /*z*/);
   int64_t lm = 0, cm = 0;
   switch (c->opt.e0_mode) {
     case POVAR_E0_IMPLICIT_LDSACC:
-      if (c->use_lpl && !c->joint)  // e0_lpl: uv + camera rank per row slot, 72-byte records, cold: position + q out
-        lm = c->v2_rows * WAVE * (20 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * 72 + cam_static + n_cold * 36 + hot_flush;
+      if (c->use_lpl)  // e0_lpl[_h]: uv + camera slot per row slot, 72 (112)-byte landmark records, cold: position + q out
+        lm = c->v2_rows * WAVE * (20 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * (c->joint ? 112 : 72) + cam_static + n_cold * 36 + hot_flush;
       else
           lm = ns * (E0_SLOT_BYTES + robust) + nl * E0_LMREC_BYTES + cam_static + n_cold * 32 + hot_flush;
       cm = hot_flush + n_cold * (32 + 24) + tail;

@@ -54,8 +54,8 @@ constexpr int HOT_REC_STRIDE = 24;  // doubles per camera in Dp::hot_rec
 constexpr int META_HOT_SHIFT = 18;     // 10 bits
 constexpr int META_HOT_MASK = 1023;
 constexpr int META_STEPS_SHIFT = 28;   // 3 bits: ceil(log2(longest landmark of the bin)), same in every lane of a bin
-constexpr int HOT_ACC_MAX = 568;    // cameras cached AND accumulated in LDS: step 1 568 * (176 + 96) B = 151 KiB,
-                                    // step 2 568 * (192 + 96) B = 159.75 KiB of the 160 KiB
+constexpr int HOT_ACC_MAX = 552;    // camera slots of a workgroup's LDS: step 2 552 * (192 + 96) B + 48 hub replicas * 96 B
+                                    // + 16 B = 163 600 of the 163 840 bytes; step 1 (176-byte records) 154 768
 constexpr int HOT_MAX = 912;        // cameras cached per workgroup: 912 * 176 B = 156.75 KiB of the 160 KiB LDS
 constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :3] (4.5) + pad
 constexpr int E0C_BLOCK = 1024;     // one workgroup per CU

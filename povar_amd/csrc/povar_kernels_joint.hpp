@@ -115,6 +115,7 @@ struct OpLinearizeH {
     const double sw = sqrt(w);
     if (!isfinite(r2) || !isfinite(sw) || !isfinite(h.D02) || !isfinite(h.D12)) atomicOr(&d.flags[0], 1);
     d.sw[slot] = sw;
+    if (d.robust && d.v2.w) d.v2.w[d.v2.of_slot[slot]] = w;
     d.rres[slot] = make_double4(sw * h.r0, sw * h.r1, 0, 0);
     double jl[8];
     hom_jl4(P, h, sw, make_double4(1, 1, 1, 1), jl);
@@ -184,8 +185,20 @@ struct OpPrepareH {
     rec[1] = d.jl_scale4[lm];
     rec[2] = make_double4(Hi[0], Hi[1], Hi[2], Hi[4]);
     rec[3] = make_double4(Hi[5], Hi[8], 0, 0);
+    if (d.v2.lmrec) {  // record of the lane-per-landmark kernel, one copy per lane the landmark occupies
+      const int lp = d.v2.lm_pos[lm], pos = lp & ((1 << 26) - 1), lanes = ((lp >> 26) & 63) + 1;
+      const double4 X = d.lms_lin4[lm], s = d.jl_scale4[lm];
+      const double rv[14] = {X.x, X.y, X.z, X.w, s.x, s.y, s.z, s.w, Hi[0], Hi[1], Hi[2], Hi[4], Hi[5], Hi[8]};
+      for (int q = 0; q < lanes; ++q) {
+        double* r2 = d.v2.lmrec + ((size_t)(pos >> 6) * 14) * WAVE + (pos & 63) + q;
+#pragma unroll
+        for (int m = 0; m < 14; ++m) r2[m * WAVE] = rv[m];
+      }
+    }
   }
 };
+
+constexpr int HOT_REC_H = 12;  // double2 per camera record of the step-2 kernels: z (12 doubles), P (12 doubles)
 
 // K10': right_mul_e0_joint (linearization_power_varproj.hpp:408-453); input z = sigma * (N_c x_c)
 struct OpE0H {
@@ -267,7 +280,7 @@ struct OpBackJoint {
 // Per-term landmark-major kernel of step 2 with the LDS camera cache + LDS accumulation of the hot
 // cameras: the step-2 twin of e0_lm_cached<true> (same pipeline, 2-row tiles, camera record = z_c (12)
 // + full P_c (12) = 192 B, landmark record = X | s | Hll^-1 = 128 B).
-constexpr int HOT_REC_H = 12;
+
 __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_wg, double* hot_out) {
   if (d.flags[1]) return;
   extern __shared__ double2 hot[];  // [n_hot][HOT_REC_H] records, then acc[12][n_hot]
@@ -677,6 +690,259 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy_h(Dp d, int mode, 
   }
 }
 
+// K10' on the lane-per-landmark layout (right_mul_e0_joint, linearization_power_varproj.hpp:408-453): e0_lpl's
+// structure (povar_kernels.hpp) with the 2-row tiles of step 2.  Records are 192 bytes (z = sigma * N_c x_c, then the
+// full P_c), the landmark lane carries X, the Jl column scale and Hll^-1 (the column scale cannot be folded into
+// Hll^-1 here: the tangent basis N_l sits between them).
+constexpr int LPL_REC_H = 14;  // doubles per landmark lane in V2::lmrec (step 2)
+__host__ __device__ inline size_t lpl_lds_bytes_h(int n_hot) {
+  return (size_t)n_hot * 12 * sizeof(double2) + (size_t)(n_hot + 3 * lpl_hubs(n_hot)) * 96 + 16;
+}
+template <bool ROBUST>
+__global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
+  const int done = d.flags[1];  // requested first, tested after the LDS staging (no global side effects before)
+  extern __shared__ double2 hot[];  // [n_hot][HOT_REC_H] records, then acc[12][n_slots], then the tile counter
+  const V2& v = d.v2;
+  // this workgroup's camera slots: the records of the cameras it keeps in LDS (lpl_layout.hpp) and their accumulators
+  const int cam0 = v.wg_cam_off[blockIdx.x];
+  const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  const int hubs = v.hubs, n_slots = n_hot + 3 * hubs;
+  double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC_H);
+  int* grab_ctr = reinterpret_cast<int*>(acc + n_slots * 12);
+  for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
+  if (threadIdx.x == 0) *grab_ctr = 0;
+  const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
+  {
+    // staging: slot -> camera rank -> record, two dependent L2 round trips; every thread first requests all its
+    // ranks, then all its record pieces, then writes LDS (a plain loop pays the two latencies once per pass)
+    constexpr int PASSES = (HOT_ACC_MAX * HOT_REC_H + E0C_BLOCK - 1) / E0C_BLOCK;
+    int rk[PASSES];
+    double2 piece[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      rk[u] = i < n_hot * HOT_REC_H ? v.wg_cams[cam0 + i / HOT_REC_H] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      piece[u] = rec_img[(size_t)rk[u] * (HOT_REC_STRIDE / 2) + i % HOT_REC_H];
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      if (i < n_hot * HOT_REC_H) hot[i] = piece[u];
+    }
+  }
+  __syncthreads();
+  if (done) return;
+  const int lane = threadIdx.x & 63;
+  // The workgroup's tiles are sorted longest first; its wavefronts take them on demand (one LDS counter), so a
+  // wavefront's last tile is a short one.  The workgroups carry equal observation totals (lpl_layout.hpp).
+  const int t_begin = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
+  const int t_end = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
+  auto grab = [&]() -> int {
+    int n = 0;
+    if (lane == 0) n = __hip_atomic_fetch_add(grab_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const long long t = (long long)t_begin + n;
+    return t < t_end ? (int)t : t_end;
+  };
+
+  // tile table through the scalar cache (constant address space + wave-uniform index => s_load_dwordx4): a vector
+  // load here would put a vmcnt(0) drain inside the row pipeline
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  const cint_p tiles = (cint_p)(uintptr_t)v.tile;
+  auto tile_info = [&](int t, int& row0, int& k, int& nh, int& fl) {
+    row0 = tiles[4 * t];
+    k = tiles[4 * t + 1];
+    nh = tiles[4 * t + 2];
+    fl = tiles[4 * t + 3];
+  };
+  LplCursor pc;
+  pc.t = grab();
+  pc.pass = 0;
+  pc.j = 0;
+  pc.row0 = 0;
+  pc.k = 1;
+  int c_t = pc.t, c_row0 = 0, c_k = 0, c_nh = 0, c_fl = 0;
+  // the tile after the one being consumed, taken when the consumer enters a tile: the prefetch cursor runs at most
+  // LPL_DEPTH = 3 rows ahead and a tile has at least 4 row steps, so it never needs more than this one
+  int nx_t = t_end;
+  if (c_t < t_end) {
+    tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+    pc.row0 = c_row0;
+    pc.k = c_k;
+    nx_t = grab();
+  }
+  // request the row under the prefetch cursor and advance it
+  auto issue = [&](LplRow& r) {
+    if (pc.t < t_end) {
+      // the backward pass walks the rows in reverse: the rows read last are the ones most likely still in L2
+      const size_t i = ((size_t)pc.row0 + (pc.pass ? pc.k - 1 - pc.j : pc.j)) * WAVE + lane;
+      r.uv = v.uv[i];
+      r.cw = v.cw[i];
+      if (ROBUST) r.w = v.w[i];
+      if (++pc.j == pc.k) {
+        pc.j = 0;
+        if (++pc.pass == 2) {
+          pc.pass = 0;
+          pc.t = nx_t;
+          if (pc.t < t_end) {
+            int nh_, fl_;
+            tile_info(pc.t, pc.row0, pc.k, nh_, fl_);
+          }
+        }
+      }
+    }
+  };
+  LplRow n1, n2, n3;
+  n1.cw = n2.cw = n3.cw = -1;
+  n1.w = n2.w = n3.w = 1.0;
+  n1.uv = n2.uv = n3.uv = make_double2(0, 0);
+  issue(n1);
+  issue(n2);
+  issue(n3);
+  // landmark record of the lane (step 2): X (4), Jl column scale s (4), Hll^-1 (6) = 14 entries of lmrec[tile][14][64];
+  // the Householder vector of X (tangent basis N_l, landmark_block.hpp:227-269) is rebuilt once per tile
+  auto load_rec = [&](int t, double4& X, double4& s4, double (&Hi)[6]) {
+    const double* rp = v.lmrec + ((size_t)t * LPL_REC_H) * WAVE + lane;
+    X = make_double4(rp[0], rp[WAVE], rp[2 * WAVE], rp[3 * WAVE]);
+    s4 = make_double4(rp[4 * WAVE], rp[5 * WAVE], rp[6 * WAVE], rp[7 * WAVE]);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) Hi[m] = rp[(8 + m) * WAVE];
+  };
+  auto read_cam = [&](const double2* hp, Cam& P) {  // entries 12..23 of a record: P row-major
+    const double2 b0 = hp[6], b1 = hp[7], b2 = hp[8], b3 = hp[9], b4 = hp[10], b5 = hp[11];
+    P.r0 = make_double4(b0.x, b0.y, b1.x, b1.y);
+    P.r1 = make_double4(b2.x, b2.y, b3.x, b3.y);
+    P.r2 = make_double4(b4.x, b4.y, b5.x, b5.y);
+  };
+  auto read_z = [&](const double2* hp, double4 (&zz)[3]) {
+    const double2 a0 = hp[0], a1 = hp[1], a2 = hp[2], a3 = hp[3], a4 = hp[4], a5 = hp[5];
+    zz[0] = make_double4(a0.x, a0.y, a1.x, a1.y);
+    zz[1] = make_double4(a2.x, a2.y, a3.x, a3.y);
+    zz[2] = make_double4(a4.x, a4.y, a5.x, a5.y);
+  };
+  double4 X = make_double4(0, 0, 0, 1), s4 = make_double4(1, 1, 1, 1);
+  double Hi[6] = {0, 0, 0, 0, 0, 0};
+  if (c_t < t_end) load_rec(c_t, X, s4, Hi);
+  while (c_t < t_end) {
+    double hw[4], hbeta;
+    house4(X, hw, hbeta);
+    double red[3] = {0, 0, 0};
+    for (int j = 0; j < c_k; ++j) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (j >= c_nh && cur.cw == -1) continue;
+      const double2* hp = (j < c_nh || cur.cw >= 0) ? hot + lpl_cw_slot(cur.cw) * HOT_REC_H
+                                                     : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
+      Cam P;
+      double4 zz[3];
+      read_z(hp, zz);
+      read_cam(hp, P);
+      const double sw = ROBUST ? sqrt(cur.w) : 1.0;
+      const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
+      double jl4[8], jl3[6], t[2];
+      hom_jl4(P, h, sw, s4, jl4);
+      jl3_of_jl4(jl4, hw, hbeta, jl3);
+      hom_jp_x(h, X, sw, zz, t);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) red[m] += jl3[m] * t[0] + jl3[3 + m] * t[1];
+    }
+    if (c_fl & 1) {  // landmarks dealt over several lanes: sum their partial u = Jl^T t (segmented wavefront scan)
+      const int sg = v.seg[(size_t)c_t * WAVE + lane];
+      seg_reduce_steps<3>(red, lane, sg & 255, (sg >> 8) & 255, 4);
+    }
+    const double g[3] = {Hi[0] * red[0] + Hi[1] * red[1] + Hi[2] * red[2], Hi[1] * red[0] + Hi[3] * red[1] + Hi[4] * red[2],
+                         Hi[2] * red[0] + Hi[4] * red[1] + Hi[5] * red[2]};
+    // the next tile's record (Hll^-1 is dead by now; X and s are still needed: second set)
+    const int n_t = nx_t;
+    double4 nX = make_double4(0, 0, 0, 1), ns4 = make_double4(1, 1, 1, 1);
+    double nHi[6] = {0, 0, 0, 0, 0, 0};
+    if (n_t < t_end) load_rec(n_t, nX, ns4, nHi);
+    const size_t base = (size_t)c_row0 * WAVE + lane;
+    for (int jj = 0; jj < c_k; ++jj) {
+      const int j = c_k - 1 - jj;
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (j >= c_nh && cur.cw == -1) continue;
+      const bool resident = j < c_nh || cur.cw >= 0;
+      int cold_at = 0;
+      if (!resident) cold_at = v.cpos[base + (size_t)j * WAVE];
+      const double2* hp = resident ? hot + lpl_cw_slot(cur.cw) * HOT_REC_H
+                                   : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
+      Cam P;
+      read_cam(hp, P);
+      const double sw = ROBUST ? sqrt(cur.w) : 1.0;
+      const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
+      double jl4[8], jl3[6];
+      hom_jl4(P, h, sw, s4, jl4);
+      jl3_of_jl4(jl4, hw, hbeta, jl3);
+      const double s0 = jl3[0] * g[0] + jl3[1] * g[1] + jl3[2] * g[2];
+      const double s1 = jl3[3] * g[0] + jl3[4] * g[1] + jl3[5] * g[2];
+      const double4 q = hom_q(h, sw, s0, s1);
+      if (resident) {
+        double* a = acc + lpl_acc_slot(cur.cw, hubs);  // acc[m][slot]: consecutive slots on consecutive banks
+        const double val[12] = {X.x * q.x, X.y * q.x, X.z * q.x, X.w * q.x, X.x * q.y, X.y * q.y,
+                                X.z * q.y, X.w * q.y, X.x * q.z, X.y * q.z, X.z * q.z, X.w * q.z};
+#pragma unroll
+        for (int m = 0; m < 12; ++m)
+          __hip_atomic_fetch_add(a + m * n_slots, val[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        d.q4c[cold_at] = q;
+      }
+    }
+    c_t = n_t;
+    if (c_t < t_end) {
+      tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+      nx_t = grab();
+    }
+    X = nX;
+    s4 = ns4;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) Hi[m] = nHi[m];
+  }
+  __syncthreads();
+  // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run)
+  // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run);
+  // 16-byte stores, all record indices requested first (one L2 round trip, not one per pass)
+  {
+    constexpr int PASSES = (HOT_ACC_MAX * 6 + E0C_BLOCK - 1) / E0C_BLOCK;
+    int rec[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      rec[u] = i < n_hot * 6 ? v.wg_slot_rec[cam0 + i / 6] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      if (i < n_hot * 6) {
+        const int r = i / 6, m = 2 * (i % 6);
+        const double* a0 = acc + m * n_slots;
+        const double* a1 = a0 + n_slots;
+        double2 s;
+        if (r < hubs) {
+          s.x = (a0[4 * r] + a0[4 * r + 1]) + (a0[4 * r + 2] + a0[4 * r + 3]);
+          s.y = (a1[4 * r] + a1[4 * r + 1]) + (a1[4 * r + 2] + a1[4 * r + 3]);
+        } else {
+          s.x = a0[r + 3 * hubs];
+          s.y = a1[r + 3 * hubs];
+        }
+        reinterpret_cast<double2*>(hot_out + (size_t)rec[u] * 12)[i % 6] = s;
+      }
+    }
+  }
+  if (d.p2p_epoch && blockIdx.x == 0 && threadIdx.x == 0) *d.p2p_epoch += 1;  // one tick per term, read by the next kernels
+}
+
+
+
 // cam_cold_sum fused with cam_binv_axpy_h (mode 2) for the unsharded LDSACC term loop of step 2
 // (the step-2 twin of cam_cold_sum_binv): per-camera sum of the E0 row, tangent projection, B^-1 (11x11),
 // AXPY and z = sigma * (N_c tmp) in one kernel.
@@ -727,7 +993,14 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv_h(Dp d, int want_norms,
       acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += hw[u] * q[u].z;
     }
   }
-  if (r > 0 && r <= d.n_hot_acc) {
+  if (d.part_range) {  // e0_lpl_h: the camera's partial records are one contiguous run
+    const int2 rr = d.part_range[c];
+    for (int wg = rr.x + t; wg < rr.y; wg += 256) {
+      const double* ip = d.hot_part + (size_t)wg * 12;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] += ip[k];
+    }
+  } else if (r > 0 && r <= d.n_hot_acc) {
     for (int wg = t; wg < d.n_hot_wg; wg += 256) {
       const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + wg) * 12;
 #pragma unroll
