@@ -20,7 +20,8 @@ def main():
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     n_c, n_l, n_o = synth.BAL_SHAPES[name]
-    path = os.path.join(out_dir, f"problem-{n_c}-{n_l}-pre.txt")
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"problem-{n_c}-{n_l}-pre.txt")  # 200 MB for venice: not into gpurun_out
     if not os.path.exists(path):
         synth.write_data_custom(path, synth.make_bal_problem(name))
     log = os.path.join(out_dir, f"ba_log_{name}.json")
