@@ -723,6 +723,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)prep_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)prep_lds_bytes(HOT_ACC_MAX)));
   }
 
   int rc = 0;
@@ -1321,10 +1325,27 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
   c->new_linearization_point = false;
   c->d.lambda_lm = lambda;  // set_landmark_damping_joint, linearizor_power_varproj.cpp:136
   hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_cams * 12, 256)), dim3(256), 0, c->stream, c->d, 1);
-  launch_lm(c, OpPrepareH{});
-  hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 1);
-  hipLaunchKernelGGL(cam_sum_items_h, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b,
-                     (const double*)c->ncw.p);
+  if (c->use_lpl && c->use_lpl_prepare && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
+    // lane-per-landmark K7' (see povar_prepare_pose): landmark half + per-camera partials, per-camera sum of the
+    // partials and the cold observations into the ambient 12-vector, then the tangent projection N_c^T
+    Dp da = ldsacc_dp(c, true);
+    HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
+    if (c->opt.robust_norm)
+      hipLaunchKernelGGL(prepare_lpl_h<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), prep_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
+    else
+      hipLaunchKernelGGL(prepare_lpl_h<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), prep_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
+    da.y = c->d.y;
+    da.p2p_peer = nullptr;
+    da.p2p_epoch = nullptr;
+    hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 1);
+    hipLaunchKernelGGL(cam_nt_project, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, c->d.y, c->d.b,
+                       (const double*)c->ncw.p);
+  } else {
+    launch_lm(c, OpPrepareH{});
+    hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 1);
+    hipLaunchKernelGGL(cam_sum_items_h, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b,
+                       (const double*)c->ncw.p);
+  }
   if (int rc = allreduce(c, c->d.b, 11 * (size_t)c->n_cams)) return rc;
   hipLaunchKernelGGL(cam_build_binv_h, dim3(grid_for(c->n_cams, K8_THREADS)), dim3(K8_THREADS), 0, c->stream, c->d,
                      lambda, (const double*)c->ncw.p);

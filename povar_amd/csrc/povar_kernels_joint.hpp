@@ -942,6 +942,209 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
 }
 
 
+// K7' on the lane-per-landmark layout: get_Hll_inv_add_Hpp_b_joint (landmark_block.hpp:474-507), the landmark half
+// of prepare_Hb_joint -- prepare_lpl (povar_kernels.hpp) with the homogeneous tile.  Forward pass: Hll = Jl3^T Jl3
+// and Jl3^T r in registers; the lane inverts Hll + lambda I, stores Hll^-1 and the landmark records of the per-term
+// kernels; backward pass: Jp^T (r - Jl3 w) into the camera accumulators (12 ambient values per observation; the
+// tangent projection N_c^T is applied per camera afterwards, cam_nt_project).  Replaces lm_regular<OpPrepareH> +
+// cm_scatter + cam_sum_items_h (495 + 124 + 6 us on venice-1778) for the LDSACC mode.
+template <bool ROBUST>
+__global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out) {
+  extern __shared__ double2 hot[];  // [n_hot][PREP_REC] records (P_c row-major), then acc[12][n_slots], then the tile counter
+  const V2& v = d.v2;
+  const int cam0 = v.wg_cam_off[blockIdx.x];
+  const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  const int hubs = v.hubs, n_slots = n_hot + 3 * hubs;
+  double* acc = reinterpret_cast<double*>(hot + n_hot * PREP_REC);
+  int* grab_ctr = reinterpret_cast<int*>(acc + n_slots * 12);
+  for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
+  if (threadIdx.x == 0) *grab_ctr = 0;
+  const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
+  for (int i = threadIdx.x; i < n_hot * PREP_REC; i += E0C_BLOCK) {
+    const int r = i / PREP_REC, j = i - r * PREP_REC;
+    hot[i] = rec_img[(size_t)v.wg_cams[cam0 + r] * (HOT_REC_STRIDE / 2) + 6 + j];  // entries 12..23 of the image
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int t_begin = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
+  const int t_end = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
+  auto grab = [&]() -> int {
+    int n = 0;
+    if (lane == 0) n = __hip_atomic_fetch_add(grab_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const long long t = (long long)t_begin + n;
+    return t < t_end ? (int)t : t_end;
+  };
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  const cint_p tiles = (cint_p)(uintptr_t)v.tile;
+  auto tile_info = [&](int t, int& row0, int& k, int& nh, int& fl) {
+    row0 = tiles[4 * t];
+    k = tiles[4 * t + 1];
+    nh = tiles[4 * t + 2];
+    fl = tiles[4 * t + 3];
+  };
+  LplCursor pc;
+  pc.t = grab();
+  pc.pass = 0;
+  pc.j = 0;
+  pc.row0 = 0;
+  pc.k = 1;
+  int c_t = pc.t, c_row0 = 0, c_k = 0, c_nh = 0, c_fl = 0, nx_t = t_end;
+  if (c_t < t_end) {
+    tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+    pc.row0 = c_row0;
+    pc.k = c_k;
+    nx_t = grab();
+  }
+  auto issue = [&](LplRow& r) {
+    if (pc.t < t_end) {
+      const size_t i = ((size_t)pc.row0 + (pc.pass ? pc.k - 1 - pc.j : pc.j)) * WAVE + lane;
+      r.uv = v.uv[i];
+      r.cw = v.cw[i];
+      if (ROBUST) r.w = v.w[i];
+      if (++pc.j == pc.k) {
+        pc.j = 0;
+        if (++pc.pass == 2) {
+          pc.pass = 0;
+          pc.t = nx_t;
+          if (pc.t < t_end) {
+            int nh_, fl_;
+            tile_info(pc.t, pc.row0, pc.k, nh_, fl_);
+          }
+        }
+      }
+    }
+  };
+  auto read_cam = [&](const double2* hp, Cam& P) {
+    const double2 b0 = hp[0], b1 = hp[1], b2 = hp[2], b3 = hp[3], b4 = hp[4], b5 = hp[5];
+    P.r0 = make_double4(b0.x, b0.y, b1.x, b1.y);
+    P.r1 = make_double4(b2.x, b2.y, b3.x, b3.y);
+    P.r2 = make_double4(b4.x, b4.y, b5.x, b5.y);
+  };
+  LplRow n1, n2, n3;
+  n1.cw = n2.cw = n3.cw = -1;
+  n1.w = n2.w = n3.w = 1.0;
+  n1.uv = n2.uv = n3.uv = make_double2(0, 0);
+  issue(n1);
+  issue(n2);
+  issue(n3);
+  while (c_t < t_end) {
+    const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
+    const int sg = v.seg[(size_t)c_t * WAVE + lane];
+    const double4 X = d.lms_lin4[lm >= 0 ? lm : 0], s4 = d.jl_scale4[lm >= 0 ? lm : 0];
+    double hw[4], hbeta;
+    house4(X, hw, hbeta);
+    double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < c_k; ++j) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      Cam P;
+      read_cam(cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PREP_REC : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
+      const double sw = ROBUST ? sqrt(cur.w) : 1.0;
+      const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
+      double jl4[8], jl3[6];
+      hom_jl4(P, h, sw, s4, jl4);
+      jl3_of_jl4(jl4, hw, hbeta, jl3);
+      const double r0 = sw * h.r0, r1 = sw * h.r1;
+      acc_h6(red, jl3);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) red[6 + m] += jl3[m] * r0 + jl3[3 + m] * r1;
+    }
+    if (c_fl & 1) seg_reduce_steps<9>(red, lane, sg & 255, (sg >> 8) & 255, 4);
+    double w3[3] = {0, 0, 0};
+    if (lm >= 0) {
+      double Hi[9];
+      hinv_damped(red, d.lambda_lm, Hi);
+      w3[0] = Hi[0] * red[6] + Hi[1] * red[7] + Hi[2] * red[8];
+      w3[1] = Hi[3] * red[6] + Hi[4] * red[7] + Hi[5] * red[8];
+      w3[2] = Hi[6] * red[6] + Hi[7] * red[7] + Hi[8] * red[8];
+      // per-term record of this lane (e0_lpl_h); Hll^-1 and the row-major record of the other kernels once per landmark
+      double* r2 = v.lmrec + ((size_t)c_t * LPL_REC_H) * WAVE + lane;
+      const double rv[LPL_REC_H] = {X.x, X.y, X.z, X.w, s4.x, s4.y, s4.z, s4.w, Hi[0], Hi[1], Hi[2], Hi[4], Hi[5], Hi[8]};
+#pragma unroll
+      for (int m = 0; m < LPL_REC_H; ++m) r2[m * WAVE] = rv[m];
+      if (lane == (sg & 255)) {
+#pragma unroll
+        for (int m = 0; m < 9; ++m) d.hll_inv[9 * (size_t)lm + m] = Hi[m];
+        double4* rec = reinterpret_cast<double4*>(d.lmrec) + 4 * (size_t)lm;
+        rec[0] = X;
+        rec[1] = s4;
+        rec[2] = make_double4(Hi[0], Hi[1], Hi[2], Hi[4]);
+        rec[3] = make_double4(Hi[5], Hi[8], 0, 0);
+      }
+    }
+    const size_t base = (size_t)c_row0 * WAVE + lane;
+    for (int jj = 0; jj < c_k; ++jj) {
+      const int j = c_k - 1 - jj;
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      Cam P;
+      read_cam(cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PREP_REC : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
+      const double sw = ROBUST ? sqrt(cur.w) : 1.0;
+      const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
+      double jl4[8], jl3[6];
+      hom_jl4(P, h, sw, s4, jl4);
+      jl3_of_jl4(jl4, hw, hbeta, jl3);
+      const double e0 = sw * h.r0 - (jl3[0] * w3[0] + jl3[1] * w3[1] + jl3[2] * w3[2]);
+      const double e1 = sw * h.r1 - (jl3[3] * w3[0] + jl3[4] * w3[1] + jl3[5] * w3[2]);
+      const double4 q = hom_q(h, sw, e0, e1);
+      if (cur.cw >= 0) {
+        double* a = acc + lpl_acc_slot(cur.cw, hubs);
+        const double val[12] = {X.x * q.x, X.y * q.x, X.z * q.x, X.w * q.x, X.x * q.y, X.y * q.y,
+                                X.z * q.y, X.w * q.y, X.x * q.z, X.y * q.z, X.z * q.z, X.w * q.z};
+#pragma unroll
+        for (int m = 0; m < 12; ++m)
+          __hip_atomic_fetch_add(a + m * n_slots, val[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        d.q4c[v.cpos[base + (size_t)j * WAVE]] = q;
+      }
+    }
+    c_t = nx_t;
+    if (c_t < t_end) {
+      tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+      nx_t = grab();
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_hot * 6; i += E0C_BLOCK) {
+    const int r = i / 6, m = 2 * (i % 6);
+    const double* a0 = acc + m * n_slots;
+    const double* a1 = a0 + n_slots;
+    double2 s;
+    if (r < hubs) {
+      s.x = (a0[4 * r] + a0[4 * r + 1]) + (a0[4 * r + 2] + a0[4 * r + 3]);
+      s.y = (a1[4 * r] + a1[4 * r + 1]) + (a1[4 * r + 2] + a1[4 * r + 3]);
+    } else {
+      s.x = a0[r + 3 * hubs];
+      s.y = a1[r + 3 * hubs];
+    }
+    reinterpret_cast<double2*>(hot_out + (size_t)v.wg_slot_rec[cam0 + r] * 12)[i % 6] = s;
+  }
+}
+
+// b11_c = N_c^T y12_c for the per-camera sums of prepare_lpl_h (cam_cold_sum has applied sigma); y12 is scratch
+// and left zeroed, as the dense-y term loop expects it
+__global__ __launch_bounds__(256) void cam_nt_project(Dp d, double* y12, double* out11, const double* ncw) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d.n_cams) return;
+  double y[12], o[11];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    y[j] = y12[12 * (size_t)c + j];
+    y12[12 * (size_t)c + j] = 0;
+  }
+  nt_apply(ncw + 13 * (size_t)c, ncw[13 * (size_t)c + 12], y, o);
+#pragma unroll
+  for (int j = 0; j < 11; ++j) out11[11 * (size_t)c + j] = o[j];
+}
+
+
 
 // cam_cold_sum fused with cam_binv_axpy_h (mode 2) for the unsharded LDSACC term loop of step 2
 // (the step-2 twin of cam_cold_sum_binv): per-camera sum of the E0 row, tangent projection, B^-1 (11x11),
