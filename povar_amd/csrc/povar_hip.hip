@@ -75,6 +75,11 @@ struct povar_ctx {
   povar_options opt{};
   hipStream_t stream = nullptr;
   size_t bytes = 0;
+  // camera-major landmark copies of the legacy kernels (cm_h and the cold views cc/c2) are built lazily in the
+  // lane-per-landmark mode, which does not read them: lin_id counts linearisations, views_lin_id is the one they hold
+  int64_t lin_id = 0, views_lin_id = -1;
+  char* pin = nullptr;  // pinned host block of the small read-backs (read_scal_flags)
+  size_t pin_bytes = 0;
 
   std::vector<int> slot_of_obs;  // host copy for exports in the reference's order
   std::vector<int> lm_off;
@@ -463,6 +468,24 @@ Dp ldsacc_dp(povar_ctx* c, bool long_in_kernel = false) {
   return dt;
 }
 
+// every kernel of the LM iteration runs on the lane-per-landmark layout: nothing reads the legacy camera-major copies
+bool lpl_only(const povar_ctx* c) {
+  return c->use_lpl && c->use_lpl_prepare && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+}
+void build_views(povar_ctx* c) {
+  const int hom = c->linearized_h ? 1 : 0;
+  hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cm_lm.p, c->cm_h.p, c->n_obs, hom);
+  if (c->n_cold > 0)
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, hom);
+  if (c->long_in_kernel && c->n_cold2 > 0)
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold2, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c2_lm.p, c->c2_h.p, c->n_cold2, hom);
+  c->views_lin_id = c->lin_id;
+}
+// called by every entry point that may run a legacy kernel (cm_scatter, the cold views of e0_lm_cached)
+void ensure_views(povar_ctx* c) {
+  if (c->views_lin_id != c->lin_id && (c->linearized || c->linearized_h)) build_views(c);
+}
+
 // OR of a per-rank failure flag over the ranks (is_numerically_valid, linearisation failure)
 int combine_flag(povar_ctx* c, int* flag) {
   if (!sharded(c)) return 0;
@@ -482,6 +505,7 @@ int combine_flag(povar_ctx* c, int* flag) {
 // so the unsharded step-1 LDSACC path may run them inside the per-camera sum (binv_mode 4: done)
 int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
   prof_mark(c, 0);
+  if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_views(c);  // cm_scatter / legacy cold views
   if (c->joint) {
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
     if (acc && c->use_lpl) {
@@ -613,9 +637,43 @@ int check_ctx(povar_ctx* c) {
   return 0;
 }
 
-int read_flags(povar_ctx* c, int (&f)[4]) {
-  HIP_TRY(hipMemcpyAsync(f, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+// Small results come back through one pinned block: an asynchronous copy into pageable memory is staged by the
+// runtime (a synchronisation per copy), two of those per API call were most of its latency.
+// Layout of the block: [0, 16) the four flags, [64, 64 + 8 * 16) scalars, [256, ...) one 12 n_cams vector.
+int ensure_pin(povar_ctx* c) {
+  if (c->pin) return 0;
+  c->pin_bytes = 256 + sizeof(double) * 12 * (size_t)std::max(c->n_cams, 1);
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->pin), c->pin_bytes, hipHostMallocDefault));
+  return 0;
+}
+int read_scal_flags(povar_ctx* c, double* h, int n, int (&f)[4]) {
+  if (int rc = ensure_pin(c)) return rc;
+  if (n > 0) HIP_TRY(hipMemcpyAsync(c->pin + 64, c->scal.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->pin, c->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  std::memcpy(f, c->pin, sizeof(int) * 4);
+  if (n > 0) std::memcpy(h, c->pin + 64, sizeof(double) * n);
+  return 0;
+}
+int read_flags(povar_ctx* c, int (&f)[4]) { return read_scal_flags(c, nullptr, 0, f); }
+int read_scal(povar_ctx* c, double* h, int n) {
+  if (int rc = ensure_pin(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->pin + 64, c->scal.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  std::memcpy(h, c->pin + 64, sizeof(double) * n);
+  return 0;
+}
+int write_cam_vector(povar_ctx* c, double* dst, const double* in, size_t n) {  // completes with the caller's next sync
+  if (int rc = ensure_pin(c)) return rc;
+  std::memcpy(c->pin + 256, in, sizeof(double) * n);
+  HIP_TRY(hipMemcpyAsync(dst, c->pin + 256, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+int read_cam_vector(povar_ctx* c, double* out, const double* src, size_t n) {
+  if (int rc = ensure_pin(c)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->pin + 256, src, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  std::memcpy(out, c->pin + 256, sizeof(double) * n);
   return 0;
 }
 
@@ -723,6 +781,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)back_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)back_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -831,7 +893,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
   ALLOC(hot_rec, (size_t)std::max(n_cams, HOT_MAX) * HOT_REC_STRIDE);  // every camera, in popularity order
   ALLOC(norm_part, 2 * (size_t)std::max(c->n_cam_blocks, n_cams)); ALLOC(norms, 4); ALLOC(flags, 4);
-  ALLOC(part, n_part * 2); ALLOC(scal, 8);
+  ALLOC(part, n_part * 2 + 8 * 1024); ALLOC(scal, 8);  // + one slot set per workgroup of the lane-per-landmark kernels
   ALLOC(stage, std::max(3 * nl, 144 * nc));
 #undef ALLOC
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, c->stream));
@@ -876,6 +938,7 @@ void povar_destroy(povar_ctx* c) {
   (void)hipSetDevice(c->opt.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
+  if (c->pin) (void)hipHostFree(c->pin);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   for (size_t p = 0; p < c->peer_host.size(); ++p)
     if (c->peer_host[p] && c->peer_host[p] != c->xbuf) (void)hipIpcCloseMemHandle(c->peer_host[p]);
@@ -992,8 +1055,7 @@ int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
   if (int rc = allreduce(c, c->scal.p, 3)) return rc;
   double h[3];
   int f[4];
-  HIP_TRY(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  if (int rc = read_flags(c, f)) return rc;
+  if (int rc = read_scal_flags(c, h, 3, f)) return rc;
   if (int rc = combine_flag(c, &f[0])) return rc;
   out->all_num_obs = (int64_t)std::llround(h[2]);
   out->all_error = h[0];
@@ -1015,14 +1077,13 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   launch_lm(c, OpLinearize{});
-  hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cm_lm.p, c->cm_h.p, c->n_obs, 0);
-  if (c->n_cold > 0)
-    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, 0);
-  if (c->long_in_kernel && c->n_cold2 > 0)
-    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold2, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c2_lm.p, c->c2_h.p, c->n_cold2, 0);
+  ++c->lin_id;
+  c->linearized = true;
+  const bool lazy = lpl_only(c);  // the camera-major landmark copies are built when a legacy kernel asks (ensure_views)
+  if (!lazy) build_views(c);
   if (c->n_cold3 > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 0);
-  hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
+  hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
   if (sharded(c)) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
     hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr);
@@ -1067,6 +1128,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
     da.p2p_epoch = nullptr;
     hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 0);
   } else {
+    ensure_views(c);
     launch_lm(c, OpPrepare{});
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 0);
     hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b, 1);
@@ -1119,6 +1181,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (int rc = check_ctx(c)) return rc;
   if (m < 0) return fail(-1, "power_sc_iterations < 0");
   TimeScope ts(c, 2);
+  if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_views(c);  // not inside the graph capture
   const bool norms = q_tol > 0 || r_tol > 0;
   // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
   // RCCL-in-capture is not something a 1-GPU box can validate); POVAR_GRAPH_COMM=1 opts in
@@ -1172,16 +1235,12 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
 
 int povar_get_increment(povar_ctx* c, double* inc) {
   if (int rc = check_ctx(c)) return rc;
-  HIP_TRY(hipMemcpyAsync(inc, c->accum.p, sizeof(double) * (c->joint ? 11 : 12) * c->n_cams, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return 0;
+  return read_cam_vector(c, inc, c->accum.p, (size_t)(c->joint ? 11 : 12) * c->n_cams);
 }
 
 int povar_get_term(povar_ctx* c, double* term) {
   if (int rc = check_ctx(c)) return rc;
-  HIP_TRY(hipMemcpyAsync(term, c->tmp.p, sizeof(double) * (c->joint ? 11 : 12) * c->n_cams, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return 0;
+  return read_cam_vector(c, term, c->tmp.p, (size_t)(c->joint ? 11 : 12) * c->n_cams);
 }
 
 int povar_solve_pose(povar_ctx* c, double lambda, int32_t solver_type, int32_t m, double q_tol,
@@ -1221,23 +1280,35 @@ int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const doub
   const size_t n = 12 * (size_t)c->n_cams;
   set_alpha(c, alpha);
   TimeScope ts(c, 3);
-  HIP_TRY(hipMemcpyAsync(c->inc.p, inc, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  if (int rc = write_cam_vector(c, c->inc.p, inc, n)) return rc;
+  bool lpl_back = false;
   if (solver_type == POVAR_POWER_VARPROJ) {
     // cpp:250-256: scale, update cameras, unscale, back-substitute at the new cameras
     hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 0);
-    launch_lm(c, OpBackVarproj{});
+    lpl_back = c->use_lpl && c->use_lpl_prepare && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+    if (lpl_back) {
+      const Dp da = ldsacc_dp(c, true);
+      if (c->opt.robust_norm)
+        hipLaunchKernelGGL(backsub_lpl<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), back_lds_bytes(c->v2_max_slots), c->stream, da, c->part.p);
+      else
+        hipLaunchKernelGGL(backsub_lpl<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), back_lds_bytes(c->v2_max_slots), c->stream, da, c->part.p);
+    } else {
+      launch_lm(c, OpBackVarproj{});
+    }
   } else {
     // cpp:260-270: back-substitute with the stored tiles, then update cameras
     hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 1);
     launch_lm(c, OpBackPoba{});
     hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 2);
   }
-  launch_reduce<1>(c, c->scal.p);
+  if (lpl_back)
+    hipLaunchKernelGGL((reduce_partials<1>), dim3(1), dim3(1024), 0, c->stream, c->part.p, c->e0c_grid, c->scal.p);
+  else
+    launch_reduce<1>(c, c->scal.p);
   HIP_TRY(hipGetLastError());
   if (int rc = allreduce(c, c->scal.p, 1)) return rc;
   double h = 0;
-  HIP_TRY(hipMemcpyAsync(&h, c->scal.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = read_scal(c, &h, 1)) return rc;
   if (l_diff) *l_diff = h;
   return 0;
 }
@@ -1273,8 +1344,7 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
   if (int rc = allreduce(c, c->scal.p, 6)) return rc;
   double h[6];
   int f[4];
-  HIP_TRY(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  if (int rc = read_flags(c, f)) return rc;
+  if (int rc = read_scal_flags(c, h, 6, f)) return rc;
   if (int rc = combine_flag(c, &f[0])) return rc;
   out->all_error = h[0];
   out->all_residual_sum = h[1];
@@ -1293,14 +1363,13 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   launch_lm(c, OpLinearizeH{});
-  hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_obs, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cm_lm.p, c->cm_h.p, c->n_obs, 1);
-  if (c->n_cold > 0)
-    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->cc_lm.p, c->cc_h.p, c->n_cold, 1);
-  if (c->long_in_kernel && c->n_cold2 > 0)
-    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold2, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c2_lm.p, c->c2_h.p, c->n_cold2, 1);
+  ++c->lin_id;
+  c->linearized_h = true;
+  const bool lazy = lpl_only(c);
+  if (!lazy) build_views(c);
   if (c->n_cold3 > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 1);
-  hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d);
+  hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
   hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
   if (sharded(c)) {
     if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
@@ -1341,6 +1410,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
     hipLaunchKernelGGL(cam_nt_project, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, c->d.y, c->d.b,
                        (const double*)c->ncw.p);
   } else {
+    ensure_views(c);
     launch_lm(c, OpPrepareH{});
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 1);
     hipLaunchKernelGGL(cam_sum_items_h, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b,
@@ -1376,8 +1446,7 @@ int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
   HIP_TRY(hipGetLastError());
   if (int rc = allreduce(c, c->scal.p, 1)) return rc;
   double h = 0;
-  HIP_TRY(hipMemcpyAsync(&h, c->scal.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = read_scal(c, &h, 1)) return rc;
   if (l_diff) *l_diff = h;
   return 0;
 }

@@ -1700,6 +1700,181 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// K12 on the lane-per-landmark layout: back_substitute_pOSE (landmark_block.hpp:670-707), POWER_VARPROJ -- the
+// arithmetic of OpBackVarproj on prepare_lpl's row stream.  Camera records in LDS: the UPDATED camera, its increment
+// and the camera of the linearisation point (36 doubles); no accumulators.  First pass: H = Jl^T Jl and Jl^T res of
+// the fresh, unweighted, unscaled tile; the lane solves for delta; second pass: the reference's model cost change
+// (stored Jl and residual rebuilt from the linearisation point) summed per workgroup into part[blockIdx.x].
+// Replaces lm_regular<OpBackVarproj> (204 us on venice-1778) for the LDSACC mode.
+// ------------------------------------------------------------------------------------------
+constexpr int BACK_REC = 18;  // double2 per camera record: P_new (12), inc (12), P_lin (12)
+__host__ __device__ inline size_t back_lds_bytes(int n_hot) { return (size_t)n_hot * BACK_REC * sizeof(double2) + 16; }
+
+template <bool ROBUST>
+__global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
+  extern __shared__ double2 hot[];  // [n_hot][BACK_REC] records, then the tile counter
+  __shared__ double sh[E0C_BLOCK / 64];
+  const V2& v = d.v2;
+  const int cam0 = v.wg_cam_off[blockIdx.x];
+  const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * BACK_REC);
+  if (threadIdx.x == 0) *grab_ctr = 0;
+  // record piece j of a camera: 0-5 cams4, 6-11 inc, 12-17 cams_lin4 (each 12 doubles)
+  auto piece = [&](int cam, int j) -> double2 {
+    const double* src = j < 6 ? reinterpret_cast<const double*>(d.cams4) : j < 12 ? d.inc : reinterpret_cast<const double*>(d.cams_lin4);
+    return reinterpret_cast<const double2*>(src + 12 * (size_t)cam)[j % 6];
+  };
+  for (int i = threadIdx.x; i < n_hot * BACK_REC; i += E0C_BLOCK) {
+    const int r = i / BACK_REC, j = i - r * BACK_REC;
+    hot[i] = piece(d.hot_cams[v.wg_cams[cam0 + r]], j);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int t_begin = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
+  const int t_end = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
+  auto grab = [&]() -> int {
+    int n = 0;
+    if (lane == 0) n = __hip_atomic_fetch_add(grab_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const long long t = (long long)t_begin + n;
+    return t < t_end ? (int)t : t_end;
+  };
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  const cint_p tiles = (cint_p)(uintptr_t)v.tile;
+  auto tile_info = [&](int t, int& row0, int& k, int& nh, int& fl) {
+    row0 = tiles[4 * t];
+    k = tiles[4 * t + 1];
+    nh = tiles[4 * t + 2];
+    fl = tiles[4 * t + 3];
+  };
+  LplCursor pc;
+  pc.t = grab();
+  pc.pass = 0;
+  pc.j = 0;
+  pc.row0 = 0;
+  pc.k = 1;
+  int c_t = pc.t, c_row0 = 0, c_k = 0, c_nh = 0, c_fl = 0, nx_t = t_end;
+  if (c_t < t_end) {
+    tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+    pc.row0 = c_row0;
+    pc.k = c_k;
+    nx_t = grab();
+  }
+  auto issue = [&](LplRow& r) {
+    if (pc.t < t_end) {
+      const size_t i = ((size_t)pc.row0 + (pc.pass ? pc.k - 1 - pc.j : pc.j)) * WAVE + lane;
+      r.uv = v.uv[i];
+      r.cw = v.cw[i];
+      if (ROBUST) r.w = v.w[i];
+      if (++pc.j == pc.k) {
+        pc.j = 0;
+        if (++pc.pass == 2) {
+          pc.pass = 0;
+          pc.t = nx_t;
+          if (pc.t < t_end) {
+            int nh_, fl_;
+            tile_info(pc.t, pc.row0, pc.k, nh_, fl_);
+          }
+        }
+      }
+    }
+  };
+  // 12 consecutive doubles of a record (LDS) or of a camera-indexed global array (cold camera)
+  auto read12 = [&](const double2* hp, double4 (&o)[3]) {
+    const double2 b0 = hp[0], b1 = hp[1], b2 = hp[2], b3 = hp[3], b4 = hp[4], b5 = hp[5];
+    o[0] = make_double4(b0.x, b0.y, b1.x, b1.y);
+    o[1] = make_double4(b2.x, b2.y, b3.x, b3.y);
+    o[2] = make_double4(b4.x, b4.y, b5.x, b5.y);
+  };
+  auto rec_part = [&](int cw, int which) -> const double2* {  // which: 0 P_new, 1 inc, 2 P_lin
+    if (cw >= 0) return hot + lpl_cw_slot(cw) * BACK_REC + 6 * which;
+    const int cam = d.hot_cams[-2 - cw];
+    const double* src = which == 0 ? reinterpret_cast<const double*>(d.cams4)
+                                   : which == 1 ? d.inc : reinterpret_cast<const double*>(d.cams_lin4);
+    return reinterpret_cast<const double2*>(src + 12 * (size_t)cam);
+  };
+  LplRow n1, n2, n3;
+  n1.cw = n2.cw = n3.cw = -1;
+  n1.w = n2.w = n3.w = 1.0;
+  n1.uv = n2.uv = n3.uv = make_double2(0, 0);
+  issue(n1);
+  issue(n2);
+  issue(n3);
+  double sc = 0;
+  while (c_t < t_end) {
+    const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
+    const int sg = v.seg[(size_t)c_t * WAVE + lane];
+    const double4 h = d.lms4[lm >= 0 ? lm : 0], hl = d.lms_lin4[lm >= 0 ? lm : 0], s4 = d.jl_scale4[lm >= 0 ? lm : 0];
+    double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < c_k; ++j) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      double4 pp[3];
+      read12(rec_part(cur.cw, 0), pp);
+      const Cam P = {pp[0], pp[1], pp[2]};
+      double res[4], jl[12];
+      pose_residual(d, P, h, cur.uv.x, cur.uv.y, res);
+      pose_jl(d, P, cur.uv.x, cur.uv.y, 1.0, make_double4(1, 1, 1, 1), jl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[0] += jl[3 * r] * jl[3 * r];
+        red[1] += jl[3 * r] * jl[3 * r + 1];
+        red[2] += jl[3 * r] * jl[3 * r + 2];
+        red[3] += jl[3 * r + 1] * jl[3 * r + 1];
+        red[4] += jl[3 * r + 1] * jl[3 * r + 2];
+        red[5] += jl[3 * r + 2] * jl[3 * r + 2];
+        red[6] += jl[3 * r] * res[r];
+        red[7] += jl[3 * r + 1] * res[r];
+        red[8] += jl[3 * r + 2] * res[r];
+      }
+    }
+    if (c_fl & 1) seg_reduce_steps<9>(red, lane, sg & 255, (sg >> 8) & 255, 4);
+    double dl[3] = {0, 0, 0};
+    if (lm >= 0) {
+      double H[9], Hi[9];
+      sym3(red, H);
+      inv3(H, Hi);
+      dl[0] = -(Hi[0] * red[6] + Hi[1] * red[7] + Hi[2] * red[8]);
+      dl[1] = -(Hi[3] * red[6] + Hi[4] * red[7] + Hi[5] * red[8]);
+      dl[2] = -(Hi[6] * red[6] + Hi[7] * red[7] + Hi[8] * red[8]);
+      if (lane == (sg & 255)) d.lms4[lm] = make_double4(h.x + dl[0], h.y + dl[1], h.z + dl[2], h.w);
+    }
+    for (int jj = 0; jj < c_k; ++jj) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      double4 zz[3], pl[3];
+      read12(rec_part(cur.cw, 1), zz);
+      read12(rec_part(cur.cw, 2), pl);
+      const Cam Pl = {pl[0], pl[1], pl[2]};
+      const double sw = ROBUST ? sqrt(cur.w) : 1.0;
+      double jinc[4], jls[12], rr[4];
+      pose_jp_x(d, h, cur.uv.x, cur.uv.y, 1.0, zz, jinc);
+      pose_jl(d, Pl, cur.uv.x, cur.uv.y, sw, s4, jls);
+      pose_residual(d, Pl, hl, cur.uv.x, cur.uv.y, rr);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double ji = jinc[r] + (jls[3 * r] * dl[0] + jls[3 * r + 1] * dl[1] + jls[3 * r + 2] * dl[2]);
+        sc -= ji * (0.5 * ji + sw * rr[r]);
+      }
+    }
+    c_t = nx_t;
+    if (c_t < t_end) {
+      tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+      nx_t = grab();
+    }
+  }
+  double sv[1] = {sc};
+  block_sum<1, E0C_BLOCK>(sv, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = sv[0];
+}
+
 // K10 (stored tiles): right_mul_e0_pOSE on the tiles kept in HBM, blocked layout
 // tiles[bin][pair][lane] (double2): pairs 0-23 Jp (row-major 4x12), 24-29 Jl (4x3), 30-31 r.
 // Every byte of a tile is read once per term, 16 B per lane, 1 KiB contiguous per wave
@@ -2111,7 +2286,7 @@ __global__ __launch_bounds__(256) void cm_build_h(Dp d, const int* lm_of, double
 // C = [[1,0,-sb^2 u],[0,1,-sb^2 v],[.,.,sb^2(u^2+v^2)]] (sa^2 + sb^2 = 1), so four weighted
 // moments of h h^T (10 unique entries each) per camera carry both get_Jp_diag2_pOSE
 // (linearization_varproj.hpp:183-222) and the Hpp blocks (landmark_block.hpp:530-536).
-__global__ __launch_bounds__(256) void cm_gram(Dp d) {
+__global__ __launch_bounds__(256) void cm_gram(Dp d, int gather) {
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (item >= d.n_items) return;
@@ -2121,7 +2296,14 @@ __global__ __launch_bounds__(256) void cm_gram(Dp d) {
   for (int k = 0; k < 40; ++k) acc[k] = 0;
   for (int p = b + lane; p < e; p += WAVE) {
     const double sw = d.robust ? d.sw[d.cm_slot[p]] : 1.0;  // no gather at all without a robust norm
-    const double4 h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], 1.0);
+    // gather: the camera-major copy of the landmarks is not kept (lane-per-landmark mode), read them in place
+    double4 h;
+    if (gather) {
+      h = d.lms_lin4[d.cm_lm[p]];
+      h.w = 1.0;
+    } else {
+      h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], 1.0);
+    }
     const double2 uv = d.cm_uv[p];
     const double w = sw * sw;
     const double m[4] = {w, w * uv.x, w * uv.y, w * (uv.x * uv.x + uv.y * uv.y)};

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_w
 
 // Gram moments of the unscaled weighted Jp12: Jp12^T Jp12 = w * (C (x) X X^T),
 // C = [[D00^2, 0, D00 D02], [0, D00^2, D00 D12], [., ., D02^2 + D12^2]]
-__global__ __launch_bounds__(256) void cm_gram_h(Dp d) {
+__global__ __launch_bounds__(256) void cm_gram_h(Dp d, int gather) {
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (item >= d.n_items) return;
@@ -464,7 +464,8 @@ __global__ __launch_bounds__(256) void cm_gram_h(Dp d) {
   for (int k = 0; k < 40; ++k) acc[k] = 0;
   for (int p = b + lane; p < e; p += WAVE) {
     const double sw = d.robust ? d.sw[d.cm_slot[p]] : 1.0;
-    const double4 X = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], d.cm_h[3 * d.n_obs + p]);
+    const double4 X = gather ? d.lms_lin4[d.cm_lm[p]]
+                             : make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], d.cm_h[3 * d.n_obs + p]);
     const double2 uv = d.cm_uv[p];
     const Hom h = hom_project(P, X, uv.x, uv.y);
     const double w = sw * sw;
