@@ -139,26 +139,42 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
 
 def self_launch(argv, n):
     """`python bench.py --gpus N` as the driver calls it: start the N ranks as fresh child processes (this
-    process has not touched the GPU), relay rank 0's JSON line, return the children's exit code."""
+    process has not touched the GPU), relay rank 0's JSON line, return the children's exit code.  A sharded run
+    that dies or stalls with the peer-to-peer term exchange is run once more on the communicator's all-reduce."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for l in r.stdout.splitlines():
-        if l.startswith("{") and '"metric"' in l:
-            line = l
-        elif l.strip():
-            print(l, file=sys.stderr)
+
+    def attempt(extra, limit):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv + extra
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)  # the group this call started, nothing else
+            out, _ = p.communicate()
+            print(f"[bench] the {n}-rank run did not finish within {limit} s", file=sys.stderr)
+        line = None
+        for l in (out or "").splitlines():
+            if l.startswith("{") and '"metric"' in l:
+                line = l
+            elif l.strip():
+                print(l, file=sys.stderr)
+        return p.returncode, line
+
+    rc, line = attempt([], float(os.environ.get("POVAR_BENCH_P2P_LIMIT_S", "1500")))
+    if (rc != 0 or line is None) and "--no-p2p" not in argv:
+        print("[bench] sharded run failed; once more with --no-p2p (all-reduce per term)", file=sys.stderr)
+        rc, line = attempt(["--no-p2p"], None)
     if line is not None:
         print(line)
-    return r.returncode if (r.returncode or line is not None) else 1
+    return rc if (rc or line is not None) else 1
 
 
 def main():
@@ -183,6 +199,8 @@ def main():
                          "zipf0.5 / uniform = sensitivity variants of the same shape (never the headline)")
     ap.add_argument("--long-track-frac", type=float, default=0.0,
                     help="sensitivity variant: fraction of the observations on landmarks of 65..400 observations")
+    ap.add_argument("--no-p2p", action="store_true",
+                    help="sharded runs: keep the per-term exchange on the communicator's all-reduce")
     ap.add_argument("--p2p", action="store_true",
                     help="per-term exchange through the peer-to-peer push/reduce kernels (povar_p2p_attach) instead of "
                          "one all-reduce per term; the once-per-solve exchanges keep the communicator")
@@ -269,15 +287,42 @@ def main():
                 print("[bench] WARNING: exchange steps run over gloo on host buffers, not RCCL", file=sys.stderr)
 
     term_exchange = "all-reduce" if comm_used != "none" else "none"
-    if args.p2p and comm_used != "none":
-        handles = [None] * world
-        mine = ctx.p2p_export(world)
-        if dist is not None:
-            dist.all_gather_object(handles, mine)
+    # Per-term exchange of a sharded run: the peer-to-peer push/reduce kernels (no library call inside the captured
+    # term loop) unless --no-p2p; they are validated against the communicator's all-reduce below before they are
+    # trusted, and every failure (IPC attach, a peer that never delivers, a differing increment) falls back to it.
+    want_p2p = comm_used != "none" and not args.no_p2p and args.step == 1 and args.e0_mode == "ldsacc" and \
+        (args.p2p or world > 1)
+    p2p_attached, p2p_note = False, ""
+    if want_p2p:
+        def all_ok(flag):
+            if dist is None:
+                return bool(flag)
+            import torch
+            t = torch.tensor([1 if flag else 0])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+        handles, mine = [None] * world, None
+        try:
+            mine = ctx.p2p_export(world)
+        except capi.PovarError as e:
+            p2p_note = f"export failed: {e}"
+        if all_ok(mine is not None):
+            if dist is not None:
+                dist.all_gather_object(handles, mine)
+            else:
+                handles = [mine]
+            try:
+                ctx.p2p_attach(world, rank, handles)
+                p2p_attached = True
+            except capi.PovarError as e:
+                p2p_note = f"attach failed: {e}"
+            if not all_ok(p2p_attached):
+                if p2p_attached:
+                    ctx.p2p_enable(False)
+                p2p_attached = False
+                p2p_note = p2p_note or "attach failed on another rank"
         else:
-            handles = [mine]
-        ctx.p2p_attach(world, rank, handles)
-        term_exchange = "p2p push + local reduce"
+            p2p_note = p2p_note or "export failed on another rank"
     ctx.set_cameras(prob.cams)
     ctx.init_landmarks_pose(alpha)
     ok = ctx.linearize_pose(alpha)
@@ -307,6 +352,34 @@ def main():
         if dist is not None:
             dist.barrier()
         ctx.synchronize()
+
+    if want_p2p:
+        if p2p_attached:
+            # one solve through each exchange on the same prepared system; every rank runs both whatever happens
+            incs, errs = [], []
+            for on in (True, False):
+                ctx.p2p_enable(on)
+                try:
+                    ctx.power_series_pose(m, 0.0, -1.0)
+                    incs.append(ctx.get_increment())
+                except capi.PovarError as e:
+                    incs.append(None)
+                    errs.append(str(e))
+            rel = float("inf")
+            if incs[0] is not None and incs[1] is not None:
+                rel = float(np.linalg.norm(incs[0] - incs[1]) / max(np.linalg.norm(incs[1]), 1e-300))
+            if os.environ.get("POVAR_BENCH_P2P_FAIL") and rank == world - 1:
+                rel = float("inf")  # test hook: one rank reports a mismatch, every rank must fall back
+            good = all_ok(np.isfinite(rel) and rel <= 1e-10)
+            ctx.p2p_enable(good)
+            if good:
+                term_exchange = f"p2p push + local reduce (validated against the all-reduce, rel. diff {rel:.1e})"
+            else:
+                p2p_note = "; ".join(errs) or f"increment differs from the all-reduce path (rel. diff {rel:.1e})"
+        if not term_exchange.startswith("p2p"):
+            term_exchange = f"all-reduce (peer-to-peer exchange not used: {p2p_note or 'validation failed on another rank'})"
+            if rank == 0:
+                print(f"[bench] peer-to-peer term exchange not used: {p2p_note}", file=sys.stderr)
 
     def run_steps(k):
         for _ in range(k):

@@ -264,6 +264,9 @@ int povar_comm_ranks(povar_ctx* ctx);
  * the launcher gathers the handles, every rank calls povar_p2p_attach(ctx, world, rank, handles[world][64]). */
 int povar_p2p_export(povar_ctx* ctx, int32_t world, uint8_t handle[64]);
 int povar_p2p_attach(povar_ctx* ctx, int32_t world, int32_t rank, const uint8_t* handles);
+/* switch the per-term exchange between the attached peer-to-peer kernels (on != 0) and the communicator's
+ * all-reduce (0): a launcher validates the first against the second before it trusts it (bench.py does) */
+int povar_p2p_enable(povar_ctx* ctx, int32_t on);
 /* same exchange steps through a caller-supplied host all-reduce (sum, in place) instead of RCCL:
  * lets an MPI/gloo launcher or an in-process test stand in for the communicator */
 typedef void (*povar_allreduce_fn)(double* buf, int64_t n, void* user);

@@ -368,6 +368,9 @@ class Context:
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
         self._chk(self.L.povar_p2p_attach(self.h, C.c_int32(world), C.c_int32(rank), buf))
 
+    def p2p_enable(self, on: bool):
+        self._chk(self.L.povar_p2p_enable(self.h, C.c_int32(1 if on else 0)))
+
     def comm_init(self, world, rank, uid: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._chk(self.L.povar_comm_init(self.h, C.c_int32(world), C.c_int32(rank), buf))

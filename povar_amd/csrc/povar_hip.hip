@@ -1189,7 +1189,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (c->use_graph && !c->profile && m > 0 && (p2p_terms || (!c->host_fn && (!c->comm || c->graph_with_comm)))) {
     // the whole loop (memset, B^-1, m x {E0 kernels, [all-reduce], B^-1 + AXPY, [check]}) is one graph
     // launch; it is re-captured only when a kernel argument changes
-    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode, sharded(c) ? 1 : 0, norms ? 1 : 0, r_tol > 0 ? 1 : 0};
+    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode, (sharded(c) ? 1 : 0) | (p2p_terms ? 2 : 0), norms ? 1 : 0, r_tol > 0 ? 1 : 0};
     const bool same = c->series_graph && std::memcmp(key, c->series_graph_key, sizeof(key)) == 0 &&
                       std::memcmp(&c->d, &c->series_graph_d, sizeof(Dp)) == 0 &&
                       c->series_graph_tol[0] == q_tol && c->series_graph_tol[1] == r_tol;
@@ -1218,7 +1218,10 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (p2p_terms) {
     int f[4];
     if (int rc = read_flags(c, f)) return rc;
-    if (f[0] & 2) return fail(-3, "peer-to-peer exchange: a rank did not deliver its partial sums (wait timed out)");
+    if (f[0] & 2) {
+      HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+      return fail(-3, "peer-to-peer exchange: a rank did not deliver its partial sums (wait timed out)");
+    }
   }
   if (norms) {
     int f[4];
@@ -1723,6 +1726,13 @@ int povar_p2p_attach(povar_ctx* c, int32_t world, int32_t rank, const uint8_t* h
   c->world = world;
   c->rank = rank;
   c->p2p = true;
+  return 0;
+}
+
+int povar_p2p_enable(povar_ctx* c, int32_t on) {
+  if (int rc = check_ctx(c)) return rc;
+  if (on && !c->peer_dev.p) return fail(-1, "povar_p2p_enable before povar_p2p_attach");
+  c->p2p = on != 0;
   return 0;
 }
 

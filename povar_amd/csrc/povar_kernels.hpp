@@ -2695,11 +2695,12 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, in
       // peer-to-peer exchange: wait for every rank's slab of this camera (tag == epoch), sum in rank order
       const unsigned long long ep = *d.p2p_epoch;
       const double* mine = d.p2p_peer[d.p2p_rank];
+      const bool gave_up = (d.flags[0] & 2) != 0;  // an earlier wait of this solve timed out: do not wait again
       for (int p = 0; p < d.p2p_world; ++p) {
         const double* rec = mine + ((((size_t)(ep & 1) * d.p2p_world + p) * d.n_cams) + c) * 16;
         int spins = 0;
-        while (__hip_atomic_load(reinterpret_cast<const unsigned long long*>(rec + 12), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_SYSTEM) != ep) {  // relaxed poll; the data loads below bypass the caches too
+        while (!gave_up && __hip_atomic_load(reinterpret_cast<const unsigned long long*>(rec + 12), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_SYSTEM) != ep) {  // relaxed poll; the data loads below bypass the caches too
           __builtin_amdgcn_s_sleep(8);
           if (++spins > (1 << 22)) {  // a peer never arrived: flag it and go on (the host reports the failure)
             if (lane == 0) atomicOr(&d.flags[0], 2);

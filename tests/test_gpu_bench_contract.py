@@ -99,14 +99,31 @@ def test_bench_two_ranks_p2p_exchange(problem):
         d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
         outs[tag] = (d, np.load(path + tag + ".npy"))
     d, inc = outs["p2p"]
-    assert d["n_gpus"] == 2 and d["config"]["term_exchange"] == "p2p push + local reduce"
+    assert d["n_gpus"] == 2 and d["config"]["term_exchange"].startswith("p2p push + local reduce (validated")
     assert np.linalg.norm(inc - outs["one"][1]) <= 1e-11 * np.linalg.norm(inc)
+
+
+def test_bench_two_ranks_p2p_is_default_and_falls_back():
+    """`--gpus 2` with no flag validates the peer-to-peer exchange against the all-reduce and uses it; a rank that
+    reports a mismatch (test hook) sends every rank back to the all-reduce; --no-p2p never tries.  Same increment."""
+    import numpy as np
+    base = ["--no-cpu-baseline"]
+    d0, inc0 = _run_bench(base, {}, "inc_fb0.npy")
+    d, inc = _run_bench(base + ["--gpus", "2"], {}, "inc_fb1.npy")
+    assert d["config"]["term_exchange"].startswith("p2p push + local reduce (validated")
+    assert np.linalg.norm(inc - inc0) <= 1e-11 * np.linalg.norm(inc0)
+    d, inc = _run_bench(base + ["--gpus", "2"], {"POVAR_BENCH_P2P_FAIL": "1"}, "inc_fb2.npy")
+    assert d["config"]["term_exchange"].startswith("all-reduce (peer-to-peer exchange not used")
+    assert np.linalg.norm(inc - inc0) <= 1e-11 * np.linalg.norm(inc0)
+    d, inc = _run_bench(base + ["--gpus", "2", "--no-p2p"], {}, "inc_fb3.npy")
+    assert d["config"]["term_exchange"] == "all-reduce"
+    assert np.linalg.norm(inc - inc0) <= 1e-11 * np.linalg.norm(inc0)
 
 
 def test_bench_p2p_single_rank_in_graph():
     """World of one: the push/reduce kernels inside the captured term loop against the plain loop."""
     import numpy as np
     d, inc = _run_bench(["--no-cpu-baseline", "--p2p"], {"POVAR_FORCE_COMM": "1"}, "inc_p2p1.npy")
-    assert d["config"]["term_exchange"] == "p2p push + local reduce"
+    assert d["config"]["term_exchange"].startswith("p2p push + local reduce (validated")
     d1, inc1 = _run_bench(["--no-cpu-baseline"], {}, "inc_w1.npy")
     assert np.linalg.norm(inc - inc1) <= 1e-12 * np.linalg.norm(inc1)
