@@ -121,6 +121,10 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       const double score = (double)S[g] + 0.85 * (double)(S[g + tn] - S[g]);
       if (score > best) { best = score; G = g; Tn = tn; }
     }
+    if (const char* e = std::getenv("POVAR_LPL_G")) {  // measurement knob: force the number of global cameras
+      G = std::min(std::max(0, std::atoi(e)), n_acc);
+      Tn = std::min((int)std::max(0.0, (n_acc - G - A - 2) / (1.0 / A + 1.0 / B)), n_cams - G);
+    }
   }
   L.n_global = G;
   L.n_tail = Tn;
@@ -368,6 +372,10 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       std::vector<size_t> occ_off(ntw + 1, 0);
       for (int t = 0; t < ntw; ++t) occ_off[t + 1] = occ_off[t] + (size_t)L.tile[t0w + t].y * 64;
       std::vector<uint16_t> occA(occ_off[ntw], 0), occR(occ_off[ntw], 0);
+      // hub records are read too: all lanes of a read group that want the same hub are one broadcast access, the
+      // first of them puts the hub's record on its read class (hub mod 16); cntH counts them per (tile, row, group, hub)
+      std::vector<uint16_t> cntH(occ_off[ntw], 0);
+      auto idxH = [&](int t, int hub, int lane, int j) { return occ_off[t - t0w] + (size_t)j * 64 + read_group(lane) * 16 + (hub & 15); };
       auto idxA = [&](int t, int lane, int j, int acc_slot) { return occ_off[t - t0w] + (size_t)j * 64 + (lane >> 5) * 32 + (acc_slot & 31); };
       auto idxR = [&](int t, int sl, int lane, int j) { return occ_off[t - t0w] + (size_t)j * 64 + read_group(lane) * 16 + (sl & 15); };
       // What a collision costs is the WORST multiplicity of its row (per half for ds_add_f64, per lane group for
@@ -394,6 +402,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         return best;
       };
       auto read_cost = [&](int t, int sl, int lane, int j) -> long {
+        if (sl < hubs && cntH[idxH(t, sl, lane, j)] > 0) return 0;  // joins a broadcast
         const int v = occR[idxR(t, sl, lane, j)];
         return 1000L * std::max(0, v + 1 - (int)mxR_at(t, lane, j)) + v;
       };
@@ -421,7 +430,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
             const int lane = lane0 + pos % P, j = pos / P;
             int rp;
             long c = 6L * occ_of(t, sl, lane, j, rp);  // 12 atomics x 8 cycles against 16 reads x 1 cycle per extra lane
-            if (sl >= hubs) c += read_cost(t, sl, lane, j);
+            c += read_cost(t, sl, lane, j);
             cost[(size_t)a * h + pos] = c;
           }
         }
@@ -450,7 +459,13 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
             for (int q = 0; q < 32; ++q) m = std::max(m, occA[base + q]);
             mxA_at(t, lane, j) = m;
           }
-          if (sl >= hubs) {
+          bool touches_class = sl >= hubs;
+          if (sl < hubs) {  // the class sees a hub once per read group, however many lanes broadcast it
+            uint16_t& ch = cntH[idxH(t, sl, lane, j)];
+            ch += sign;
+            touches_class = sign > 0 ? ch == 1 : ch == 0;
+          }
+          if (touches_class) {
             uint16_t& cr = occR[idxR(t, sl, lane, j)];
             cr += sign;
             if (sign > 0) mxR_at(t, lane, j) = std::max(mxR_at(t, lane, j), cr);
