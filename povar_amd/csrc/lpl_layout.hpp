@@ -90,13 +90,15 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
                       int n_acc, LplLayout& L) {
   // Rows per tile are capped by dealing longer landmarks over several lanes (K0 rows: at most 2 K0 row steps per
   // tile, the unit of load balance).  A wavefront walks its tile's rows one after the other, so on a problem too small
-  // to give every wavefront a tile the cap sets the latency of the launch: 2 rows there (ladybug-49 76 k -> 106 k
-  // terms/s, trafalgar-257 61 k -> 67 k), 8 otherwise (shorter tiles cost venice shards 2-3 us: more lanes, more
-  // landmark records).
+  // to give every wavefront a tile the cap sets the latency of the launch (ladybug-49: 2 rows 106 k, 8 rows 76 k
+  // terms/s).
   grid = std::max(grid, 1);
-  int n_with_obs = 0;
-  for (int l = 0; l < n_lms; ++l) n_with_obs += lm_off[l + 1] > lm_off[l];
-  int K0 = n_with_obs / WAVE < grid * 16 / 2 ? 2 : 8;
+  // The cap follows the row steps a wavefront gets (observations / 64 lanes / 16 wavefronts per workgroup): a tile
+  // longer than a wavefront's fair share is the tail of the launch, shorter ones cost lanes (landmark records,
+  // segment sums) and leave the row placement fewer rows to dodge bank collisions with (venice-1778: 8 rows 13.8k,
+  // 20-24 rows 14.2k, 32 rows 13.4k terms/s; its 8-GPU shards and the small shapes want 2)
+  const long rows_per_wave = (long)(lm_off[n_lms] / WAVE) / ((long)grid * 16);
+  int K0 = (int)std::min<long>(24, std::max<long>(2, rows_per_wave));
   if (const char* e = std::getenv("POVAR_LPL_K0")) K0 = std::max(2, std::atoi(e));
   // ---- grid factorisation and the (G, Tn) choice
   int B = 1;

@@ -54,7 +54,10 @@ constexpr int HOT_REC_STRIDE = 24;  // doubles per camera in Dp::hot_rec
 constexpr int META_HOT_SHIFT = 18;     // 10 bits
 constexpr int META_HOT_MASK = 1023;
 constexpr int META_STEPS_SHIFT = 28;   // 3 bits: ceil(log2(longest landmark of the bin)), same in every lane of a bin
-constexpr int HOT_ACC_MAX = 552;    // camera slots of a workgroup's LDS: step 2 552 * (192 + 96) B + 48 hub replicas * 96 B
+#ifndef POVAR_HOT_ACC_MAX
+#define POVAR_HOT_ACC_MAX 552
+#endif
+constexpr int HOT_ACC_MAX = POVAR_HOT_ACC_MAX;    // camera slots of a workgroup's LDS: step 2 552 * (192 + 96) B + 48 hub replicas * 96 B
                                     // + 16 B = 163 600 of the 163 840 bytes; step 1 (176-byte records) 154 768
 constexpr int HOT_MAX = 912;        // cameras cached per workgroup: 912 * 176 B = 156.75 KiB of the 160 KiB LDS
 constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :3] (4.5) + pad
@@ -1196,7 +1199,10 @@ constexpr int LPL_DEPTH = 3;
 // Accumulator slots.  ds_add_f64 collisions inside a 32-lane half serialise, and the most observed cameras collect
 // several observations per row (Zipf hub: 9 % of all observations): the LPL_HUBS hottest cameras therefore get four
 // accumulator replicas each, chosen per observation by the layout (lpl_layout.hpp), summed at the flush.
-constexpr int LPL_HUBS = 16;
+#ifndef POVAR_LPL_HUBS
+#define POVAR_LPL_HUBS 16
+#endif
+constexpr int LPL_HUBS = POVAR_LPL_HUBS;
 __host__ __device__ inline int lpl_hubs(int n_hot) { return n_hot < LPL_HUBS ? n_hot : LPL_HUBS; }
 // cw >= 0 packs the LDS slot (low 16 bits) and, for a hub, the accumulator replica the host chose (bits 16-17)
 __host__ __device__ inline int lpl_cw_slot(int cw) { return cw & 0xffff; }
