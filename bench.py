@@ -118,7 +118,7 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
     dt = time.perf_counter() - t0
     vN = reps * m / dt
     if v1 > vN:  # the mutex scatter often does not scale at all on a hub-heavy graph: the best CPU figure is 1 thread
-        vN, cores_note = v1, f" (the {cores}-thread run was slower: {reps * m / dt:.2f} terms/s)"
+        vN, cores_note = v1, (f" (the {cores}-thread run was slower: {reps * m / dt:.2f} terms/s)" if cores > 1 else "")
         cores = 1
     else:
         cores_note = ""
