@@ -471,9 +471,10 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": {capi.E0_IMPLICIT: "E0 x (e0_lm_cached<false> + cm_scatter)",
-                       capi.E0_IMPLICIT_LDSACC: ("E0 x (e0_lm_cached<true> + cam_cold_sum[_binv])"
-                                                 if os.environ.get("POVAR_E0_V1") == "1" or args.step == 2
-                                                 else "E0 x (e0_lpl + cam_cold_sum[_binv])"),
+                       capi.E0_IMPLICIT_LDSACC: (("E0 x (e0_lpl_h + cam_cold_sum[_binv]_h)" if args.step == 2
+                                                  else "E0 x (e0_lpl + cam_cold_sum[_binv])")
+                                                 if ctx.layout_info().lane_per_landmark else
+                                                 "E0 x (e0_lm_cached<true>[_h] + cam_cold_sum[_binv])"),
                        capi.E0_TILES: "E0 x (lm_regular<OpE0Tiles> + cm_scatter)",
                        capi.E0_TILES_LDSACC: "E0 x (e0_tiles_cached + cam_cold_sum[_binv])"}[mode],
             # bytes the kernel pair streams by design (every array once) / HIP-event time of the pair
@@ -497,7 +498,9 @@ def main():
     li = ctx.layout_info()
     out["config"]["e0_layout"] = {"workgroups": li.grid, "lds_camera_slots": li.lds_slots, "global_cameras": li.n_global,
                                   "grid_cameras": li.n_tail, "rows": li.n_rows, "tiles": li.n_tiles,
-                                  "lds_resident_obs_frac": 1.0 - li.n_cold / max(li.n_obs, 1)}
+                                  "lds_resident_obs_frac": 1.0 - li.n_cold / max(li.n_obs, 1),
+                                  "term_kernels": "lane per landmark" if li.lane_per_landmark else
+                                  "lane per observation (round-1 kernels: under 65 536 observations or POVAR_E0_V1=1)"}
     if not bal_path and (args.popularity != "zipf1" or args.long_track_frac > 0):
         out["config"]["workload"] += f" [SENSITIVITY VARIANT: popularity={args.popularity}, long_track_frac={args.long_track_frac}]"
     if comm_used != "none":  # ncclCommCount of the attached communicator (host-hook runs: its world size)

@@ -244,6 +244,8 @@ typedef struct {
   int64_t n_tiles, n_rows;  /* 64-lane tiles and observation rows of the row stream */
   int64_t n_cold;       /* observations whose camera is not LDS-resident in their workgroup */
   int64_t n_obs;
+  int64_t lane_per_landmark; /* 1: the term loop runs e0_lpl / e0_lpl_h on this layout; 0: the lane-per-observation
+                                kernels (problems under 65 536 observations, POVAR_E0_V1=1) */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 

@@ -106,6 +106,7 @@ struct povar_ctx {
   DevBuf<double> v2_w, v2_lmrec;
   int64_t v2_rows = 0;
   bool use_lpl = true;        // POVAR_E0_V1=1: keep e0_lm_cached<true> (lane per observation) for A/B runs
+  bool lpl_forced = false;      // POVAR_E0_V1 set: keep the choice (the peer-to-peer exchange otherwise turns use_lpl on)
   bool use_lpl_prepare = true;  // POVAR_PREPARE_V1=1: keep lm_regular<OpPrepare> + cm_scatter
   DevBuf<double4> q4c;        // scatter scalars of the cold observations, in cold camera-major order
   DevBuf<int> lm_slot0, lm_cnt_dev;
@@ -739,7 +740,11 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
   if (const char* g = std::getenv("POVAR_NO_FUSE")) c->fuse_binv = !(g[0] == '1');
-  if (const char* g = std::getenv("POVAR_E0_V1")) c->use_lpl = !(g[0] == '1');
+  // A problem that gives the 256 x 16 wavefronts of the lane-per-landmark kernels less than a row each is bound by the
+  // launch of the 1024-thread workgroups: the lane-per-observation kernels of round 1 are faster there (ladybug-49,
+  // 31 843 observations: 127 k against 106 k terms/s; trafalgar-257, 225 911: 64.9 k against 67.0 k).
+  c->use_lpl = n_obs >= 65536;
+  if (const char* g = std::getenv("POVAR_E0_V1")) { c->use_lpl = !(g[0] == '1'); c->lpl_forced = true; }
   if (const char* g = std::getenv("POVAR_K1_NORMAL_EQ")) c->k1_qr = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_PREPARE_V1")) c->use_lpl_prepare = !(g[0] == '1');
 
@@ -1671,6 +1676,7 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->n_rows = c->v2_rows;
   out->n_cold = c->n_cold3;
   out->n_obs = c->n_obs;
+  out->lane_per_landmark = c->use_lpl ? 1 : 0;
   return 0;
 }
 
@@ -1726,6 +1732,7 @@ int povar_p2p_attach(povar_ctx* c, int32_t world, int32_t rank, const uint8_t* h
   c->world = world;
   c->rank = rank;
   c->p2p = true;
+  if (!c->lpl_forced) c->use_lpl = true;  // the push/reduce exchange belongs to the lane-per-landmark term kernels
   return 0;
 }
 

@@ -13,6 +13,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+# The library picks the term kernels by problem size (lane per landmark from 65 536 observations, the
+# lane-per-observation kernels of round 1 below: include/povar_hip.h, povar_layout_info).  The parity tests of these
+# modules use small problems: they run twice, once as the library would ("auto") and once with the lane-per-landmark
+# kernels forced (POVAR_E0_V1=0), so that both families stay compared with the oracle on every case.
+_BOTH_KERNEL_FAMILIES = {"test_gpu_step1", "test_gpu_step2", "test_gpu_fuzz", "test_gpu_sharded", "test_gpu_sc_solvers"}
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("gpu") and metafunc.module.__name__.split(".")[-1] in _BOTH_KERNEL_FAMILIES:
+        metafunc.fixturenames.append("_term_kernels")
+        metafunc.parametrize("_term_kernels", ["auto", "lane-per-landmark"], indirect=True)
+
+
+@pytest.fixture
+def _term_kernels(request, monkeypatch):
+    if request.param == "lane-per-landmark":
+        monkeypatch.setenv("POVAR_E0_V1", "0")
+    return request.param
+
+
 def rel(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
