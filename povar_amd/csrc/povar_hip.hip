@@ -77,7 +77,7 @@ struct povar_ctx {
   size_t bytes = 0;
   // camera-major landmark copies of the legacy kernels (cm_h and the cold views cc/c2) are built lazily in the
   // lane-per-landmark mode, which does not read them: lin_id counts linearisations, views_lin_id is the one they hold
-  int64_t lin_id = 0, views_lin_id = -1;
+  int64_t lin_id = 0, views_lin_id = -1, aux_lin_id = -1;  // aux: the per-slot sqrt(w) / weighted residual arrays
   char* pin = nullptr;  // pinned host block of the small read-backs (read_scal_flags)
   size_t pin_bytes = 0;
 
@@ -482,9 +482,20 @@ void build_views(povar_ctx* c) {
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold2, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c2_lm.p, c->c2_h.p, c->n_cold2, hom);
   c->views_lin_id = c->lin_id;
 }
-// called by every entry point that may run a legacy kernel (cm_scatter, the cold views of e0_lm_cached)
-void ensure_views(povar_ctx* c) {
-  if (c->views_lin_id != c->lin_id && (c->linearized || c->linearized_h)) build_views(c);
+// called by every entry point that may run a lane-per-observation ("legacy") kernel: the camera-major landmark copies
+// (cm_scatter, the cold views of e0_lm_cached) and the per-slot sqrt(w) / weighted residual arrays, which the
+// lane-per-landmark linearisation (lpl_pass<0>) does not write
+void ensure_legacy(povar_ctx* c) {
+  if (!(c->linearized || c->linearized_h)) return;
+  if (c->views_lin_id != c->lin_id) build_views(c);
+  if (c->aux_lin_id != c->lin_id && !c->linearized_h) {
+    Dp da = c->d;
+    da.lin_aux_only = 1;
+    hipLaunchKernelGGL((lm_regular<OpLinearize>), dim3(c->n_reg_blocks), dim3(LM_BLOCK), 0, c->stream, da, OpLinearize{}, c->part.p);
+    if (c->n_long > 0)
+      hipLaunchKernelGGL((lm_long<OpLinearize>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpLinearize{}, c->part.p);
+    c->aux_lin_id = c->lin_id;
+  }
 }
 
 // OR of a per-rank failure flag over the ranks (is_numerically_valid, linearisation failure)
@@ -506,7 +517,7 @@ int combine_flag(povar_ctx* c, int* flag) {
 // so the unsharded step-1 LDSACC path may run them inside the per-camera sum (binv_mode 4: done)
 int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
   prof_mark(c, 0);
-  if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_views(c);  // cm_scatter / legacy cold views
+  if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // cm_scatter / legacy cold views
   if (c->joint) {
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
     if (acc && c->use_lpl) {
@@ -625,6 +636,7 @@ int ensure_tiles(povar_ctx* c) {
     c->tiles_valid = false;
   }
   if (!c->tiles_valid) {
+    ensure_legacy(c);
     hipLaunchKernelGGL(materialize_tiles, dim3(grid_for(c->n_slots, LM_BLOCK)), dim3(LM_BLOCK), 0,
                        c->stream, c->d);
     c->tiles_valid = true;
@@ -786,6 +798,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)pass_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)pass_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)back_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1054,8 +1070,13 @@ int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
   TimeScope ts(c, 4);
   set_alpha(c, alpha);
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
-  launch_lm(c, OpError{});
-  launch_reduce<3>(c, c->scal.p);
+  if (c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
+    hipLaunchKernelGGL(lpl_pass<1>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
+    hipLaunchKernelGGL((reduce_partials<3>), dim3(1), dim3(1024), 0, c->stream, c->part.p, c->e0c_grid, c->scal.p);
+  } else {
+    launch_lm(c, OpError{});
+    launch_reduce<3>(c, c->scal.p);
+  }
   HIP_TRY(hipGetLastError());
   if (int rc = allreduce(c, c->scal.p, 3)) return rc;
   double h[3];
@@ -1081,11 +1102,18 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
-  launch_lm(c, OpLinearize{});
   ++c->lin_id;
   c->linearized = true;
-  const bool lazy = lpl_only(c);  // the camera-major landmark copies are built when a legacy kernel asks (ensure_views)
-  if (!lazy) build_views(c);
+  // lane-per-landmark mode: one forward walk over the row stream; the per-slot arrays and the camera-major landmark
+  // copies of the lane-per-observation kernels are built when one of them asks (ensure_legacy)
+  const bool lazy = lpl_only(c);
+  if (lazy) {
+    hipLaunchKernelGGL(lpl_pass<0>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
+  } else {
+    launch_lm(c, OpLinearize{});
+    c->aux_lin_id = c->lin_id;
+    build_views(c);
+  }
   if (c->n_cold3 > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 0);
   hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
@@ -1133,7 +1161,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
     da.p2p_epoch = nullptr;
     hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 0);
   } else {
-    ensure_views(c);
+    ensure_legacy(c);
     launch_lm(c, OpPrepare{});
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 0);
     hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b, 1);
@@ -1186,7 +1214,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (int rc = check_ctx(c)) return rc;
   if (m < 0) return fail(-1, "power_sc_iterations < 0");
   TimeScope ts(c, 2);
-  if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_views(c);  // not inside the graph capture
+  if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // not inside the graph capture
   const bool norms = q_tol > 0 || r_tol > 0;
   // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
   // RCCL-in-capture is not something a 1-GPU box can validate); POVAR_GRAPH_COMM=1 opts in
@@ -1301,11 +1329,13 @@ int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const doub
       else
         hipLaunchKernelGGL(backsub_lpl<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), back_lds_bytes(c->v2_max_slots), c->stream, da, c->part.p);
     } else {
+      ensure_legacy(c);
       launch_lm(c, OpBackVarproj{});
     }
   } else {
     // cpp:260-270: back-substitute with the stored tiles, then update cameras
     hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 1);
+    ensure_legacy(c);
     launch_lm(c, OpBackPoba{});
     hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 2);
   }
@@ -1372,6 +1402,7 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   launch_lm(c, OpLinearizeH{});
   ++c->lin_id;
+  c->aux_lin_id = c->lin_id;
   c->linearized_h = true;
   const bool lazy = lpl_only(c);
   if (!lazy) build_views(c);
@@ -1418,7 +1449,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
     hipLaunchKernelGGL(cam_nt_project, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, c->d.y, c->d.b,
                        (const double*)c->ncw.p);
   } else {
-    ensure_views(c);
+    ensure_legacy(c);
     launch_lm(c, OpPrepareH{});
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 1);
     hipLaunchKernelGGL(cam_sum_items_h, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b,
@@ -1477,6 +1508,7 @@ int povar_set_e0_mode(povar_ctx* c, int32_t mode) {
 
 int povar_get_buffer(povar_ctx* c, int32_t which, double* out, int64_t n) {
   if (int rc = check_ctx(c)) return rc;
+  ensure_legacy(c);  // exports rebuild the reference's tile from the per-slot arrays
   const size_t nc = c->n_cams, nl = c->n_lms;
   auto copy = [&](const void* src, size_t count) -> int {
     if ((size_t)n != count) return fail(-1, "povar_get_buffer: wrong size");
@@ -1958,6 +1990,7 @@ int povar_solve_pose_sc(povar_ctx* c, double lambda, int32_t method, int32_t min
   if (method != POVAR_SC_PCG && method != POVAR_SC_CHOLESKY) return fail(-1, "povar_solve_pose_sc: unknown method");
   // LinearizorSC::solve (linearizor_sc.cpp:85-160): no landmark damping on this path
   if (int rc = povar_prepare_pose(c, lambda, POVAR_POWER_VARPROJ)) return rc;
+  ensure_legacy(c);
   if (int rc = ensure_sc(c)) return rc;
   if (int rc = build_schur_jacobi<false>(c, lambda)) return rc;
   {

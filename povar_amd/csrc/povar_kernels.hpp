@@ -114,6 +114,7 @@ struct Dp {
   const int* cam;
   const int* lm;
   const int* meta;
+  int lin_aux_only;     // OpLinearize: write only the per-slot sqrt(w) / weighted residual (legacy arrays, filled lazily)
   const int* hot_cams;  // cameras cached in LDS by e0_lm_cached, most observed first
   double* hot_rec;      // [HOT_MAX][24] contiguous LDS image of the hot cameras' records: z_c (12, rewritten by
                         // every B^-1 kernel) then the static camera part (step 1: P[:, :3] (9), step 2: P (12))
@@ -751,7 +752,7 @@ struct OpLinearize {
     const double sw = sqrt(w);
     if (!isfinite(r2) || !isfinite(sw)) atomicOr(&d.flags[0], 1);
     d.sw[slot] = sw;
-    if (d.robust && d.v2.w) d.v2.w[d.v2.of_slot[slot]] = w;
+    if (d.robust && d.v2.w && !d.lin_aux_only) d.v2.w[d.v2.of_slot[slot]] = w;
     d.rres[slot] = make_double4(sw * res[0], sw * res[1], sw * res[2], sw * res[3]);
     double jl[12];
     pose_jl(d, P, uv.x, uv.y, sw, make_double4(1, 1, 1, 1), jl);
@@ -764,6 +765,7 @@ struct OpLinearize {
   }
   __device__ void phase2(const Dp&, int, int, int, double2, Local&, const double*, double*) const {}
   __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    if (d.lin_aux_only) return;  // only the per-slot sqrt(w) / residual arrays are wanted (ensure_legacy, povar_hip.hip)
     // LinearizorSC::linearize_pOSE leaves the Jl columns unscaled (linearizor_sc.cpp:163-191)
     d.jl_scale4[lm] = d.scale_jl ? make_double4(1.0 / (d.eps + sqrt(tot[0])), 1.0 / (d.eps + sqrt(tot[1])),
                                                 1.0 / (d.eps + sqrt(tot[2])), 0.0)
@@ -1447,7 +1449,6 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
     hx = nhx; hy = nhy; hz = nhz;
   }
   __syncthreads();
-  // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run)
   // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run);
   // 16-byte stores, all record indices requested first (one L2 round trip, not one per pass)
   {
@@ -1881,6 +1882,138 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
   if (threadIdx.x == 0) part[blockIdx.x] = sv[0];
 }
 
+// ------------------------------------------------------------------------------------------
+// K2 / K3 + K5 on the lane-per-landmark layout: one forward walk over the rows, camera matrices in LDS (96 B per slot),
+// no accumulators.
+//   MODE 0  linearize_landmark_pOSE + scale_Jl_cols_pOSE (landmark_block.hpp:135-178, 284-295) at (cams_lin4, lms_lin4):
+//           robust weight per observation (V2::w), Jl column scale per landmark, finiteness flag.  The per-slot
+//           sqrt(w) / weighted residual arrays of the lane-per-observation kernels are NOT written: the lane-per-landmark
+//           kernels rebuild both from (P, x, u, v, w); povar_hip.hip fills them when a legacy kernel asks (ensure_legacy).
+//   MODE 1  compute_error_pOSE (bal_bundle_adjustment_helper.cpp:117-154) at (cams4, lms4): (error, |r|, count) summed per
+//           workgroup into part[3 * blockIdx.x ..].
+// ------------------------------------------------------------------------------------------
+constexpr int PASS_REC = 6;  // double2 per camera record: P row-major
+__host__ __device__ inline size_t pass_lds_bytes(int n_hot) { return (size_t)n_hot * PASS_REC * sizeof(double2) + 16; }
+
+template <int MODE>
+__global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
+  extern __shared__ double2 hot[];  // [n_hot][PASS_REC] records, then the tile counter
+  __shared__ double sh[3 * (E0C_BLOCK / 64)];
+  const V2& v = d.v2;
+  const double4* cams = MODE == 0 ? d.cams_lin4 : d.cams4;
+  const double4* lms = MODE == 0 ? d.lms_lin4 : d.lms4;
+  const int cam0 = v.wg_cam_off[blockIdx.x];
+  const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * PASS_REC);
+  if (threadIdx.x == 0) *grab_ctr = 0;
+  for (int i = threadIdx.x; i < n_hot * PASS_REC; i += E0C_BLOCK) {
+    const int r = i / PASS_REC, j = i - r * PASS_REC;
+    hot[i] = reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[v.wg_cams[cam0 + r]])[j];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int t_begin = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
+  const int t_end = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
+  auto grab = [&]() -> int {
+    int n = 0;
+    if (lane == 0) n = __hip_atomic_fetch_add(grab_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const long long t = (long long)t_begin + n;
+    return t < t_end ? (int)t : t_end;
+  };
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  const cint_p tiles = (cint_p)(uintptr_t)v.tile;
+  // single pass: the prefetch cursor walks tile after tile, three rows ahead (a tile has at least two rows here, so the
+  // cursor may need the tile after the next one: two tiles are taken ahead)
+  int c_t = grab(), q1 = c_t < t_end ? grab() : t_end, q2 = q1 < t_end ? grab() : t_end;
+  int pc_t = c_t, pc_ahead = 0, pc_j = 0, pc_row0 = 0, pc_k = 1;  // pc_ahead: 0 = c_t, 1 = q1, 2 = q2
+  if (pc_t < t_end) { pc_row0 = tiles[4 * pc_t]; pc_k = tiles[4 * pc_t + 1]; }
+  auto issue = [&](LplRow& r) {
+    if (pc_t < t_end) {
+      const size_t i = ((size_t)pc_row0 + pc_j) * WAVE + lane;
+      r.uv = v.uv[i];
+      r.cw = v.cw[i];
+      if (++pc_j == pc_k) {
+        pc_j = 0;
+        ++pc_ahead;
+        pc_t = pc_ahead == 1 ? q1 : pc_ahead == 2 ? q2 : t_end;
+        if (pc_t < t_end) { pc_row0 = tiles[4 * pc_t]; pc_k = tiles[4 * pc_t + 1]; }
+      }
+    }
+  };
+  LplRow n1, n2, n3;
+  n1.cw = n2.cw = n3.cw = -1;
+  n1.w = n2.w = n3.w = 1.0;
+  n1.uv = n2.uv = n3.uv = make_double2(0, 0);
+  issue(n1);
+  issue(n2);
+  issue(n3);
+  double sc[3] = {0, 0, 0};
+  int bad = 0;
+  while (c_t < t_end) {
+    const int c_row0 = tiles[4 * c_t], c_k = tiles[4 * c_t + 1], c_fl = tiles[4 * c_t + 3];
+    const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
+    const double4 h = lms[lm >= 0 ? lm : 0];
+    double red[3] = {0, 0, 0};
+    for (int j = 0; j < c_k; ++j) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PASS_REC
+                                      : reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[-2 - cur.cw]);
+      const double2 b0 = hp[0], b1 = hp[1], b2 = hp[2], b3 = hp[3], b4 = hp[4], b5 = hp[5];
+      const Cam P = {make_double4(b0.x, b0.y, b1.x, b1.y), make_double4(b2.x, b2.y, b3.x, b3.y),
+                     make_double4(b4.x, b4.y, b5.x, b5.y)};
+      double res[4];
+      pose_residual(d, P, h, cur.uv.x, cur.uv.y, res);
+      const double r2 = res[0] * res[0] + res[1] * res[1] + res[2] * res[2] + res[3] * res[3];
+      double e, w;
+      error_weight(d, r2, e, w);
+      if (MODE == 0) {
+        const double sw = sqrt(w);
+        bad |= !isfinite(r2) || !isfinite(sw);
+        if (d.robust && v.w) v.w[((size_t)c_row0 + j) * WAVE + lane] = w;
+        double jl[12];
+        pose_jl(d, P, cur.uv.x, cur.uv.y, sw, make_double4(1, 1, 1, 1), jl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          red[0] += jl[3 * r] * jl[3 * r];
+          red[1] += jl[3 * r + 1] * jl[3 * r + 1];
+          red[2] += jl[3 * r + 2] * jl[3 * r + 2];
+        }
+      } else {
+        bad |= !isfinite(r2);
+        sc[0] += e;
+        sc[1] += sqrt(r2);
+        sc[2] += 1.0;
+      }
+    }
+    if (MODE == 0) {
+      const int sg = v.seg[(size_t)c_t * WAVE + lane];
+      if (c_fl & 1) seg_reduce_steps<3>(red, lane, sg & 255, (sg >> 8) & 255, 4);
+      if (lm >= 0 && lane == (sg & 255))
+        d.jl_scale4[lm] = d.scale_jl ? make_double4(1.0 / (d.eps + sqrt(red[0])), 1.0 / (d.eps + sqrt(red[1])),
+                                                    1.0 / (d.eps + sqrt(red[2])), 0.0)
+                                     : make_double4(1.0, 1.0, 1.0, 0.0);
+    }
+    c_t = q1;
+    q1 = q2;
+    q2 = q1 < t_end ? grab() : t_end;
+    --pc_ahead;
+  }
+  if (bad) atomicOr(&d.flags[0], 1);
+  if (MODE == 1) {
+    block_sum<3, E0C_BLOCK>(sc, sh);
+    if (threadIdx.x == 0) {
+      part[3 * (size_t)blockIdx.x] = sc[0];
+      part[3 * (size_t)blockIdx.x + 1] = sc[1];
+      part[3 * (size_t)blockIdx.x + 2] = sc[2];
+    }
+  }
+}
+
 // K10 (stored tiles): right_mul_e0_pOSE on the tiles kept in HBM, blocked layout
 // tiles[bin][pair][lane] (double2): pairs 0-23 Jp (row-major 4x12), 24-29 Jl (4x3), 30-31 r.
 // Every byte of a tile is read once per term, 16 B per lane, 1 KiB contiguous per wave
@@ -2300,9 +2433,10 @@ __global__ __launch_bounds__(256) void cm_gram(Dp d, int gather) {
   double acc[40];
 #pragma unroll
   for (int k = 0; k < 40; ++k) acc[k] = 0;
+  const Cam Pc = load_cam(d.cams_lin4, d.item_cam[item]);
   for (int p = b + lane; p < e; p += WAVE) {
-    const double sw = d.robust ? d.sw[d.cm_slot[p]] : 1.0;  // no gather at all without a robust norm
-    // gather: the camera-major copy of the landmarks is not kept (lane-per-landmark mode), read them in place
+    // gather: the camera-major copy of the landmarks and the per-slot sqrt(w) are not kept (lane-per-landmark mode):
+    // the landmark is read in place and the robust weight recomputed from the residual
     double4 h;
     if (gather) {
       h = d.lms_lin4[d.cm_lm[p]];
@@ -2311,7 +2445,17 @@ __global__ __launch_bounds__(256) void cm_gram(Dp d, int gather) {
       h = make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], 1.0);
     }
     const double2 uv = d.cm_uv[p];
-    const double w = sw * sw;
+    double w = 1.0;
+    if (d.robust && gather) {
+      double res[4], e_;
+      pose_residual(d, Pc, h, uv.x, uv.y, res);
+      error_weight(d, res[0] * res[0] + res[1] * res[1] + res[2] * res[2] + res[3] * res[3], e_, w);
+      const double sw = sqrt(w);  // the reference squares the stored sqrt(w) (landmark_block.hpp:162-169)
+      w = sw * sw;
+    } else if (d.robust) {
+      const double sw = d.sw[d.cm_slot[p]];
+      w = sw * sw;
+    }
     const double m[4] = {w, w * uv.x, w * uv.y, w * (uv.x * uv.x + uv.y * uv.y)};
     const double hh[10] = {h.x * h.x, h.x * h.y, h.x * h.z, h.x * h.w, h.y * h.y,
                            h.y * h.z, h.y * h.w, h.z * h.z, h.z * h.w, h.w * h.w};

@@ -909,7 +909,6 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
     for (int m = 0; m < 6; ++m) Hi[m] = nHi[m];
   }
   __syncthreads();
-  // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run)
   // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run);
   // 16-byte stores, all record indices requested first (one L2 round trip, not one per pass)
   {
