@@ -78,6 +78,8 @@ struct povar_ctx {
   // camera-major landmark copies of the legacy kernels (cm_h and the cold views cc/c2) are built lazily in the
   // lane-per-landmark mode, which does not read them: lin_id counts linearisations, views_lin_id is the one they hold
   int64_t lin_id = 0, views_lin_id = -1, aux_lin_id = -1;  // aux: the per-slot sqrt(w) / weighted residual arrays
+  // prepare_lpl[_h] writes only the lane-per-landmark records; hll_inv / lmrec of the legacy kernels follow lazily
+  int64_t prep_id = 0, aux_prep_id = 0, prep_lin_id = -1;
   char* pin = nullptr;  // pinned host block of the small read-backs (read_scal_flags)
   size_t pin_bytes = 0;
 
@@ -495,6 +497,21 @@ void ensure_legacy(povar_ctx* c) {
     if (c->n_long > 0)
       hipLaunchKernelGGL((lm_long<OpLinearize>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpLinearize{}, c->part.p);
     c->aux_lin_id = c->lin_id;
+  }
+  if (c->prep_id && c->aux_prep_id != c->prep_id && c->prep_lin_id == c->lin_id) {
+    // the landmark half of prepare_Hb again, on the lane-per-observation layout: Hll^-1 and the packed landmark records
+    Dp da = c->d;
+    da.prep_aux_only = 1;
+    if (c->joint) {
+      hipLaunchKernelGGL((lm_regular<OpPrepareH>), dim3(c->n_reg_blocks), dim3(LM_BLOCK), 0, c->stream, da, OpPrepareH{}, c->part.p);
+      if (c->n_long > 0)
+        hipLaunchKernelGGL((lm_long<OpPrepareH>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpPrepareH{}, c->part.p);
+    } else {
+      hipLaunchKernelGGL((lm_regular<OpPrepare>), dim3(c->n_reg_blocks), dim3(LM_BLOCK), 0, c->stream, da, OpPrepare{}, c->part.p);
+      if (c->n_long > 0)
+        hipLaunchKernelGGL((lm_long<OpPrepare>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpPrepare{}, c->part.p);
+    }
+    c->aux_prep_id = c->prep_id;
   }
 }
 
@@ -1140,6 +1157,8 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   if (!c->linearized) return fail(-1, "povar_prepare_pose before povar_linearize_pose");
   set_alpha(c, c->alpha_lin);
   c->joint = false;
+  ++c->prep_id;
+  c->prep_lin_id = c->lin_id;
   TimeScope ts(c, 1);
   // scale_Jp_cols_pOSE on a new linearisation point (linearizor_power_varproj.cpp:192-195):
   // the scaling is part of the implicit tile; only stored tiles need (re)materialising.
@@ -1150,6 +1169,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
     // lane-per-landmark K7: Hll^-1, landmark records and the per-camera partial sums of b in one kernel, then the
     // per-camera sum of the partials and the cold observations (same kernel as the per-term one, output b)
     Dp da = ldsacc_dp(c, true);
+    da.prep_lpl_only = 1;
     // cam_cold_sum honours the series-done flag of the term loop: clear what an early exit of the last solve left
     HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
     if (c->opt.robust_norm)
@@ -1161,6 +1181,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
     da.p2p_epoch = nullptr;
     hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 0);
   } else {
+    c->aux_prep_id = c->prep_id;  // this branch writes them
     ensure_legacy(c);
     launch_lm(c, OpPrepare{});
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 0);
@@ -1430,6 +1451,8 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
   if (!c->linearized_h) return fail(-1, "povar_prepare_joint before povar_linearize_homogeneous");
   TimeScope ts(c, 1);
   c->joint = true;
+  ++c->prep_id;
+  c->prep_lin_id = c->lin_id;
   c->new_linearization_point = false;
   c->d.lambda_lm = lambda;  // set_landmark_damping_joint, linearizor_power_varproj.cpp:136
   hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_cams * 12, 256)), dim3(256), 0, c->stream, c->d, 1);
@@ -1437,6 +1460,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
     // lane-per-landmark K7' (see povar_prepare_pose): landmark half + per-camera partials, per-camera sum of the
     // partials and the cold observations into the ambient 12-vector, then the tangent projection N_c^T
     Dp da = ldsacc_dp(c, true);
+    da.prep_lpl_only = 1;
     HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
     if (c->opt.robust_norm)
       hipLaunchKernelGGL(prepare_lpl_h<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), prep_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
@@ -1449,6 +1473,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
     hipLaunchKernelGGL(cam_nt_project, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, c->d.y, c->d.b,
                        (const double*)c->ncw.p);
   } else {
+    c->aux_prep_id = c->prep_id;
     ensure_legacy(c);
     launch_lm(c, OpPrepareH{});
     hipLaunchKernelGGL(cm_scatter, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, 0, 1);

@@ -115,6 +115,8 @@ struct Dp {
   const int* lm;
   const int* meta;
   int lin_aux_only;     // OpLinearize: write only the per-slot sqrt(w) / weighted residual (legacy arrays, filled lazily)
+  int prep_aux_only;    // OpPrepare[H]: leave the lane-per-landmark records alone (called to fill hll_inv / lmrec lazily)
+  int prep_lpl_only;    // prepare_lpl[_h]: write only the lane-per-landmark records, not hll_inv / lmrec (filled lazily)
   const int* hot_cams;  // cameras cached in LDS by e0_lm_cached, most observed first
   double* hot_rec;      // [HOT_MAX][24] contiguous LDS image of the hot cameras' records: z_c (12, rewritten by
                         // every B^-1 kernel) then the static camera part (step 1: P[:, :3] (9), step 2: P (12))
@@ -836,7 +838,7 @@ struct OpPrepare {
     rec[0] = make_double4(h.x, h.y, h.z, s.x);
     rec[1] = make_double4(s.y, s.z, Hi[0], Hi[1]);
     rec[2] = make_double4(Hi[2], Hi[4], Hi[5], Hi[8]);
-    if (d.v2.lmrec) {
+    if (d.v2.lmrec && !d.prep_aux_only) {
       // record of the lane-per-landmark kernel: the Jl column scale is folded into G = diag(s) Hll^-1 diag(s)
       const int lp = d.v2.lm_pos[lm], pos = lp & ((1 << 26) - 1), lanes = ((lp >> 26) & 63) + 1;
       const double G[6] = {s.x * Hi[0] * s.x, s.x * Hi[1] * s.y, s.x * Hi[2] * s.z,
@@ -1646,7 +1648,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
       r2[0] = hx; r2[WAVE] = hy; r2[2 * WAVE] = hz;
       r2[3 * WAVE] = s4.x * Hi[0] * s4.x; r2[4 * WAVE] = s4.x * Hi[1] * s4.y; r2[5 * WAVE] = s4.x * Hi[2] * s4.z;
       r2[6 * WAVE] = s4.y * Hi[4] * s4.y; r2[7 * WAVE] = s4.y * Hi[5] * s4.z; r2[8 * WAVE] = s4.z * Hi[8] * s4.z;
-      if (lane == (sg & 255)) {
+      if (lane == (sg & 255) && !d.prep_lpl_only) {
 #pragma unroll
         for (int m = 0; m < 9; ++m) d.hll_inv[9 * (size_t)lm + m] = Hi[m];
         double4* rec = reinterpret_cast<double4*>(d.lmrec) + 3 * (size_t)lm;

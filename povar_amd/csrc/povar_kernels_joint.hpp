@@ -185,7 +185,7 @@ struct OpPrepareH {
     rec[1] = d.jl_scale4[lm];
     rec[2] = make_double4(Hi[0], Hi[1], Hi[2], Hi[4]);
     rec[3] = make_double4(Hi[5], Hi[8], 0, 0);
-    if (d.v2.lmrec) {  // record of the lane-per-landmark kernel, one copy per lane the landmark occupies
+    if (d.v2.lmrec && !d.prep_aux_only) {  // record of the lane-per-landmark kernel, one copy per lane the landmark occupies
       const int lp = d.v2.lm_pos[lm], pos = lp & ((1 << 26) - 1), lanes = ((lp >> 26) & 63) + 1;
       const double4 X = d.lms_lin4[lm], s = d.jl_scale4[lm];
       const double rv[14] = {X.x, X.y, X.z, X.w, s.x, s.y, s.z, s.w, Hi[0], Hi[1], Hi[2], Hi[4], Hi[5], Hi[8]};
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
       const double rv[LPL_REC_H] = {X.x, X.y, X.z, X.w, s4.x, s4.y, s4.z, s4.w, Hi[0], Hi[1], Hi[2], Hi[4], Hi[5], Hi[8]};
 #pragma unroll
       for (int m = 0; m < LPL_REC_H; ++m) r2[m * WAVE] = rv[m];
-      if (lane == (sg & 255)) {
+      if (lane == (sg & 255) && !d.prep_lpl_only) {
 #pragma unroll
         for (int m = 0; m < 9; ++m) d.hll_inv[9 * (size_t)lm + m] = Hi[m];
         double4* rec = reinterpret_cast<double4*>(d.lmrec) + 4 * (size_t)lm;
