@@ -1188,7 +1188,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
     hipLaunchKernelGGL(cam_sum_items, dim3(grid_for(c->n_cams, 4)), dim3(256), 0, c->stream, c->d, c->d.b, 1);
   }
   if (int rc = allreduce(c, c->d.b, 12 * (size_t)c->n_cams)) return rc;
-  hipLaunchKernelGGL(cam_build_binv, dim3(grid_for(c->n_cams, K8_THREADS)), dim3(K8_THREADS), 0, c->stream,
+  hipLaunchKernelGGL(cam_build_binv, dim3(grid_for(c->n_cams, K8_CAMS_PER_WG)), dim3(K8_THREADS), 0, c->stream,
                      c->d, lambda);
   if (int rc = ensure_tiles(c)) return rc;
   HIP_TRY(hipGetLastError());
@@ -1481,7 +1481,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
                        (const double*)c->ncw.p);
   }
   if (int rc = allreduce(c, c->d.b, 11 * (size_t)c->n_cams)) return rc;
-  hipLaunchKernelGGL(cam_build_binv_h, dim3(grid_for(c->n_cams, K8_THREADS)), dim3(K8_THREADS), 0, c->stream, c->d,
+  hipLaunchKernelGGL(cam_build_binv_h, dim3(grid_for(c->n_cams, K8_CAMS_PER_WG)), dim3(K8_THREADS), 0, c->stream, c->d,
                      lambda, (const double*)c->ncw.p);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1866,7 +1866,7 @@ int build_schur_jacobi(povar_ctx* c, double lambda) {
   hipLaunchKernelGGL(cam_sum_parts60, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)c->sc.dm_part,
                      c->sc.dm);
   if (int rc = allreduce(c, c->sc.dm, 60 * (size_t)c->n_cams)) return rc;
-  const dim3 g(grid_for(c->n_cams, K8_THREADS)), b(K8_THREADS);
+  const dim3 g(grid_for(c->n_cams, K8_SC_THREADS)), b(K8_SC_THREADS);
   hipLaunchKernelGGL((cam_build_sc<HOM>), g, b, 0, c->stream, c->d, lambda, c->sc.ncw, (const double*)nullptr,
                      (double*)nullptr, c->sc.bmat);
   hipLaunchKernelGGL((cam_build_sc<HOM>), g, b, 0, c->stream, c->d, lambda, c->sc.ncw, (const double*)c->sc.dm,

@@ -2517,65 +2517,82 @@ __global__ __launch_bounds__(1024) void cam_finish_linearize(Dp d, const double*
   }
 }
 
+// Cholesky inverse of a small SPD matrix by the 16 lanes that own it (LDS, row stride 12; reads the upper triangle,
+// leaves L in the lower one): column j of L in two lock steps (the diagonal by lane j, the rest by lanes i > j), then
+// lane `col` solves L L^T x = e_col in registers.  Same operation order as the serial form
+// (linearization_power_varproj.hpp:145-148: llt().solve(Identity)) -- bit-identical results, 12 x the lanes.
+// Every thread of the workgroup must call it (barriers); out: N x N row-major or nullptr.
+template <int N>
+__device__ inline void chol_inverse_16(double* A, int l, double* out) {
+  for (int j = 0; j < N; ++j) {
+    if (l == j) {
+      double dd = A[j * 12 + j];
+      for (int k = 0; k < j; ++k) dd -= A[j * 12 + k] * A[j * 12 + k];
+      A[j * 12 + j] = sqrt(dd);
+    }
+    __syncthreads();
+    if (l > j && l < N) {
+      double sv = A[j * 12 + l];
+      for (int k = 0; k < j; ++k) sv -= A[l * 12 + k] * A[j * 12 + k];
+      A[l * 12 + j] = sv / A[j * 12 + j];
+    }
+    __syncthreads();
+  }
+  if (l < N) {
+    double x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double sv = (i == l) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) sv -= A[i * 12 + k] * x[k];
+      x[i] = sv / A[i * 12 + i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+      double sv = x[i];
+#pragma unroll
+      for (int k = i + 1; k < N; ++k) sv -= A[k * 12 + i] * x[k];
+      x[i] = sv / A[i * 12 + i];
+    }
+    if (out) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) out[N * i + l] = x[i];
+    }
+  }
+}
+
 // K8: B_c = Hpp_c + lambda I, B_c^-1 by Cholesky (upper triangle) and solve against I
-// (linearization_power_varproj.hpp:141-154).  One thread per camera, matrices in LDS laid out
-// [element][thread] (bank-conflict free).
-constexpr int K8_THREADS = 32;
+// (linearization_power_varproj.hpp:141-154).  Sixteen lanes per camera, four cameras per 64-thread workgroup
+// (one thread per camera was a 1 900-step dependent chain through LDS: 31 us for 1 778 cameras).
+constexpr int K8_THREADS = 64, K8_CAMS_PER_WG = 4;
 __global__ __launch_bounds__(K8_THREADS) void cam_build_binv(Dp d, double lambda) {
-  __shared__ double A[144 * K8_THREADS];
-  __shared__ double X[144 * K8_THREADS];
-  const int t = threadIdx.x;
-  const int c = blockIdx.x * K8_THREADS + t;
-  if (c >= d.n_cams) return;
-#define A_(i, j) A[((i) * 12 + (j)) * K8_THREADS + t]
-#define X_(i, j) X[((i) * 12 + (j)) * K8_THREADS + t]
-  const double* g = d.G + 40 * (size_t)c;
-  const double* sg = d.sigma + 12 * (size_t)c;
-  const double sb2 = d.sb * d.sb;
-  for (int a = 0; a < 3; ++a)
-    for (int b = 0; b < 3; ++b)
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-          const int ij = sym10(i, j);
-          double v;
-          if (a == b) v = a < 2 ? g[ij] : sb2 * g[30 + ij];
-          else if (a + b == 1) v = 0;
-          else {
-            const int k = (a == 2 ? b : a);  // 0 -> u moment, 1 -> v moment
-            v = -sb2 * g[10 * (k + 1) + ij];
-          }
-          A_(4 * a + i, 4 * b + j) = v * sg[4 * a + i] * sg[4 * b + j];
-        }
-  for (int j = 0; j < 12; ++j) A_(j, j) += lambda;
-  // Cholesky: L stored in the lower triangle of A (reads the upper triangle of the input)
-  for (int j = 0; j < 12; ++j) {
-    double dd = A_(j, j);
-    for (int k = 0; k < j; ++k) dd -= A_(j, k) * A_(j, k);
-    dd = sqrt(dd);
-    A_(j, j) = dd;
-    for (int i = j + 1; i < 12; ++i) {
-      double s = A_(j, i);
-      for (int k = 0; k < j; ++k) s -= A_(i, k) * A_(j, k);
-      A_(i, j) = s / dd;
+  __shared__ double As[K8_CAMS_PER_WG][144];
+  const int q = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const int c = blockIdx.x * K8_CAMS_PER_WG + q;
+  const bool in = c < d.n_cams;
+  double* A = As[q];
+  if (in) {
+    const double* g = d.G + 40 * (size_t)c;
+    const double* sg = d.sigma + 12 * (size_t)c;
+    const double sb2 = d.sb * d.sb;
+    for (int e = l; e < 144; e += 16) {
+      const int r = e / 12, cc = e % 12, a = r >> 2, i = r & 3, b = cc >> 2, j = cc & 3;
+      const int ij = sym10(i, j);
+      double v;
+      if (a == b) v = a < 2 ? g[ij] : sb2 * g[30 + ij];
+      else if (a + b == 1) v = 0;
+      else {
+        const int k = (a == 2 ? b : a);  // 0 -> u moment, 1 -> v moment
+        v = -sb2 * g[10 * (k + 1) + ij];
+      }
+      v = v * sg[r] * sg[cc];
+      A[e] = r == cc ? v + lambda : v;
     }
+  } else {
+    for (int e = l; e < 144; e += 16) A[e] = (e / 12 == e % 12) ? 1.0 : 0.0;
   }
-  for (int col = 0; col < 12; ++col) {
-    for (int i = 0; i < 12; ++i) {
-      double s = (i == col) ? 1.0 : 0.0;
-      for (int k = 0; k < i; ++k) s -= A_(i, k) * X_(k, col);
-      X_(i, col) = s / A_(i, i);
-    }
-    for (int i = 11; i >= 0; --i) {
-      double s = X_(i, col);
-      for (int k = i + 1; k < 12; ++k) s -= A_(k, i) * X_(k, col);
-      X_(i, col) = s / A_(i, i);
-    }
-  }
-  double* out = d.binv + 144 * (size_t)c;
-  for (int i = 0; i < 12; ++i)
-    for (int j = 0; j < 12; ++j) out[12 * i + j] = X_(i, j);
-#undef A_
-#undef X_
+  __syncthreads();
+  chol_inverse_16<12>(A, l, in ? d.binv + 144 * (size_t)c : nullptr);
 }
 
 // z_c = sigma * x_c goes to the dense vector and, for a cached camera, into the contiguous record

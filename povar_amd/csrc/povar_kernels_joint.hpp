@@ -532,70 +532,49 @@ __global__ __launch_bounds__(1024) void cam_finish_linearize_h(Dp d, const doubl
 }
 
 // K8': B_c = N_c^T (Hpp12 + lambda I) N_c = N_c^T Hpp12 N_c + lambda I_11, Cholesky inverse 11x11
-// (linearization_power_varproj.hpp:91-121).  One thread per camera, matrices in LDS [element][thread].
+// (linearization_power_varproj.hpp:91-121).  Sixteen lanes per camera as cam_build_binv: lane i owns row i of the two
+// projections, then chol_inverse_16<11>.
 __global__ __launch_bounds__(K8_THREADS) void cam_build_binv_h(Dp d, double lambda, const double* ncw) {
-  __shared__ double A[144 * K8_THREADS];
-  __shared__ double X[144 * K8_THREADS];
-  const int t = threadIdx.x;
-  const int c = blockIdx.x * K8_THREADS + t;
-  if (c >= d.n_cams) return;
-#define A_(i, j) A[((i) * 12 + (j)) * K8_THREADS + t]
-#define X_(i, j) X[((i) * 12 + (j)) * K8_THREADS + t]
-  const double* g = d.G + 40 * (size_t)c;
-  const double* sg = d.sigma + 12 * (size_t)c;
-  const double* w = ncw + 13 * (size_t)c;
+  __shared__ double As[K8_CAMS_PER_WG][144];
+  __shared__ double Ts[K8_CAMS_PER_WG][144];
+  const int q = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const int c = blockIdx.x * K8_CAMS_PER_WG + q;
+  const bool in = c < d.n_cams;
+  double* A = As[q];
+  double* T = Ts[q];
+  const double* w = ncw + 13 * (size_t)(in ? c : 0);
   const double beta = w[12];
-  for (int a = 0; a < 3; ++a)
-    for (int b = 0; b < 3; ++b)
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-          const int ij = sym10(i, j);
-          double v;
-          if (a == b) v = a < 2 ? g[ij] : g[30 + ij];
-          else if (a + b == 1) v = 0;
-          else v = g[10 * ((a == 2 ? b : a) + 1) + ij];
-          A_(4 * a + i, 4 * b + j) = v * sg[4 * a + i] * sg[4 * b + j];
-        }
-  // T = A N (12 x 11) into X, then M = N^T T (11 x 11) back into A (row stride kept at 12)
-  for (int i = 0; i < 12; ++i) {
+  if (in) {
+    const double* g = d.G + 40 * (size_t)c;
+    const double* sg = d.sigma + 12 * (size_t)c;
+    for (int e = l; e < 144; e += 16) {
+      const int r = e / 12, cc = e % 12, a = r >> 2, i = r & 3, b = cc >> 2, j = cc & 3;
+      const int ij = sym10(i, j);
+      double v;
+      if (a == b) v = a < 2 ? g[ij] : g[30 + ij];
+      else if (a + b == 1) v = 0;
+      else v = g[10 * ((a == 2 ? b : a) + 1) + ij];
+      A[e] = v * sg[r] * sg[cc];
+    }
+  }
+  __syncthreads();
+  // T = A N (12 x 11): row i by lane i
+  if (in && l < 12) {
     double aw = 0;
-    for (int k = 0; k < 12; ++k) aw += A_(i, k) * w[k];
-    for (int j = 0; j < 11; ++j) X_(i, j) = A_(i, j + 1) - beta * aw * w[j + 1];
+    for (int k = 0; k < 12; ++k) aw += A[l * 12 + k] * w[k];
+    for (int j = 0; j < 11; ++j) T[l * 12 + j] = A[l * 12 + j + 1] - beta * aw * w[j + 1];
   }
-  for (int j = 0; j < 11; ++j) {
+  __syncthreads();
+  // M = N^T T (11 x 11) back into A (row stride kept at 12): column j by lane j
+  if (in && l < 11) {
     double wt = 0;
-    for (int k = 0; k < 12; ++k) wt += w[k] * X_(k, j);
-    for (int i = 0; i < 11; ++i) A_(i, j) = X_(i + 1, j) - beta * w[i + 1] * wt;
+    for (int k = 0; k < 12; ++k) wt += w[k] * T[k * 12 + l];
+    for (int i = 0; i < 11; ++i) A[i * 12 + l] = T[(i + 1) * 12 + l] - beta * w[i + 1] * wt + (i == l ? lambda : 0.0);
   }
-  for (int j = 0; j < 11; ++j) A_(j, j) += lambda;
-  for (int j = 0; j < 11; ++j) {
-    double dd = A_(j, j);
-    for (int k = 0; k < j; ++k) dd -= A_(j, k) * A_(j, k);
-    dd = sqrt(dd);
-    A_(j, j) = dd;
-    for (int i = j + 1; i < 11; ++i) {
-      double s = A_(j, i);
-      for (int k = 0; k < j; ++k) s -= A_(i, k) * A_(j, k);
-      A_(i, j) = s / dd;
-    }
-  }
-  for (int col = 0; col < 11; ++col) {
-    for (int i = 0; i < 11; ++i) {
-      double s = (i == col) ? 1.0 : 0.0;
-      for (int k = 0; k < i; ++k) s -= A_(i, k) * X_(k, col);
-      X_(i, col) = s / A_(i, i);
-    }
-    for (int i = 10; i >= 0; --i) {
-      double s = X_(i, col);
-      for (int k = i + 1; k < 11; ++k) s -= A_(k, i) * X_(k, col);
-      X_(i, col) = s / A_(i, i);
-    }
-  }
-  double* out = d.binv + 144 * (size_t)c;  // 11x11 row-major in the first 121 entries
-  for (int i = 0; i < 11; ++i)
-    for (int j = 0; j < 11; ++j) out[11 * i + j] = X_(i, j);
-#undef A_
-#undef X_
+  if (!in)
+    for (int e = l; e < 144; e += 16) A[e] = (e / 12 == e % 12) ? 1.0 : 0.0;
+  __syncthreads();
+  chol_inverse_16<11>(A, l, in ? d.binv + 144 * (size_t)c : nullptr);  // 11x11 row-major in the first 121 entries
 }
 
 // tangent projection of a per-camera 12-vector: out11 = N_c^T (in12)

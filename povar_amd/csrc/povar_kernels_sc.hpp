@@ -159,17 +159,18 @@ __global__ __launch_bounds__(1024) void cam_sum_parts60(Dp d, const double* part
 // in step 2 (N_c^T A N_c), + lambda I.  out_mat receives A (dim x dim row-major), out_inv its
 // inverse by Cholesky of the upper triangle (preconditioner.hpp:104-107 / LPV:145-148).
 // One thread per camera, matrices in LDS [element][thread] like cam_build_binv.
+constexpr int K8_SC_THREADS = 32;  // one thread per camera (explicit-SC path: not tuned further)
 template <bool HOM>
-__global__ __launch_bounds__(K8_THREADS) void cam_build_sc(Dp d, double lambda, const double* ncw, const double* dm,
+__global__ __launch_bounds__(K8_SC_THREADS) void cam_build_sc(Dp d, double lambda, const double* ncw, const double* dm,
                                                            double* out_inv, double* out_mat) {
-  __shared__ double A[144 * K8_THREADS];
-  __shared__ double X[144 * K8_THREADS];
+  __shared__ double A[144 * K8_SC_THREADS];
+  __shared__ double X[144 * K8_SC_THREADS];
   const int t = threadIdx.x;
-  const int c = blockIdx.x * K8_THREADS + t;
+  const int c = blockIdx.x * K8_SC_THREADS + t;
   if (c >= d.n_cams) return;
   constexpr int DIM = HOM ? 11 : 12;
-#define A_(i, j) A[((i) * 12 + (j)) * K8_THREADS + t]
-#define X_(i, j) X[((i) * 12 + (j)) * K8_THREADS + t]
+#define A_(i, j) A[((i) * 12 + (j)) * K8_SC_THREADS + t]
+#define X_(i, j) X[((i) * 12 + (j)) * K8_SC_THREADS + t]
   const double* g = d.G + 40 * (size_t)c;
   const double* sg = d.sigma + 12 * (size_t)c;
   const double sb2 = d.sb * d.sb;
