@@ -9,7 +9,7 @@ set -u
 tag=${1:-r02}
 cd "$(dirname "$0")/.." || exit 1
 out=gpurun_out/$tag
-mkdir -p $out
+rm -rf $out && mkdir -p $out   # (locally: also delete gpurun_out/<tag> before merging a new run, run ids differ)
 tools/profile_e0.sh $tag > $out/profile.log 2>&1
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --step 2 --no-cpu-baseline --no-secondary > $out/bench_step2.json 2> /dev/null
