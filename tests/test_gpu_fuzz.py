@@ -1,6 +1,8 @@
 """Seeded random sweep of the whole C ABI against the CPU oracle: problem shape (including single-camera-heavy
 graphs, two-view landmarks and >64-observation landmarks), robust norm, damping, series length, E0 mode and
 linear solver are drawn per case; every stage of one LM inner iteration is compared."""
+import os
+
 import numpy as np
 import pytest
 
@@ -337,3 +339,171 @@ def test_device_timings():
     ctx.solve_pose(1e-4, capi.POWER_VARPROJ, 20)
     assert ctx.timings().solve_calls == 0
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("POVAR_FUZZ_SEQ_SEEDS", "6"))))
+def test_api_sequence_differential(seed, monkeypatch):
+    """Random sequences of C-ABI calls on two contexts over the same problem: A in the shipping mode with the
+    lane-per-landmark kernels forced (lazy legacy arrays, mode switches in the middle of an iteration, exports),
+    B in the bit-reproducible POVAR_E0_IMPLICIT mode (every legacy array written eagerly).  Whatever the order of the
+    calls, both must return the same numbers: a stale lazily-built array would show up here."""
+    from povar_amd import capi
+    monkeypatch.setenv("POVAR_E0_V1", "0")
+    rng = np.random.default_rng(7000 + seed)
+    n_c, lm_off, cam_idx, obs, cams = _random_problem(rng)
+    norm = ["NONE", "HUBER", "CAUCHY"][int(rng.integers(0, 3))]
+    kw = dict(robust_norm=norm, huber=float(rng.uniform(0.1, 2.0)))
+    A = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=capi.E0_IMPLICIT_LDSACC, **kw)
+    B = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=capi.E0_IMPLICIT, **kw)
+    assert A.layout_info().lane_per_landmark == 1
+    for c in (A, B):
+        c.set_cameras(cams)
+        c.init_landmarks_pose(ALPHA)
+    B.set_landmarks(A.get_landmarks())
+    both = lambda f: (f(A), f(B))  # noqa: E731
+    linearized = prepared = False
+    solver = capi.POWER_VARPROJ
+    inc = None
+    modes = [capi.E0_IMPLICIT_LDSACC, capi.E0_IMPLICIT, capi.E0_TILES, capi.E0_TILES_LDSACC]
+    log = []
+    for step in range(int(os.environ.get("POVAR_FUZZ_SEQ_LEN", "40"))):
+        ops = ["error", "linearize", "mode"]
+        if linearized:
+            ops += ["prepare", "export_lin"]
+        if prepared:
+            ops += ["series", "e0", "export_prep", "series"]
+        if prepared and inc is not None:
+            ops += ["apply"]
+        op = ops[int(rng.integers(0, len(ops)))]
+        log.append(op)
+        if op == "error":
+            ra, rb = both(lambda c: c.error_pose(ALPHA))
+            assert ra.all_num_obs == rb.all_num_obs and abs(ra.all_error - rb.all_error) <= 1e-12 * abs(rb.all_error), log
+        elif op == "linearize":
+            oa, ob = both(lambda c: c.linearize_pose(ALPHA))
+            assert oa and ob
+            linearized, prepared, inc = True, False, None
+        elif op == "mode":
+            A.set_e0_mode(modes[int(rng.integers(0, 4))] if rng.random() < 0.5 else capi.E0_IMPLICIT_LDSACC)
+        elif op == "prepare":
+            lam = float(10 ** rng.uniform(-4, 0))
+            solver = capi.POWER_VARPROJ if rng.random() < 0.7 else capi.POWER_SCHUR_COMPLEMENT
+            both(lambda c: c.prepare_pose(lam, solver))
+            prepared, inc = True, None
+        elif op == "export_lin":
+            for which in (capi.BUF_DIAG2, capi.BUF_POSE_SCALING, capi.BUF_JL_COL_SCALE):
+                a, b = both(lambda c: c.get_buffer(which))
+                assert rel(a, b) < 1e-12, (log, which)
+        elif op == "export_prep":
+            for which, tol in ((capi.BUF_HLL_INV, 1e-9), (capi.BUF_B, 1e-10), (capi.BUF_B_INV, 1e-9), (capi.BUF_STORAGE, 1e-12)):
+                a, b = both(lambda c: c.get_buffer(which))
+                assert rel(a, b) < tol, (log, which)
+        elif op == "series":
+            m = int(rng.integers(0, 12))
+            both(lambda c: c.power_series_pose(m))
+            ia, ib = both(lambda c: c.get_increment())
+            assert rel(ia, ib) < 1e-10, log
+            inc = ib
+        elif op == "e0":
+            x = rng.normal(size=12 * n_c)
+            ya, yb = both(lambda c: c.right_mul_e0_pose(x))
+            assert rel(ya, yb) < 1e-11, log
+        elif op == "apply":
+            both(lambda c: c.backup_pose())
+            la, lb = both(lambda c: c.apply_pose(solver, ALPHA, inc))
+            assert abs(la - lb) <= 1e-8 * max(abs(lb), 1e-300), log
+            ca, cb = both(lambda c: c.get_cameras())
+            xa, xb = both(lambda c: c.get_landmarks())
+            assert rel(ca, cb) < 1e-12 and rel(xa, xb) < 1e-8, log
+            if rng.random() < 0.5:  # rejected step: back to the linearisation point, the prepared system stays valid
+                both(lambda c: c.restore_pose())
+            else:
+                B.set_landmarks(xa)  # accepted: new state, identical in both
+                B.set_cameras(ca)
+                A.set_landmarks(xa)
+                A.set_cameras(ca)
+                linearized = prepared = False
+            inc = None
+    A.close()
+    B.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("POVAR_FUZZ_SEQ_SEEDS", "4"))))
+def test_api_sequence_differential_step2(seed, monkeypatch):
+    """The same differential sequence test for the projective refinement (linearize_homogeneous / prepare_joint /
+    series / apply_joint / normalize_joint): lane-per-landmark shipping mode against POVAR_E0_IMPLICIT."""
+    from povar_amd import capi
+    monkeypatch.setenv("POVAR_E0_V1", "0")
+    rng = np.random.default_rng(9000 + seed)
+    n_c, lm_off, cam_idx, obs, _ = _random_problem(rng)
+    n_l = len(lm_off) - 1
+    cams = rng.normal(size=(n_c, 12))
+    cams[:, 8:11] *= 0.1
+    cams[:, 11] = 5 + rng.random(n_c)
+    cams /= np.linalg.norm(cams, axis=1, keepdims=True)
+    lms_h = np.concatenate([rng.normal(size=(n_l, 3)), np.ones((n_l, 1))], 1)
+    obs = obs / 50.0
+    norm = ["NONE", "HUBER"][int(rng.integers(0, 2))]
+    kw = dict(robust_norm=norm, huber=float(rng.uniform(0.01, 0.5)))
+    A = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=capi.E0_IMPLICIT_LDSACC, **kw)
+    B = capi.Context(n_c, lm_off, cam_idx, obs, e0_mode=capi.E0_IMPLICIT, **kw)
+    for c in (A, B):
+        c.set_cameras(cams)
+        c.set_landmarks_homogeneous(lms_h)
+    both = lambda f: (f(A), f(B))  # noqa: E731
+    linearized = prepared = False
+    inc = None
+    log = []
+    for step in range(int(os.environ.get("POVAR_FUZZ_SEQ_LEN", "40"))):
+        ops = ["error", "linearize", "mode"]
+        if linearized:
+            ops += ["prepare"]
+        if prepared:
+            ops += ["series", "export_prep", "series"]
+        if prepared and inc is not None:
+            ops += ["apply"]
+        op = ops[int(rng.integers(0, len(ops)))]
+        log.append(op)
+        if op == "error":
+            ra, rb = both(lambda c: c.error_homogeneous())
+            assert ra.valid_num_obs == rb.valid_num_obs and abs(ra.all_error - rb.all_error) <= 1e-12 * abs(rb.all_error), log
+        elif op == "linearize":
+            oa, ob = both(lambda c: c.linearize_homogeneous())
+            assert oa and ob
+            linearized, prepared, inc = True, False, None
+        elif op == "mode":
+            A.set_e0_mode(capi.E0_IMPLICIT if rng.random() < 0.4 else capi.E0_IMPLICIT_LDSACC)
+        elif op == "prepare":
+            lam = float(10 ** rng.uniform(-4, 0))
+            both(lambda c: c.prepare_joint(lam))
+            prepared, inc = True, None
+        elif op == "export_prep":
+            for which, tol in ((capi.BUF_HLL_INV, 1e-9), (capi.BUF_B_JOINT, 1e-10), (capi.BUF_B_INV_JOINT, 1e-9),
+                               (capi.BUF_JL_COL_SCALE_H, 1e-12), (capi.BUF_DIAG2, 1e-12)):
+                a, b = both(lambda c: c.get_buffer(which))
+                assert rel(a, b) < tol, (log, which)
+        elif op == "series":
+            m = int(rng.integers(0, 10))
+            both(lambda c: c.power_series_pose(m))
+            ia, ib = both(lambda c: c.get_increment(11))
+            assert rel(ia, ib) < 1e-10, log
+            inc = ib
+        elif op == "apply":
+            both(lambda c: c.backup_joint())
+            la, lb = both(lambda c: c.apply_joint(inc))
+            assert abs(la - lb) <= 1e-8 * max(abs(lb), 1e-300), log
+            ca, cb = both(lambda c: c.get_cameras())
+            xa, xb = both(lambda c: c.get_landmarks_homogeneous())
+            assert rel(ca, cb) < 1e-12 and rel(xa, xb) < 1e-8, log
+            if rng.random() < 0.5:
+                both(lambda c: c.restore_joint())
+            else:
+                both(lambda c: c.normalize_joint())
+                ca, xa = A.get_cameras(), A.get_landmarks_homogeneous()
+                for c in (A, B):
+                    c.set_cameras(ca)
+                    c.set_landmarks_homogeneous(xa)
+                linearized = prepared = False
+            inc = None
+    A.close()
+    B.close()
