@@ -490,12 +490,18 @@ void build_views(povar_ctx* c) {
 void ensure_legacy(povar_ctx* c) {
   if (!(c->linearized || c->linearized_h)) return;
   if (c->views_lin_id != c->lin_id) build_views(c);
-  if (c->aux_lin_id != c->lin_id && !c->linearized_h) {
+  if (c->aux_lin_id != c->lin_id) {
     Dp da = c->d;
     da.lin_aux_only = 1;
-    hipLaunchKernelGGL((lm_regular<OpLinearize>), dim3(c->n_reg_blocks), dim3(LM_BLOCK), 0, c->stream, da, OpLinearize{}, c->part.p);
-    if (c->n_long > 0)
-      hipLaunchKernelGGL((lm_long<OpLinearize>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpLinearize{}, c->part.p);
+    if (c->linearized_h) {
+      hipLaunchKernelGGL((lm_regular<OpLinearizeH>), dim3(c->n_reg_blocks), dim3(LM_BLOCK), 0, c->stream, da, OpLinearizeH{}, c->part.p);
+      if (c->n_long > 0)
+        hipLaunchKernelGGL((lm_long<OpLinearizeH>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpLinearizeH{}, c->part.p);
+    } else {
+      hipLaunchKernelGGL((lm_regular<OpLinearize>), dim3(c->n_reg_blocks), dim3(LM_BLOCK), 0, c->stream, da, OpLinearize{}, c->part.p);
+      if (c->n_long > 0)
+        hipLaunchKernelGGL((lm_long<OpLinearize>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpLinearize{}, c->part.p);
+    }
     c->aux_lin_id = c->lin_id;
   }
   if (c->prep_id && c->aux_prep_id != c->prep_id && c->prep_lin_id == c->lin_id) {
@@ -815,6 +821,14 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass_h<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)pass_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass_h<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)pass_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)back_lds_bytes_h(HOT_ACC_MAX)));
+    HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)back_lds_bytes_h(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)pass_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1397,8 +1411,13 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
   if (!out) return fail(-1, "null argument");
   TimeScope ts(c, 4);
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
-  launch_lm(c, OpErrorH{});
-  launch_reduce<6>(c, c->scal.p);
+  if (c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
+    hipLaunchKernelGGL(lpl_pass_h<1>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
+    hipLaunchKernelGGL((reduce_partials<6>), dim3(1), dim3(1024), 0, c->stream, c->part.p, c->e0c_grid, c->scal.p);
+  } else {
+    launch_lm(c, OpErrorH{});
+    launch_reduce<6>(c, c->scal.p);
+  }
   HIP_TRY(hipGetLastError());
   if (int rc = allreduce(c, c->scal.p, 6)) return rc;
   double h[6];
@@ -1421,12 +1440,16 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
-  launch_lm(c, OpLinearizeH{});
   ++c->lin_id;
-  c->aux_lin_id = c->lin_id;
   c->linearized_h = true;
   const bool lazy = lpl_only(c);
-  if (!lazy) build_views(c);
+  if (lazy) {
+    hipLaunchKernelGGL(lpl_pass_h<0>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
+  } else {
+    launch_lm(c, OpLinearizeH{});
+    c->aux_lin_id = c->lin_id;
+    build_views(c);
+  }
   if (c->n_cold3 > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 1);
   hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
@@ -1503,10 +1526,25 @@ int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
   TimeScope ts(c, 3);
   HIP_TRY(hipMemcpyAsync(c->inc.p, inc, sizeof(double) * 11 * c->n_cams, hipMemcpyHostToDevice, c->stream));
   // cpp:280: back-substitute first (old cameras), then update the cameras (cpp:283-305)
+  const bool lpl_back = lpl_only(c);
+  if (lpl_back)  // the record image: P of the linearisation point (12..23), then z = sigma * N_c inc by cam_apply_inc_h (0..11)
+    hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_cams * 12, 256)), dim3(256), 0, c->stream, c->d, 1);
   hipLaunchKernelGGL(cam_apply_inc_h, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, 1, (const double*)c->ncw.p);
-  launch_lm(c, OpBackJoint{});
+  if (lpl_back) {
+    const Dp da = ldsacc_dp(c, true);
+    if (c->opt.robust_norm)
+      hipLaunchKernelGGL(backsub_lpl_h<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), back_lds_bytes_h(c->v2_max_slots), c->stream, da, c->part.p);
+    else
+      hipLaunchKernelGGL(backsub_lpl_h<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), back_lds_bytes_h(c->v2_max_slots), c->stream, da, c->part.p);
+  } else {
+    ensure_legacy(c);
+    launch_lm(c, OpBackJoint{});
+  }
   hipLaunchKernelGGL(cam_apply_inc_h, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, 2, (const double*)c->ncw.p);
-  launch_reduce<1>(c, c->scal.p);
+  if (lpl_back)
+    hipLaunchKernelGGL((reduce_partials<1>), dim3(1), dim3(1024), 0, c->stream, c->part.p, c->e0c_grid, c->scal.p);
+  else
+    launch_reduce<1>(c, c->scal.p);
   HIP_TRY(hipGetLastError());
   if (int rc = allreduce(c, c->scal.p, 1)) return rc;
   double h = 0;

@@ -115,7 +115,7 @@ struct OpLinearizeH {
     const double sw = sqrt(w);
     if (!isfinite(r2) || !isfinite(sw) || !isfinite(h.D02) || !isfinite(h.D12)) atomicOr(&d.flags[0], 1);
     d.sw[slot] = sw;
-    if (d.robust && d.v2.w) d.v2.w[d.v2.of_slot[slot]] = w;
+    if (d.robust && d.v2.w && !d.lin_aux_only) d.v2.w[d.v2.of_slot[slot]] = w;
     d.rres[slot] = make_double4(sw * h.r0, sw * h.r1, 0, 0);
     double jl[8];
     hom_jl4(P, h, sw, make_double4(1, 1, 1, 1), jl);
@@ -124,6 +124,7 @@ struct OpLinearizeH {
   }
   __device__ void phase2(const Dp&, int, int, int, double2, Local&, const double*, double*) const {}
   __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
+    if (d.lin_aux_only) return;  // only the per-slot arrays are wanted (ensure_legacy, povar_hip.hip)
     d.jl_scale4[lm] = make_double4(1.0 / (d.eps + sqrt(tot[0])), 1.0 / (d.eps + sqrt(tot[1])),
                                    1.0 / (d.eps + sqrt(tot[2])), 1.0 / (d.eps + sqrt(tot[3])));
   }
@@ -463,11 +464,17 @@ __global__ __launch_bounds__(256) void cm_gram_h(Dp d, int gather) {
 #pragma unroll
   for (int k = 0; k < 40; ++k) acc[k] = 0;
   for (int p = b + lane; p < e; p += WAVE) {
-    const double sw = d.robust ? d.sw[d.cm_slot[p]] : 1.0;
+    double sw = 1.0;
+    if (d.robust && !gather) sw = d.sw[d.cm_slot[p]];
     const double4 X = gather ? d.lms_lin4[d.cm_lm[p]]
                              : make_double4(d.cm_h[p], d.cm_h[d.n_obs + p], d.cm_h[2 * d.n_obs + p], d.cm_h[3 * d.n_obs + p]);
     const double2 uv = d.cm_uv[p];
     const Hom h = hom_project(P, X, uv.x, uv.y);
+    if (d.robust && gather) {  // the per-slot sqrt(w) is not kept in the lane-per-landmark mode: recompute it
+      double e_, w_;
+      error_weight(d, h.r0 * h.r0 + h.r1 * h.r1, e_, w_);
+      sw = sqrt(w_);
+    }
     const double w = sw * sw;
     const double m[4] = {w * h.D00 * h.D00, w * h.D00 * h.D02, w * h.D00 * h.D12, w * (h.D02 * h.D02 + h.D12 * h.D12)};
     const double hh[10] = {X.x * X.x, X.x * X.y, X.x * X.z, X.x * X.w, X.y * X.y,
@@ -1124,6 +1131,273 @@ __global__ __launch_bounds__(256) void cam_nt_project(Dp d, double* y12, double*
 }
 
 
+
+// K2' / K3' + K5' on the lane-per-landmark layout (the step-2 twins of lpl_pass, povar_kernels.hpp):
+//   MODE 0  linearize_landmark_projective_space_homogeneous + scale_Jl_cols_homogeneous (landmark_block.hpp:180-225,
+//           298-309) at (cams_lin4, lms_lin4): robust weight per observation (V2::w), the four Jl column scales per
+//           landmark, finiteness flag; the per-slot arrays of the lane-per-observation kernels follow lazily.
+//   MODE 1  compute_error_projective_space_homogeneous (helper.cpp:157-196) at (cams4, lms4): the six sums of OpErrorH
+//           per workgroup into part[6 * blockIdx.x ..].
+template <int MODE>
+__global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
+  extern __shared__ double2 hot[];  // [n_hot][PASS_REC] records (P_c row-major), then the tile counter
+  __shared__ double sh[6 * (E0C_BLOCK / 64)];
+  const V2& v = d.v2;
+  const double4* cams = MODE == 0 ? d.cams_lin4 : d.cams4;
+  const double4* lms = MODE == 0 ? d.lms_lin4 : d.lms4;
+  const int cam0 = v.wg_cam_off[blockIdx.x];
+  const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * PASS_REC);
+  if (threadIdx.x == 0) *grab_ctr = 0;
+  for (int i = threadIdx.x; i < n_hot * PASS_REC; i += E0C_BLOCK) {
+    const int r = i / PASS_REC, j = i - r * PASS_REC;
+    hot[i] = reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[v.wg_cams[cam0 + r]])[j];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int t_begin = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
+  const int t_end = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
+  auto grab = [&]() -> int {
+    int n = 0;
+    if (lane == 0) n = __hip_atomic_fetch_add(grab_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const long long t = (long long)t_begin + n;
+    return t < t_end ? (int)t : t_end;
+  };
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  const cint_p tiles = (cint_p)(uintptr_t)v.tile;
+  int c_t = grab(), q1 = c_t < t_end ? grab() : t_end, q2 = q1 < t_end ? grab() : t_end;
+  int pc_t = c_t, pc_ahead = 0, pc_j = 0, pc_row0 = 0, pc_k = 1;
+  if (pc_t < t_end) { pc_row0 = tiles[4 * pc_t]; pc_k = tiles[4 * pc_t + 1]; }
+  auto issue = [&](LplRow& r) {
+    if (pc_t < t_end) {
+      const size_t i = ((size_t)pc_row0 + pc_j) * WAVE + lane;
+      r.uv = v.uv[i];
+      r.cw = v.cw[i];
+      if (++pc_j == pc_k) {
+        pc_j = 0;
+        ++pc_ahead;
+        pc_t = pc_ahead == 1 ? q1 : pc_ahead == 2 ? q2 : t_end;
+        if (pc_t < t_end) { pc_row0 = tiles[4 * pc_t]; pc_k = tiles[4 * pc_t + 1]; }
+      }
+    }
+  };
+  LplRow n1, n2, n3;
+  n1.cw = n2.cw = n3.cw = -1;
+  n1.w = n2.w = n3.w = 1.0;
+  n1.uv = n2.uv = n3.uv = make_double2(0, 0);
+  issue(n1);
+  issue(n2);
+  issue(n3);
+  double sc[6] = {0, 0, 0, 0, 0, 0};
+  int bad = 0;
+  while (c_t < t_end) {
+    const int c_row0 = tiles[4 * c_t], c_k = tiles[4 * c_t + 1], c_fl = tiles[4 * c_t + 3];
+    const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
+    const double4 X = lms[lm >= 0 ? lm : 0];
+    double red[4] = {0, 0, 0, 0};
+    for (int j = 0; j < c_k; ++j) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PASS_REC
+                                      : reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[-2 - cur.cw]);
+      const double2 b0 = hp[0], b1 = hp[1], b2 = hp[2], b3 = hp[3], b4 = hp[4], b5 = hp[5];
+      const Cam P = {make_double4(b0.x, b0.y, b1.x, b1.y), make_double4(b2.x, b2.y, b3.x, b3.y),
+                     make_double4(b4.x, b4.y, b5.x, b5.y)};
+      const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
+      const double r2 = h.r0 * h.r0 + h.r1 * h.r1;
+      double e, w;
+      error_weight(d, r2, e, w);
+      if (MODE == 0) {
+        const double sw = sqrt(w);
+        bad |= !isfinite(r2) || !isfinite(sw) || !isfinite(h.D02) || !isfinite(h.D12);
+        if (d.robust && v.w) v.w[((size_t)c_row0 + j) * WAVE + lane] = w;
+        double jl[8];
+        hom_jl4(P, h, sw, make_double4(1, 1, 1, 1), jl);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) red[m] += jl[m] * jl[m] + jl[4 + m] * jl[4 + m];
+      } else {
+        bad |= !isfinite(r2);
+        sc[0] += e; sc[1] += sqrt(r2); sc[2] += 1.0;
+        if (h.valid) { sc[3] += e; sc[4] += sqrt(r2); sc[5] += 1.0; }
+      }
+    }
+    if (MODE == 0) {
+      const int sg = v.seg[(size_t)c_t * WAVE + lane];
+      if (c_fl & 1) seg_reduce_steps<4>(red, lane, sg & 255, (sg >> 8) & 255, 4);
+      if (lm >= 0 && lane == (sg & 255))
+        d.jl_scale4[lm] = make_double4(1.0 / (d.eps + sqrt(red[0])), 1.0 / (d.eps + sqrt(red[1])),
+                                       1.0 / (d.eps + sqrt(red[2])), 1.0 / (d.eps + sqrt(red[3])));
+    }
+    c_t = q1;
+    q1 = q2;
+    q2 = q1 < t_end ? grab() : t_end;
+    --pc_ahead;
+  }
+  if (bad) atomicOr(&d.flags[0], 1);
+  if (MODE == 1) {
+    block_sum<6, E0C_BLOCK>(sc, sh);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) part[6 * (size_t)blockIdx.x + k] = sc[k];
+    }
+  }
+}
+
+__host__ __device__ inline size_t back_lds_bytes_h(int n_hot) { return (size_t)n_hot * HOT_REC_H * sizeof(double2) + 16; }
+
+// K12' on the lane-per-landmark layout: back_substitute_joint (landmark_block.hpp:574-623) -- OpBackJoint's arithmetic
+// on e0_lpl_h's records (z = sigma * N_c inc, left in the record image by cam_apply_inc_h, and P of the linearisation
+// point).  First pass: H = Jl3^T Jl3 and Jl3^T (r + Jp inc); the lane solves for the damped increment and lifts it with
+// the landmark's tangent basis; second pass: the model cost change, summed per workgroup into part[blockIdx.x].
+template <bool ROBUST>
+__global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl_h(Dp d, double* part) {
+  extern __shared__ double2 hot[];  // [n_hot][HOT_REC_H] records, then the tile counter
+  __shared__ double sh[E0C_BLOCK / 64];
+  const V2& v = d.v2;
+  const int cam0 = v.wg_cam_off[blockIdx.x];
+  const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * HOT_REC_H);
+  if (threadIdx.x == 0) *grab_ctr = 0;
+  const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
+  for (int i = threadIdx.x; i < n_hot * HOT_REC_H; i += E0C_BLOCK)
+    hot[i] = rec_img[(size_t)v.wg_cams[cam0 + i / HOT_REC_H] * (HOT_REC_STRIDE / 2) + i % HOT_REC_H];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int t_begin = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
+  const int t_end = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
+  auto grab = [&]() -> int {
+    int n = 0;
+    if (lane == 0) n = __hip_atomic_fetch_add(grab_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const long long t = (long long)t_begin + n;
+    return t < t_end ? (int)t : t_end;
+  };
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  const cint_p tiles = (cint_p)(uintptr_t)v.tile;
+  auto tile_info = [&](int t, int& row0, int& k, int& nh, int& fl) {
+    row0 = tiles[4 * t];
+    k = tiles[4 * t + 1];
+    nh = tiles[4 * t + 2];
+    fl = tiles[4 * t + 3];
+  };
+  LplCursor pc;
+  pc.t = grab();
+  pc.pass = 0;
+  pc.j = 0;
+  pc.row0 = 0;
+  pc.k = 1;
+  int c_t = pc.t, c_row0 = 0, c_k = 0, c_nh = 0, c_fl = 0, nx_t = t_end;
+  if (c_t < t_end) {
+    tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+    pc.row0 = c_row0;
+    pc.k = c_k;
+    nx_t = grab();
+  }
+  auto issue = [&](LplRow& r) {
+    if (pc.t < t_end) {
+      const size_t i = ((size_t)pc.row0 + (pc.pass ? pc.k - 1 - pc.j : pc.j)) * WAVE + lane;
+      r.uv = v.uv[i];
+      r.cw = v.cw[i];
+      if (ROBUST) r.w = v.w[i];
+      if (++pc.j == pc.k) {
+        pc.j = 0;
+        if (++pc.pass == 2) {
+          pc.pass = 0;
+          pc.t = nx_t;
+          if (pc.t < t_end) {
+            int nh_, fl_;
+            tile_info(pc.t, pc.row0, pc.k, nh_, fl_);
+          }
+        }
+      }
+    }
+  };
+  // an observation's tile at the linearisation point and Jp * inc (z part of the record)
+  auto obs = [&](const LplRow& cur, const double4& X, const double4& s4, const double (&hw)[4], double hbeta, Hom& h,
+                 double (&jl4)[8], double (&jl3)[6], double& sw, double (&jpi)[2]) {
+    const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * HOT_REC_H
+                                    : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
+    const double2 a0 = hp[0], a1 = hp[1], a2 = hp[2], a3 = hp[3], a4 = hp[4], a5 = hp[5];
+    const double2 b0 = hp[6], b1 = hp[7], b2 = hp[8], b3 = hp[9], b4 = hp[10], b5 = hp[11];
+    const double4 zz[3] = {make_double4(a0.x, a0.y, a1.x, a1.y), make_double4(a2.x, a2.y, a3.x, a3.y),
+                           make_double4(a4.x, a4.y, a5.x, a5.y)};
+    const Cam P = {make_double4(b0.x, b0.y, b1.x, b1.y), make_double4(b2.x, b2.y, b3.x, b3.y),
+                   make_double4(b4.x, b4.y, b5.x, b5.y)};
+    sw = ROBUST ? sqrt(cur.w) : 1.0;
+    h = hom_project(P, X, cur.uv.x, cur.uv.y);
+    hom_jl4(P, h, sw, s4, jl4);
+    jl3_of_jl4(jl4, hw, hbeta, jl3);
+    hom_jp_x(h, X, sw, zz, jpi);
+  };
+  LplRow n1, n2, n3;
+  n1.cw = n2.cw = n3.cw = -1;
+  n1.w = n2.w = n3.w = 1.0;
+  n1.uv = n2.uv = n3.uv = make_double2(0, 0);
+  issue(n1);
+  issue(n2);
+  issue(n3);
+  double sc = 0;
+  while (c_t < t_end) {
+    const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
+    const int sg = v.seg[(size_t)c_t * WAVE + lane];
+    const double4 X = d.lms_lin4[lm >= 0 ? lm : 0], s4 = d.jl_scale4[lm >= 0 ? lm : 0];
+    double hw[4], hbeta;
+    house4(X, hw, hbeta);
+    double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < c_k; ++j) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      Hom h;
+      double jl4[8], jl3[6], sw, jpi[2];
+      obs(cur, X, s4, hw, hbeta, h, jl4, jl3, sw, jpi);
+      acc_h6(red, jl3);
+      const double a0 = sw * h.r0 + jpi[0], a1 = sw * h.r1 + jpi[1];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) red[6 + m] += jl3[m] * a0 + jl3[3 + m] * a1;
+    }
+    if (c_fl & 1) seg_reduce_steps<9>(red, lane, sg & 255, (sg >> 8) & 255, 4);
+    double dp[4] = {0, 0, 0, 0};
+    if (lm >= 0) {
+      OpBackJoint::delta4(d, X, red, dp);
+      if (lane == (sg & 255)) {
+        double4 Xc = d.lms4[lm];
+        Xc.x += dp[0] * s4.x; Xc.y += dp[1] * s4.y; Xc.z += dp[2] * s4.z; Xc.w += dp[3] * s4.w;
+        d.lms4[lm] = Xc;
+      }
+    }
+    for (int jj = 0; jj < c_k; ++jj) {
+      const LplRow cur = n1;
+      n1 = n2;
+      n2 = n3;
+      issue(n3);
+      if (cur.cw == -1) continue;
+      Hom h;
+      double jl4[8], jl3[6], sw, jpi[2];
+      obs(cur, X, s4, hw, hbeta, h, jl4, jl3, sw, jpi);
+      const double rr[2] = {sw * h.r0, sw * h.r1};
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double ji = jpi[r] + (jl4[4 * r] * dp[0] + jl4[4 * r + 1] * dp[1] + jl4[4 * r + 2] * dp[2] + jl4[4 * r + 3] * dp[3]);
+        sc -= ji * (0.5 * ji + rr[r]);
+      }
+    }
+    c_t = nx_t;
+    if (c_t < t_end) {
+      tile_info(c_t, c_row0, c_k, c_nh, c_fl);
+      nx_t = grab();
+    }
+  }
+  double sv[1] = {sc};
+  block_sum<1, E0C_BLOCK>(sv, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = sv[0];
+}
 
 // cam_cold_sum fused with cam_binv_axpy_h (mode 2) for the unsharded LDSACC term loop of step 2
 // (the step-2 twin of cam_cold_sum_binv): per-camera sum of the E0 row, tangent projection, B^-1 (11x11),
