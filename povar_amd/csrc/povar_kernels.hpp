@@ -55,9 +55,9 @@ constexpr int META_HOT_SHIFT = 18;     // 10 bits
 constexpr int META_HOT_MASK = 1023;
 constexpr int META_STEPS_SHIFT = 28;   // 3 bits: ceil(log2(longest landmark of the bin)), same in every lane of a bin
 #ifndef POVAR_HOT_ACC_MAX
-#define POVAR_HOT_ACC_MAX 552
+#define POVAR_HOT_ACC_MAX 520
 #endif
-constexpr int HOT_ACC_MAX = POVAR_HOT_ACC_MAX;    // camera slots of a workgroup's LDS: step 2 552 * (192 + 96) B + 48 hub replicas * 96 B
+constexpr int HOT_ACC_MAX = POVAR_HOT_ACC_MAX;    // camera slots of a workgroup's LDS: step 2 520 * (208 + 96) B + 48 hub replicas * 96 B
                                     // + 16 B = 163 600 of the 163 840 bytes; step 1 (176-byte records) 154 768
 constexpr int HOT_MAX = 912;        // cameras cached per workgroup: 912 * 176 B = 156.75 KiB of the 160 KiB LDS
 constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :3] (4.5) + pad
@@ -1494,6 +1494,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
 // cam_sum_items (214 + 109 + 6 us on venice-1778) for the LDSACC mode.
 // ------------------------------------------------------------------------------------------
 constexpr int PREP_REC = 6;  // double2 per camera record: P[:, :3] row-major (9), then the translation column (3)
+// LDS strides of the records are odd numbers of 16-byte quads: slot -> bank-quad class is then a bijection mod 16, the
+// relation the row placement of the layout assumes (an even stride leaves 8, 4 or 2 classes: built-in conflicts)
+constexpr int PREP_STRIDE = PREP_REC | 1;
 
 struct PrepObs {
   double jl[12], r[4];
@@ -1523,7 +1526,7 @@ __device__ inline void prep_read_rec(const double2* h, double* P) {
   }
 }
 __host__ __device__ inline size_t prep_lds_bytes(int n_hot) {
-  return (size_t)n_hot * PREP_REC * sizeof(double2) + (size_t)(n_hot + 3 * lpl_hubs(n_hot)) * 96 + 16;
+  return (size_t)n_hot * PREP_STRIDE * sizeof(double2) + (size_t)(n_hot + 3 * lpl_hubs(n_hot)) * 96 + 16;
 }
 
 template <bool ROBUST>
@@ -1533,14 +1536,14 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
   const int hubs = v.hubs, n_slots = n_hot + 3 * hubs;
-  double* acc = reinterpret_cast<double*>(hot + n_hot * PREP_REC);
+  double* acc = reinterpret_cast<double*>(hot + n_hot * PREP_STRIDE);
   int* grab_ctr = reinterpret_cast<int*>(acc + n_slots * 12);
   for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
   if (threadIdx.x == 0) *grab_ctr = 0;
   const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
   for (int i = threadIdx.x; i < n_hot * PREP_REC; i += E0C_BLOCK) {
     const int r = i / PREP_REC, j = i - r * PREP_REC;
-    hot[i] = rec_img[(size_t)v.wg_cams[cam0 + r] * (HOT_REC_STRIDE / 2) + 6 + j];  // entries 12..23 of the image
+    hot[r * PREP_STRIDE + j] = rec_img[(size_t)v.wg_cams[cam0 + r] * (HOT_REC_STRIDE / 2) + 6 + j];  // entries 12..23 of the image
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -1614,7 +1617,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
       issue(n3);
       if (cur.cw == -1) continue;
       double P[12];
-      if (cur.cw >= 0) prep_read_rec(hot + lpl_cw_slot(cur.cw) * PREP_REC, P);
+      if (cur.cw >= 0) prep_read_rec(hot + lpl_cw_slot(cur.cw) * PREP_STRIDE, P);
       else prep_read_rec(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
       PrepObs o;
       o.set(d, P, cur.uv, ROBUST ? cur.w : 1.0, hx, hy, hz, s4.x, s4.y, s4.z);
@@ -1666,7 +1669,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
       issue(n3);
       if (cur.cw == -1) continue;
       double P[12];
-      if (cur.cw >= 0) prep_read_rec(hot + lpl_cw_slot(cur.cw) * PREP_REC, P);
+      if (cur.cw >= 0) prep_read_rec(hot + lpl_cw_slot(cur.cw) * PREP_STRIDE, P);
       else prep_read_rec(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
       PrepObs o;
       const double w = ROBUST ? cur.w : 1.0;
@@ -1718,7 +1721,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
 // Replaces lm_regular<OpBackVarproj> (204 us on venice-1778) for the LDSACC mode.
 // ------------------------------------------------------------------------------------------
 constexpr int BACK_REC = 18;  // double2 per camera record: P_new (12), inc (12), P_lin (12)
-__host__ __device__ inline size_t back_lds_bytes(int n_hot) { return (size_t)n_hot * BACK_REC * sizeof(double2) + 16; }
+constexpr int BACK_STRIDE = BACK_REC | 1;
+__host__ __device__ inline size_t back_lds_bytes(int n_hot) { return (size_t)n_hot * BACK_STRIDE * sizeof(double2) + 16; }
 
 template <bool ROBUST>
 __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
@@ -1727,7 +1731,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
   const V2& v = d.v2;
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
-  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * BACK_REC);
+  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * BACK_STRIDE);
   if (threadIdx.x == 0) *grab_ctr = 0;
   // record piece j of a camera: 0-5 cams4, 6-11 inc, 12-17 cams_lin4 (each 12 doubles)
   auto piece = [&](int cam, int j) -> double2 {
@@ -1736,7 +1740,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
   };
   for (int i = threadIdx.x; i < n_hot * BACK_REC; i += E0C_BLOCK) {
     const int r = i / BACK_REC, j = i - r * BACK_REC;
-    hot[i] = piece(d.hot_cams[v.wg_cams[cam0 + r]], j);
+    hot[r * BACK_STRIDE + j] = piece(d.hot_cams[v.wg_cams[cam0 + r]], j);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -1797,7 +1801,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
     o[2] = make_double4(b4.x, b4.y, b5.x, b5.y);
   };
   auto rec_part = [&](int cw, int which) -> const double2* {  // which: 0 P_new, 1 inc, 2 P_lin
-    if (cw >= 0) return hot + lpl_cw_slot(cw) * BACK_REC + 6 * which;
+    if (cw >= 0) return hot + lpl_cw_slot(cw) * BACK_STRIDE + 6 * which;
     const int cam = d.hot_cams[-2 - cw];
     const double* src = which == 0 ? reinterpret_cast<const double*>(d.cams4)
                                    : which == 1 ? d.inc : reinterpret_cast<const double*>(d.cams_lin4);
@@ -1895,7 +1899,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
 //           workgroup into part[3 * blockIdx.x ..].
 // ------------------------------------------------------------------------------------------
 constexpr int PASS_REC = 6;  // double2 per camera record: P row-major
-__host__ __device__ inline size_t pass_lds_bytes(int n_hot) { return (size_t)n_hot * PASS_REC * sizeof(double2) + 16; }
+constexpr int PASS_STRIDE = PASS_REC | 1;
+__host__ __device__ inline size_t pass_lds_bytes(int n_hot) { return (size_t)n_hot * PASS_STRIDE * sizeof(double2) + 16; }
 
 template <int MODE>
 __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
@@ -1906,11 +1911,11 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
   const double4* lms = MODE == 0 ? d.lms_lin4 : d.lms4;
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
-  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * PASS_REC);
+  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * PASS_STRIDE);
   if (threadIdx.x == 0) *grab_ctr = 0;
   for (int i = threadIdx.x; i < n_hot * PASS_REC; i += E0C_BLOCK) {
     const int r = i / PASS_REC, j = i - r * PASS_REC;
-    hot[i] = reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[v.wg_cams[cam0 + r]])[j];
+    hot[r * PASS_STRIDE + j] = reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[v.wg_cams[cam0 + r]])[j];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -1963,7 +1968,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
       n2 = n3;
       issue(n3);
       if (cur.cw == -1) continue;
-      const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PASS_REC
+      const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PASS_STRIDE
                                       : reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[-2 - cur.cw]);
       const double2 b0 = hp[0], b1 = hp[1], b2 = hp[2], b3 = hp[3], b4 = hp[4], b5 = hp[5];
       const Cam P = {make_double4(b0.x, b0.y, b1.x, b1.y), make_double4(b2.x, b2.y, b3.x, b3.y),

@@ -682,8 +682,16 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy_h(Dp d, int mode, 
 // full P_c), the landmark lane carries X, the Jl column scale and Hll^-1 (the column scale cannot be folded into
 // Hll^-1 here: the tangent basis N_l sits between them).
 constexpr int LPL_REC_H = 14;  // doubles per landmark lane in V2::lmrec (step 2)
+// LDS stride of a camera record in the lane-per-landmark kernels of step 2, in double2: the record has 12 (192 B), but
+// a 12-quad stride puts every record on one of FOUR bank-quad classes (12 s mod 16) -- four-way ds_read_b128 conflicts
+// whatever the placement does; 13 gives the slot -> class bijection of step 1 (11 s mod 16), which the row placement of
+// the layout (lpl_layout.hpp) is built for
+#ifndef POVAR_LPL_CAMREC_H
+#define POVAR_LPL_CAMREC_H 13
+#endif
+constexpr int LPL_CAMREC_H = POVAR_LPL_CAMREC_H;
 __host__ __device__ inline size_t lpl_lds_bytes_h(int n_hot) {
-  return (size_t)n_hot * 12 * sizeof(double2) + (size_t)(n_hot + 3 * lpl_hubs(n_hot)) * 96 + 16;
+  return (size_t)n_hot * LPL_CAMREC_H * sizeof(double2) + (size_t)(n_hot + 3 * lpl_hubs(n_hot)) * 96 + 16;
 }
 template <bool ROBUST>
 __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
@@ -694,7 +702,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
   const int hubs = v.hubs, n_slots = n_hot + 3 * hubs;
-  double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC_H);
+  double* acc = reinterpret_cast<double*>(hot + n_hot * LPL_CAMREC_H);
   int* grab_ctr = reinterpret_cast<int*>(acc + n_slots * 12);
   for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
   if (threadIdx.x == 0) *grab_ctr = 0;
@@ -718,7 +726,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
 #pragma unroll
     for (int u = 0; u < PASSES; ++u) {
       const int i = threadIdx.x + u * E0C_BLOCK;
-      if (i < n_hot * HOT_REC_H) hot[i] = piece[u];
+      if (i < n_hot * HOT_REC_H) hot[(i / HOT_REC_H) * LPL_CAMREC_H + i % HOT_REC_H] = piece[u];
     }
   }
   __syncthreads();
@@ -824,7 +832,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
       n2 = n3;
       issue(n3);
       if (j >= c_nh && cur.cw == -1) continue;
-      const double2* hp = (j < c_nh || cur.cw >= 0) ? hot + lpl_cw_slot(cur.cw) * HOT_REC_H
+      const double2* hp = (j < c_nh || cur.cw >= 0) ? hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H
                                                      : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
       Cam P;
       double4 zz[3];
@@ -861,7 +869,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
       const bool resident = j < c_nh || cur.cw >= 0;
       int cold_at = 0;
       if (!resident) cold_at = v.cpos[base + (size_t)j * WAVE];
-      const double2* hp = resident ? hot + lpl_cw_slot(cur.cw) * HOT_REC_H
+      const double2* hp = resident ? hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H
                                    : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
       Cam P;
       read_cam(hp, P);
@@ -941,14 +949,14 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
   const int hubs = v.hubs, n_slots = n_hot + 3 * hubs;
-  double* acc = reinterpret_cast<double*>(hot + n_hot * PREP_REC);
+  double* acc = reinterpret_cast<double*>(hot + n_hot * PREP_STRIDE);
   int* grab_ctr = reinterpret_cast<int*>(acc + n_slots * 12);
   for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
   if (threadIdx.x == 0) *grab_ctr = 0;
   const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
   for (int i = threadIdx.x; i < n_hot * PREP_REC; i += E0C_BLOCK) {
     const int r = i / PREP_REC, j = i - r * PREP_REC;
-    hot[i] = rec_img[(size_t)v.wg_cams[cam0 + r] * (HOT_REC_STRIDE / 2) + 6 + j];  // entries 12..23 of the image
+    hot[r * PREP_STRIDE + j] = rec_img[(size_t)v.wg_cams[cam0 + r] * (HOT_REC_STRIDE / 2) + 6 + j];  // entries 12..23 of the image
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -1028,7 +1036,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
       issue(n3);
       if (cur.cw == -1) continue;
       Cam P;
-      read_cam(cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PREP_REC : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
+      read_cam(cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PREP_STRIDE : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
       const double sw = ROBUST ? sqrt(cur.w) : 1.0;
       const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
       double jl4[8], jl3[6];
@@ -1071,7 +1079,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
       issue(n3);
       if (cur.cw == -1) continue;
       Cam P;
-      read_cam(cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PREP_REC : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
+      read_cam(cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PREP_STRIDE : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
       const double sw = ROBUST ? sqrt(cur.w) : 1.0;
       const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
       double jl4[8], jl3[6];
@@ -1147,11 +1155,11 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
   const double4* lms = MODE == 0 ? d.lms_lin4 : d.lms4;
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
-  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * PASS_REC);
+  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * PASS_STRIDE);
   if (threadIdx.x == 0) *grab_ctr = 0;
   for (int i = threadIdx.x; i < n_hot * PASS_REC; i += E0C_BLOCK) {
     const int r = i / PASS_REC, j = i - r * PASS_REC;
-    hot[i] = reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[v.wg_cams[cam0 + r]])[j];
+    hot[r * PASS_STRIDE + j] = reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[v.wg_cams[cam0 + r]])[j];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -1202,7 +1210,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
       n2 = n3;
       issue(n3);
       if (cur.cw == -1) continue;
-      const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PASS_REC
+      const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PASS_STRIDE
                                       : reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[-2 - cur.cw]);
       const double2 b0 = hp[0], b1 = hp[1], b2 = hp[2], b3 = hp[3], b4 = hp[4], b5 = hp[5];
       const Cam P = {make_double4(b0.x, b0.y, b1.x, b1.y), make_double4(b2.x, b2.y, b3.x, b3.y),
@@ -1247,7 +1255,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
   }
 }
 
-__host__ __device__ inline size_t back_lds_bytes_h(int n_hot) { return (size_t)n_hot * HOT_REC_H * sizeof(double2) + 16; }
+__host__ __device__ inline size_t back_lds_bytes_h(int n_hot) { return (size_t)n_hot * LPL_CAMREC_H * sizeof(double2) + 16; }
 
 // K12' on the lane-per-landmark layout: back_substitute_joint (landmark_block.hpp:574-623) -- OpBackJoint's arithmetic
 // on e0_lpl_h's records (z = sigma * N_c inc, left in the record image by cam_apply_inc_h, and P of the linearisation
@@ -1260,11 +1268,12 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl_h(Dp d, double* part) {
   const V2& v = d.v2;
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
-  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * HOT_REC_H);
+  int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * LPL_CAMREC_H);
   if (threadIdx.x == 0) *grab_ctr = 0;
   const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
   for (int i = threadIdx.x; i < n_hot * HOT_REC_H; i += E0C_BLOCK)
-    hot[i] = rec_img[(size_t)v.wg_cams[cam0 + i / HOT_REC_H] * (HOT_REC_STRIDE / 2) + i % HOT_REC_H];
+    hot[(i / HOT_REC_H) * LPL_CAMREC_H + i % HOT_REC_H] =
+        rec_img[(size_t)v.wg_cams[cam0 + i / HOT_REC_H] * (HOT_REC_STRIDE / 2) + i % HOT_REC_H];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int t_begin = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
@@ -1319,7 +1328,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl_h(Dp d, double* part) {
   // an observation's tile at the linearisation point and Jp * inc (z part of the record)
   auto obs = [&](const LplRow& cur, const double4& X, const double4& s4, const double (&hw)[4], double hbeta, Hom& h,
                  double (&jl4)[8], double (&jl3)[6], double& sw, double (&jpi)[2]) {
-    const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * HOT_REC_H
+    const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H
                                     : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
     const double2 a0 = hp[0], a1 = hp[1], a2 = hp[2], a3 = hp[3], a4 = hp[4], a5 = hp[5];
     const double2 b0 = hp[6], b1 = hp[7], b2 = hp[8], b3 = hp[9], b4 = hp[10], b5 = hp[11];
