@@ -831,21 +831,38 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
       n1 = n2;
       n2 = n3;
       issue(n3);
-      if (j >= c_nh && cur.cw == -1) continue;
-      const double2* hp = (j < c_nh || cur.cw >= 0) ? hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H
-                                                     : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
+      // The record is read through an LDS pointer or a global pointer, never through a select of the two: a generic
+      // pointer makes every read a flat_load (texture path into the LDS, both wait counters).  Rows [0, c_nh) have an
+      // LDS-resident camera in every lane: wave-uniform branch, LDS reads only.
+      auto fwd = [&](const Cam& P, const double4 (&zz)[3]) {
+        const double sw = ROBUST ? sqrt(cur.w) : 1.0;
+        const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
+        double jl4[8], jl3[6], t[2];
+        hom_jl4(P, h, sw, s4, jl4);
+        jl3_of_jl4(jl4, hw, hbeta, jl3);
+        hom_jp_x(h, X, sw, zz, t);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) red[m] += jl3[m] * t[0] + jl3[3 + m] * t[1];
+      };
       Cam P;
       double4 zz[3];
-      read_z(hp, zz);
-      read_cam(hp, P);
-      const double sw = ROBUST ? sqrt(cur.w) : 1.0;
-      const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
-      double jl4[8], jl3[6], t[2];
-      hom_jl4(P, h, sw, s4, jl4);
-      jl3_of_jl4(jl4, hw, hbeta, jl3);
-      hom_jp_x(h, X, sw, zz, t);
-#pragma unroll
-      for (int m = 0; m < 3; ++m) red[m] += jl3[m] * t[0] + jl3[3 + m] * t[1];
+      if (j < c_nh) {
+        const double2* hp = hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H;
+        read_z(hp, zz);
+        read_cam(hp, P);
+        fwd(P, zz);
+      } else if (cur.cw != -1) {
+        if (cur.cw >= 0) {
+          const double2* hp = hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H;
+          read_z(hp, zz);
+          read_cam(hp, P);
+        } else {
+          const double2* hp = rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
+          read_z(hp, zz);
+          read_cam(hp, P);
+        }
+        fwd(P, zz);
+      }
     }
     if (c_fl & 1) {  // landmarks dealt over several lanes: sum their partial u = Jl^T t (segmented wavefront scan)
       const int sg = v.seg[(size_t)c_t * WAVE + lane];
@@ -865,31 +882,35 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
       n1 = n2;
       n2 = n3;
       issue(n3);
-      if (j >= c_nh && cur.cw == -1) continue;
-      const bool resident = j < c_nh || cur.cw >= 0;
-      int cold_at = 0;
-      if (!resident) cold_at = v.cpos[base + (size_t)j * WAVE];
-      const double2* hp = resident ? hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H
-                                   : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
-      Cam P;
-      read_cam(hp, P);
-      const double sw = ROBUST ? sqrt(cur.w) : 1.0;
-      const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
-      double jl4[8], jl3[6];
-      hom_jl4(P, h, sw, s4, jl4);
-      jl3_of_jl4(jl4, hw, hbeta, jl3);
-      const double s0 = jl3[0] * g[0] + jl3[1] * g[1] + jl3[2] * g[2];
-      const double s1 = jl3[3] * g[0] + jl3[4] * g[1] + jl3[5] * g[2];
-      const double4 q = hom_q(h, sw, s0, s1);
-      if (resident) {
+      auto bwd = [&](const Cam& P) -> double4 {
+        const double sw = ROBUST ? sqrt(cur.w) : 1.0;
+        const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
+        double jl4[8], jl3[6];
+        hom_jl4(P, h, sw, s4, jl4);
+        jl3_of_jl4(jl4, hw, hbeta, jl3);
+        const double s0 = jl3[0] * g[0] + jl3[1] * g[1] + jl3[2] * g[2];
+        const double s1 = jl3[3] * g[0] + jl3[4] * g[1] + jl3[5] * g[2];
+        return hom_q(h, sw, s0, s1);
+      };
+      auto scatter = [&](const double4& q) {
         double* a = acc + lpl_acc_slot(cur.cw, hubs);  // acc[m][slot]: consecutive slots on consecutive banks
         const double val[12] = {X.x * q.x, X.y * q.x, X.z * q.x, X.w * q.x, X.x * q.y, X.y * q.y,
                                 X.z * q.y, X.w * q.y, X.x * q.z, X.y * q.z, X.z * q.z, X.w * q.z};
 #pragma unroll
         for (int m = 0; m < 12; ++m)
           __hip_atomic_fetch_add(a + m * n_slots, val[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else {
-        d.q4c[cold_at] = q;
+      };
+      Cam P;
+      if (j < c_nh) {  // wave-uniform: LDS only
+        read_cam(hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H, P);
+        scatter(bwd(P));
+      } else if (cur.cw >= 0) {
+        read_cam(hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H, P);
+        scatter(bwd(P));
+      } else if (cur.cw < -1) {
+        const int cold_at = v.cpos[base + (size_t)j * WAVE];
+        read_cam(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2), P);
+        d.q4c[cold_at] = bwd(P);
       }
     }
     c_t = n_t;
