@@ -1800,12 +1800,17 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
     o[1] = make_double4(b2.x, b2.y, b3.x, b3.y);
     o[2] = make_double4(b4.x, b4.y, b5.x, b5.y);
   };
-  auto rec_part = [&](int cw, int which) -> const double2* {  // which: 0 P_new, 1 inc, 2 P_lin
-    if (cw >= 0) return hot + lpl_cw_slot(cw) * BACK_STRIDE + 6 * which;
-    const int cam = d.hot_cams[-2 - cw];
-    const double* src = which == 0 ? reinterpret_cast<const double*>(d.cams4)
-                                   : which == 1 ? d.inc : reinterpret_cast<const double*>(d.cams_lin4);
-    return reinterpret_cast<const double2*>(src + 12 * (size_t)cam);
+  // which: 0 P_new, 1 inc, 2 P_lin.  LDS pointer or global pointer, never a select of the two (a generic pointer turns
+  // the reads into flat_loads)
+  auto read_part = [&](int cw, int which, double4 (&o)[3]) {
+    if (cw >= 0) {
+      read12(hot + lpl_cw_slot(cw) * BACK_STRIDE + 6 * which, o);
+    } else {
+      const int cam = d.hot_cams[-2 - cw];
+      const double* src = which == 0 ? reinterpret_cast<const double*>(d.cams4)
+                                     : which == 1 ? d.inc : reinterpret_cast<const double*>(d.cams_lin4);
+      read12(reinterpret_cast<const double2*>(src + 12 * (size_t)cam), o);
+    }
   };
   LplRow n1, n2, n3;
   n1.cw = n2.cw = n3.cw = -1;
@@ -1827,7 +1832,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
       issue(n3);
       if (cur.cw == -1) continue;
       double4 pp[3];
-      read12(rec_part(cur.cw, 0), pp);
+      read_part(cur.cw, 0, pp);
       const Cam P = {pp[0], pp[1], pp[2]};
       double res[4], jl[12];
       pose_residual(d, P, h, cur.uv.x, cur.uv.y, res);
@@ -1863,8 +1868,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
       issue(n3);
       if (cur.cw == -1) continue;
       double4 zz[3], pl[3];
-      read12(rec_part(cur.cw, 1), zz);
-      read12(rec_part(cur.cw, 2), pl);
+      read_part(cur.cw, 1, zz);
+      read_part(cur.cw, 2, pl);
       const Cam Pl = {pl[0], pl[1], pl[2]};
       const double sw = ROBUST ? sqrt(cur.w) : 1.0;
       double jinc[4], jls[12], rr[4];
@@ -1968,6 +1973,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
       n2 = n3;
       issue(n3);
       if (cur.cw == -1) continue;
+      // (a select of an LDS and a global pointer: six flat_loads.  Measured against ds_read / global_load in two branches
+      // -- profiles/r02_ablations.txt item 16 --: the branches join with a wait on both counters, which drains the row
+      // prefetch every step: 50 instead of 44 us here; the two-pass kernels with their longer steps gain from the split)
       const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PASS_STRIDE
                                       : reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[-2 - cur.cw]);
       const double2 b0 = hp[0], b1 = hp[1], b2 = hp[2], b3 = hp[3], b4 = hp[4], b5 = hp[5];

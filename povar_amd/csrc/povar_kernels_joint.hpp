@@ -1057,7 +1057,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
       issue(n3);
       if (cur.cw == -1) continue;
       Cam P;
-      read_cam(cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PREP_STRIDE : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
+      // LDS pointer or global pointer, never a select of the two (a generic pointer turns the reads into flat_loads)
+      if (cur.cw >= 0) read_cam(hot + lpl_cw_slot(cur.cw) * PREP_STRIDE, P);
+      else read_cam(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
       const double sw = ROBUST ? sqrt(cur.w) : 1.0;
       const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
       double jl4[8], jl3[6];
@@ -1100,7 +1102,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
       issue(n3);
       if (cur.cw == -1) continue;
       Cam P;
-      read_cam(cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PREP_STRIDE : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
+      // LDS pointer or global pointer, never a select of the two (a generic pointer turns the reads into flat_loads)
+      if (cur.cw >= 0) read_cam(hot + lpl_cw_slot(cur.cw) * PREP_STRIDE, P);
+      else read_cam(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2) + 6, P);
       const double sw = ROBUST ? sqrt(cur.w) : 1.0;
       const Hom h = hom_project(P, X, cur.uv.x, cur.uv.y);
       double jl4[8], jl3[6];
@@ -1231,6 +1235,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
       n2 = n3;
       issue(n3);
       if (cur.cw == -1) continue;
+      // (a select of an LDS and a global pointer: six flat_loads.  Measured against ds_read / global_load in two branches
+      // -- profiles/r02_ablations.txt item 16 --: the branches join with a wait on both counters, which drains the row
+      // prefetch every step: 50 instead of 44 us here; the two-pass kernels with their longer steps gain from the split)
       const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * PASS_STRIDE
                                       : reinterpret_cast<const double2*>(cams + 3 * (size_t)d.hot_cams[-2 - cur.cw]);
       const double2 b0 = hp[0], b1 = hp[1], b2 = hp[2], b3 = hp[3], b4 = hp[4], b5 = hp[5];
@@ -1349,6 +1356,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl_h(Dp d, double* part) {
   // an observation's tile at the linearisation point and Jp * inc (z part of the record)
   auto obs = [&](const LplRow& cur, const double4& X, const double4& s4, const double (&hw)[4], double hbeta, Hom& h,
                  double (&jl4)[8], double (&jl3)[6], double& sw, double (&jpi)[2]) {
+    // (select of an LDS and a global pointer: flat_loads; the split form spills here, see lpl_pass)
     const double2* hp = cur.cw >= 0 ? hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H
                                     : rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2);
     const double2 a0 = hp[0], a1 = hp[1], a2 = hp[2], a3 = hp[3], a4 = hp[4], a5 = hp[5];
