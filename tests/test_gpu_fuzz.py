@@ -395,14 +395,14 @@ def test_api_sequence_differential(seed, monkeypatch):
                 a, b = both(lambda c: c.get_buffer(which))
                 assert rel(a, b) < 1e-12, (log, which)
         elif op == "export_prep":
-            for which, tol in ((capi.BUF_HLL_INV, 1e-9), (capi.BUF_B, 1e-10), (capi.BUF_B_INV, 1e-9), (capi.BUF_STORAGE, 1e-12)):
+            for which, tol in ((capi.BUF_HLL_INV, 1e-8), (capi.BUF_B, 1e-8), (capi.BUF_B_INV, 1e-8), (capi.BUF_STORAGE, 1e-12)):
                 a, b = both(lambda c: c.get_buffer(which))
                 assert rel(a, b) < tol, (log, which)
         elif op == "series":
             m = int(rng.integers(0, 12))
             both(lambda c: c.power_series_pose(m))
             ia, ib = both(lambda c: c.get_increment())
-            assert rel(ia, ib) < 1e-10, log
+            assert rel(ia, ib) < 1e-8, log
             inc = ib
         elif op == "e0":
             x = rng.normal(size=12 * n_c)
@@ -478,7 +478,8 @@ def test_api_sequence_differential_step2(seed, monkeypatch):
             both(lambda c: c.prepare_joint(lam))
             prepared, inc = True, None
         elif op == "export_prep":
-            for which, tol in ((capi.BUF_HLL_INV, 1e-9), (capi.BUF_B_JOINT, 1e-10), (capi.BUF_B_INV_JOINT, 1e-9),
+            # (tolerances: the two modes sum in different orders; b = Jp^T (r - Jl w) cancels, a stale array would be O(1) off)
+            for which, tol in ((capi.BUF_HLL_INV, 1e-8), (capi.BUF_B_JOINT, 1e-8), (capi.BUF_B_INV_JOINT, 1e-8),
                                (capi.BUF_JL_COL_SCALE_H, 1e-12), (capi.BUF_DIAG2, 1e-12)):
                 a, b = both(lambda c: c.get_buffer(which))
                 assert rel(a, b) < tol, (log, which)
@@ -486,7 +487,7 @@ def test_api_sequence_differential_step2(seed, monkeypatch):
             m = int(rng.integers(0, 10))
             both(lambda c: c.power_series_pose(m))
             ia, ib = both(lambda c: c.get_increment(11))
-            assert rel(ia, ib) < 1e-10, log
+            assert rel(ia, ib) < 1e-8, log
             inc = ib
         elif op == "apply":
             both(lambda c: c.backup_joint())
