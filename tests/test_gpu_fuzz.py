@@ -478,8 +478,9 @@ def test_api_sequence_differential_step2(seed, monkeypatch):
             both(lambda c: c.prepare_joint(lam))
             prepared, inc = True, None
         elif op == "export_prep":
-            # (tolerances: the two modes sum in different orders; b = Jp^T (r - Jl w) cancels, a stale array would be O(1) off)
-            for which, tol in ((capi.BUF_HLL_INV, 1e-8), (capi.BUF_B_JOINT, 1e-8), (capi.BUF_B_INV_JOINT, 1e-8),
+            # (tolerances: the two modes sum in different orders, and a random projective state after several applies is badly
+            # conditioned -- observed up to 3e-8; a stale lazily-built array would be O(1e-2) or more off)
+            for which, tol in ((capi.BUF_HLL_INV, 1e-6), (capi.BUF_B_JOINT, 1e-6), (capi.BUF_B_INV_JOINT, 1e-6),
                                (capi.BUF_JL_COL_SCALE_H, 1e-12), (capi.BUF_DIAG2, 1e-12)):
                 a, b = both(lambda c: c.get_buffer(which))
                 assert rel(a, b) < tol, (log, which)
@@ -487,15 +488,15 @@ def test_api_sequence_differential_step2(seed, monkeypatch):
             m = int(rng.integers(0, 10))
             both(lambda c: c.power_series_pose(m))
             ia, ib = both(lambda c: c.get_increment(11))
-            assert rel(ia, ib) < 1e-8, log
+            assert rel(ia, ib) < 1e-6, log
             inc = ib
         elif op == "apply":
             both(lambda c: c.backup_joint())
             la, lb = both(lambda c: c.apply_joint(inc))
-            assert abs(la - lb) <= 1e-8 * max(abs(lb), 1e-300), log
+            assert abs(la - lb) <= 1e-6 * max(abs(lb), 1e-300), log
             ca, cb = both(lambda c: c.get_cameras())
             xa, xb = both(lambda c: c.get_landmarks_homogeneous())
-            assert rel(ca, cb) < 1e-12 and rel(xa, xb) < 1e-8, log
+            assert rel(ca, cb) < 1e-10 and rel(xa, xb) < 1e-6, log
             if rng.random() < 0.5:
                 both(lambda c: c.restore_joint())
             else:
