@@ -98,17 +98,25 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
     t0 = time.perf_counter()
     orc.solve_pose(st, hll, binv, b, m1, n_threads=1)
     v1 = m1 / (time.perf_counter() - t0)
-    # the per-camera mutex makes the reference's scheme contention-bound on hub cameras: time a few
-    # thread counts on two terms and keep the fastest (the count used is reported as "cores")
-    best = (2.0 / v1, 1)
-    for nt in sorted({ncpu, max(ncpu // 4, 1), min(16, ncpu), min(4, ncpu)} - {1}, reverse=True):
-        orc.solve_pose(st, hll, binv, b, 1, n_threads=nt)
-        t0 = time.perf_counter()
-        orc.solve_pose(st, hll, binv, b, 2, n_threads=nt)
-        dt = time.perf_counter() - t0
-        if dt < best[0]:
-            best = (dt, nt)
-    cores = best[1]
+    # Thread sweep, ALWAYS reported (threads_tried): 4 / 16 / a quarter of / all hardware threads, each with one
+    # static landmark range per thread and with on-demand chunks (TBB's default auto_partitioner hands out
+    # sub-ranges dynamically, linearization_power_varproj.hpp:402-403).  The per-camera mutex (LPV:393-397) makes
+    # the scheme contention-bound on hub cameras, so the fastest count is often small; two terms per probe.
+    tried = {"1": v1 * scale}
+    best = (v1, 1, 0)
+    grain_dyn = max(64, n_l // (64 * ncpu))
+    for nt in sorted({ncpu, max(ncpu // 4, 1), min(16, ncpu), min(4, ncpu)} - {1}):
+        for grain in (0, grain_dyn):
+            O.set_e0_schedule(grain)
+            orc.solve_pose(st, hll, binv, b, 1, n_threads=nt)
+            t0 = time.perf_counter()
+            orc.solve_pose(st, hll, binv, b, 2, n_threads=nt)
+            v = 2.0 / (time.perf_counter() - t0)
+            tried[f"{nt}" + ("-dynamic" if grain else "")] = v * scale
+            if v > best[0]:
+                best = (v, nt, grain)
+    cores, grain = best[1], best[2]
+    O.set_e0_schedule(grain)
     t0 = time.perf_counter()
     reps = 0
     while True:
@@ -117,12 +125,12 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
         if time.perf_counter() - t0 > 8.0 or reps >= 20:
             break
     dt = time.perf_counter() - t0
+    O.set_e0_schedule(0)
     vN = reps * m / dt
+    cores_note = f", {'on-demand chunks of %d landmarks' % grain if grain else 'static ranges'}" if cores > 1 else ""
     if v1 > vN:  # the mutex scatter often does not scale at all on a hub-heavy graph: the best CPU figure is 1 thread
-        vN, cores_note = v1, (f" (the {cores}-thread run was slower: {reps * m / dt:.2f} terms/s)" if cores > 1 else "")
-        cores = 1
-    else:
-        cores_note = ""
+        cores_note = f" (the {cores}-thread run was slower: {reps * m / dt:.2f} terms/s)" if cores > 1 else ""
+        vN, cores = v1, 1
     what = "the full workload" if scale == 1.0 else \
         f"the first {n_l} landmarks / {n_o} observations (all cameras), scaled by {n_o}/{prob.n_obs}"
     return {
@@ -131,6 +139,8 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
         "cores": cores,
         "kind": "port",
         "value_1_thread": v1 * scale,
+        "threads_tried": {k: round(v, 3) for k, v in tried.items()},
+        "value_all_cores": max(tried.get(str(ncpu), 0.0), tried.get(f"{ncpu}-dynamic", 0.0)),
         "host_cpus": ncpu,
         "cpu_model": cpu_model(),
         "sample": f"{what}: {reps} x solve_pOSE of {m} terms with {cores} threads in {dt:.1f} s; "
@@ -291,9 +301,10 @@ def main():
     # Per-term exchange of a sharded run: the peer-to-peer push/reduce kernels (no library call inside the captured
     # term loop) unless --no-p2p; they are validated against the communicator's all-reduce below before they are
     # trusted, and every failure (IPC attach, a peer that never delivers, a differing increment) falls back to it.
-    want_p2p = comm_used != "none" and not args.no_p2p and args.step == 1 and args.e0_mode == "ldsacc" and \
-        (args.p2p or world > 1)
-    p2p_attached, p2p_note = False, ""
+    # Opt-in (--p2p): its publication order over xGMI has only ever run with both ranks on ONE device, so the
+    # driver's multi-GPU run stays on RCCL, the exchange BASELINE.json names.
+    want_p2p = comm_used != "none" and not args.no_p2p and args.step == 1 and args.e0_mode == "ldsacc" and args.p2p
+    p2p_attached, p2p_note, inc_allreduce = False, "", None
     if want_p2p:
         def all_ok(flag):
             if dist is None:
@@ -372,6 +383,7 @@ def main():
             if os.environ.get("POVAR_BENCH_P2P_FAIL") and rank == world - 1:
                 rel = float("inf")  # test hook: one rank reports a mismatch, every rank must fall back
             good = all_ok(np.isfinite(rel) and rel <= 1e-10)
+            inc_allreduce = incs[1]
             ctx.p2p_enable(good)
             if good:
                 term_exchange = f"p2p push + local reduce (validated against the all-reduce, rel. diff {rel:.1e})"
@@ -386,12 +398,26 @@ def main():
         for _ in range(k):
             ctx.power_series_pose(m, 0.0, -1.0)
 
-    run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed():
+        run_steps(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        return time.perf_counter() - t0
+
+    dt = timed()
+    if term_exchange.startswith("p2p"):
+        # the solve is deterministic: the increment the timed loop ended with must still be the validated one; a
+        # stale slab anywhere sends every rank back to the all-reduce and the timing is taken again
+        inc_now = ctx.get_increment()
+        rel2 = float(np.linalg.norm(inc_now - inc_allreduce) / max(np.linalg.norm(inc_allreduce), 1e-300))
+        if not all_ok(np.isfinite(rel2) and rel2 <= 1e-10):
+            ctx.p2p_enable(False)
+            term_exchange = f"all-reduce (peer-to-peer exchange dropped after the timed loop: increment off by {rel2:.1e})"
+            if rank == 0:
+                print(f"[bench] {term_exchange}", file=sys.stderr)
+            dt = timed()
     # per-kernel durations: the same K steps again with HIP events recorded on the library's stream
     # around every E0 / B^-1 / all-reduce launch (event mode launches kernel by kernel instead of
     # replaying the captured hipGraph, so it is kept out of the headline timing)
@@ -429,7 +455,12 @@ def main():
         try:
             with open(tpath) as fh:
                 tj = json.load(fh)
-            key = f"{args.problem}:{args.e0_mode}:{world}"
+            # the figure belongs to ONE kernel pair on ONE graph: every knob that changes the kernels or the bytes is in
+            # the key (defaults -- step 1, NONE, zipf1, synthetic -- add nothing)
+            key = f"{args.problem}:{args.e0_mode}:{world}" + (":step2" if args.step == 2 else "") + \
+                (f":{args.robust_norm}" if args.robust_norm != "NONE" else "") + \
+                (f":{args.popularity}" if args.popularity != "zipf1" else "") + \
+                (f":ltf{args.long_track_frac:g}" if args.long_track_frac > 0 else "") + (":file" if bal_path else "")
             if key in tj:
                 if tj.get("_source_sha", {}).get(key) == kernel_source_sha():
                     traffic, traffic_note = tj[key], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/"

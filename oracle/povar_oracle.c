@@ -466,14 +466,32 @@ typedef struct {
   double* y;
   int l0, l1;
   pthread_mutex_t* locks;
+  int* next;  /* dynamic schedule: shared chunk cursor (NULL = this job's static range [l0, l1)) */
+  int grain;
 } e0_job;
 
 static void* e0_worker(void* arg) {
   e0_job* j = (e0_job*)arg;
+  if (j->next) {
+    /* tbb::parallel_for's default auto_partitioner hands out sub-ranges on demand (work stealing): restated as
+     * chunks of `grain` landmarks taken from one shared cursor */
+    for (;;) {
+      const int l0 = __atomic_fetch_add(j->next, j->grain, __ATOMIC_RELAXED);
+      if (l0 >= j->p->n_lms) break;
+      const int l1 = l0 + j->grain < j->p->n_lms ? l0 + j->grain : j->p->n_lms;
+      for (int l = l0; l < l1; ++l) e0_landmark_pose(j->p, j->storage, j->hll_inv, j->x, j->y, l, j->locks);
+    }
+    return NULL;
+  }
   for (int l = j->l0; l < j->l1; ++l)
     e0_landmark_pose(j->p, j->storage, j->hll_inv, j->x, j->y, l, j->locks);
   return NULL;
 }
+
+/* 0: contiguous landmark ranges balanced by observation count, one per thread (tbb static_partitioner analogue);
+ * g > 0: chunks of g landmarks on demand (auto_partitioner analogue, LPV:402-403 uses TBB's default). */
+static int g_e0_grain = 0;
+void orc_set_e0_schedule(int32_t grain) { g_e0_grain = grain > 0 ? grain : 0; }
 
 /* persistent worker pool (the reference runs on TBB's pool: thread creation is not part of its
  * per-term cost).  Workers park on a barrier pair; one pool per thread count, never torn down. */
@@ -541,12 +559,14 @@ void orc_right_mul_e0_pose_mt(const orc_problem* p, const double* storage, const
     n_locks = p->n_cams;
   }
   int l = 0;
+  static int cursor;
+  cursor = 0;
   for (int t = 0; t < n_threads; ++t) {
     const int64_t target = p->n_obs * (int64_t)(t + 1) / n_threads;
     int l1 = l;
     while (l1 < p->n_lms && p->lm_off[l1 + 1] <= target) ++l1;
     if (t == n_threads - 1) l1 = p->n_lms;
-    pool->jobs[t] = (e0_job){p, storage, hll_inv, x, y, l, l1, locks};
+    pool->jobs[t] = (e0_job){p, storage, hll_inv, x, y, l, l1, locks, g_e0_grain > 0 ? &cursor : NULL, g_e0_grain};
     l = l1;
   }
   pthread_barrier_wait(&pool->start);

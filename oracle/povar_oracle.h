@@ -96,7 +96,10 @@ void orc_prepare_hb_pose(const orc_problem* p, const double* storage, double lam
 void orc_right_mul_b_inv(int32_t n_cams, int32_t dim, const double* b_inv, const double* x, double* y);
 void orc_right_mul_e0_pose(const orc_problem* p, const double* storage, const double* hll_inv,
                            const double* x, double* y);
-/* reference-faithful threaded variant: contiguous landmark ranges per thread, per-camera mutex */
+/* reference-faithful threaded variant: tbb::parallel_for over landmarks (LPV:402-403) + per-camera mutex.
+ * orc_set_e0_schedule(0): one contiguous landmark range per thread, balanced by observations (static partitioner);
+ * orc_set_e0_schedule(g > 0): chunks of g landmarks taken on demand (TBB's default auto_partitioner analogue). */
+void orc_set_e0_schedule(int32_t grain);
 void orc_right_mul_e0_pose_mt(const orc_problem* p, const double* storage, const double* hll_inv,
                               const double* x, double* y, int32_t n_threads);
 int orc_solve_pose(const orc_problem* p, const double* storage, const double* hll_inv,

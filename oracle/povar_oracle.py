@@ -58,6 +58,12 @@ def _p(a):
     return C.c_void_p(a.ctypes.data)
 
 
+def set_e0_schedule(grain: int) -> None:
+    """Threaded E0 (orc_right_mul_e0_pose_mt): 0 = one static landmark range per thread, g > 0 = chunks of g
+    landmarks on demand (TBB auto_partitioner analogue, linearization_power_varproj.hpp:402-403)."""
+    lib().orc_set_e0_schedule(C.c_int32(grain))
+
+
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 

@@ -1810,6 +1810,18 @@ int povar_p2p_attach(povar_ctx* c, int32_t world, int32_t rank, const uint8_t* h
   if (int rc = check_ctx(c)) return rc;
   if (world < 1 || rank < 0 || rank >= world || !handles || !c->xbuf) return fail(-1, "bad p2p arguments (export first)");
   if ((size_t)2 * world * c->n_cams * 16 != c->xbuf_count) return fail(-1, "p2p world size differs from the exported buffer");
+  // the once-per-solve exchanges (G, b, scalars) stay on the communicator: the push/reduce kernels only replace the
+  // per-term all-reduce of an already sharded context
+  if (!(c->comm || c->host_fn) || c->world != world || c->rank != rank)
+    return fail(-1, "povar_p2p_attach needs the communicator of the same world/rank attached first (povar_comm_init)");
+  // re-attach: drop the mappings, the pointer table and the captured term loop of the previous attachment
+  for (size_t p = 0; p < c->peer_host.size(); ++p)
+    if (c->peer_host[p] && c->peer_host[p] != c->xbuf) (void)hipIpcCloseMemHandle(c->peer_host[p]);
+  c->peer_host.clear();
+  c->peer_dev.release();
+  c->p2p_epoch.release();
+  if (c->series_graph) { (void)hipGraphExecDestroy(c->series_graph); c->series_graph = nullptr; }
+  c->p2p = false;
   c->peer_host.assign(world, nullptr);
   for (int p = 0; p < world; ++p) {
     if (p == rank) { c->peer_host[p] = c->xbuf; continue; }

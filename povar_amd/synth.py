@@ -99,8 +99,13 @@ def _sample_cameras(rng, n_cams, lm_off, zipf_s=1.0):
     return cam[order].astype(np.int32)
 
 
-def make_problem(n_cams, n_lms, n_obs, seed=0, noise_px=0.5, popularity="zipf1", long_track_frac=0.0) -> Problem:
+def make_problem(n_cams, n_lms, n_obs, seed=0, noise_px=0.5, popularity="zipf1", long_track_frac=0.0,
+                 init="random", init_noise=0.0) -> Problem:
     """popularity: camera popularity law of the graph ("zipf1" = SURVEY 8(d), "zipf0.5", "uniform").
+    init: "random" = the reference's --create-dataset cameras (rows 0-1 ~ N(0,1), row 2 = [0 0 0 1]); "gt" = the
+    ground-truth projection matrices K[R|t], each divided by its mean depth (the pOSE affine term wants P_2 X ~ 1)
+    and perturbed entrywise by a relative N(0, init_noise^2) -- a start inside the basin of both steps, used by the
+    known-answer tests at BASELINE sizes (a converged run must end on the chi-square floor of `noise_px`).
     long_track_frac: fraction of the observations moved onto landmarks of 65..min(n_cams, 400) observations
     (real photo collections have such tracks; the SURVEY 8(d) degree law caps them at 49 for venice)."""
     rng = np.random.default_rng(seed)
@@ -148,14 +153,25 @@ def make_problem(n_cams, n_lms, n_obs, seed=0, noise_px=0.5, popularity="zipf1",
     cams[:, 11] = 1.0
     cams = np.round(cams, 6)
     lms = np.round(rng.normal(size=(n_lms, 3)), 6)
+    if init == "gt":
+        K = np.zeros((n_cams, 3, 3))
+        K[:, 0, 0] = K[:, 1, 1] = f
+        K[:, 2, 2] = 1.0
+        P = np.einsum("cij,cjk->cik", K, np.concatenate([R, t[:, :, None]], axis=2))
+        depth = np.bincount(cam_idx, weights=pc[:, 2], minlength=n_cams) / np.maximum(np.bincount(cam_idx, minlength=n_cams), 1)
+        P /= np.where(depth > 0, depth, 1.0)[:, None, None]
+        P *= 1.0 + init_noise * np.random.default_rng(seed + 77).normal(size=P.shape)
+        cams = np.round(P.reshape(n_cams, 12), 6)
+    elif init != "random":
+        raise ValueError(init)
     return Problem(n_cams, n_lms, lm_off.astype(np.int32), cam_idx, np.ascontiguousarray(uv), cams, lms)
 
 
-def make_bal_problem(name: str, popularity="zipf1", long_track_frac=0.0) -> Problem:
+def make_bal_problem(name: str, popularity="zipf1", long_track_frac=0.0, **kw) -> Problem:
     """Seeded synthetic problem with the exact shape of a BAL problem (BASELINE.json configs).  The defaults are the
     SURVEY 8(d) workload; the other popularity laws / a long-track tail are sensitivity variants of the same shape."""
     n_c, n_l, n_o = BAL_SHAPES[name]
-    return make_problem(n_c, n_l, n_o, seed=BAL_SEEDS[name], popularity=popularity, long_track_frac=long_track_frac)
+    return make_problem(n_c, n_l, n_o, seed=BAL_SEEDS[name], popularity=popularity, long_track_frac=long_track_frac, **kw)
 
 
 def write_data_custom(path: str, prob: Problem) -> None:

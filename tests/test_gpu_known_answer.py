@@ -26,7 +26,7 @@ def test_bal_hip_reaches_noise_floor(tmp_path, monkeypatch, shape, seed, flags, 
 
 
 def test_bal_hip_truncation_stall_and_cure(tmp_path):
-    """Same statement as test_default_alpha_stall_is_truncation_not_algebra, on the HIP path."""
+    """Same statement as test_random_start_stall_is_the_route_not_the_algebra, on the HIP path."""
     p, f = write_problem(tmp_path, (10, 300, 1300), 21)
     common = ["--solver-type-step-2", "RIPOBA", "--max-num-iterations-step-1", "100", "--max-num-iterations-step-2", "300", "--quiet"]
     short = run_bal("bin/bal", f, str(tmp_path / "a.json"), ["--solver-type-step-1", "POWER_VARPROJ", "--power-sc-iterations", "20"] + common)
