@@ -23,6 +23,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <queue>
 #include <thread>
 #include <vector>
@@ -46,26 +48,69 @@ struct LplLayout {
   int n_part_rec = 0, max_slots = 0, n_global = 0, n_tail = 0, grid_a = 1, grid_b = 1;
 };
 
+// fn(item) for item in [0, n_items) on up to n_threads host threads (items taken on demand; the caller's thread works too)
+template <class F>
+inline void lpl_parallel(int n_items, int n_threads, F&& fn) {
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n_items) break;
+      fn(i);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < std::min(n_threads, n_items); ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+}
+
 // Minimum-cost assignment of h items to h positions (Hungarian algorithm, O(h^3); h is the number of resident
 // observations of one landmark: 2..8 for almost all of them).  assign[item] = position.
 inline void lpl_assign(int h, const std::vector<long>& cost, std::vector<int>& assign) {
+  assign.resize(h);
+  if (h == 1) { assign[0] = 0; return; }
+  if (h == 2) {  // the two permutations (ties: identity, as the general algorithm below resolves them)
+    const bool swap = cost[1] + cost[2] < cost[0] + cost[3];
+    assign[0] = swap ? 1 : 0;
+    assign[1] = swap ? 0 : 1;
+    return;
+  }
   const long INF = 1L << 60;
-  std::vector<long> u(h + 1, 0), v(h + 1, 0), minv(h + 1);
-  std::vector<int> p(h + 1, 0), way(h + 1, 0);
-  std::vector<char> used(h + 1);
+  // no heap traffic on the hot path (a million landmarks, several calls each): h <= 64 always (tile height <= 48,
+  // a landmark dealt over lanes is only re-ordered up to 64 observations)
+  constexpr int HMAX = 65;
+  long u_s[HMAX], v_s[HMAX], minv_s[HMAX];
+  int p_s[HMAX], way_s[HMAX];
+  char used_s[HMAX];
+  std::vector<long> heap_l;
+  std::vector<int> heap_i;
+  std::vector<char> heap_c;
+  long *u = u_s, *v = v_s, *minv = minv_s;
+  int *p = p_s, *way = way_s;
+  char* used = used_s;
+  if (h + 1 > HMAX) {
+    heap_l.assign(3 * (size_t)(h + 1), 0);
+    heap_i.assign(2 * (size_t)(h + 1), 0);
+    heap_c.assign(h + 1, 0);
+    u = heap_l.data(); v = u + h + 1; minv = v + h + 1;
+    p = heap_i.data(); way = p + h + 1;
+    used = heap_c.data();
+  }
+  for (int j = 0; j <= h; ++j) { u[j] = 0; v[j] = 0; p[j] = 0; way[j] = 0; }
   for (int i = 1; i <= h; ++i) {
     p[0] = i;
     int j0 = 0;
-    std::fill(minv.begin(), minv.end(), INF);
-    std::fill(used.begin(), used.end(), 0);
+    for (int j = 0; j <= h; ++j) { minv[j] = INF; used[j] = 0; }
     do {
       used[j0] = 1;
       const int i0 = p[j0];
       long delta = INF;
       int j1 = 0;
+      const long* crow = cost.data() + (size_t)(i0 - 1) * h - 1;
       for (int j = 1; j <= h; ++j)
         if (!used[j]) {
-          const long cur = cost[(size_t)(i0 - 1) * h + (j - 1)] - u[i0] - v[j];
+          const long cur = crow[j] - u[i0] - v[j];
           if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
           if (minv[j] < delta) { delta = minv[j]; j1 = j; }
         }
@@ -80,7 +125,6 @@ inline void lpl_assign(int h, const std::vector<long>& cost, std::vector<int>& a
       j0 = j1;
     } while (j0);
   }
-  assign.assign(h, 0);
   for (int j = 1; j <= h; ++j) assign[p[j] - 1] = j - 1;
 }
 
@@ -93,6 +137,18 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   // to give every wavefront a tile the cap sets the latency of the launch (ladybug-49: 2 rows 106 k, 8 rows 76 k
   // terms/s).
   grid = std::max(grid, 1);
+  // every phase below is cut into independent pieces (landmark chunks, workgroups); the result does not depend on the
+  // thread count
+  int n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 128u);
+  if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
+  const bool timing = std::getenv("POVAR_LAYOUT_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[build_lpl] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   // The cap follows the row steps a wavefront gets (observations / 64 lanes / 16 wavefronts per workgroup): a tile
   // longer than a wavefront's fair share is the tail of the launch, shorter ones cost lanes (landmark records,
   // segment sums) and leave the row placement fewer rows to dodge bank collisions with (venice-1778: 8 rows 13.8k,
@@ -106,10 +162,25 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     if (grid % b == 0) B = b;
   const int A = grid / B;
   std::vector<int64_t> S(n_cams + 1, 0);  // prefix sums of the observation counts in popularity order
+  const int64_t n_obs_all = lm_off[n_lms];
+  // landmark chunks of about equal observation counts: the unit of the parallel passes over the observations
+  const int n_chunks = std::max(1, std::min(4 * n_threads, n_lms / 256 + 1));
+  std::vector<int> chunk_lm(n_chunks + 1, n_lms);
+  chunk_lm[0] = 0;
+  for (int q = 1; q < n_chunks; ++q)
+    chunk_lm[q] = (int)(std::upper_bound(lm_off, lm_off + n_lms + 1, (int32_t)(n_obs_all * q / n_chunks)) - lm_off) - 1;
+  for (int q = 1; q <= n_chunks; ++q) chunk_lm[q] = std::max(chunk_lm[q], chunk_lm[q - 1]);
   {
-    std::vector<int64_t> cnt(n_cams, 0);
-    for (int64_t i = 0; i < lm_off[n_lms]; ++i) cnt[rank1[cam_idx[i]] - 1]++;
-    for (int r = 0; r < n_cams; ++r) S[r + 1] = S[r] + cnt[r];
+    std::vector<std::vector<int64_t>> cnt_q(n_chunks);
+    lpl_parallel(n_chunks, n_threads, [&](int q) {
+      cnt_q[q].assign(n_cams, 0);
+      for (int64_t i = lm_off[chunk_lm[q]]; i < lm_off[chunk_lm[q + 1]]; ++i) cnt_q[q][rank1[cam_idx[i]] - 1]++;
+    });
+    for (int r = 0; r < n_cams; ++r) {
+      int64_t c = 0;
+      for (int q = 0; q < n_chunks; ++q) c += cnt_q[q][r];
+      S[r + 1] = S[r] + c;
+    }
   }
   int G = std::min(n_cams, n_acc), Tn = 0;
   if (n_cams > n_acc && std::getenv("POVAR_LPL_NOGRID") == nullptr) {
@@ -132,31 +203,46 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   L.n_tail = Tn;
   L.grid_a = A;
   L.grid_b = B;
+  // grid coordinates of every camera by rank (-1: not a grid camera)
+  std::vector<int16_t> tx(n_cams, -1), ty(n_cams, -1);
+  for (int t = 0; t < Tn; ++t) {
+    tx[G + t] = (int16_t)(t % A);
+    ty[G + t] = (int16_t)((t / A) % B);
+  }
   auto tail_xy = [&](int r0, int& x, int& y) {  // r0: 0-based rank; false if not a grid camera
-    const int t = r0 - G;
-    if (t < 0 || t >= Tn) return false;
-    x = t % A;
-    y = (t / A) % B;
-    return true;
+    x = tx[r0];
+    y = ty[r0];
+    return x >= 0;
   };
   auto resident = [&](int w, int r0) {
     if (r0 < G) return true;
-    int x, y;
-    if (!tail_xy(r0, x, y)) return false;
-    return x == w % A || y == w / A;
+    return tx[r0] >= 0 && (tx[r0] == w % A || ty[r0] == w / A);
   };
+  lap("grid choice");
   // ---- landmark -> workgroup
   std::vector<int> wg_of(n_lms, -1);
   std::vector<int64_t> load(grid, 0);
   {
     std::vector<int> n_tail_of(n_lms, 0), order;
-    for (int l = 0; l < n_lms; ++l) {
-      if (lm_off[l + 1] == lm_off[l]) continue;
-      int x, y;
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) n_tail_of[l] += tail_xy(rank1[cam_idx[i]] - 1, x, y);
-      order.push_back(l);
+    lpl_parallel(n_chunks, n_threads, [&](int q) {
+      for (int l = chunk_lm[q]; l < chunk_lm[q + 1]; ++l) {
+        int n = 0;
+        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) n += tx[rank1[cam_idx[i]] - 1] >= 0;
+        n_tail_of[l] = n;
+      }
+    });
+    {
+      // most grid observations first, landmark order inside a count (a stable counting sort)
+      int mx = 0;
+      for (int l = 0; l < n_lms; ++l) mx = std::max(mx, n_tail_of[l]);
+      std::vector<int> first(mx + 2, 0);
+      for (int l = 0; l < n_lms; ++l)
+        if (lm_off[l + 1] > lm_off[l]) first[mx - n_tail_of[l] + 1]++;
+      for (int v = 0; v <= mx; ++v) first[v + 1] += first[v];
+      order.resize(first[mx + 1]);
+      for (int l = 0; l < n_lms; ++l)
+        if (lm_off[l + 1] > lm_off[l]) order[first[mx - n_tail_of[l]]++] = l;
     }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_tail_of[a] > n_tail_of[b]; });
     std::vector<int> xs, ys;
     size_t pos = 0;
     for (; pos < order.size() && n_tail_of[order[pos]] > 0; ++pos) {
@@ -188,9 +274,16 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     // landmarks without tail observations fill the workgroups up, longest first into the least loaded
     std::priority_queue<std::pair<int64_t, int>, std::vector<std::pair<int64_t, int>>, std::greater<>> heap;
     for (int w = 0; w < grid; ++w) heap.push({load[w], w});
-    std::vector<int> rest(order.begin() + pos, order.end());
-    std::stable_sort(rest.begin(), rest.end(),
-                     [&](int a, int b) { return lm_off[a + 1] - lm_off[a] > lm_off[b + 1] - lm_off[b]; });
+    std::vector<int> rest(order.size() - pos);
+    {
+      // longest first, landmark order inside a length (stable counting sort)
+      int mx = 0;
+      for (size_t n = pos; n < order.size(); ++n) mx = std::max(mx, (int)(lm_off[order[n] + 1] - lm_off[order[n]]));
+      std::vector<int> first(mx + 2, 0);
+      for (size_t n = pos; n < order.size(); ++n) first[mx - (lm_off[order[n] + 1] - lm_off[order[n]]) + 1]++;
+      for (int v = 0; v <= mx; ++v) first[v + 1] += first[v];
+      for (size_t n = pos; n < order.size(); ++n) rest[first[mx - (lm_off[order[n] + 1] - lm_off[order[n]])]++] = order[n];
+    }
     for (int l : rest) {
       auto [ld, w] = heap.top();
       heap.pop();
@@ -199,27 +292,45 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       heap.push({load[w], w});
     }
   }
+  lap("landmark -> workgroup");
   // ---- cold view: observations whose camera is not resident in their landmark's workgroup, camera-major
   const int64_t n_obs = lm_off[n_lms];
   std::vector<int> cold_pos_of_obs(n_obs, -1);
   {
-    std::vector<int> ccnt(n_cams + 1, 0);
-    for (int l = 0; l < n_lms; ++l)
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
-        if (!resident(wg_of[l], rank1[cam_idx[i]] - 1)) ccnt[cam_idx[i] + 1]++;
-    for (int c = 0; c < n_cams; ++c) ccnt[c + 1] += ccnt[c];
+    // per (chunk, camera) counts -> every chunk fills its own sub-run of a camera's run: the order inside a camera is
+    // the landmark order, whatever the thread count
+    std::vector<std::vector<int>> cq(n_chunks);
+    lpl_parallel(n_chunks, n_threads, [&](int q) {
+      std::vector<int>& c = cq[q];
+      c.assign(n_cams, 0);
+      for (int l = chunk_lm[q]; l < chunk_lm[q + 1]; ++l)
+        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
+          if (!resident(wg_of[l], rank1[cam_idx[i]] - 1)) c[cam_idx[i]]++;
+    });
     L.cold_range.resize(n_cams);
-    for (int c = 0; c < n_cams; ++c) L.cold_range[c] = make_int2(ccnt[c], ccnt[c + 1]);
-    L.cold_lm.resize(ccnt[n_cams]);
-    std::vector<int> fill(ccnt.begin(), ccnt.end() - 1);
-    for (int l = 0; l < n_lms; ++l)
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
-        if (!resident(wg_of[l], rank1[cam_idx[i]] - 1)) {
-          const int p = fill[cam_idx[i]]++;
-          cold_pos_of_obs[i] = p;
-          L.cold_lm[p] = l;
-        }
+    int run = 0;
+    for (int c = 0; c < n_cams; ++c) {
+      const int first = run;
+      for (int q = 0; q < n_chunks; ++q) {
+        const int n = cq[q][c];
+        cq[q][c] = run;  // where chunk q starts inside camera c's run
+        run += n;
+      }
+      L.cold_range[c] = make_int2(first, run);
+    }
+    L.cold_lm.resize(run);
+    lpl_parallel(n_chunks, n_threads, [&](int q) {
+      std::vector<int>& fill = cq[q];
+      for (int l = chunk_lm[q]; l < chunk_lm[q + 1]; ++l)
+        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
+          if (!resident(wg_of[l], rank1[cam_idx[i]] - 1)) {
+            const int p = fill[cam_idx[i]]++;
+            cold_pos_of_obs[i] = p;
+            L.cold_lm[p] = l;
+          }
+    });
   }
+  lap("cold view");
   // ---- per workgroup: camera slots (global cameras in rank order, then the tail cameras its landmarks use), tiles
   std::vector<std::vector<int>> lms_of(grid);
   for (int l = 0; l < n_lms; ++l)
@@ -232,24 +343,25 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   std::vector<int> parts_of(n_lms, 0), psize_of(n_lms, 0), cold_of(n_lms, 0);
   std::vector<std::vector<int>> order_of(grid);
   {
-    std::vector<char> mark(n_cams, 0);
-    for (int w = 0; w < grid; ++w) {
-      const int slot0 = (int)L.wg_cams.size();
+    // every workgroup on its own (parallel): slots, lane order, tiles with workgroup-local tile numbers ...
+    struct WgOut {
+      std::vector<int> cams, seg, lm_of;
+      std::vector<int4> tile;
+    };
+    std::vector<WgOut> out(grid);
+    lpl_parallel(grid, n_threads, [&](int w) {
+      WgOut& o = out[w];
       // slots: the replicated hub cameras always (fixed slots 0..hubs-1), then only the resident cameras this
       // workgroup's landmarks actually observe, in rank order (a small shard touches far fewer than G + its grid
       // cameras: fewer records to stage, fewer partial records to flush and to sum)
       const int hubs_w = lpl_hubs(G);
-      std::vector<int> used;
+      std::vector<long> wcnt(n_cams, 0);  // this workgroup's observations per camera (by rank)
       for (int l : lms_of[w])
-        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) {
-          const int r0 = rank1[cam_idx[i]] - 1;
-          if (r0 >= hubs_w && !mark[r0] && resident(w, r0)) {
-            mark[r0] = 1;
-            used.push_back(r0);
-          }
-        }
-      std::sort(used.begin(), used.end());
-      for (int r0 = 0; r0 < hubs_w; ++r0) L.wg_cams.push_back(r0);
+        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) wcnt[rank1[cam_idx[i]] - 1]++;
+      std::vector<int> used;
+      for (int r0 = hubs_w; r0 < n_cams; ++r0)
+        if (wcnt[r0] > 0 && resident(w, r0)) used.push_back(r0);
+      for (int r0 = 0; r0 < hubs_w; ++r0) o.cams.push_back(r0);
       // Which slot a camera gets decides its LDS bank (accumulators: (slot + 3 hubs) mod 32, records: slot mod 16).
       // In rank order the popular cameras pile up on the low banks and force collisions no row placement can avoid
       // (a bank hit by more observations than the tile has rows must repeat inside a row).  So the cameras are dealt
@@ -257,9 +369,6 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       // workgroup's observations per camera; the hubs' four replicas are pre-loaded with a quarter each).
       {
         const int n_rest = (int)used.size(), n_w_ = hubs_w + n_rest;
-        std::vector<long> wcnt(n_cams, 0);
-        for (int l : lms_of[w])
-          for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) wcnt[rank1[cam_idx[i]] - 1]++;
         std::vector<double> load(32, 0.0);
         for (int r0 = 0; r0 < hubs_w; ++r0)
           for (int q = 0; q < 4; ++q) load[(4 * r0 + q) & 31] += 0.25 * (double)wcnt[r0];
@@ -277,13 +386,8 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
           cam_of_slot[sl] = r0;
           load[best] += (double)wcnt[r0];
         }
-        for (int sl = hubs_w; sl < n_w_; ++sl) L.wg_cams.push_back(cam_of_slot[sl]);
-        for (int r0 : used) mark[r0] = 0;
+        for (int sl = hubs_w; sl < n_w_; ++sl) o.cams.push_back(cam_of_slot[sl]);
       }
-      const int n_w = (int)L.wg_cams.size() - slot0;
-      L.max_slots = std::max(L.max_slots, n_w);
-      for (int s = 0; s < n_w; ++s) holders[L.wg_cams[slot0 + s]].push_back(w);
-      L.wg_cam_off[w + 1] = (int)L.wg_cams.size();
       // tiles: lanes sorted by (rows per lane, cold rows per lane), longest first
       std::vector<int>& order = order_of[w];
       for (int l : lms_of[w]) {
@@ -298,44 +402,63 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         return psize_of[a] != psize_of[b] ? psize_of[a] > psize_of[b] : cold_of[a] > cold_of[b];
       });
-      const int tile0 = (int)L.tile.size();
-      int tile = tile0, fill = 0;
+      int tile = 0, fill = 0;
       for (int l : order) {
         if (fill + parts_of[l] > WAVE) { ++tile; fill = 0; }
-        L.lm_pos[l] = (tile * WAVE + fill) | ((parts_of[l] - 1) << 26);
+        L.lm_pos[l] = (tile * WAVE + fill) | ((parts_of[l] - 1) << 26);  // local tile number: rebased below
         fill += parts_of[l];
       }
-      const int n_tiles_w = order.empty() ? 0 : tile - tile0 + 1;
-      L.tile.resize(tile0 + n_tiles_w, make_int4(0, 0, 1 << 30, 0));
-      L.seg.resize((size_t)(tile0 + n_tiles_w) * WAVE);
-      L.lm_of.resize((size_t)(tile0 + n_tiles_w) * WAVE, -1);
-      for (size_t i = (size_t)tile0 * WAVE; i < L.seg.size(); ++i) L.seg[i] = (int)(i & 63) | ((int)(i & 63) << 8);
+      const int n_tiles_w = order.empty() ? 0 : tile + 1;
+      o.tile.assign(n_tiles_w, make_int4(0, 0, 1 << 30, 0));
+      o.seg.resize((size_t)n_tiles_w * WAVE);
+      o.lm_of.assign((size_t)n_tiles_w * WAVE, -1);
+      for (size_t i = 0; i < o.seg.size(); ++i) o.seg[i] = (int)(i & 63) | ((int)(i & 63) << 8);
       std::vector<int> lanes_used(n_tiles_w, 0);
       for (int l : order) {
         const int pos = L.lm_pos[l] & ((1 << 26) - 1), t = pos >> 6, lane0 = pos & 63, P = parts_of[l];
         int hot = 0;
         for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) hot += cold_pos_of_obs[i] < 0;
-        int4& ti = L.tile[t];
+        int4& ti = o.tile[t];
         ti.y = std::max(ti.y, psize_of[l]);
         ti.z = std::min(ti.z, hot / P);  // leading rows in which every lane of the landmark has a resident camera
         if (P > 1) ti.w |= 1;
         for (int q = 0; q < P; ++q) {
-          L.seg[(size_t)t * WAVE + lane0 + q] = lane0 | ((lane0 + P - 1) << 8);
-          L.lm_of[(size_t)t * WAVE + lane0 + q] = l;
+          o.seg[(size_t)t * WAVE + lane0 + q] = lane0 | ((lane0 + P - 1) << 8);
+          o.lm_of[(size_t)t * WAVE + lane0 + q] = l;
         }
-        lanes_used[t - tile0] += P;
+        lanes_used[t] += P;
       }
-      for (int t = tile0; t < tile0 + n_tiles_w; ++t) {
-        if (lanes_used[t - tile0] < WAVE) L.tile[t].z = 0;  // unused lanes: no branch-free rows
+      for (int t = 0; t < n_tiles_w; ++t) {
+        if (lanes_used[t] < WAVE) o.tile[t].z = 0;  // unused lanes: no branch-free rows
         // at least two rows = four row steps per tile: the prefetch cursor (three rows ahead) then never needs a
         // tile beyond the one the consumer has already taken
-        L.tile[t].y = std::max(L.tile[t].y, 2);
-        L.tile[t].x = (int)L.rows;
-        L.rows += L.tile[t].y;
+        o.tile[t].y = std::max(o.tile[t].y, 2);
       }
+    });
+    // ... then the workgroups one after the other: global slot / tile / row numbers
+    std::vector<int> tile0_of(grid, 0);
+    for (int w = 0; w < grid; ++w) {
+      const WgOut& o = out[w];
+      const int slot0 = (int)L.wg_cams.size(), n_w = (int)o.cams.size();
+      L.wg_cams.insert(L.wg_cams.end(), o.cams.begin(), o.cams.end());
+      L.max_slots = std::max(L.max_slots, n_w);
+      for (int s = 0; s < n_w; ++s) holders[L.wg_cams[slot0 + s]].push_back(w);
+      L.wg_cam_off[w + 1] = (int)L.wg_cams.size();
+      tile0_of[w] = (int)L.tile.size();
+      for (int4 ti : o.tile) {
+        ti.x = (int)L.rows;
+        L.rows += ti.y;
+        L.tile.push_back(ti);
+      }
+      L.seg.insert(L.seg.end(), o.seg.begin(), o.seg.end());
+      L.lm_of.insert(L.lm_of.end(), o.lm_of.begin(), o.lm_of.end());
       L.wg_tile_off[w + 1] = (int)L.tile.size();
     }
+    lpl_parallel(grid, n_threads, [&](int w) {
+      for (int l : lms_of[w]) L.lm_pos[l] += tile0_of[w] * WAVE;
+    });
   }
+  lap("slots and tiles");
   L.uv.assign((size_t)L.rows * WAVE, make_double2(0, 0));
   L.cw.assign((size_t)L.rows * WAVE, -1);
   L.cpos.assign((size_t)L.rows * WAVE, -1);
@@ -354,18 +477,15 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     return g + 2 * (lane >> 5);
   };
   const int hubs = lpl_hubs(G);
-  int n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-  if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
   const bool no_place = std::getenv("POVAR_LPL_NOPLACE") != nullptr;  // measurement knob: natural order
-  std::atomic<int> next_wg{0};
-  auto worker = [&]() {
+  int max_tiles_tried = 1 << 30;
+  if (const char* e = std::getenv("POVAR_LPL_TILES_TRIED")) max_tiles_tried = std::max(1, std::atoi(e));
+  auto place_wg = [&](int w) {
     std::vector<int> slot_of_rank(n_cams, -1);
     std::vector<int> hot_idx, cold_idx, assign, assign2;
     std::vector<char> rep_tmp;
     std::vector<long> cost;
-    for (;;) {
-      const int w = next_wg.fetch_add(1);
-      if (w >= grid) break;
+    {
       const int slot0 = L.wg_cam_off[w], n_w = L.wg_cam_off[w + 1] - slot0;
       for (int s = 0; s < n_w; ++s) slot_of_rank[L.wg_cams[slot0 + s]] = s;
       const std::vector<int>& order = order_of[w];
@@ -510,7 +630,10 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
           for (size_t o = a; o < b; ++o) {
             long best = -1;
             int best_t = -1, best_lane = -1;
-            for (int t = ta; t <= tb && best != 0; ++t) {
+            int tiles_tried = 0;
+            for (int t = ta; t <= tb && best != 0 && tiles_tried < max_tiles_tried; ++t) {
+              if (!free_mask[t - ta]) continue;
+              ++tiles_tried;
               unsigned seen = 0;
               for (unsigned long long m = free_mask[t - ta]; m && best != 0; m &= m - 1) {
                 const int lane = __builtin_ctzll(m), cls = (lane >> 5) * 2 + (read_group(lane) & 1);
@@ -565,15 +688,10 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
           }
         }
       }
-      for (int s = 0; s < n_w; ++s) slot_of_rank[L.wg_cams[slot0 + s]] = -1;
     }
   };
-  {
-    std::vector<std::thread> pool;
-    for (int i = 1; i < n_threads; ++i) pool.emplace_back(worker);
-    worker();
-    for (auto& th : pool) th.join();
-  }
+  lpl_parallel(grid, n_threads, place_wg);
+  lap("row placement (threads)");
   // ---- partial records, camera-major: camera c's slots in the workgroups that hold it form one contiguous run, so
   // the per-camera kernel streams them.  (Workgroup-major records -- one contiguous 53 KB flush per workgroup, the
   // per-camera kernel gathering through an index list -- were measured too: the flush is bound by the 13.5 MB it
@@ -594,6 +712,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     for (int w = 0; w < grid; ++w)
       for (int s = L.wg_cam_off[w]; s < L.wg_cam_off[w + 1]; ++s) L.wg_slot_rec[s] = next[L.wg_cams[s]]++;
   }
+  lap("partial records");
 }
 
 }  // namespace povar
