@@ -74,6 +74,32 @@ def cpu_model():
     return "unknown"
 
 
+def effective_cpus():
+    """CPUs this process may use: hardware threads cut by the cgroup CPU quota (the GPU boxes show 256 hardware
+    threads under a 16-CPU quota: more than 16 busy threads are throttled, not faster)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                q = int(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                period = int(fh.read())
+            if q > 0 and period > 0:
+                n = min(n, max(1, -(-q // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
     """Oracle (reference-faithful [4k x 16] storage + loop nest of linearization_power_varproj.hpp:364-406,
     per-camera mutex scatter) on the FULL workload: terms/s at 1 thread and at the fastest thread count.
@@ -91,14 +117,14 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
     st, diag2, jls, sigma, ok = orc.stage1_pose(alpha, prob.cams, lms)
     orc.scale_jp_cols_pose(st, sigma)
     hll, b, binv = orc.prepare_hb_pose(st, lam)
-    ncpu = os.cpu_count() or 1
+    ncpu = effective_cpus()  # "all cores" = what the cgroup lets this process use, not the hardware threads it can see
     # 1 thread: a few terms are enough (the term cost is constant)
     orc.solve_pose(st, hll, binv, b, 1, n_threads=1)
     m1 = max(1, min(m, int(2.0e7 / max(n_o, 1))))
     t0 = time.perf_counter()
     orc.solve_pose(st, hll, binv, b, m1, n_threads=1)
     v1 = m1 / (time.perf_counter() - t0)
-    # Thread sweep, ALWAYS reported (threads_tried): 4 / 16 / a quarter of / all hardware threads, each with one
+    # Thread sweep, ALWAYS reported (threads_tried): 4 / 16 / a quarter of / all usable CPUs, each with one
     # static landmark range per thread and with on-demand chunks (TBB's default auto_partitioner hands out
     # sub-ranges dynamically, linearization_power_varproj.hpp:402-403).  The per-camera mutex (LPV:393-397) makes
     # the scheme contention-bound on hub cameras, so the fastest count is often small; two terms per probe.
@@ -140,8 +166,9 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
         "kind": "port",
         "value_1_thread": v1 * scale,
         "threads_tried": {k: round(v, 3) for k, v in tried.items()},
-        "value_all_cores": max(tried.get(str(ncpu), 0.0), tried.get(f"{ncpu}-dynamic", 0.0)),
-        "host_cpus": ncpu,
+        "value_all_cores": max(tried.get(str(ncpu), 0.0), tried.get(f"{ncpu}-dynamic", 0.0)) if ncpu > 1 else v1 * scale,
+        "host_cpus": os.cpu_count() or 1,
+        "usable_cpus": ncpu,
         "cpu_model": cpu_model(),
         "sample": f"{what}: {reps} x solve_pOSE of {m} terms with {cores} threads in {dt:.1f} s; "
                   f"{m1} terms with 1 thread at {v1:.2f} terms/s{cores_note}",

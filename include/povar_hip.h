@@ -246,6 +246,9 @@ typedef struct {
   int64_t n_obs;
   int64_t lane_per_landmark; /* 1: the term loop runs e0_lpl / e0_lpl_h on this layout; 0: the lane-per-observation
                                 kernels (problems under 65 536 observations, POVAR_E0_V1=1) */
+  double create_ms;     /* host wall time of povar_create: layout construction + uploads (the reference's counterpart,
+                           allocating the landmark blocks, sc/linearization_varproj.hpp:44-60, is part of its
+                           preprocessor_time_in_seconds too, bal_bundle_adjustment.cpp:260-286) */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 

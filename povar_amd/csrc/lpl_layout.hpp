@@ -48,6 +48,29 @@ struct LplLayout {
   int n_part_rec = 0, max_slots = 0, n_global = 0, n_tail = 0, grid_a = 1, grid_b = 1;
 };
 
+// CPUs this process may actually use: the hardware threads, cut by the cgroup CPU quota when there is one (a container
+// that sees 256 hardware threads under a 16-CPU quota gets slower, not faster, beyond 16 busy threads)
+inline int lpl_effective_cpus() {
+  int n = (int)std::max(1u, std::thread::hardware_concurrency());
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+    char q[32] = {0};
+    long period = 0;
+    if (std::fscanf(f, "%31s %ld", q, &period) == 2 && q[0] != 'm' && period > 0)
+      n = std::min<long>(n, std::max<long>(1, (std::atol(q) + period - 1) / period));
+    std::fclose(f);
+  } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+    long quota = -1, period = 0;
+    if (std::fscanf(g, "%ld", &quota) != 1) quota = -1;
+    std::fclose(g);
+    if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (std::fscanf(h, "%ld", &period) != 1) period = 0;
+      std::fclose(h);
+    }
+    if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+  }
+  return n;
+}
+
 // fn(item) for item in [0, n_items) on up to n_threads host threads (items taken on demand; the caller's thread works too)
 template <class F>
 inline void lpl_parallel(int n_items, int n_threads, F&& fn) {
@@ -139,7 +162,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   grid = std::max(grid, 1);
   // every phase below is cut into independent pieces (landmark chunks, workgroups); the result does not depend on the
   // thread count
-  int n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 128u);
+  int n_threads = std::min(lpl_effective_cpus(), 128);
   if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
   const bool timing = std::getenv("POVAR_LAYOUT_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
@@ -335,12 +358,16 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   std::vector<std::vector<int>> lms_of(grid);
   for (int l = 0; l < n_lms; ++l)
     if (wg_of[l] >= 0) lms_of[wg_of[l]].push_back(l);
+  lap("  lms_of lists");
   L.wg_cam_off.assign(grid + 1, 0);
   L.wg_tile_off.assign(grid + 1, 0);
   L.lm_pos.assign(n_lms, -1);
   L.of_slot.assign(n_slots, -1);
   std::vector<std::vector<int>> holders(n_cams);  // rank -> workgroups with a slot for it (for the partial records)
-  std::vector<int> parts_of(n_lms, 0), psize_of(n_lms, 0), cold_of(n_lms, 0);
+  // per workgroup, aligned with its lane order order_of[w] (workgroup-local arrays: the landmarks of a workgroup are
+  // spread over the whole index range, per-landmark arrays shared by the threads would bounce between their caches)
+  struct LmInfo { int l, parts, psize, cold, pos; };
+  std::vector<std::vector<LmInfo>> info_of(grid);
   std::vector<std::vector<int>> order_of(grid);
   {
     // every workgroup on its own (parallel): slots, lane order, tiles with workgroup-local tile numbers ...
@@ -390,23 +417,28 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       }
       // tiles: lanes sorted by (rows per lane, cold rows per lane), longest first
       std::vector<int>& order = order_of[w];
+      std::vector<LmInfo>& info = info_of[w];
       for (int l : lms_of[w]) {
         const int k = lm_off[l + 1] - lm_off[l];
         int cold = 0;
         for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) cold += cold_pos_of_obs[i] >= 0;
-        parts_of[l] = k <= K0 ? 1 : std::min(WAVE, (k + K0 - 1) / K0);
-        psize_of[l] = (k + parts_of[l] - 1) / parts_of[l];
-        cold_of[l] = (cold + parts_of[l] - 1) / parts_of[l];
-        order.push_back(l);
+        LmInfo f;
+        f.l = l;
+        f.parts = k <= K0 ? 1 : std::min(WAVE, (k + K0 - 1) / K0);
+        f.psize = (k + f.parts - 1) / f.parts;
+        f.cold = (cold + f.parts - 1) / f.parts;
+        f.pos = 0;
+        info.push_back(f);
       }
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        return psize_of[a] != psize_of[b] ? psize_of[a] > psize_of[b] : cold_of[a] > cold_of[b];
+      std::stable_sort(info.begin(), info.end(), [&](const LmInfo& a, const LmInfo& b) {
+        return a.psize != b.psize ? a.psize > b.psize : a.cold > b.cold;
       });
       int tile = 0, fill = 0;
-      for (int l : order) {
-        if (fill + parts_of[l] > WAVE) { ++tile; fill = 0; }
-        L.lm_pos[l] = (tile * WAVE + fill) | ((parts_of[l] - 1) << 26);  // local tile number: rebased below
-        fill += parts_of[l];
+      for (LmInfo& f : info) {
+        order.push_back(f.l);
+        if (fill + f.parts > WAVE) { ++tile; fill = 0; }
+        f.pos = tile * WAVE + fill;  // local tile number: rebased below
+        fill += f.parts;
       }
       const int n_tiles_w = order.empty() ? 0 : tile + 1;
       o.tile.assign(n_tiles_w, make_int4(0, 0, 1 << 30, 0));
@@ -414,12 +446,12 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       o.lm_of.assign((size_t)n_tiles_w * WAVE, -1);
       for (size_t i = 0; i < o.seg.size(); ++i) o.seg[i] = (int)(i & 63) | ((int)(i & 63) << 8);
       std::vector<int> lanes_used(n_tiles_w, 0);
-      for (int l : order) {
-        const int pos = L.lm_pos[l] & ((1 << 26) - 1), t = pos >> 6, lane0 = pos & 63, P = parts_of[l];
+      for (const LmInfo& f : info) {
+        const int l = f.l, pos = f.pos, t = pos >> 6, lane0 = pos & 63, P = f.parts;
         int hot = 0;
         for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) hot += cold_pos_of_obs[i] < 0;
         int4& ti = o.tile[t];
-        ti.y = std::max(ti.y, psize_of[l]);
+        ti.y = std::max(ti.y, f.psize);
         ti.z = std::min(ti.z, hot / P);  // leading rows in which every lane of the landmark has a resident camera
         if (P > 1) ti.w |= 1;
         for (int q = 0; q < P; ++q) {
@@ -435,6 +467,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         o.tile[t].y = std::max(o.tile[t].y, 2);
       }
     });
+    lap("  slots+tiles parallel part");
     // ... then the workgroups one after the other: global slot / tile / row numbers
     std::vector<int> tile0_of(grid, 0);
     for (int w = 0; w < grid; ++w) {
@@ -455,7 +488,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       L.wg_tile_off[w + 1] = (int)L.tile.size();
     }
     lpl_parallel(grid, n_threads, [&](int w) {
-      for (int l : lms_of[w]) L.lm_pos[l] += tile0_of[w] * WAVE;
+      for (LmInfo& f : info_of[w]) f.pos += tile0_of[w] * WAVE;
     });
   }
   lap("slots and tiles");
@@ -489,6 +522,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       const int slot0 = L.wg_cam_off[w], n_w = L.wg_cam_off[w + 1] - slot0;
       for (int s = 0; s < n_w; ++s) slot_of_rank[L.wg_cams[slot0 + s]] = s;
       const std::vector<int>& order = order_of[w];
+      const std::vector<LmInfo>& info = info_of[w];
       const int t0w = L.wg_tile_off[w], ntw = L.wg_tile_off[w + 1] - t0w;
       // bank occupancy of every tile of the workgroup: [tile][row][2 halves x 32 | 4 groups x 16]
       std::vector<size_t> occ_off(ntw + 1, 0);
@@ -529,25 +563,43 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         return 1000L * std::max(0, v + 1 - (int)mxR_at(t, lane, j)) + v;
       };
       const size_t n_o = order.size();
-      std::vector<std::vector<int>> placed(n_o);   // per landmark: its resident observations in position order
-      std::vector<std::vector<char>> reps(n_o);    // and the accumulator replica of each (hubs)
-      std::vector<int> tile_of(n_o), lane_of(n_o);
+      // per landmark: its resident observations in position order (one flat array per workgroup, no per-landmark
+      // allocations), the LDS slot of each (looked up once) and the accumulator replica of each (hubs)
+      std::vector<int> placed_off(n_o + 1, 0), tile_of(n_o), lane_of(n_o);
       for (size_t o = 0; o < n_o; ++o) {
-        const int pos = L.lm_pos[order[o]] & ((1 << 26) - 1);
+        const int pos = info[o].pos;
         tile_of[o] = pos >> 6;
         lane_of[o] = pos & 63;
-        for (int i = lm_off[order[o]]; i < lm_off[order[o] + 1]; ++i)
-          if (cold_pos_of_obs[i] < 0) placed[o].push_back(i);
-        reps[o].assign(placed[o].size(), 0);
+        int hot = 0;
+        for (int i = lm_off[order[o]]; i < lm_off[order[o] + 1]; ++i) hot += cold_pos_of_obs[i] < 0;
+        placed_off[o + 1] = placed_off[o] + hot;
       }
-      auto slot_of_obs_ = [&](int i) { return slot_of_rank[rank1[cam_idx[i]] - 1]; };
+      std::vector<int> placed_obs(placed_off[n_o]), placed_slot(placed_off[n_o]);
+      std::vector<char> placed_rep(placed_off[n_o], 0);
+      for (size_t o = 0; o < n_o; ++o) {
+        int n = placed_off[o];
+        for (int i = lm_off[order[o]]; i < lm_off[order[o] + 1]; ++i)
+          if (cold_pos_of_obs[i] < 0) {
+            placed_obs[n] = i;
+            placed_slot[n] = slot_of_rank[rank1[cam_idx[i]] - 1];
+            ++n;
+          }
+      }
+      struct Placed {  // view of one landmark's run
+        int *obs, *slot;
+        char* rep;
+        int n;
+        int size() const { return n; }
+      };
+      auto placed = [&](size_t o) { return Placed{placed_obs.data() + placed_off[o], placed_slot.data() + placed_off[o],
+                                                   placed_rep.data() + placed_off[o], placed_off[o + 1] - placed_off[o]}; };
       // cheapest assignment of the landmark's resident observations to the rows of lanes [lane0, lane0 + P) of tile t
-      auto place_cost = [&](const std::vector<int>& cur, int t, int lane0, int P, std::vector<int>& out_assign) -> long {
-        const int h = (int)cur.size();
+      auto place_cost = [&](const Placed& cur, int t, int lane0, int P, std::vector<int>& out_assign) -> long {
+        const int h = cur.size();
         if (h == 0) return 0;
         cost.assign((size_t)h * h, 0);
         for (int a = 0; a < h; ++a) {
-          const int sl = slot_of_obs_(cur[a]);
+          const int sl = cur.slot[a];
           for (int pos = 0; pos < h; ++pos) {
             const int lane = lane0 + pos % P, j = pos / P;
             int rp;
@@ -562,14 +614,14 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         return tot;
       };
       auto commit = [&](size_t o, int sign, bool choose_rep) {
-        const std::vector<int>& cur = placed[o];
-        const int P = parts_of[order[o]];
-        for (size_t n = 0; n < cur.size(); ++n) {
-          const int sl = slot_of_obs_(cur[n]), lane = lane_of[o] + (int)(n % P), j = (int)(n / P), t = tile_of[o];
+        const Placed cur = placed(o);
+        const int P = info[o].parts;
+        for (int n = 0; n < cur.size(); ++n) {
+          const int sl = cur.slot[n], lane = lane_of[o] + n % P, j = n / P, t = tile_of[o];
           int acc_slot = sl + 3 * hubs;
           if (sl < hubs) {
-            int rp = reps[o][n];
-            if (choose_rep) { occ_of(t, sl, lane, j, rp); reps[o][n] = (char)rp; }
+            int rp = cur.rep[n];
+            if (choose_rep) { occ_of(t, sl, lane, j, rp); cur.rep[n] = (char)rp; }
             acc_slot = 4 * sl + rp;
           }
           uint16_t& ca = occA[idxA(t, lane, j, acc_slot)];
@@ -601,27 +653,32 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         }
       };
       auto reorder = [&](size_t o) {
-        std::vector<int>& cur = placed[o];
-        const int h = (int)cur.size();
+        const Placed cur = placed(o);
+        const int h = cur.size();
         if (h <= 1) return;
-        hot_idx.assign(h, 0);
-        for (int a = 0; a < h; ++a) hot_idx[assign[a]] = cur[a];
-        cur = hot_idx;
+        hot_idx.assign(2 * (size_t)h, 0);
+        for (int a = 0; a < h; ++a) {
+          hot_idx[assign[a]] = cur.obs[a];
+          hot_idx[h + assign[a]] = cur.slot[a];
+        }
+        for (int a = 0; a < h; ++a) {
+          cur.obs[a] = hot_idx[a];
+          cur.slot[a] = hot_idx[h + a];
+        }
       };
       if (!no_place) {
         // (1) landmarks dealt over several lanes keep their lanes: rows only
         for (size_t o = 0; o < n_o; ++o)
-          if (parts_of[order[o]] > 1) {
-            if (placed[o].size() <= 64) { place_cost(placed[o], tile_of[o], lane_of[o], parts_of[order[o]], assign); reorder(o); }
+          if (info[o].parts > 1) {
+            if (placed(o).size() <= 64) { place_cost(placed(o), tile_of[o], lane_of[o], info[o].parts, assign); reorder(o); }
             commit(o, +1, true);
           }
         // (2) single-lane landmarks of one class (same rows per lane, same cold rows) are interchangeable.
         size_t a = 0;
         while (a < n_o) {
-          if (parts_of[order[a]] > 1) { ++a; continue; }
+          if (info[a].parts > 1) { ++a; continue; }
           size_t b = a;
-          while (b < n_o && parts_of[order[b]] == 1 && psize_of[order[b]] == psize_of[order[a]] &&
-                 cold_of[order[b]] == cold_of[order[a]]) ++b;
+          while (b < n_o && info[b].parts == 1 && info[b].psize == info[a].psize && info[b].cold == info[a].cold) ++b;
           const int ta = tile_of[a], tb = tile_of[b - 1];
           std::vector<unsigned long long> free_mask(tb - ta + 1, 0);
           for (size_t o = a; o < b; ++o) free_mask[tile_of[o] - ta] |= 1ull << lane_of[o];
@@ -639,7 +696,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
                 const int lane = __builtin_ctzll(m), cls = (lane >> 5) * 2 + (read_group(lane) & 1);
                 if (seen & (1u << cls)) continue;
                 seen |= 1u << cls;
-                const long c = place_cost(placed[o], t, lane, 1, assign2);
+                const long c = place_cost(placed(o), t, lane, 1, assign2);
                 if (best < 0 || c < best) { best = c; best_t = t; best_lane = lane; assign = assign2; }
               }
             }
@@ -653,9 +710,9 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         }
         // (3) once more with everything placed: rows only (not the exactly placed ones)
         for (size_t o = 0; o < n_o; ++o) {
-          if (placed[o].size() < 2 || placed[o].size() > 64) continue;
+          if (placed(o).size() < 2 || placed(o).size() > 64) continue;
           commit(o, -1, false);
-          place_cost(placed[o], tile_of[o], lane_of[o], parts_of[order[o]], assign);
+          place_cost(placed(o), tile_of[o], lane_of[o], info[o].parts, assign);
           reorder(o);
           commit(o, +1, true);
         }
@@ -664,24 +721,22 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       }
       // write the rows
       for (size_t o = 0; o < n_o; ++o) {
-        const int l = order[o], t = tile_of[o], lane0 = lane_of[o], P = parts_of[l];
-        if (P == 1) {
-          L.lm_pos[l] = t * WAVE + lane0;
-          L.lm_of[(size_t)t * WAVE + lane0] = l;
-        }
-        const std::vector<int>& cur = placed[o];
-        const int h = (int)cur.size();
+        const int l = order[o], t = tile_of[o], lane0 = lane_of[o], P = info[o].parts;
+        L.lm_pos[l] = (t * WAVE + lane0) | ((P - 1) << 26);
+        if (P == 1) L.lm_of[(size_t)t * WAVE + lane0] = l;
+        const Placed cur = placed(o);
+        const int h = cur.size();
         cold_idx.clear();
         for (int i = lm_off[l]; i < lm_off[l + 1]; ++i)
           if (cold_pos_of_obs[i] >= 0) cold_idx.push_back(i);
         for (int n = 0; n < h + (int)cold_idx.size(); ++n) {
-          const int i = n < h ? cur[n] : cold_idx[n - h];
+          const int i = n < h ? cur.obs[n] : cold_idx[n - h];
           const int q = n % P, j = n / P, r0 = rank1[cam_idx[i]] - 1, lane = lane0 + q;
           const size_t idx = ((size_t)L.tile[t].x + j) * WAVE + lane;
           L.uv[idx] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
           L.of_slot[slot_of_obs[i]] = (int)idx;
           if (n < h) {
-            L.cw[idx] = slot_of_rank[r0] | ((int)reps[o][n] << 16);
+            L.cw[idx] = cur.slot[n] | ((int)cur.rep[n] << 16);
           } else {
             L.cw[idx] = -2 - r0;  // cold: the record is gathered from the rank-ordered image
             L.cpos[idx] = cold_pos_of_obs[i];

@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -155,6 +156,7 @@ struct povar_ctx {
   int world = 1, rank = 0;
 
   // hipGraph of the m-term series loop (launch-bound on small problems and at 8 GPUs)
+  double create_ms = 0;  // host wall time of povar_create (layout construction + uploads)
   hipGraphExec_t series_graph = nullptr;
   Dp series_graph_d{};
   int series_graph_key[6] = {0, 0, 0, 0, 0, 0};
@@ -490,6 +492,19 @@ void build_views(povar_ctx* c) {
 void ensure_legacy(povar_ctx* c) {
   if (!(c->linearized || c->linearized_h)) return;
   if (c->views_lin_id != c->lin_id) build_views(c);
+  // the lazily rebuilt sqrt(w) / residual arrays and landmark records belong to the LINEARISATION: they are built
+  // with its alpha, whatever alpha the caller (apply_pose, error_pose) has put into the context meanwhile
+  struct AlphaGuard {
+    povar_ctx* c;
+    double sa, sb;
+    explicit AlphaGuard(povar_ctx* c_) : c(c_), sa(c_->d.sa), sb(c_->d.sb) {
+      if (c->linearized && !c->linearized_h) {
+        c->d.sa = std::sqrt(c->alpha_lin);
+        c->d.sb = std::sqrt(1.0 - c->alpha_lin);
+      }
+    }
+    ~AlphaGuard() { c->d.sa = sa; c->d.sb = sb; }
+  } guard(c);
   if (c->aux_lin_id != c->lin_id) {
     Dp da = c->d;
     da.lin_aux_only = 1;
@@ -745,12 +760,30 @@ int povar_shard_range(int32_t n_lms, const int32_t* lm_offsets, int32_t world, i
   return 0;
 }
 
+// inside povar_create, once the context exists: a failing HIP call releases everything allocated so far
+#define HIP_TRY_C(expr)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      povar_destroy(c);                                                                     \
+      return fail(-(int)e_ - 1000, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    }                                                                                       \
+  } while (0)
 int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                  const int32_t* lm_offsets, const int32_t* cam_idx, const double* obs,
                  const povar_options* options) {
   if (!out || !lm_offsets || !cam_idx || !obs || !options) return fail(-1, "null argument");
   if (n_cams <= 0 || n_lms <= 0 || n_obs <= 0 || lm_offsets[0] != 0 || lm_offsets[n_lms] != n_obs)
     return fail(-1, "invalid problem sizes");
+  const bool timing = std::getenv("POVAR_LAYOUT_TIMING") != nullptr;
+  const auto t_create = std::chrono::steady_clock::now();
+  auto t_last = t_create;
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[povar_create] %-26s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   for (int l = 0; l < n_lms; ++l) {
     if (lm_offsets[l + 1] < lm_offsets[l]) return fail(-1, "lm_offsets not monotone");
     for (int i = lm_offsets[l]; i < lm_offsets[l + 1]; ++i) {
@@ -760,6 +793,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
         return fail(-1, "camera indices of a landmark must be strictly ascending");
     }
   }
+  lap("argument checks");
   int n_dev = 0;
   HIP_TRY(hipGetDeviceCount(&n_dev));
   if (n_dev <= 0) return fail(-2, "no HIP device: the MI355X path has no CPU fallback");
@@ -771,7 +805,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   c->n_lms = n_lms;
   c->n_obs = n_obs;
   c->lm_off.assign(lm_offsets, lm_offsets + n_lms + 1);
-  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
   if (const char* g = std::getenv("POVAR_NO_FUSE")) c->fuse_binv = !(g[0] == '1');
@@ -783,8 +817,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   if (const char* g = std::getenv("POVAR_K1_NORMAL_EQ")) c->k1_qr = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_PREPARE_V1")) c->use_lpl_prepare = !(g[0] == '1');
 
+  lap("device, stream");
   Layout L;
   build_layout(n_cams, n_lms, lm_offsets, cam_idx, obs, L);
+  lap("build_layout (lane/obs)");
   c->n_bins = L.n_bins;
   c->n_slots = L.n_bins * WAVE;
   c->n_items = (int)L.item_cam.size();
@@ -795,51 +831,51 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   {
     // one 1024-thread workgroup per CU for the LDS-cached E0 kernel
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, options->device));
+    HIP_TRY_C(hipGetDeviceProperties(&prop, options->device));
     int cus = std::max(prop.multiProcessorCount, 1);
     if (const char* e = std::getenv("POVAR_E0_WGS")) cus = std::max(std::atoi(e), 1);  // tuning knob: E0 workgroups
     c->e0c_bins_per_wg = std::max((c->n_bins + cus - 1) / cus, 1);
     c->e0c_grid = (c->n_bins + c->e0c_bins_per_wg - 1) / c->e0c_bins_per_wg;
     c->n_hot = std::min(n_cams, HOT_MAX);
-    HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_lm_cached<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_MAX * HOT_REC * (int)sizeof(double2)));
-    HIP_TRY(hipFuncSetAttribute((const void*)e0_tiles_cached, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_tiles_cached, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_ACC_MAX * (HOT_REC_T * (int)sizeof(double2) + 96)));
-    HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached_h, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_lm_cached_h, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_ACC_MAX * (HOT_REC_H * (int)sizeof(double2) + 96)));
-    HIP_TRY(hipFuncSetAttribute((const void*)e0_lm_cached<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_lm_cached<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HOT_ACC_MAX * (HOT_REC * (int)sizeof(double2) + 96)));
-    HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lpl_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lpl_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lpl_lds_bytes_h(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)e0_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lpl_lds_bytes_h(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)prepare_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)prepare_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass_h<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)lpl_pass_h<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)pass_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass_h<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)lpl_pass_h<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)pass_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)backsub_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)back_lds_bytes_h(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)backsub_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)back_lds_bytes_h(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)lpl_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)pass_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)lpl_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)lpl_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)pass_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)backsub_lpl<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)back_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)backsub_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)backsub_lpl<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)back_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)prepare_lpl_h<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
-    HIP_TRY(hipFuncSetAttribute((const void*)prepare_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY_C(hipFuncSetAttribute((const void*)prepare_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
   }
 
@@ -855,6 +891,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     povar_destroy(c);
     return rc;
   }
+  lap("uploads (lane/obs)");
   const size_t nc = n_cams, nl = n_lms, ns = c->n_slots, ni = std::max(c->n_items, 1);
   const size_t n_part = (size_t)(c->n_reg_blocks + c->n_long) * 4;
 #define ALLOC(buf, count)                                  \
@@ -879,14 +916,14 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     std::vector<int2> range(n_cams);
     for (int k = 0; k < n_cams; ++k)
       range[k] = make_int2(L.cc_item_off[L.cc_cam_item_off[k]], L.cc_item_off[L.cc_cam_item_off[k + 1]]);
-    if (int rc = upload(c->cc_cam_range, range, c)) return rc;
-    if (int rc = upload(c->cold_pos, L.cold_pos, c)) return rc;
+    if (int rc = upload(c->cc_cam_range, range, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->cold_pos, L.cold_pos, c)) { povar_destroy(c); return rc; }
     if (!L.long_lm.empty()) {
       c->n_cold2 = (int64_t)L.c2_lm.size();
-      if (int rc = upload(c->c2_lm, L.c2_lm, c)) return rc;
-      if (int rc = upload(c->c2_pos, L.c2_pos, c)) return rc;
-      if (int rc = upload(c->c2_range, L.c2_range, c)) return rc;
-      HIP_TRY(c->c2_h.alloc(4 * std::max<size_t>(L.c2_lm.size(), 1), &c->bytes));
+      if (int rc = upload(c->c2_lm, L.c2_lm, c)) { povar_destroy(c); return rc; }
+      if (int rc = upload(c->c2_pos, L.c2_pos, c)) { povar_destroy(c); return rc; }
+      if (int rc = upload(c->c2_range, L.c2_range, c)) { povar_destroy(c); return rc; }
+      HIP_TRY_C(c->c2_h.alloc(4 * std::max<size_t>(L.c2_lm.size(), 1), &c->bytes));
       // knob POVAR_LONG_SEPARATE: keep the lm_long kernel (old lane-per-observation kernels only; e0_lpl has no
       // long/short distinction and always uses this cold view)
       c->long_in_kernel = c->use_lpl || std::getenv("POVAR_LONG_SEPARATE") == nullptr;
@@ -899,48 +936,51 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       cnt[l] = lm_offsets[l + 1] - lm_offsets[l];
       s0[l] = cnt[l] > 0 ? L.slot_of_obs[lm_offsets[l]] : 0;
     }
-    if (int rc = upload(c->lm_slot0, s0, c)) return rc;
-    if (int rc = upload(c->lm_cnt_dev, cnt, c)) return rc;
+    if (int rc = upload(c->lm_slot0, s0, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->lm_cnt_dev, cnt, c)) { povar_destroy(c); return rc; }
     c->d.lm_slot0 = c->lm_slot0.p;
     c->d.lm_cnt = c->lm_cnt_dev.p;
   }
+  lap("allocations");
   {
     // lane-per-landmark layout of e0_lpl (lpl_layout.hpp)
     LplLayout V;
     build_lpl(n_cams, n_lms, lm_offsets, cam_idx, obs, L.cam_hot, L.slot_of_obs, (size_t)c->n_slots, c->e0c_grid,
               c->n_hot_acc, V);
+    lap("build_lpl (lane/landmark)");
     if (V.max_slots > c->n_hot_acc) { povar_destroy(c); return fail(-1, "lpl layout: workgroup camera set exceeds the LDS capacity"); }
     c->v2_rows = V.rows;
     c->v2_max_slots = V.max_slots;
     c->v2_n_global = V.n_global;
     c->v2_n_tail = V.n_tail;
     c->n_cold3 = (int64_t)V.cold_lm.size();
-    if (int rc = upload(c->v2_uv, V.uv, c)) return rc;
-    if (int rc = upload(c->v2_cw, V.cw, c)) return rc;
-    if (int rc = upload(c->v2_cpos, V.cpos, c)) return rc;
-    if (int rc = upload(c->v2_lm_pos, V.lm_pos, c)) return rc;
-    if (int rc = upload(c->v2_lm_of, V.lm_of, c)) return rc;
-    if (int rc = upload(c->v2_of_slot, V.of_slot, c)) return rc;
-    if (int rc = upload(c->v2_tile, V.tile, c)) return rc;
-    if (int rc = upload(c->v2_seg, V.seg, c)) return rc;
-    if (int rc = upload(c->v2_wg_tile_off, V.wg_tile_off, c)) return rc;
-    if (int rc = upload(c->v2_wg_cam_off, V.wg_cam_off, c)) return rc;
-    if (int rc = upload(c->v2_wg_cams, V.wg_cams, c)) return rc;
-    if (int rc = upload(c->v2_wg_slot_rec, V.wg_slot_rec, c)) return rc;
-    if (int rc = upload(c->v2_part_range, V.part_range, c)) return rc;
-    if (int rc = upload(c->c3_lm, V.cold_lm, c)) return rc;
-    if (int rc = upload(c->c3_range, V.cold_range, c)) return rc;
+    if (int rc = upload(c->v2_uv, V.uv, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_cw, V.cw, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_cpos, V.cpos, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_lm_pos, V.lm_pos, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_lm_of, V.lm_of, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_of_slot, V.of_slot, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_tile, V.tile, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_seg, V.seg, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_wg_tile_off, V.wg_tile_off, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_wg_cam_off, V.wg_cam_off, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_wg_cams, V.wg_cams, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_wg_slot_rec, V.wg_slot_rec, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_part_range, V.part_range, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->c3_lm, V.cold_lm, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->c3_range, V.cold_range, c)) { povar_destroy(c); return rc; }
     const int nt = (int)V.tile.size();
-    HIP_TRY(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * LPL_REC_H * WAVE, &c->bytes));  // 9 entries used by step 1
-    HIP_TRY(c->v2_part.alloc((size_t)std::max(V.n_part_rec, 1) * 12, &c->bytes));
-    HIP_TRY(c->c3_h.alloc(4 * std::max<size_t>(V.cold_lm.size(), 1), &c->bytes));
-    if (options->robust_norm) HIP_TRY(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
+    HIP_TRY_C(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * LPL_REC_H * WAVE, &c->bytes));  // 9 entries used by step 1
+    HIP_TRY_C(c->v2_part.alloc((size_t)std::max(V.n_part_rec, 1) * 12, &c->bytes));
+    HIP_TRY_C(c->c3_h.alloc(4 * std::max<size_t>(V.cold_lm.size(), 1), &c->bytes));
+    if (options->robust_norm) HIP_TRY_C(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
     // scatter scalars of the cold observations: one buffer, sized for the largest of the cold views
-    HIP_TRY(c->q4c.alloc(std::max<size_t>(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), V.cold_lm.size()), 1), &c->bytes));
+    HIP_TRY_C(c->q4c.alloc(std::max<size_t>(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), V.cold_lm.size()), 1), &c->bytes));
     c->d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
                  c->v2_lm_of.p, c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
                  c->v2_wg_slot_rec.p, nt, lpl_hubs(V.n_global)};
   }
+  lap("uploads (lane/landmark)");
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
   ALLOC(hot_rec, (size_t)std::max(n_cams, HOT_MAX) * HOT_REC_STRIDE);  // every camera, in popularity order
@@ -948,16 +988,16 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(part, n_part * 2 + 8 * 1024); ALLOC(scal, 8);  // + one slot set per workgroup of the lane-per-landmark kernels
   ALLOC(stage, std::max(3 * nl, 144 * nc));
 #undef ALLOC
-  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, c->stream));
-  HIP_TRY(hipMemsetAsync(c->lms4.p, 0, sizeof(double4) * nl, c->stream));
-  HIP_TRY(hipMemsetAsync(c->cams4.p, 0, sizeof(double4) * 3 * nc, c->stream));
-  HIP_TRY(hipMemsetAsync(c->y.p, 0, sizeof(double) * 12 * nc, c->stream));
-  HIP_TRY(hipMemsetAsync(c->q4.p, 0, sizeof(double4) * ns, c->stream));
-  HIP_TRY(hipMemsetAsync(c->sw.p, 0, sizeof(double) * ns, c->stream));
-  HIP_TRY(hipMemsetAsync(c->rres.p, 0, sizeof(double4) * ns, c->stream));
+  HIP_TRY_C(hipMemsetAsync(c->flags.p, 0, sizeof(int) * 4, c->stream));
+  HIP_TRY_C(hipMemsetAsync(c->lms4.p, 0, sizeof(double4) * nl, c->stream));
+  HIP_TRY_C(hipMemsetAsync(c->cams4.p, 0, sizeof(double4) * 3 * nc, c->stream));
+  HIP_TRY_C(hipMemsetAsync(c->y.p, 0, sizeof(double) * 12 * nc, c->stream));
+  HIP_TRY_C(hipMemsetAsync(c->q4.p, 0, sizeof(double4) * ns, c->stream));
+  HIP_TRY_C(hipMemsetAsync(c->sw.p, 0, sizeof(double) * ns, c->stream));
+  HIP_TRY_C(hipMemsetAsync(c->rres.p, 0, sizeof(double4) * ns, c->stream));
   // every initialisation above (uploads on the null stream, memsets on the context's non-blocking
   // stream) is complete before the context is handed out
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY_C(hipDeviceSynchronize());
 
   Dp& d = c->d;
   d.n_cams = n_cams; d.n_lms = n_lms; d.n_bins = c->n_bins; d.n_items = c->n_items;
@@ -981,10 +1021,14 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.flags = c->flags.p; d.norm_part = c->norm_part.p; d.norms = c->norms.p;
   d.sa = 0; d.sb = 1; d.eps = options->jacobi_scaling_eps; d.huber = options->huber_parameter;
   d.lambda_lm = 0; d.robust = options->robust_norm; d.scale_jl = 1;
+  lap("allocations, memsets, sync");
+  c->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
+  if (timing) std::fprintf(stderr, "[povar_create] total %.1f ms\n", c->create_ms);
   *out = c;
   return 0;
 }
 
+#undef HIP_TRY_C
 void povar_destroy(povar_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->opt.device);
@@ -1772,6 +1816,7 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->n_cold = c->n_cold3;
   out->n_obs = c->n_obs;
   out->lane_per_landmark = c->use_lpl ? 1 : 0;
+  out->create_ms = c->create_ms;
   return 0;
 }
 

@@ -197,7 +197,20 @@ int main(int argc, char** argv) {
   }
   int64_t mx = 0, mn = 1LL << 60;
   for (int w = 0; w < grid; ++w) { mx = std::max(mx, wg_rows[w]); mn = std::min(mn, wg_rows[w]); }
-  std::printf("{\"ok\": 1, \"n_global\": %d, \"n_tail\": %d, \"grid\": [%d, %d], \"max_slots\": %d, \"rows\": %lld, "
+  // fingerprint of everything the kernels read (the layout must not depend on the number of host threads)
+  unsigned long long fp = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t bytes) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < bytes; ++i) { fp ^= b[i]; fp *= 1099511628211ull; }
+  };
+  mix(L.cw.data(), L.cw.size() * sizeof(int)); mix(L.cpos.data(), L.cpos.size() * sizeof(int));
+  mix(L.uv.data(), L.uv.size() * sizeof(double2)); mix(L.lm_pos.data(), L.lm_pos.size() * sizeof(int));
+  mix(L.lm_of.data(), L.lm_of.size() * sizeof(int)); mix(L.seg.data(), L.seg.size() * sizeof(int));
+  mix(L.tile.data(), L.tile.size() * sizeof(int4)); mix(L.wg_cams.data(), L.wg_cams.size() * sizeof(int));
+  mix(L.wg_slot_rec.data(), L.wg_slot_rec.size() * sizeof(int)); mix(L.cold_lm.data(), L.cold_lm.size() * sizeof(int));
+  mix(L.of_slot.data(), L.of_slot.size() * sizeof(int));
+  std::printf("{\"fingerprint\": \"%016llx\", ", fp);
+  std::printf("\"ok\": 1, \"n_global\": %d, \"n_tail\": %d, \"grid\": [%d, %d], \"max_slots\": %d, \"rows\": %lld, "
               "\"tiles\": %zu, \"cold\": %lld, \"cold_frac\": %.5f, \"pad_frac\": %.5f, \"wg_rows_min\": %lld, "
               "\"wg_rows_max\": %lld, \"part_recs\": %d, \"extra_atomic_lanes_per_half\": %.3f, \"extra_records_per_read_group\": %.3f}\n",
               L.n_global, L.n_tail, L.grid_a, L.grid_b, L.max_slots, (long long)L.rows, L.tile.size(),

@@ -58,3 +58,13 @@ def test_layout_venice_shape_coverage(tmp_path):
     assert s["wg_rows_max"] <= 1.05 * s["wg_rows_min"] + 8
     g = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 256, 568, env={"POVAR_LPL_NOGRID": "1"})
     assert g["ok"] == 1 and 0.10 < g["cold_frac"] < 0.18
+
+
+def test_layout_does_not_depend_on_the_thread_count(tmp_path):
+    """Every parallel phase of build_lpl cuts its work into independent pieces (landmark chunks, workgroups): the layout
+    built on 1, 3 and 8 host threads is the same, byte for byte."""
+    from povar_amd import synth
+    p = synth.make_problem(300, 20000, 90000, seed=5)
+    fps = {t: _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 64, 120, env={"POVAR_LAYOUT_THREADS": str(t)})["fingerprint"]
+           for t in (1, 3, 8)}
+    assert len(set(fps.values())) == 1, fps

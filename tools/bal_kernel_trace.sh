@@ -8,7 +8,9 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 python3 tools/run_bal_config.py $name "$@" > $out/bal_summary.json 2> $out/bal.err   # also writes the data file
-f=$(ls /tmp/problem-*-pre.txt | head -1)
+# the file run_bal_config.py wrote for THIS problem (same formula: $TMPDIR/problem-<cams>-<landmarks>-pre.txt)
+f=$(python3 -c "import sys, os, tempfile; sys.path.insert(0, '.'); from povar_amd import synth; c, l, _ = synth.BAL_SHAPES['$name']; print(os.path.join(tempfile.gettempdir(), f'problem-{c}-{l}-pre.txt'))")
+[ -f "$f" ] || { echo "missing $f" >&2; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- bin/bal --input $f --quiet "$@" > $out/bal_trace.stdout 2> $out/kt.err
 python3 - "$out" <<'PY'
 import csv, glob, sys
