@@ -157,6 +157,12 @@ struct povar_ctx {
 
   // hipGraph of the m-term series loop (launch-bound on small problems and at 8 GPUs)
   double create_ms = 0;  // host wall time of povar_create (layout construction + uploads)
+  // lane-ordered mirrors of lms4 / lms_lin4 / jl_scale4 (V2::lmx, lml, lsc): lms_ver counts the writes to lms4, the
+  // *_ver / *_lin_id fields say what each mirror currently reflects
+  DevBuf<double4> v2_lmx, v2_lml, v2_lsc;
+  uint64_t lms_ver = 1, lmx_ver = 0;
+  int64_t lml_lin_id = -1, lsc_lin_id = -1;
+  int64_t jls_lin_id = -1;  // linearisation whose Jl column scale the landmark-order master jl_scale4 holds
   hipGraphExec_t series_graph = nullptr;
   Dp series_graph_d{};
   int series_graph_key[6] = {0, 0, 0, 0, 0, 0};
@@ -489,8 +495,32 @@ void build_views(povar_ctx* c) {
 // called by every entry point that may run a lane-per-observation ("legacy") kernel: the camera-major landmark copies
 // (cm_scatter, the cold views of e0_lm_cached) and the per-slot sqrt(w) / weighted residual arrays, which the
 // lane-per-landmark linearisation (lpl_pass<0>) does not write
+// lane-ordered mirrors (V2::lmx / lml / lsc), rebuilt from the landmark-order masters when stale
+void lanes_from(povar_ctx* c, const double4* src, double4* dst) {
+  const int64_t n = (int64_t)c->d.v2.n_tiles * WAVE;
+  if (n > 0) hipLaunchKernelGGL(lm_to_lanes, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d.v2.lm_of, src, dst, n);
+}
+void ensure_lmx(povar_ctx* c) {
+  if (c->lmx_ver == c->lms_ver) return;
+  lanes_from(c, c->lms4.p, c->v2_lmx.p);
+  c->lmx_ver = c->lms_ver;
+}
+void ensure_lin_mirrors(povar_ctx* c) {
+  if (c->lml_lin_id != c->lin_id) { lanes_from(c, c->lms_lin4.p, c->v2_lml.p); c->lml_lin_id = c->lin_id; }
+  if (c->lsc_lin_id != c->lin_id) { lanes_from(c, c->jl_scale4.p, c->v2_lsc.p); c->lsc_lin_id = c->lin_id; }
+}
+
+void ensure_jl_scale4(povar_ctx* c) {
+  if (c->jls_lin_id == c->lin_id) return;
+  const int64_t n = (int64_t)c->d.v2.n_tiles * WAVE;
+  if (n > 0) hipLaunchKernelGGL(lanes_to_lm, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d.v2.lm_of, c->d.v2.seg,
+                                (const double4*)c->v2_lsc.p, c->jl_scale4.p, n);
+  c->jls_lin_id = c->lin_id;
+}
+
 void ensure_legacy(povar_ctx* c) {
   if (!(c->linearized || c->linearized_h)) return;
+  ensure_jl_scale4(c);
   if (c->views_lin_id != c->lin_id) build_views(c);
   // the lazily rebuilt sqrt(w) / residual arrays and landmark records belong to the LINEARISATION: they are built
   // with its alpha, whatever alpha the caller (apply_pose, error_pose) has put into the context meanwhile
@@ -971,13 +1001,16 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (int rc = upload(c->c3_range, V.cold_range, c)) { povar_destroy(c); return rc; }
     const int nt = (int)V.tile.size();
     HIP_TRY_C(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * LPL_REC_H * WAVE, &c->bytes));  // 9 entries used by step 1
+    HIP_TRY_C(c->v2_lmx.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
+    HIP_TRY_C(c->v2_lml.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
+    HIP_TRY_C(c->v2_lsc.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
     HIP_TRY_C(c->v2_part.alloc((size_t)std::max(V.n_part_rec, 1) * 12, &c->bytes));
     HIP_TRY_C(c->c3_h.alloc(4 * std::max<size_t>(V.cold_lm.size(), 1), &c->bytes));
     if (options->robust_norm) HIP_TRY_C(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
     // scatter scalars of the cold observations: one buffer, sized for the largest of the cold views
     HIP_TRY_C(c->q4c.alloc(std::max<size_t>(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), V.cold_lm.size()), 1), &c->bytes));
     c->d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
-                 c->v2_lm_of.p, c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
+                 c->v2_lm_of.p, c->v2_lmx.p, c->v2_lml.p, c->v2_lsc.p, c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
                  c->v2_wg_slot_rec.p, nt, lpl_hubs(V.n_global)};
   }
   lap("uploads (lane/landmark)");
@@ -1059,7 +1092,7 @@ void povar_destroy(povar_ctx* c) {
   c->cc_cam_range.release(); c->cold_pos.release(); c->q4c.release();
   c->v2_uv.release(); c->v2_cw.release(); c->v2_cpos.release(); c->v2_lm_pos.release(); c->v2_of_slot.release();
   c->v2_lm_of.release(); c->v2_seg.release(); c->v2_tile.release(); c->v2_wg_tile_off.release(); c->v2_wg_cam_off.release(); c->v2_wg_cams.release();
-  c->v2_wg_slot_rec.release(); c->c3_lm.release(); c->v2_part_range.release(); c->c3_range.release(); c->c3_h.release(); c->v2_part.release(); c->v2_w.release(); c->v2_lmrec.release();
+  c->v2_wg_slot_rec.release(); c->c3_lm.release(); c->v2_part_range.release(); c->c3_range.release(); c->c3_h.release(); c->v2_part.release(); c->v2_w.release(); c->v2_lmrec.release(); c->v2_lmx.release(); c->v2_lml.release(); c->v2_lsc.release();
   c->c2_lm.release(); c->c2_pos.release(); c->c2_range.release(); c->c2_h.release();
   c->cam_hot.release(); c->cc_slot.release(); c->cc_lm.release(); c->cc_item_off.release(); c->cc_cam_item_off.release(); c->hot_cams.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1093,6 +1126,7 @@ int povar_set_landmarks(povar_ctx* c, const double* lms) {
   HIP_TRY(hipMemcpyAsync(c->stage.p, lms, sizeof(double) * 3 * c->n_lms, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(lms3_to_4, dim3(grid_for(c->n_lms, 256)), dim3(256), 0, c->stream, c->stage.p,
                      c->lms4.p, c->n_lms);
+  ++c->lms_ver;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1117,6 +1151,7 @@ int povar_restore_pose(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
   HIP_TRY(hipMemcpyAsync(c->cams4.p, c->cams_bak4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms4.p, c->lms_bak4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
+  ++c->lms_ver;
   return 0;
 }
 
@@ -1127,6 +1162,7 @@ static void set_alpha(povar_ctx* c, double alpha) {
 
 int povar_init_landmarks_pose(povar_ctx* c, double alpha) {
   if (int rc = check_ctx(c)) return rc;
+  ++c->lms_ver;
   set_alpha(c, alpha);
   TimeScope ts(c, 4);
   if (c->k1_qr) {
@@ -1146,6 +1182,7 @@ int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
   set_alpha(c, alpha);
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
   if (c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
+    ensure_lmx(c);
     hipLaunchKernelGGL(lpl_pass<1>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
     hipLaunchKernelGGL((reduce_partials<3>), dim3(1), dim3(1024), 0, c->stream, c->part.p, c->e0c_grid, c->scal.p);
   } else {
@@ -1183,10 +1220,14 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   // copies of the lane-per-observation kernels are built when one of them asks (ensure_legacy)
   const bool lazy = lpl_only(c);
   if (lazy) {
+    // the linearisation point in lane order is a plain copy of the current mirror; the kernel writes the scale mirror
+    ensure_lmx(c);
+    HIP_TRY(hipMemcpyAsync(c->v2_lml.p, c->v2_lmx.p, sizeof(double4) * (size_t)c->d.v2.n_tiles * WAVE, hipMemcpyDeviceToDevice, c->stream));
+    c->lml_lin_id = c->lsc_lin_id = c->lin_id;
     hipLaunchKernelGGL(lpl_pass<0>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
   } else {
     launch_lm(c, OpLinearize{});
-    c->aux_lin_id = c->lin_id;
+    c->aux_lin_id = c->jls_lin_id = c->lin_id;
     build_views(c);
   }
   if (c->n_cold3 > 0)
@@ -1228,6 +1269,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
     // per-camera sum of the partials and the cold observations (same kernel as the per-term one, output b)
     Dp da = ldsacc_dp(c, true);
     da.prep_lpl_only = 1;
+    ensure_lin_mirrors(c);
     // cam_cold_sum honours the series-done flag of the term loop: clear what an early exit of the last solve left
     HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
     if (c->opt.robust_norm)
@@ -1403,6 +1445,8 @@ int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const doub
     lpl_back = c->use_lpl && c->use_lpl_prepare && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
     if (lpl_back) {
       const Dp da = ldsacc_dp(c, true);
+      ensure_lmx(c);
+      ensure_lin_mirrors(c);
       if (c->opt.robust_norm)
         hipLaunchKernelGGL(backsub_lpl<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), back_lds_bytes(c->v2_max_slots), c->stream, da, c->part.p);
       else
@@ -1418,6 +1462,8 @@ int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const doub
     launch_lm(c, OpBackPoba{});
     hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 2);
   }
+  ++c->lms_ver;
+  if (lpl_back) c->lmx_ver = c->lms_ver;  // backsub_lpl wrote the new landmarks into the lane-ordered mirror too
   if (lpl_back)
     hipLaunchKernelGGL((reduce_partials<1>), dim3(1), dim3(1024), 0, c->stream, c->part.p, c->e0c_grid, c->scal.p);
   else
@@ -1436,6 +1482,7 @@ int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const doub
 int povar_set_landmarks_homogeneous(povar_ctx* c, const double* lms_h) {
   if (int rc = check_ctx(c)) return rc;
   HIP_TRY(hipMemcpyAsync(c->lms4.p, lms_h, sizeof(double) * 4 * c->n_lms, hipMemcpyHostToDevice, c->stream));
+  ++c->lms_ver;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1494,6 +1541,7 @@ int povar_linearize_homogeneous(povar_ctx* c) {
     c->aux_lin_id = c->lin_id;
     build_views(c);
   }
+  c->jls_lin_id = c->lin_id;  // both step-2 kernels write the landmark-order scale themselves
   if (c->n_cold3 > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 1);
   hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
@@ -1567,6 +1615,7 @@ int povar_solve_joint(povar_ctx* c, double lambda, int32_t m, double q_tol, doub
 int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
   if (int rc = check_ctx(c)) return rc;
   if (!c->linearized_h) return fail(-1, "povar_apply_joint before povar_linearize_homogeneous");
+  ++c->lms_ver;
   TimeScope ts(c, 3);
   HIP_TRY(hipMemcpyAsync(c->inc.p, inc, sizeof(double) * 11 * c->n_cams, hipMemcpyHostToDevice, c->stream));
   // cpp:280: back-substitute first (old cameras), then update the cameras (cpp:283-305)
@@ -1600,6 +1649,7 @@ int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
 int povar_normalize_joint(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
   hipLaunchKernelGGL(normalize_joint, dim3(grid_for(std::max(c->n_cams, c->n_lms), 256)), dim3(256), 0, c->stream, c->d);
+  ++c->lms_ver;
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -29,13 +29,6 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
-#ifndef POVAR_EXP
-#define POVAR_EXP 0  // timing-only ablation builds (tools, never shipped): see DESIGN.md experiment log
-#endif
-#ifndef POVAR_LPLX
-#define POVAR_LPLX 0  // e0_lpl ablation mask (timing-only builds): 1 no LDS atomics, 2 no backward record reads,
-                      // 4 no forward record reads (branch-free rows), 8 no cold observations, 16 no tiles at all
-#endif
 #include <stdint.h>
 
 namespace povar {
@@ -61,7 +54,13 @@ constexpr int HOT_ACC_MAX = POVAR_HOT_ACC_MAX;    // camera slots of a workgroup
                                     // + 16 B = 163 600 of the 163 840 bytes; step 1 (176-byte records) 154 768
 constexpr int HOT_MAX = 912;        // cameras cached per workgroup: 912 * 176 B = 156.75 KiB of the 160 KiB LDS
 constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :3] (4.5) + pad
-constexpr int E0C_BLOCK = 1024;     // one workgroup per CU
+#ifndef POVAR_E0C_BLOCK
+#define POVAR_E0C_BLOCK 1024
+#endif
+constexpr int E0C_BLOCK = POVAR_E0C_BLOCK;  // one workgroup per CU
+#ifndef POVAR_NT
+#define POVAR_NT 0  // experiment mask: 1 backward-pass rows non-temporal, 2 landmark records non-temporal
+#endif
 constexpr int E0_SLOT_BYTES = 32;   // e0_lm_cached<true> per-slot stream: uv 16 + meta 4 + cam 4 + lm 4 + cold_pos 4
 constexpr int E0_LMREC_BYTES = 96;  // packed landmark record read by the per-term kernel
 
@@ -95,6 +94,13 @@ struct V2 {
   const int* seg;      // [n_tiles][64] first | last << 8 lane of the landmark a lane belongs to (read for flagged tiles)
   double* lmrec;       // [n_tiles][9][64]: x, y, z, then G = diag(s) Hll^-1 diag(s) (00,01,02,11,12,22)
   const int* lm_of;    // [n_tiles][64] landmark of each lane (-1: unused lane)
+  // lane-ordered mirrors of the per-landmark arrays (Dp::lms4, lms_lin4, jl_scale4 stay the masters, in landmark order):
+  // one coalesced, prefetchable 32-byte load per lane and tile instead of an index load + a 32-byte gather that drags
+  // 64..128-byte lines through the memory system.  lmx follows lms4 (povar_hip.hip: ensure_lmx, rebuilt by lm_to_lanes
+  // when a landmark writer outside these kernels has run), lml / lsc belong to the linearisation.
+  double4* lmx;        // [n_tiles][64] current landmark of each lane
+  double4* lml;        // [n_tiles][64] landmark at the linearisation point
+  double4* lsc;        // [n_tiles][64] Jl column scale
   const int* lm_pos;   // [n_lms] tile * 64 + first lane of each landmark | (lanes - 1) << 26 (-1: no observation)
   const int* of_slot;  // [n_slots] row * 64 + lane of each wave-bin slot (-1: padding)
   // per E0 workgroup (lpl_layout.hpp): its tiles, the cameras it keeps in LDS, where their accumulators are flushed
@@ -1229,9 +1235,6 @@ struct LplCursor {  // wave-uniform (SGPRs)
 template <bool ROBUST>
 __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   const int done = d.flags[1];  // requested first, tested after the LDS staging (no global side effects before)
-#if POVAR_LPLX & 32
-  if (done >= 0) return;
-#endif
   extern __shared__ double2 hot[];  // [n_hot][HOT_REC] records, then acc[12][n_slots], then the tile counter
   const V2& v = d.v2;
   // this workgroup's camera slots: the records of the cameras it keeps in LDS (lpl_layout.hpp) and their accumulators
@@ -1267,9 +1270,6 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   }
   __syncthreads();
   if (done) return;
-#if POVAR_LPLX & 64
-  if (done >= 0) return;
-#endif
   const int lane = threadIdx.x & 63;
   // The workgroup's tiles are sorted longest first; its wavefronts take them on demand (one LDS counter), so a
   // wavefront's last tile is a short one.  The workgroups carry equal observation totals (lpl_layout.hpp).
@@ -1294,11 +1294,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
     fl = tiles[4 * t + 3];
   };
   LplCursor pc;
-#if POVAR_LPLX & 16
-  pc.t = t_end;
-#else
   pc.t = grab();
-#endif
   pc.pass = 0;
   pc.j = 0;
   pc.row0 = 0;
@@ -1318,9 +1314,20 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
     if (pc.t < t_end) {
       // the backward pass walks the rows in reverse: the rows read last are the ones most likely still in L2
       const size_t i = ((size_t)pc.row0 + (pc.pass ? pc.k - 1 - pc.j : pc.j)) * WAVE + lane;
-      r.uv = v.uv[i];
-      r.cw = v.cw[i];
-      if (ROBUST) r.w = v.w[i];
+#if POVAR_NT & 1
+      if (pc.pass) {  // last use of the row: do not keep it in L2
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(v.uv) + i);
+        r.uv = make_double2(t.x, t.y);
+        r.cw = __builtin_nontemporal_load(v.cw + i);
+        if (ROBUST) r.w = __builtin_nontemporal_load(v.w + i);
+      } else
+#endif
+      {
+        r.uv = v.uv[i];
+        r.cw = v.cw[i];
+        if (ROBUST) r.w = v.w[i];
+      }
       if (++pc.j == pc.k) {
         pc.j = 0;
         if (++pc.pass == 2) {
@@ -1344,8 +1351,13 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   double hx = 0, hy = 0, hz = 0, G00 = 0, G01 = 0, G02 = 0, G11 = 0, G12 = 0, G22 = 0;
   if (c_t < t_end) {
     const double* rp = v.lmrec + ((size_t)c_t * 9) * WAVE + lane;
-    hx = rp[0]; hy = rp[WAVE]; hz = rp[2 * WAVE];
-    G00 = rp[3 * WAVE]; G01 = rp[4 * WAVE]; G02 = rp[5 * WAVE]; G11 = rp[6 * WAVE]; G12 = rp[7 * WAVE]; G22 = rp[8 * WAVE];
+#if POVAR_NT & 2
+#define LPL_LD(p) __builtin_nontemporal_load(p)
+#else
+#define LPL_LD(p) (*(p))
+#endif
+    hx = LPL_LD(rp); hy = LPL_LD(rp + WAVE); hz = LPL_LD(rp + 2 * WAVE);
+    G00 = LPL_LD(rp + 3 * WAVE); G01 = LPL_LD(rp + 4 * WAVE); G02 = LPL_LD(rp + 5 * WAVE); G11 = LPL_LD(rp + 6 * WAVE); G12 = LPL_LD(rp + 7 * WAVE); G22 = LPL_LD(rp + 8 * WAVE);
   }
   while (c_t < t_end) {
     double red[3] = {0, 0, 0};
@@ -1359,19 +1371,10 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
       o.set(d, cur.uv, ROBUST ? cur.w : 1.0);
       if (j < c_nh) {  // wave-uniform: every lane has an observation of an LDS-resident camera in this row
         const double2* h = hot + lpl_cw_slot(cur.cw) * HOT_REC;
-#if POVAR_LPLX & 4
-        for (int m = 0; m < 12; ++m) zz[m] = cur.uv.x + m;
-        for (int m = 0; m < 9; ++m) P3[m] = cur.uv.y + m + (double)(size_t)h;
-#else
         lpl_read_zz(h, zz);
         lpl_read_p3(h, P3);
-#endif
         lpl_forward(o, zz, P3, hx, hy, hz, red);
-#if POVAR_LPLX & 8
-      } else if (cur.cw >= 0) {
-#else
       } else if (cur.cw != -1) {
-#endif
         if (cur.cw >= 0) {
           const double2* h = hot + lpl_cw_slot(cur.cw) * HOT_REC;
           lpl_read_zz(h, zz);
@@ -1395,8 +1398,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
     double nhx = 0, nhy = 0, nhz = 0;
     if (n_t < t_end) {
       const double* rp = v.lmrec + ((size_t)n_t * 9) * WAVE + lane;
-      nhx = rp[0]; nhy = rp[WAVE]; nhz = rp[2 * WAVE];
-      G00 = rp[3 * WAVE]; G01 = rp[4 * WAVE]; G02 = rp[5 * WAVE]; G11 = rp[6 * WAVE]; G12 = rp[7 * WAVE]; G22 = rp[8 * WAVE];
+      nhx = LPL_LD(rp); nhy = LPL_LD(rp + WAVE); nhz = LPL_LD(rp + 2 * WAVE);
+      G00 = LPL_LD(rp + 3 * WAVE); G01 = LPL_LD(rp + 4 * WAVE); G02 = LPL_LD(rp + 5 * WAVE); G11 = LPL_LD(rp + 6 * WAVE); G12 = LPL_LD(rp + 7 * WAVE); G22 = LPL_LD(rp + 8 * WAVE);
+#undef LPL_LD
     }
     const size_t base = (size_t)c_row0 * WAVE + lane;
     for (int jj = 0; jj < c_k; ++jj) {
@@ -1408,34 +1412,16 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
       double P3[9], q[3];
       LplObs o;
       o.set(d, cur.uv, ROBUST ? cur.w : 1.0);
-#if POVAR_LPLX & 8
-      if (j < c_nh) {
-#else
       if (j < c_nh || cur.cw >= 0) {
-#endif
-#if POVAR_LPLX & 2
-        for (int m = 0; m < 9; ++m) P3[m] = cur.uv.y + m;
-#else
         lpl_read_p3(hot + lpl_cw_slot(cur.cw) * HOT_REC, P3);
-#endif
         lpl_backward(o, P3, g, q);
         double* a = acc + lpl_acc_slot(cur.cw, hubs);  // acc[m][slot]: consecutive slots on consecutive banks
         const double val[12] = {hx * q[0], hy * q[0], hz * q[0], q[0], hx * q[1], hy * q[1],
                                 hz * q[1], q[1], hx * q[2], hy * q[2], hz * q[2], q[2]};
-#if POVAR_LPLX & 1
-        double sacc = 0;
-        for (int m = 0; m < 12; ++m) sacc += val[m];
-        if (sacc == 1.2345e-300) a[0] = sacc;
-#else
 #pragma unroll
         for (int m = 0; m < 12; ++m)
           __hip_atomic_fetch_add(a + m * n_slots, val[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-#if POVAR_LPLX & 8
-      } else if (false) {
-#else
       } else if (cur.cw < -1) {
-#endif
         // the position of q in the cold view is requested together with the record: one round trip, not two
         const int cold_at = v.cpos[base + (size_t)j * WAVE];
         lpl_read_p3(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2), P3);
@@ -1607,7 +1593,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
     // the lane's landmark: coordinates and Jl column scale (gathers; once per tile)
     const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
     const int sg = v.seg[(size_t)c_t * WAVE + lane];
-    const double4 h4 = d.lms_lin4[lm >= 0 ? lm : 0], s4 = d.jl_scale4[lm >= 0 ? lm : 0];
+    const double4 h4 = v.lml[(size_t)c_t * WAVE + lane], s4 = v.lsc[(size_t)c_t * WAVE + lane];
     const double hx = h4.x, hy = h4.y, hz = h4.z;
     double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < c_k; ++j) {
@@ -1823,7 +1809,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
   while (c_t < t_end) {
     const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
     const int sg = v.seg[(size_t)c_t * WAVE + lane];
-    const double4 h = d.lms4[lm >= 0 ? lm : 0], hl = d.lms_lin4[lm >= 0 ? lm : 0], s4 = d.jl_scale4[lm >= 0 ? lm : 0];
+    const size_t li = (size_t)c_t * WAVE + lane;
+    const double4 h = v.lmx[li], hl = v.lml[li], s4 = v.lsc[li];
     double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < c_k; ++j) {
       const LplRow cur = n1;
@@ -1859,7 +1846,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
       dl[0] = -(Hi[0] * red[6] + Hi[1] * red[7] + Hi[2] * red[8]);
       dl[1] = -(Hi[3] * red[6] + Hi[4] * red[7] + Hi[5] * red[8]);
       dl[2] = -(Hi[6] * red[6] + Hi[7] * red[7] + Hi[8] * red[8]);
-      if (lane == (sg & 255)) d.lms4[lm] = make_double4(h.x + dl[0], h.y + dl[1], h.z + dl[2], h.w);
+      const double4 hn = make_double4(h.x + dl[0], h.y + dl[1], h.z + dl[2], h.w);
+      v.lmx[li] = hn;  // the mirror stays current: no rebuild after an accepted step
+      if (lane == (sg & 255)) d.lms4[lm] = hn;
     }
     for (int jj = 0; jj < c_k; ++jj) {
       const LplRow cur = n1;
@@ -1913,7 +1902,6 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
   __shared__ double sh[3 * (E0C_BLOCK / 64)];
   const V2& v = d.v2;
   const double4* cams = MODE == 0 ? d.cams_lin4 : d.cams4;
-  const double4* lms = MODE == 0 ? d.lms_lin4 : d.lms4;
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
   int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * PASS_STRIDE);
@@ -1964,8 +1952,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
   int bad = 0;
   while (c_t < t_end) {
     const int c_row0 = tiles[4 * c_t], c_k = tiles[4 * c_t + 1], c_fl = tiles[4 * c_t + 3];
-    const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
-    const double4 h = lms[lm >= 0 ? lm : 0];
+    const double4 h = (MODE == 0 ? v.lml : v.lmx)[(size_t)c_t * WAVE + lane];
     double red[3] = {0, 0, 0};
     for (int j = 0; j < c_k; ++j) {
       const LplRow cur = n1;
@@ -2008,10 +1995,12 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
     if (MODE == 0) {
       const int sg = v.seg[(size_t)c_t * WAVE + lane];
       if (c_fl & 1) seg_reduce_steps<3>(red, lane, sg & 255, (sg >> 8) & 255, 4);
-      if (lm >= 0 && lane == (sg & 255))
-        d.jl_scale4[lm] = d.scale_jl ? make_double4(1.0 / (d.eps + sqrt(red[0])), 1.0 / (d.eps + sqrt(red[1])),
+      const double4 sc4 = d.scale_jl ? make_double4(1.0 / (d.eps + sqrt(red[0])), 1.0 / (d.eps + sqrt(red[1])),
                                                     1.0 / (d.eps + sqrt(red[2])), 0.0)
                                      : make_double4(1.0, 1.0, 1.0, 0.0);
+      // every lane of the landmark holds the segment total.  The landmark-order copy (Dp::jl_scale4) is not written
+      // here: lanes_to_lm fills it when a lane-per-observation kernel or an export asks (povar_hip.hip: ensure_legacy)
+      v.lsc[(size_t)c_t * WAVE + lane] = sc4;
     }
     c_t = q1;
     q1 = q2;
@@ -2768,9 +2757,6 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
   }
   if (done) return;
   constexpr int U = 4;
-#if POVAR_EXP == 22
-  if (false)
-#endif
   for (int pb = p0 + t; pb < p1; pb += U * 256) {
     double hx[U], hy[U], hz[U];
     double4 q[U];
@@ -2791,9 +2777,6 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
       acc[8] += hx[u] * q[u].z; acc[9] += hy[u] * q[u].z; acc[10] += hz[u] * q[u].z; acc[11] += q[u].z;
     }
   }
-#if POVAR_EXP == 21
-  if (false)
-#endif
   if (d.part_range) {  // e0_lpl: the camera's partial records are one contiguous run
     const int2 rr = d.part_range[c];
     for (int w = rr.x + t; w < rr.y; w += 256) {
@@ -2973,6 +2956,20 @@ __global__ __launch_bounds__(256) void cam_apply_inc(Dp d, int mode) {
   }
 }
 
+// lane-ordered mirror of a per-landmark array (V2::lmx / lml / lsc): out[tile][lane] = in[landmark of the lane]
+__global__ __launch_bounds__(256) void lm_to_lanes(const int* lm_of, const double4* in, double4* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int lm = lm_of[i];
+  out[i] = lm >= 0 ? in[lm] : make_double4(0, 0, 0, 0);
+}
+// and back: the landmark-order master of a lane-ordered array (first lane of each landmark)
+__global__ __launch_bounds__(256) void lanes_to_lm(const int* lm_of, const int* seg, const double4* in, double4* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int lm = lm_of[i];
+  if (lm >= 0 && (int)(i & 63) == (seg[i] & 255)) out[lm] = in[i];
+}
 __global__ __launch_bounds__(256) void lms3_to_4(const double* in, double4* out, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = make_double4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 1.0);
