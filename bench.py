@@ -565,6 +565,9 @@ def main():
     out["config"]["e0_layout"] = {"workgroups": li.grid, "lds_camera_slots": li.lds_slots, "global_cameras": li.n_global,
                                   "grid_cameras": li.n_tail, "rows": li.n_rows, "tiles": li.n_tiles,
                                   "lds_resident_obs_frac": 1.0 - li.n_cold / max(li.n_obs, 1),
+                                  "assignment": "contiguous landmark ranges, per-workgroup camera sets" if li.strategy else
+                                  "rank-based camera grid",
+                                  "layout_build_ms": li.create_ms,
                                   "term_kernels": "lane per landmark" if li.lane_per_landmark else
                                   "lane per observation (round-1 kernels: under 65 536 observations or POVAR_E0_V1=1)"}
     if not bal_path and (args.popularity != "zipf1" or args.long_track_frac > 0):

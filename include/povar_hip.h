@@ -249,6 +249,10 @@ typedef struct {
   double create_ms;     /* host wall time of povar_create: layout construction + uploads (the reference's counterpart,
                            allocating the landmark blocks, sc/linearization_varproj.hpp:44-60, is part of its
                            preprocessor_time_in_seconds too, bal_bundle_adjustment.cpp:260-286) */
+  int32_t strategy;     /* landmark -> workgroup assignment the layout chose: 0 rank-based camera grid (graphs without
+                           locality), 1 contiguous landmark ranges with per-workgroup camera sets (the file's landmark
+                           order carries the locality, as for the reference: bal/bal_problem.cpp:183-303) */
+  int32_t hubs;         /* camera slots per workgroup with four accumulator replicas */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 

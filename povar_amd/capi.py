@@ -46,7 +46,7 @@ class ProfileInfo(C.Structure):
 class LayoutInfo(C.Structure):
     _fields_ = [("grid", C.c_int32), ("lds_slots", C.c_int32), ("n_global", C.c_int32), ("n_tail", C.c_int32),
                 ("n_tiles", C.c_int64), ("n_rows", C.c_int64), ("n_cold", C.c_int64), ("n_obs", C.c_int64), ("lane_per_landmark", C.c_int64),
-                ("create_ms", C.c_double)]
+                ("create_ms", C.c_double), ("strategy", C.c_int32), ("hubs", C.c_int32)]
 
 
 class TimingsInfo(C.Structure):

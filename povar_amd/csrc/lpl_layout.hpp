@@ -46,6 +46,8 @@ struct LplLayout {
   std::vector<int2> cold_range;  // [n_cams] run of each camera in the cold view
   int64_t rows = 0;
   int n_part_rec = 0, max_slots = 0, n_global = 0, n_tail = 0, grid_a = 1, grid_b = 1;
+  int hubs = 0;      // leading slots of every workgroup with four accumulator replicas (V2::hubs)
+  int strategy = 0;  // 0: rank-based camera grid, 1: contiguous landmark ranges with per-workgroup camera sets
 };
 
 // CPUs this process may actually use: the hardware threads, cut by the cgroup CPU quota when there is one (a container
@@ -222,6 +224,63 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       Tn = std::min((int)std::max(0.0, (n_acc - G - A - 2) / (1.0 / A + 1.0 / B)), n_cams - G);
     }
   }
+  // ---- the alternative for graphs with locality: contiguous landmark ranges, each workgroup keeping the cameras ITS
+  // landmarks observe most.  The reference gets its locality from the landmark order of the file
+  // (bal/bal_problem.cpp:183-303); in a real reconstruction neighbouring landmarks share cameras, so a range of
+  // 1 / grid of the landmarks touches a few hundred cameras and nearly all of its observations become LDS-resident,
+  // whatever the global popularity law.  On a graph WITHOUT locality (the SURVEY 8(d) Zipf workload: every landmark
+  // samples the whole camera set) a range sees every camera and the rank-based grid above covers more.  Both covers
+  // are counted and the better one is taken (POVAR_LPL_STRATEGY=grid|range forces one).
+  std::vector<int> range_lm(grid + 1, n_lms);
+  range_lm[0] = 0;
+  for (int w = 1; w < grid; ++w)
+    range_lm[w] = (int)(std::upper_bound(lm_off, lm_off + n_lms + 1, (int32_t)(n_obs_all * w / grid)) - lm_off) - 1;
+  for (int w = 1; w <= grid; ++w) range_lm[w] = std::max(range_lm[w], range_lm[w - 1]);
+  const int hubs_r = lpl_hubs(std::min(n_cams, n_acc));
+  std::vector<std::vector<int>> range_set(grid);   // resident ranks of workgroup w, ascending (range strategy)
+  std::vector<std::vector<int>> range_hubs(grid);  // its hubs_r most observed ones: the slots with accumulator replicas
+  bool use_range = false;
+  if (n_cams > n_acc) {
+    std::vector<int64_t> cov(grid, 0);
+    lpl_parallel(grid, n_threads, [&](int w) {
+      std::vector<int> cnt(n_cams, 0);
+      for (int64_t i = lm_off[range_lm[w]]; i < lm_off[range_lm[w + 1]]; ++i) cnt[rank1[cam_idx[i]] - 1]++;
+      std::vector<int> cand;
+      for (int r0 = 0; r0 < n_cams; ++r0)
+        if (cnt[r0] > 0) cand.push_back(r0);
+      const size_t keep = std::min(cand.size(), (size_t)n_acc);
+      std::partial_sort(cand.begin(), cand.begin() + keep, cand.end(),
+                        [&](int a, int b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+      cand.resize(keep);
+      int64_t c = 0;
+      for (int r0 : cand) c += cnt[r0];
+      range_hubs[w].assign(cand.begin(), cand.begin() + std::min(cand.size(), (size_t)hubs_r));
+      // a workgroup with fewer cameras than hub slots fills them with unused ranks (the slots must exist)
+      for (int r0 = 0; (int)range_hubs[w].size() < hubs_r && r0 < n_cams; ++r0)
+        if (std::find(cand.begin(), cand.end(), r0) == cand.end() && (int)cand.size() < n_acc) {
+          range_hubs[w].push_back(r0);
+          cand.push_back(r0);
+        }
+      std::sort(cand.begin(), cand.end());
+      range_set[w] = cand;
+      cov[w] = c;
+    });
+    int64_t cov_range = 0;
+    for (int w = 0; w < grid; ++w) cov_range += cov[w];
+    // the grid's cover: global cameras, and the first two grid observations of a landmark (counted below exactly by
+    // the assignment; here the same estimate that chose (G, Tn))
+    const double cov_grid = (double)S[G] + 0.85 * (double)(S[G + Tn] - S[G]);
+    use_range = (double)cov_range > cov_grid;
+    if (const char* e = std::getenv("POVAR_LPL_STRATEGY")) use_range = e[0] == 'r';
+    if (timing) std::fprintf(stderr, "[build_lpl] cover: ranges %.4f, grid (estimate) %.4f -> %s\n", (double)cov_range / n_obs_all,
+                             cov_grid / n_obs_all, use_range ? "ranges" : "grid");
+  }
+  if (use_range) {
+    G = 0;  // nothing is resident everywhere: every workgroup has its own camera set, hubs included
+    Tn = 0;
+  }
+  L.strategy = use_range ? 1 : 0;
+  L.hubs = use_range ? hubs_r : lpl_hubs(G);
   L.n_global = G;
   L.n_tail = Tn;
   L.grid_a = A;
@@ -239,13 +298,19 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   };
   auto resident = [&](int w, int r0) {
     if (r0 < G) return true;
+    if (use_range) return std::binary_search(range_set[w].begin(), range_set[w].end(), r0);
     return tx[r0] >= 0 && (tx[r0] == w % A || ty[r0] == w / A);
   };
   lap("grid choice");
   // ---- landmark -> workgroup
   std::vector<int> wg_of(n_lms, -1);
   std::vector<int64_t> load(grid, 0);
-  {
+  if (use_range) {
+    lpl_parallel(grid, n_threads, [&](int w) {
+      for (int l = range_lm[w]; l < range_lm[w + 1]; ++l)
+        if (lm_off[l + 1] > lm_off[l]) wg_of[l] = w;
+    });
+  } else {
     std::vector<int> n_tail_of(n_lms, 0), order;
     lpl_parallel(n_chunks, n_threads, [&](int q) {
       for (int l = chunk_lm[q]; l < chunk_lm[q + 1]; ++l) {
@@ -381,14 +446,21 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       // slots: the replicated hub cameras always (fixed slots 0..hubs-1), then only the resident cameras this
       // workgroup's landmarks actually observe, in rank order (a small shard touches far fewer than G + its grid
       // cameras: fewer records to stage, fewer partial records to flush and to sum)
-      const int hubs_w = lpl_hubs(G);
+      const int hubs_w = L.hubs;
       std::vector<long> wcnt(n_cams, 0);  // this workgroup's observations per camera (by rank)
       for (int l : lms_of[w])
         for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) wcnt[rank1[cam_idx[i]] - 1]++;
+      // hub slots: the cameras with four accumulator replicas -- the most observed ones overall (grid strategy: the
+      // same in every workgroup) or of this workgroup (range strategy)
+      std::vector<int> hub_cams;
+      if (use_range) hub_cams = range_hubs[w];
+      else for (int r0 = 0; r0 < hubs_w; ++r0) hub_cams.push_back(r0);
+      std::vector<char> is_hub(n_cams, 0);
+      for (int r0 : hub_cams) is_hub[r0] = 1;
       std::vector<int> used;
-      for (int r0 = hubs_w; r0 < n_cams; ++r0)
-        if (wcnt[r0] > 0 && resident(w, r0)) used.push_back(r0);
-      for (int r0 = 0; r0 < hubs_w; ++r0) o.cams.push_back(r0);
+      for (int r0 = 0; r0 < n_cams; ++r0)
+        if (!is_hub[r0] && wcnt[r0] > 0 && resident(w, r0)) used.push_back(r0);
+      for (int r0 : hub_cams) o.cams.push_back(r0);
       // Which slot a camera gets decides its LDS bank (accumulators: (slot + 3 hubs) mod 32, records: slot mod 16).
       // In rank order the popular cameras pile up on the low banks and force collisions no row placement can avoid
       // (a bank hit by more observations than the tile has rows must repeat inside a row).  So the cameras are dealt
@@ -397,8 +469,8 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       {
         const int n_rest = (int)used.size(), n_w_ = hubs_w + n_rest;
         std::vector<double> load(32, 0.0);
-        for (int r0 = 0; r0 < hubs_w; ++r0)
-          for (int q = 0; q < 4; ++q) load[(4 * r0 + q) & 31] += 0.25 * (double)wcnt[r0];
+        for (int hs = 0; hs < hubs_w; ++hs)
+          for (int q = 0; q < 4; ++q) load[(4 * hs + q) & 31] += 0.25 * (double)wcnt[hub_cams[hs]];
         std::vector<std::vector<int>> free_slots(32);  // by accumulator bank, ascending
         for (int sl = n_w_ - 1; sl >= hubs_w; --sl) free_slots[(sl + 3 * hubs_w) & 31].push_back(sl);
         std::vector<int> by_weight(used);
@@ -509,7 +581,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     const int g = (l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 1;
     return g + 2 * (lane >> 5);
   };
-  const int hubs = lpl_hubs(G);
+  const int hubs = L.hubs;
   const bool no_place = std::getenv("POVAR_LPL_NOPLACE") != nullptr;  // measurement knob: natural order
   int max_tiles_tried = 1 << 30;
   if (const char* e = std::getenv("POVAR_LPL_TILES_TRIED")) max_tiles_tried = std::max(1, std::atoi(e));

@@ -104,7 +104,7 @@ struct povar_ctx {
   DevBuf<int2> v2_part_range, c3_range;
   DevBuf<double> c3_h, v2_part;
   int64_t n_cold3 = 0;
-  int v2_max_slots = 0, v2_n_global = 0, v2_n_tail = 0;
+  int v2_max_slots = 0, v2_n_global = 0, v2_n_tail = 0, v2_strategy = 0;
   DevBuf<int4> v2_tile;
   DevBuf<double> v2_w, v2_lmrec;
   int64_t v2_rows = 0;
@@ -982,6 +982,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     c->v2_rows = V.rows;
     c->v2_max_slots = V.max_slots;
     c->v2_n_global = V.n_global;
+    c->v2_strategy = V.strategy;
     c->v2_n_tail = V.n_tail;
     c->n_cold3 = (int64_t)V.cold_lm.size();
     if (int rc = upload(c->v2_uv, V.uv, c)) { povar_destroy(c); return rc; }
@@ -1011,7 +1012,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     HIP_TRY_C(c->q4c.alloc(std::max<size_t>(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), V.cold_lm.size()), 1), &c->bytes));
     c->d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
                  c->v2_lm_of.p, c->v2_lmx.p, c->v2_lml.p, c->v2_lsc.p, c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
-                 c->v2_wg_slot_rec.p, nt, lpl_hubs(V.n_global)};
+                 c->v2_wg_slot_rec.p, nt, V.hubs};
   }
   lap("uploads (lane/landmark)");
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
@@ -1867,6 +1868,8 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->n_obs = c->n_obs;
   out->lane_per_landmark = c->use_lpl ? 1 : 0;
   out->create_ms = c->create_ms;
+  out->strategy = c->v2_strategy;
+  out->hubs = c->d.v2.hubs;
   return 0;
 }
 

@@ -64,7 +64,51 @@ def _degrees(rng, n_cams, n_lms, n_obs):
     return k
 
 
-POPULARITY = {"zipf1": 1.0, "zipf0.5": 0.5, "uniform": 0.0}
+POPULARITY = {"zipf1": 1.0, "zipf0.5": 0.5, "uniform": 0.0, "local": None}
+
+
+def _sample_cameras_local(rng, n_cams, lm_off, hub_frac=0.1):
+    """A graph with the locality of a real reconstruction (the "local" sensitivity variant): the cameras sit on a ring
+    (a trajectory), landmark l is seen from around position l / n_lms of it -- so neighbouring landmarks of the file
+    share cameras, as they do in the BAL files (bal_problem.cpp:183-303 keeps the file's landmark order) -- by cameras
+    at two-sided geometric (Laplace) offsets of scale 24 positions -- how many cameras see one region of a scene does
+    not grow with the size of the collection --, and `hub_frac` of the observations go to Zipf(1) hub cameras anywhere
+    on the ring."""
+    n_obs = int(lm_off[-1])
+    n_lms = lm_off.shape[0] - 1
+    lm_of = np.repeat(np.arange(n_lms, dtype=np.int64), np.diff(lm_off))
+    centre = (lm_of * n_cams) // n_lms
+    scale = min(24.0, max(2.0, n_cams / 8.0))
+    w = 1.0 / np.arange(1, n_cams + 1)
+    cdf = np.cumsum(w / w.sum())
+    cdf[-1] = 1.0
+    perm = rng.permutation(n_cams)
+
+    def draw(idx):
+        off = np.rint(rng.laplace(scale=scale, size=idx.shape[0])).astype(np.int64)
+        c = (centre[idx] + off) % n_cams
+        hub = rng.random(idx.shape[0]) < hub_frac
+        c[hub] = perm[np.searchsorted(cdf, rng.random(int(hub.sum())), side="right")]
+        return c
+
+    cam = draw(np.arange(n_obs))
+    active = np.arange(n_obs)
+    while True:
+        key = lm_of[active] * n_cams + cam[active]
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        dup = np.zeros(active.shape[0], dtype=bool)
+        dup[order[1:]] = ks[1:] == ks[:-1]
+        if not dup.any():
+            break
+        bad_lm = np.unique(lm_of[active[dup]])
+        redraw = active[dup]
+        cam[redraw] = draw(redraw)
+        mask = np.zeros(n_lms, dtype=bool)
+        mask[bad_lm] = True
+        active = active[mask[lm_of[active]]]
+    order = np.lexsort((cam, lm_of))
+    return cam[order].astype(np.int32)
 
 
 def _sample_cameras(rng, n_cams, lm_off, zipf_s=1.0):
@@ -101,7 +145,8 @@ def _sample_cameras(rng, n_cams, lm_off, zipf_s=1.0):
 
 def make_problem(n_cams, n_lms, n_obs, seed=0, noise_px=0.5, popularity="zipf1", long_track_frac=0.0,
                  init="random", init_noise=0.0) -> Problem:
-    """popularity: camera popularity law of the graph ("zipf1" = SURVEY 8(d), "zipf0.5", "uniform").
+    """popularity: camera popularity law of the graph ("zipf1" = SURVEY 8(d), "zipf0.5", "uniform"; "local" = cameras
+    on a ring, landmarks seen by neighbouring cameras, 10 % hub observations: the locality of a real reconstruction).
     init: "random" = the reference's --create-dataset cameras (rows 0-1 ~ N(0,1), row 2 = [0 0 0 1]); "gt" = the
     ground-truth projection matrices K[R|t], each divided by its mean depth (the pOSE affine term wants P_2 X ~ 1)
     and perturbed entrywise by a relative N(0, init_noise^2) -- a start inside the basin of both steps, used by the
@@ -128,7 +173,8 @@ def make_problem(n_cams, n_lms, n_obs, seed=0, noise_px=0.5, popularity="zipf1",
         rng.shuffle(k)
     lm_off = np.zeros(n_lms + 1, dtype=np.int64)
     np.cumsum(k, out=lm_off[1:])
-    cam_idx = _sample_cameras(rng, n_cams, lm_off, POPULARITY[popularity])
+    cam_idx = _sample_cameras_local(rng, n_cams, lm_off) if popularity == "local" else \
+        _sample_cameras(rng, n_cams, lm_off, POPULARITY[popularity])
     lm_of = np.repeat(np.arange(n_lms), k)
 
     # ground truth: points in a unit cube, cameras 5-15 units away looking at it

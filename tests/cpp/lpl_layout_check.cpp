@@ -129,7 +129,7 @@ int main(int argc, char** argv) {
   // cycles on each of the 12 ds_add_f64) and extra records per bank quad per ds_read_b128 lane group
   double extra_a = 0, extra_r = 0;
   {
-    const int hubs = lpl_hubs(L.n_global);
+    const int hubs = L.hubs;
     auto read_group = [](int lane) {
       const int l = lane & 31;
       const int g = (l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 1;
@@ -210,6 +210,7 @@ int main(int argc, char** argv) {
   mix(L.wg_slot_rec.data(), L.wg_slot_rec.size() * sizeof(int)); mix(L.cold_lm.data(), L.cold_lm.size() * sizeof(int));
   mix(L.of_slot.data(), L.of_slot.size() * sizeof(int));
   std::printf("{\"fingerprint\": \"%016llx\", ", fp);
+  std::printf("\"strategy\": \"%s\", \"hubs\": %d, ", L.strategy ? "ranges" : "grid", L.hubs);
   std::printf("\"ok\": 1, \"n_global\": %d, \"n_tail\": %d, \"grid\": [%d, %d], \"max_slots\": %d, \"rows\": %lld, "
               "\"tiles\": %zu, \"cold\": %lld, \"cold_frac\": %.5f, \"pad_frac\": %.5f, \"wg_rows_min\": %lld, "
               "\"wg_rows_max\": %lld, \"part_recs\": %d, \"extra_atomic_lanes_per_half\": %.3f, \"extra_records_per_read_group\": %.3f}\n",

@@ -68,3 +68,20 @@ def test_layout_does_not_depend_on_the_thread_count(tmp_path):
     fps = {t: _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 64, 120, env={"POVAR_LAYOUT_THREADS": str(t)})["fingerprint"]
            for t in (1, 3, 8)}
     assert len(set(fps.values())) == 1, fps
+
+
+def test_layout_strategy_follows_the_graph(tmp_path):
+    """A graph with locality (cameras on a ring, landmarks seen by neighbouring cameras, file order = position) gets
+    contiguous landmark ranges with per-workgroup camera sets and is almost entirely LDS-resident; the SURVEY 8(d) Zipf
+    graph (no locality) keeps the rank-based camera grid.  Both strategies satisfy every layout invariant on both."""
+    from povar_amd import synth
+    loc = synth.make_problem(1200, 60000, 300000, seed=11, popularity="local")
+    zipf = synth.make_problem(1200, 60000, 300000, seed=11)
+    a = _run(tmp_path, loc.n_cams, loc.lm_off, loc.cam_idx, loc.obs, 64, 200)
+    assert a["ok"] == 1 and a["strategy"] == "ranges" and a["cold_frac"] < 0.05
+    g = _run(tmp_path, loc.n_cams, loc.lm_off, loc.cam_idx, loc.obs, 64, 200, env={"POVAR_LPL_STRATEGY": "grid"})
+    assert g["ok"] == 1 and g["strategy"] == "grid" and g["cold_frac"] > 2 * a["cold_frac"]
+    z = _run(tmp_path, zipf.n_cams, zipf.lm_off, zipf.cam_idx, zipf.obs, 64, 200)
+    assert z["ok"] == 1 and z["strategy"] == "grid"
+    zr = _run(tmp_path, zipf.n_cams, zipf.lm_off, zipf.cam_idx, zipf.obs, 64, 200, env={"POVAR_LPL_STRATEGY": "range"})
+    assert zr["ok"] == 1 and zr["strategy"] == "ranges" and zr["cold_frac"] > z["cold_frac"]

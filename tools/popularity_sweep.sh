@@ -4,7 +4,7 @@
 out=${1:-gpurun_out/popularity}
 mkdir -p $out
 cd "$(dirname "$0")/.." || exit 1
-for v in "zipf1 0" "zipf0.5 0" "uniform 0" "zipf1 0.1" "zipf1 0.25" "zipf0.5 0.1"; do
+for v in "zipf1 0" "zipf0.5 0" "uniform 0" "local 0" "zipf1 0.1" "zipf1 0.25" "zipf0.5 0.1"; do
   set -- $v
   python3 bench.py --no-cpu-baseline --no-secondary --steps 10 --popularity $1 --long-track-frac $2 > $out/pop_$1_$2.json 2> $out/pop_$1_$2.err
   python3 - <<PY
