@@ -78,7 +78,7 @@ def test_layout_strategy_follows_the_graph(tmp_path):
     loc = synth.make_problem(1200, 60000, 300000, seed=11, popularity="local")
     zipf = synth.make_problem(1200, 60000, 300000, seed=11)
     a = _run(tmp_path, loc.n_cams, loc.lm_off, loc.cam_idx, loc.obs, 64, 200)
-    assert a["ok"] == 1 and a["strategy"] == "ranges" and a["cold_frac"] < 0.05
+    assert a["ok"] == 1 and a["strategy"] == "ranges" and a["cold_frac"] < 0.10
     g = _run(tmp_path, loc.n_cams, loc.lm_off, loc.cam_idx, loc.obs, 64, 200, env={"POVAR_LPL_STRATEGY": "grid"})
     assert g["ok"] == 1 and g["strategy"] == "grid" and g["cold_frac"] > 2 * a["cold_frac"]
     z = _run(tmp_path, zipf.n_cams, zipf.lm_off, zipf.cam_idx, zipf.obs, 64, 200)
