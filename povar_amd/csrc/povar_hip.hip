@@ -1504,6 +1504,7 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
   TimeScope ts(c, 4);
   HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
   if (c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
+    ensure_lmx(c);
     hipLaunchKernelGGL(lpl_pass_h<1>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
     hipLaunchKernelGGL((reduce_partials<6>), dim3(1), dim3(1024), 0, c->stream, c->part.p, c->e0c_grid, c->scal.p);
   } else {
@@ -1536,13 +1537,15 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   c->linearized_h = true;
   const bool lazy = lpl_only(c);
   if (lazy) {
+    ensure_lmx(c);
+    HIP_TRY(hipMemcpyAsync(c->v2_lml.p, c->v2_lmx.p, sizeof(double4) * (size_t)c->d.v2.n_tiles * WAVE, hipMemcpyDeviceToDevice, c->stream));
+    c->lml_lin_id = c->lsc_lin_id = c->lin_id;  // the kernel writes the scale mirror; jl_scale4 follows on demand
     hipLaunchKernelGGL(lpl_pass_h<0>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
   } else {
     launch_lm(c, OpLinearizeH{});
-    c->aux_lin_id = c->lin_id;
+    c->aux_lin_id = c->jls_lin_id = c->lin_id;
     build_views(c);
   }
-  c->jls_lin_id = c->lin_id;  // both step-2 kernels write the landmark-order scale themselves
   if (c->n_cold3 > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 1);
   hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
@@ -1577,6 +1580,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
     // partials and the cold observations into the ambient 12-vector, then the tangent projection N_c^T
     Dp da = ldsacc_dp(c, true);
     da.prep_lpl_only = 1;
+    ensure_lin_mirrors(c);
     HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
     if (c->opt.robust_norm)
       hipLaunchKernelGGL(prepare_lpl_h<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), prep_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
@@ -1616,7 +1620,6 @@ int povar_solve_joint(povar_ctx* c, double lambda, int32_t m, double q_tol, doub
 int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
   if (int rc = check_ctx(c)) return rc;
   if (!c->linearized_h) return fail(-1, "povar_apply_joint before povar_linearize_homogeneous");
-  ++c->lms_ver;
   TimeScope ts(c, 3);
   HIP_TRY(hipMemcpyAsync(c->inc.p, inc, sizeof(double) * 11 * c->n_cams, hipMemcpyHostToDevice, c->stream));
   // cpp:280: back-substitute first (old cameras), then update the cameras (cpp:283-305)
@@ -1626,6 +1629,8 @@ int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
   hipLaunchKernelGGL(cam_apply_inc_h, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, 1, (const double*)c->ncw.p);
   if (lpl_back) {
     const Dp da = ldsacc_dp(c, true);
+    ensure_lmx(c);
+    ensure_lin_mirrors(c);
     if (c->opt.robust_norm)
       hipLaunchKernelGGL(backsub_lpl_h<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), back_lds_bytes_h(c->v2_max_slots), c->stream, da, c->part.p);
     else
@@ -1634,6 +1639,8 @@ int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
     ensure_legacy(c);
     launch_lm(c, OpBackJoint{});
   }
+  ++c->lms_ver;
+  if (lpl_back) c->lmx_ver = c->lms_ver;  // backsub_lpl_h keeps the lane-ordered mirror current
   hipLaunchKernelGGL(cam_apply_inc_h, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, 2, (const double*)c->ncw.p);
   if (lpl_back)
     hipLaunchKernelGGL((reduce_partials<1>), dim3(1), dim3(1024), 0, c->stream, c->part.p, c->e0c_grid, c->scal.p);

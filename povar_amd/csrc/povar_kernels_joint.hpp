@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
   while (c_t < t_end) {
     const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
     const int sg = v.seg[(size_t)c_t * WAVE + lane];
-    const double4 X = d.lms_lin4[lm >= 0 ? lm : 0], s4 = d.jl_scale4[lm >= 0 ? lm : 0];
+    const double4 X = v.lml[(size_t)c_t * WAVE + lane], s4 = v.lsc[(size_t)c_t * WAVE + lane];  // lane-ordered mirrors (V2)
     double hw[4], hbeta;
     house4(X, hw, hbeta);
     double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1177,7 +1177,6 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
   __shared__ double sh[6 * (E0C_BLOCK / 64)];
   const V2& v = d.v2;
   const double4* cams = MODE == 0 ? d.cams_lin4 : d.cams4;
-  const double4* lms = MODE == 0 ? d.lms_lin4 : d.lms4;
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_hot = v.wg_cam_off[blockIdx.x + 1] - cam0;
   int* grab_ctr = reinterpret_cast<int*>(hot + n_hot * PASS_STRIDE);
@@ -1226,8 +1225,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
   int bad = 0;
   while (c_t < t_end) {
     const int c_row0 = tiles[4 * c_t], c_k = tiles[4 * c_t + 1], c_fl = tiles[4 * c_t + 3];
-    const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
-    const double4 X = lms[lm >= 0 ? lm : 0];
+    const double4 X = (MODE == 0 ? v.lml : v.lmx)[(size_t)c_t * WAVE + lane];
     double red[4] = {0, 0, 0, 0};
     for (int j = 0; j < c_k; ++j) {
       const LplRow cur = n1;
@@ -1264,9 +1262,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
     if (MODE == 0) {
       const int sg = v.seg[(size_t)c_t * WAVE + lane];
       if (c_fl & 1) seg_reduce_steps<4>(red, lane, sg & 255, (sg >> 8) & 255, 4);
-      if (lm >= 0 && lane == (sg & 255))
-        d.jl_scale4[lm] = make_double4(1.0 / (d.eps + sqrt(red[0])), 1.0 / (d.eps + sqrt(red[1])),
-                                       1.0 / (d.eps + sqrt(red[2])), 1.0 / (d.eps + sqrt(red[3])));
+      // lane-ordered; the landmark-order copy (Dp::jl_scale4) is filled on demand (povar_hip.hip: ensure_jl_scale4)
+      v.lsc[(size_t)c_t * WAVE + lane] = make_double4(1.0 / (d.eps + sqrt(red[0])), 1.0 / (d.eps + sqrt(red[1])),
+                                                      1.0 / (d.eps + sqrt(red[2])), 1.0 / (d.eps + sqrt(red[3])));
     }
     c_t = q1;
     q1 = q2;
@@ -1382,7 +1380,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl_h(Dp d, double* part) {
   while (c_t < t_end) {
     const int lm = v.lm_of[(size_t)c_t * WAVE + lane];
     const int sg = v.seg[(size_t)c_t * WAVE + lane];
-    const double4 X = d.lms_lin4[lm >= 0 ? lm : 0], s4 = d.jl_scale4[lm >= 0 ? lm : 0];
+    const double4 X = v.lml[(size_t)c_t * WAVE + lane], s4 = v.lsc[(size_t)c_t * WAVE + lane];  // lane-ordered mirrors (V2)
     double hw[4], hbeta;
     house4(X, hw, hbeta);
     double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1404,11 +1402,10 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl_h(Dp d, double* part) {
     double dp[4] = {0, 0, 0, 0};
     if (lm >= 0) {
       OpBackJoint::delta4(d, X, red, dp);
-      if (lane == (sg & 255)) {
-        double4 Xc = d.lms4[lm];
-        Xc.x += dp[0] * s4.x; Xc.y += dp[1] * s4.y; Xc.z += dp[2] * s4.z; Xc.w += dp[3] * s4.w;
-        d.lms4[lm] = Xc;
-      }
+      double4 Xc = v.lmx[(size_t)c_t * WAVE + lane];
+      Xc.x += dp[0] * s4.x; Xc.y += dp[1] * s4.y; Xc.z += dp[2] * s4.z; Xc.w += dp[3] * s4.w;
+      v.lmx[(size_t)c_t * WAVE + lane] = Xc;  // the mirror stays current
+      if (lane == (sg & 255)) d.lms4[lm] = Xc;
     }
     for (int jj = 0; jj < c_k; ++jj) {
       const LplRow cur = n1;
