@@ -81,11 +81,12 @@ def test_bench_rccl_communicator_in_and_out_of_graph(graph_comm):
     assert np.linalg.norm(inc - inc1) <= 1e-12 * np.linalg.norm(inc1)
 
 
-@pytest.mark.parametrize("problem", ["ladybug-49", "trafalgar-257"])
+@pytest.mark.parametrize("problem", ["ladybug-49", "trafalgar-257", "venice-1778"])
 def test_bench_two_ranks_p2p_exchange(problem):
     """The peer-to-peer term exchange (povar_p2p_attach: push the per-camera partials into every rank's buffer over
     IPC-mapped memory, reduce locally behind epoch tags) with TWO ranks -- on a 1-GPU box both processes share device
-    0, which the kernels do not mind (RCCL does).  Same increment as one rank."""
+    0, which the kernels do not mind (RCCL does).  Same increment as one rank; venice-1778 (shards of 2.5 M observations)
+    is the lane-per-landmark sharded path at BASELINE config 4's size."""
     import numpy as np
     path = os.path.join(ROOT, "gpurun_out", f"inc_p2p_{problem}.npy")
     os.makedirs(os.path.dirname(path), exist_ok=True)
