@@ -31,7 +31,7 @@ def main():
     data = {}
     if os.path.exists(out):
         data = json.load(open(out))
-    problem, mode, world = key.split(":")
+    problem, mode, world = key.split(":")[:3]  # further fields (step2, HUBER, local, ...) only qualify the key
     lm = [k for k in e0 if (("e0_lpl" in k or "e0_lm_cached" in k) if mode != "tiles" else "OpE0Tiles" in k)]
     # camera-major half of E0: cm_scatter (deterministic modes) or cam_cold_sum[_binv] (LDSACC modes; the fused
     # kernel also carries the 2 MB of B^-1 reads of the AXPY)
