@@ -13,6 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "povar_kernels.hpp"
@@ -201,16 +202,25 @@ struct Layout {
   int n_bins = 0;
 };
 
-void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx,
-                  const double* obs, Layout& L) {
+// Temporaries that part A of the layout construction hands to part B.
+struct LayoutTmp {
+  std::vector<int> seg_first, seg_last, rank;
+  std::vector<char> is_long;
+  std::vector<int64_t> cnt;  // prefix sums of the observations per camera
+};
+
+// Part A: what everything else needs first -- the wave-bin slot of every observation, the popularity rank of every
+// camera (the order of the record image, the key of the lane-per-landmark layout) and the camera-major work items.
+void build_layout_a(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx, Layout& L, LayoutTmp& T) {
   const int64_t n_obs = lm_off[n_lms];
   L.slot_of_obs.resize(n_obs);
   // pass 1: assign slots.  Regular landmarks are packed greedily, in order, into 64-lane wave
   // bins that never split a landmark; a landmark with more than 64 observations gets
   // ceil(k/64) bins of its own and is handled by the lm_long driver.
   int bin = 0, fill = 0;
-  std::vector<int> seg_first(n_obs), seg_last(n_obs);
-  std::vector<char> is_long(n_obs, 0);
+  T.seg_first.resize(n_obs);
+  T.seg_last.resize(n_obs);
+  T.is_long.assign(n_obs, 0);
   for (int l = 0; l < n_lms; ++l) {
     const int b = lm_off[l], k = lm_off[l + 1] - b;
     if (k == 0) continue;
@@ -221,7 +231,7 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
       L.long_cnt.push_back(k);
       for (int j = 0; j < k; ++j) {
         L.slot_of_obs[b + j] = bin * WAVE + j;
-        is_long[b + j] = 1;
+        T.is_long[b + j] = 1;
       }
       bin += (k + WAVE - 1) / WAVE;
       continue;
@@ -229,13 +239,48 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
     if (fill + k > WAVE) { ++bin; fill = 0; }
     for (int j = 0; j < k; ++j) {
       L.slot_of_obs[b + j] = bin * WAVE + fill + j;
-      seg_first[b + j] = fill;
-      seg_last[b + j] = fill + k - 1;
+      T.seg_first[b + j] = fill;
+      T.seg_last[b + j] = fill + k - 1;
     }
     fill += k;
   }
   if (fill > 0) ++bin;
   L.n_bins = std::max(bin, 1);
+  std::vector<int64_t>& cnt = T.cnt;
+  cnt.assign(n_cams + 1, 0);
+  for (int64_t i = 0; i < n_obs; ++i) cnt[cam_idx[i] + 1]++;
+  for (int c = 0; c < n_cams; ++c) cnt[c + 1] += cnt[c];
+  // popularity rank of EVERY camera (1-based; ties: lower index): the record image (Dp::hot_rec) is in this order, so
+  // the first n records are the LDS image of a kernel that caches n cameras and colder cameras gather theirs by rank
+  std::vector<int> order(n_cams);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int a, int b) { return cnt[a + 1] - cnt[a] > cnt[b + 1] - cnt[b]; });
+  T.rank.assign(n_cams, 0);
+  L.hot_cams.assign(order.begin(), order.end());
+  for (int r = 0; r < n_cams; ++r) T.rank[order[r]] = r + 1;
+  L.cam_hot = T.rank;
+  // camera-major work items of at most CM_ITEM_MAX observations of one camera
+  L.cam_item_off.assign(n_cams + 1, 0);
+  for (int c = 0; c < n_cams; ++c) {
+    L.cam_item_off[c] = (int)L.item_cam.size();
+    for (int64_t p = cnt[c]; p < cnt[c + 1]; p += CM_ITEM_MAX) {
+      L.item_off.push_back((int)p);
+      L.item_cam.push_back(c);
+    }
+  }
+  L.cam_item_off[n_cams] = (int)L.item_cam.size();
+  L.item_off.push_back((int)n_obs);
+}
+
+// Part B: the arrays of the lane-per-observation kernels (wave-bin slots, camera-major inverse index, cold views).
+// Independent of the lane-per-landmark layout: povar_create builds the two side by side.
+void build_layout_b(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx, const double* obs, Layout& L,
+                    const LayoutTmp& T) {
+  const int64_t n_obs = lm_off[n_lms];
+  const std::vector<int>&seg_first = T.seg_first, &seg_last = T.seg_last, &rank = T.rank;
+  const std::vector<char>& is_long = T.is_long;
+  const std::vector<int64_t>& cnt = T.cnt;
   const size_t n_slots = (size_t)L.n_bins * WAVE;
   L.uv.assign(n_slots, make_double2(0, 0));
   L.cam.assign(n_slots, -1);
@@ -269,11 +314,6 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
     while ((1 << steps) < mx) ++steps;
     for (int l = 0; l < WAVE; ++l) L.meta[(size_t)b * WAVE + l] |= steps << META_STEPS_SHIFT;
   }
-  // pass 2: camera-major inverse index, ascending slot order inside a camera, cut into work
-  // items of at most CM_ITEM_MAX observations of one camera.
-  std::vector<int64_t> cnt(n_cams + 1, 0);
-  for (int64_t i = 0; i < n_obs; ++i) cnt[cam_idx[i] + 1]++;
-  for (int c = 0; c < n_cams; ++c) cnt[c + 1] += cnt[c];
   L.cm_slot.resize(n_obs);
   L.cm_lm.resize(n_obs);
   L.cm_uv.resize(n_obs);
@@ -289,21 +329,10 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
         L.cm_uv[p] = make_double2(obs[2 * (size_t)i], obs[2 * (size_t)i + 1]);
       }
   }
-  // LDS camera cache of e0_lm_cached: the HOT_MAX cameras with most observations (ties: lower index)
   {
-    std::vector<int> order(n_cams);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int a, int b) { return cnt[a + 1] - cnt[a] > cnt[b + 1] - cnt[b]; });
-    // popularity rank of EVERY camera (1-based): the record image (Dp::hot_rec) is in this order, so the first
-    // n records are the LDS image of a kernel that caches n cameras and colder cameras gather theirs by rank
     const int n_hot = std::min(n_cams, HOT_MAX);
-    std::vector<int> rank(n_cams, 0);
-    L.hot_cams.assign(order.begin(), order.end());
-    for (int r = 0; r < n_cams; ++r) rank[order[r]] = r + 1;
     for (size_t s = 0; s < n_slots; ++s)
       if ((L.meta[s] & META_REAL) && rank[L.cam[s]] <= n_hot) L.meta[s] |= rank[L.cam[s]] << META_HOT_SHIFT;
-    L.cam_hot = rank;
     // "cold" camera-major structure for POVAR_E0_IMPLICIT_LDSACC: only the observations whose
     // Jp^T s is NOT accumulated in LDS (camera outside the HOT_ACC_MAX hottest, or a long landmark,
     // which the lm_long driver handles through q4)
@@ -342,18 +371,6 @@ void build_layout(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* c
       }
     }
   }
-  L.cam_item_off.assign(n_cams + 1, 0);
-  L.item_off.clear();
-  L.item_cam.clear();
-  for (int c = 0; c < n_cams; ++c) {
-    L.cam_item_off[c] = (int)L.item_cam.size();
-    for (int64_t p = cnt[c]; p < cnt[c + 1]; p += CM_ITEM_MAX) {
-      L.item_off.push_back((int)p);
-      L.item_cam.push_back(c);
-    }
-  }
-  L.cam_item_off[n_cams] = (int)L.item_cam.size();
-  L.item_off.push_back((int)n_obs);
 }
 
 template <class T>
@@ -849,8 +866,9 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
 
   lap("device, stream");
   Layout L;
-  build_layout(n_cams, n_lms, lm_offsets, cam_idx, obs, L);
-  lap("build_layout (lane/obs)");
+  LayoutTmp LT;
+  build_layout_a(n_cams, n_lms, lm_offsets, cam_idx, L, LT);
+  lap("slots, camera ranks");
   c->n_bins = L.n_bins;
   c->n_slots = L.n_bins * WAVE;
   c->n_items = (int)L.item_cam.size();
@@ -858,6 +876,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   c->n_reg_blocks = grid_for(c->n_slots, LM_BLOCK);
   c->n_cam_blocks = grid_for(n_cams, K9_CAMS);
   c->slot_of_obs = L.slot_of_obs;
+  c->n_hot_acc = hot_acc_cap(n_cams);
   {
     // one 1024-thread workgroup per CU for the LDS-cached E0 kernel
     hipDeviceProp_t prop;
@@ -909,6 +928,58 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
   }
 
+  // The arrays of the lane-per-observation kernels (part B) are built on a second host thread while this one builds
+  // and uploads the lane-per-landmark layout: the two only share the slot numbers and camera ranks of part A.
+  std::thread part_b([&]() { build_layout_b(n_cams, n_lms, lm_offsets, cam_idx, obs, L, LT); });
+  struct Joiner {  // every early return below must wait for the thread
+    std::thread& t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } joiner{part_b};
+  size_t n_cold_lpl = 0;
+  {
+    // lane-per-landmark layout of e0_lpl (lpl_layout.hpp)
+    LplLayout V;
+    build_lpl(n_cams, n_lms, lm_offsets, cam_idx, obs, L.cam_hot, L.slot_of_obs, (size_t)c->n_slots, c->e0c_grid,
+              c->n_hot_acc, V);
+    lap("build_lpl (lane/landmark)");
+    if (V.max_slots > c->n_hot_acc) { povar_destroy(c); return fail(-1, "lpl layout: workgroup camera set exceeds the LDS capacity"); }
+    c->v2_rows = V.rows;
+    c->v2_max_slots = V.max_slots;
+    c->v2_n_global = V.n_global;
+    c->v2_strategy = V.strategy;
+    c->v2_n_tail = V.n_tail;
+    c->n_cold3 = (int64_t)V.cold_lm.size();
+    if (int rc = upload(c->v2_uv, V.uv, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_cw, V.cw, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_cpos, V.cpos, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_lm_pos, V.lm_pos, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_lm_of, V.lm_of, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_of_slot, V.of_slot, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_tile, V.tile, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_seg, V.seg, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_wg_tile_off, V.wg_tile_off, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_wg_cam_off, V.wg_cam_off, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_wg_cams, V.wg_cams, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_wg_slot_rec, V.wg_slot_rec, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->v2_part_range, V.part_range, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->c3_lm, V.cold_lm, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->c3_range, V.cold_range, c)) { povar_destroy(c); return rc; }
+    const int nt = (int)V.tile.size();
+    HIP_TRY_C(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * LPL_REC_H * WAVE, &c->bytes));  // 9 entries used by step 1
+    HIP_TRY_C(c->v2_lmx.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
+    HIP_TRY_C(c->v2_lml.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
+    HIP_TRY_C(c->v2_lsc.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
+    HIP_TRY_C(c->v2_part.alloc((size_t)std::max(V.n_part_rec, 1) * 12, &c->bytes));
+    HIP_TRY_C(c->c3_h.alloc(4 * std::max<size_t>(V.cold_lm.size(), 1), &c->bytes));
+    if (options->robust_norm) HIP_TRY_C(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
+    n_cold_lpl = V.cold_lm.size();
+    c->d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
+                 c->v2_lm_of.p, c->v2_lmx.p, c->v2_lml.p, c->v2_lsc.p, c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
+                 c->v2_wg_slot_rec.p, nt, V.hubs};
+  }
+  lap("uploads (lane/landmark)");
+  part_b.join();
+  lap("wait for the lane/obs arrays");
   int rc = 0;
   if ((rc = upload(c->uv, L.uv, c)) || (rc = upload(c->cam, L.cam, c)) || (rc = upload(c->lm, L.lm, c)) ||
       (rc = upload(c->meta, L.meta, c)) || (rc = upload(c->hot_cams, L.hot_cams, c)) || (rc = upload(c->cam_hot, L.cam_hot, c)) ||
@@ -959,7 +1030,6 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       c->long_in_kernel = c->use_lpl || std::getenv("POVAR_LONG_SEPARATE") == nullptr;
     }
   }
-  c->n_hot_acc = hot_acc_cap(n_cams);
   {
     std::vector<int> s0(n_lms, 0), cnt(n_lms, 0);
     for (int l = 0; l < n_lms; ++l) {
@@ -971,50 +1041,9 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     c->d.lm_slot0 = c->lm_slot0.p;
     c->d.lm_cnt = c->lm_cnt_dev.p;
   }
-  lap("allocations");
-  {
-    // lane-per-landmark layout of e0_lpl (lpl_layout.hpp)
-    LplLayout V;
-    build_lpl(n_cams, n_lms, lm_offsets, cam_idx, obs, L.cam_hot, L.slot_of_obs, (size_t)c->n_slots, c->e0c_grid,
-              c->n_hot_acc, V);
-    lap("build_lpl (lane/landmark)");
-    if (V.max_slots > c->n_hot_acc) { povar_destroy(c); return fail(-1, "lpl layout: workgroup camera set exceeds the LDS capacity"); }
-    c->v2_rows = V.rows;
-    c->v2_max_slots = V.max_slots;
-    c->v2_n_global = V.n_global;
-    c->v2_strategy = V.strategy;
-    c->v2_n_tail = V.n_tail;
-    c->n_cold3 = (int64_t)V.cold_lm.size();
-    if (int rc = upload(c->v2_uv, V.uv, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_cw, V.cw, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_cpos, V.cpos, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_lm_pos, V.lm_pos, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_lm_of, V.lm_of, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_of_slot, V.of_slot, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_tile, V.tile, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_seg, V.seg, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_wg_tile_off, V.wg_tile_off, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_wg_cam_off, V.wg_cam_off, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_wg_cams, V.wg_cams, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_wg_slot_rec, V.wg_slot_rec, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->v2_part_range, V.part_range, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->c3_lm, V.cold_lm, c)) { povar_destroy(c); return rc; }
-    if (int rc = upload(c->c3_range, V.cold_range, c)) { povar_destroy(c); return rc; }
-    const int nt = (int)V.tile.size();
-    HIP_TRY_C(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * LPL_REC_H * WAVE, &c->bytes));  // 9 entries used by step 1
-    HIP_TRY_C(c->v2_lmx.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
-    HIP_TRY_C(c->v2_lml.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
-    HIP_TRY_C(c->v2_lsc.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
-    HIP_TRY_C(c->v2_part.alloc((size_t)std::max(V.n_part_rec, 1) * 12, &c->bytes));
-    HIP_TRY_C(c->c3_h.alloc(4 * std::max<size_t>(V.cold_lm.size(), 1), &c->bytes));
-    if (options->robust_norm) HIP_TRY_C(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
-    // scatter scalars of the cold observations: one buffer, sized for the largest of the cold views
-    HIP_TRY_C(c->q4c.alloc(std::max<size_t>(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), V.cold_lm.size()), 1), &c->bytes));
-    c->d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
-                 c->v2_lm_of.p, c->v2_lmx.p, c->v2_lml.p, c->v2_lsc.p, c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
-                 c->v2_wg_slot_rec.p, nt, V.hubs};
-  }
-  lap("uploads (lane/landmark)");
+  lap("uploads, allocations (lane/obs)");
+  // scatter scalars of the cold observations: one buffer, sized for the largest of the cold views
+  HIP_TRY_C(c->q4c.alloc(std::max<size_t>(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), n_cold_lpl), 1), &c->bytes));
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
   ALLOC(hot_rec, (size_t)std::max(n_cams, HOT_MAX) * HOT_REC_STRIDE);  // every camera, in popularity order
