@@ -28,13 +28,28 @@ ALPHA, LAM, M = 0.01, 1e-4, 20
 NT = min(os.cpu_count() or 1, 16)
 
 
-@pytest.mark.parametrize("name", ["ladybug-49", "trafalgar-257", "venice-1778"])
+def _problem(name):
+    """A BASELINE shape, or "local-900": a graph with locality (cameras on a ring, synth popularity="local") that makes the
+    layout take its second assignment strategy -- contiguous landmark ranges with per-workgroup camera sets and hubs."""
+    from povar_amd import synth
+    if name == "local-900":
+        return synth.make_problem(900, 40000, 200000, seed=9, popularity="local")
+    return synth.make_bal_problem(name)
+
+
+def _check_strategy(ctx, name):
+    assert ctx.layout_info().strategy == (1 if name.startswith("local") else 0)
+
+
+@pytest.mark.parametrize("name", ["ladybug-49", "trafalgar-257", "venice-1778", "local-900"])
 def test_step1_oracle_parity_at_size(name):
     from povar_amd import capi, synth
     from oracle import povar_oracle as O
-    p = synth.make_bal_problem(name)
+    p = _problem(name)
     orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs)
     ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    if p.n_cams > 520:
+        _check_strategy(ctx, name)
     ctx.set_cameras(p.cams)
     ctx.init_landmarks_pose(ALPHA)
     lms = orc.init_landmarks_pose(ALPHA, p.cams)
@@ -66,12 +81,12 @@ def test_step1_oracle_parity_at_size(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778"])
+@pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778", "local-900"])
 def test_step1_apply_at_size(name):
     """apply (camera update + back-substitution + l_diff) and the cost at the new state: backsub_lpl at full size."""
     from povar_amd import capi, synth
     from oracle import povar_oracle as O
-    p = synth.make_bal_problem(name)
+    p = _problem(name)
     orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs)
     ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
     lms = orc.init_landmarks_pose(ALPHA, p.cams)
@@ -95,13 +110,13 @@ def test_step1_apply_at_size(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778"])
+@pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778", "local-900"])
 def test_step2_at_size(name):
     """solve_joint (RIPOBA inner solve: prepare_lpl_h, e0_lpl_h term by term) and apply_joint against the oracle,
     bench-default mode."""
     from povar_amd import capi, synth
     from oracle import povar_oracle as O
-    p = synth.make_bal_problem(name)
+    p = _problem(name)
     rng = np.random.default_rng(11)
     cams = rng.normal(size=(p.n_cams, 12))
     cams[:, 8:11] *= 0.1
