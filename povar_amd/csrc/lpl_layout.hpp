@@ -331,33 +331,47 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       for (int l = 0; l < n_lms; ++l)
         if (lm_off[l + 1] > lm_off[l]) order[first[mx - n_tail_of[l]]++] = l;
     }
-    std::vector<int> xs, ys;
+    // Landmarks with grid observations: most constrained first, each to the eligible workgroup that covers most of its
+    // grid cameras (ties: the least loaded).  The only coupling between landmarks is the load balance, so the list is
+    // dealt round-robin over a FIXED number of independent lanes (64, whatever the thread count: the layout must not
+    // depend on it), each balancing its own share; the shares are equal mixes of all constraint levels.
     size_t pos = 0;
-    for (; pos < order.size() && n_tail_of[order[pos]] > 0; ++pos) {
-      const int l = order[pos], k = lm_off[l + 1] - lm_off[l];
-      xs.clear();
-      ys.clear();
-      for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) {
-        int x, y;
-        if (tail_xy(rank1[cam_idx[i]] - 1, x, y)) { xs.push_back(x); ys.push_back(y); }
-      }
-      const int nt = (int)xs.size(), nc = std::min(nt, 8);
-      int best_w = -1, best_cov = -1;
-      auto consider = [&](int a, int b) {
-        int cov = 0;
-        for (int m = 0; m < nt; ++m) cov += xs[m] == a || ys[m] == b;
-        const int w = a + A * b;
-        if (cov > best_cov || (cov == best_cov && load[w] < load[best_w])) { best_cov = cov; best_w = w; }
-      };
-      if (nt == 1) {  // any workgroup of the column or the row
-        for (int b = 0; b < B; ++b) consider(xs[0], b);
-        for (int a = 0; a < A; ++a) consider(a, ys[0]);
-      } else {
-        for (int i = 0; i < nc; ++i)
-          for (int j = 0; j < nc; ++j) consider(xs[i], ys[j]);
-      }
-      wg_of[l] = best_w;
-      load[best_w] += k;
+    while (pos < order.size() && n_tail_of[order[pos]] > 0) ++pos;
+    {
+      constexpr int LANES = 64;
+      std::vector<std::vector<int64_t>> load_q(LANES, std::vector<int64_t>(grid, 0));
+      lpl_parallel(LANES, n_threads, [&](int q) {
+        std::vector<int64_t>& ld = load_q[q];
+        std::vector<int> xs, ys;
+        for (size_t n = q; n < pos; n += LANES) {
+          const int l = order[n], k = lm_off[l + 1] - lm_off[l];
+          xs.clear();
+          ys.clear();
+          for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) {
+            int x, y;
+            if (tail_xy(rank1[cam_idx[i]] - 1, x, y)) { xs.push_back(x); ys.push_back(y); }
+          }
+          const int nt = (int)xs.size(), nc = std::min(nt, 8);
+          int best_w = -1, best_cov = -1;
+          auto consider = [&](int a, int b) {
+            int cov = 0;
+            for (int m = 0; m < nt; ++m) cov += xs[m] == a || ys[m] == b;
+            const int w = a + A * b;
+            if (cov > best_cov || (cov == best_cov && ld[w] < ld[best_w])) { best_cov = cov; best_w = w; }
+          };
+          if (nt == 1) {  // any workgroup of the column or the row
+            for (int b = 0; b < B; ++b) consider(xs[0], b);
+            for (int a = 0; a < A; ++a) consider(a, ys[0]);
+          } else {
+            for (int i = 0; i < nc; ++i)
+              for (int j = 0; j < nc; ++j) consider(xs[i], ys[j]);
+          }
+          wg_of[l] = best_w;
+          ld[best_w] += k;
+        }
+      });
+      for (int q = 0; q < LANES; ++q)
+        for (int w = 0; w < grid; ++w) load[w] += load_q[q][w];
     }
     // landmarks without tail observations fill the workgroups up, longest first into the least loaded
     std::priority_queue<std::pair<int64_t, int>, std::vector<std::pair<int64_t, int>>, std::greater<>> heap;

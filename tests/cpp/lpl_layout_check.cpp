@@ -177,7 +177,7 @@ int main(int argc, char** argv) {
     extra_r /= (double)L.rows * 4;
     // lower bound of extra_a for the given tile membership and lane halves: a bank hit by deg observations in a
     // half-tile of R rows repeats at least ceil(deg / R) - 1 times in some row (printed to stderr)
-    double bound = 0;
+    double bound = 0, bound_mean = 0;
     for (size_t t = 0; t < L.tile.size(); ++t) {
       const int R = L.tile[t].y;
       for (int hlf = 0; hlf < 2; ++hlf) {
@@ -191,8 +191,10 @@ int main(int argc, char** argv) {
         for (int b = 0; b < 32; ++b) mx = std::max(mx, deg[b]);
         // the best any placement can do: the heaviest bank spread evenly; averaged over the rows
         bound += (double)std::max(0, (mx + R - 1) / R - 1) ;
+        bound_mean += std::max(0.0, (double)mx / R - 1.0);
       }
     }
+    std::fprintf(stderr, "lower bound of the MEAN extra atomic lanes per row half for this tile membership: %.3f\n", bound_mean / (L.tile.size() * 2));
     std::fprintf(stderr, "lower bound of the worst row per half-tile (max over rows, not the mean): %.3f\n", bound / (L.tile.size() * 2));
   }
   int64_t mx = 0, mn = 1LL << 60;
