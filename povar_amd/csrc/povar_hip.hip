@@ -623,7 +623,7 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
       launch_lm(c, OpE0H{});
     }
     if (acc && fuse_norms >= 0 && !sharded(c) && c->fuse_binv) {
-      hipLaunchKernelGGL(cam_cold_sum_binv_h, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c, true), fuse_norms,
+      hipLaunchKernelGGL(cam_cold_sum_binv_h<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, ldsacc_dp(c, true), fuse_norms,
                          (const double*)c->ncw.p);
       *binv_mode = 4;  // B^-1, AXPY and z already done
     } else if (acc) {
@@ -672,7 +672,10 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
     if ((c->opt.e0_mode == POVAR_E0_IMPLICIT || c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) && c->n_long > 0 && !lik)
       hipLaunchKernelGGL((lm_long<OpE0>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpE0{}, c->part.p);
     if (acc && fuse_norms >= 0 && !sharded(c) && c->fuse_binv) {
-      hipLaunchKernelGGL(cam_cold_sum_binv, dim3(c->n_cams), dim3(256), 0, c->stream, da, fuse_norms);
+      // 128 threads per camera: a camera's run is at most one partial record per workgroup (256) plus ~85 cold
+      // observations; two wavefronts keep four loads per thread in flight and halve the cross-wavefront reduction
+      // (256 threads: 71.7 us per term, 128: 69.5, 64: 69.6 on venice-1778)
+      hipLaunchKernelGGL(cam_cold_sum_binv<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, da, fuse_norms);
       *binv_mode = 4;  // B^-1, AXPY and z already done
     } else if (acc) {
       hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 0);

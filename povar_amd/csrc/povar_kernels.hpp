@@ -2733,7 +2733,9 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
 // has just summed camera c's E0 row applies B_c^-1, the AXPY and the sigma scaling itself, so the term
 // needs one kernel less (the dense y is never materialised).  Norm partials are per camera
 // (series_check then sums n_cams entries).
-__global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
+constexpr int CCS_THREADS = 128;  // threads per camera of the fused per-camera kernels of the term loop
+template <int NT>
+__global__ __launch_bounds__(NT) void cam_cold_sum_binv(Dp d, int want_norms) {
   const int done = d.flags[1];  // tested after the first batch of loads is in flight
   __shared__ double sh[4 * 12];
   const int c = blockIdx.x, t = threadIdx.x;
@@ -2757,12 +2759,12 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
   }
   if (done) return;
   constexpr int U = 4;
-  for (int pb = p0 + t; pb < p1; pb += U * 256) {
+  for (int pb = p0 + t; pb < p1; pb += U * NT) {
     double hx[U], hy[U], hz[U];
     double4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = pb + u * 256;
+      const int p = pb + u * NT;
       const bool in = p < p1;
       const int pc = in ? p : p0;
       hx[u] = d.cmv.h[pc];
@@ -2779,19 +2781,19 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv(Dp d, int want_norms) {
   }
   if (d.part_range) {  // e0_lpl: the camera's partial records are one contiguous run
     const int2 rr = d.part_range[c];
-    for (int w = rr.x + t; w < rr.y; w += 256) {
+    for (int w = rr.x + t; w < rr.y; w += NT) {
       const double* ip = d.hot_part + (size_t)w * 12;
 #pragma unroll
       for (int k = 0; k < 12; ++k) acc[k] += ip[k];
     }
   } else if (r > 0 && r <= d.n_hot_acc) {
-    for (int w = t; w < d.n_hot_wg; w += 256) {
+    for (int w = t; w < d.n_hot_wg; w += NT) {
       const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + w) * 12;
 #pragma unroll
       for (int k = 0; k < 12; ++k) acc[k] += ip[k];
     }
   }
-  block_sum_dpp<12, 256>(acc, sh);  // every thread now holds the 12 sums
+  block_sum_dpp<12, NT>(acc, sh);  // every thread now holds the 12 sums
   if (t >= 64) return;
   double nrm[2] = {0, 0};
   if (t < 12) {

@@ -1437,7 +1437,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl_h(Dp d, double* part) {
 // cam_cold_sum fused with cam_binv_axpy_h (mode 2) for the unsharded LDSACC term loop of step 2
 // (the step-2 twin of cam_cold_sum_binv): per-camera sum of the E0 row, tangent projection, B^-1 (11x11),
 // AXPY and z = sigma * (N_c tmp) in one kernel.
-__global__ __launch_bounds__(256) void cam_cold_sum_binv_h(Dp d, int want_norms, const double* ncw) {
+template <int NT>
+__global__ __launch_bounds__(NT) void cam_cold_sum_binv_h(Dp d, int want_norms, const double* ncw) {
   const int done = d.flags[1];
   __shared__ double sh[4 * 12];
   const int c = blockIdx.x, t = threadIdx.x;
@@ -1463,12 +1464,12 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv_h(Dp d, int want_norms,
   }
   if (done) return;
   constexpr int U = 4;
-  for (int pb = p0 + t; pb < p1; pb += U * 256) {
+  for (int pb = p0 + t; pb < p1; pb += U * NT) {
     double hx[U], hy[U], hz[U], hw[U];
     double4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = pb + u * 256;
+      const int p = pb + u * NT;
       const bool in = p < p1;
       const int pc = in ? p : p0;
       hx[u] = d.cmv.h[pc];
@@ -1486,19 +1487,19 @@ __global__ __launch_bounds__(256) void cam_cold_sum_binv_h(Dp d, int want_norms,
   }
   if (d.part_range) {  // e0_lpl_h: the camera's partial records are one contiguous run
     const int2 rr = d.part_range[c];
-    for (int wg = rr.x + t; wg < rr.y; wg += 256) {
+    for (int wg = rr.x + t; wg < rr.y; wg += NT) {
       const double* ip = d.hot_part + (size_t)wg * 12;
 #pragma unroll
       for (int k = 0; k < 12; ++k) acc[k] += ip[k];
     }
   } else if (r > 0 && r <= d.n_hot_acc) {
-    for (int wg = t; wg < d.n_hot_wg; wg += 256) {
+    for (int wg = t; wg < d.n_hot_wg; wg += NT) {
       const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + wg) * 12;
 #pragma unroll
       for (int k = 0; k < 12; ++k) acc[k] += ip[k];
     }
   }
-  block_sum_dpp<12, 256>(acc, sh);  // every thread now holds the 12 ambient sums
+  block_sum_dpp<12, NT>(acc, sh);  // every thread now holds the 12 ambient sums
   if (t >= 64) return;
   double y[12], y11[11];
 #pragma unroll
