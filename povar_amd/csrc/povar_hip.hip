@@ -627,7 +627,7 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
                          (const double*)c->ncw.p);
       *binv_mode = 4;  // B^-1, AXPY and z already done
     } else if (acc) {
-      hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, ldsacc_dp(c, true), 1);
+      hipLaunchKernelGGL(cam_cold_sum<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, ldsacc_dp(c, true), 1);
       *binv_mode = 2;  // dense y (sigma applied)
     } else {
       hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(c->n_items, 1), 4)), dim3(256), 0, c->stream, c->d, 1, 1);
@@ -678,7 +678,7 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
       hipLaunchKernelGGL(cam_cold_sum_binv<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, da, fuse_norms);
       *binv_mode = 4;  // B^-1, AXPY and z already done
     } else if (acc) {
-      hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 0);
+      hipLaunchKernelGGL(cam_cold_sum<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, da, 0);
       *binv_mode = 2;  // dense y (sigma applied)
     } else {
       hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(c->n_items, 1), 4)), dim3(256), 0, c->stream, c->d, 1, 0);
@@ -1268,11 +1268,11 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
   if (sharded(c)) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
-    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr);
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(CFL_THREADS), 0, c->stream, c->d, (const double*)nullptr);
     if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
-    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)c->d.G);
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(CFL_THREADS), 0, c->stream, c->d, (const double*)c->d.G);
   } else {
-    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr);
+    hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(CFL_THREADS), 0, c->stream, c->d, (const double*)nullptr);
   }
   HIP_TRY(hipGetLastError());
   int f[4];
@@ -1312,7 +1312,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
     da.y = c->d.b;
     da.p2p_peer = nullptr;  // b goes through the ordinary exchange below, not the per-term push
     da.p2p_epoch = nullptr;
-    hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 0);
+    hipLaunchKernelGGL(cam_cold_sum<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, da, 0);
   } else {
     c->aux_prep_id = c->prep_id;  // this branch writes them
     ensure_legacy(c);
@@ -1581,10 +1581,10 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   if (c->n_cold3 > 0)
     hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 1);
   hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
-  hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
+  hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(CFL_THREADS), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
   if (sharded(c)) {
     if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
-    hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(1024), 0, c->stream, c->d, (const double*)c->d.G, c->ncw.p);
+    hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(CFL_THREADS), 0, c->stream, c->d, (const double*)c->d.G, c->ncw.p);
   }
   HIP_TRY(hipGetLastError());
   int f[4];
@@ -1621,7 +1621,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
     da.y = c->d.y;
     da.p2p_peer = nullptr;
     da.p2p_epoch = nullptr;
-    hipLaunchKernelGGL(cam_cold_sum, dim3(c->n_cams), dim3(256), 0, c->stream, da, 1);
+    hipLaunchKernelGGL(cam_cold_sum<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, da, 1);
     hipLaunchKernelGGL(cam_nt_project, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, c->d.y, c->d.b,
                        (const double*)c->ncw.p);
   } else {

@@ -2485,9 +2485,11 @@ __device__ inline int sym10(int i, int j) {  // index of (i,j) in the packed upp
 }
 
 // per camera: G = sum of item Gram parts; diag2 and pose scaling (linearizor_power_varproj.cpp:62-70)
-__global__ __launch_bounds__(1024) void cam_finish_linearize(Dp d, const double* G_in) {
+constexpr int CFL_THREADS = 1024;  // sixteen item streams per camera: the hub camera (880 items on venice) is the tail of this launch (256 threads: 56 instead of 18 us)
+__global__ __launch_bounds__(CFL_THREADS) void cam_finish_linearize(Dp d, const double* G_in) {
   const int c = blockIdx.x;
-  __shared__ double part[16][40];
+  constexpr int NQ = CFL_THREADS / 64;
+  __shared__ double part[NQ][40];
   __shared__ double g[40];
   if (G_in) {
     if (threadIdx.x < 40) g[threadIdx.x] = G_in[40 * (size_t)c + threadIdx.x];
@@ -2496,7 +2498,7 @@ __global__ __launch_bounds__(1024) void cam_finish_linearize(Dp d, const double*
     const int e = threadIdx.x % 64, q = threadIdx.x / 64;
     if (e < 40) {
       double s = 0;
-      for (int it = d.cam_item_off[c] + q; it < d.cam_item_off[c + 1]; it += 16)
+      for (int it = d.cam_item_off[c] + q; it < d.cam_item_off[c + 1]; it += NQ)
         s += d.item_partG[40 * (size_t)it + e];
       part[q][e] = s;
     }
@@ -2504,7 +2506,7 @@ __global__ __launch_bounds__(1024) void cam_finish_linearize(Dp d, const double*
     if (threadIdx.x < 40) {
       double sum = 0;  // fixed order
 #pragma unroll
-      for (int k = 0; k < 16; ++k) sum += part[k][threadIdx.x];
+      for (int k = 0; k < NQ; ++k) sum += part[k][threadIdx.x];
       g[threadIdx.x] = sum;
     }
   }
@@ -2651,9 +2653,11 @@ __device__ inline void camera_item_sum(const Dp& d, int c, int lane, double (&y)
 
 // LDSACC modes: y_c = sigma * ( sum over the camera's COLD observations of (h q0; h q1; h q2)
 //                                + sum of the workgroups' LDS-accumulated partials of a cached camera ).
-// One 256-thread workgroup per camera, fixed summation order; replaces cm_scatter + the item sums
+constexpr int CCS_THREADS = 128;  // threads per camera of the per-camera kernels of the term loop (cam_cold_sum[_binv][_h])
+// One CCS_THREADS-thread workgroup per camera, fixed summation order; replaces cm_scatter + the item sums
 // (a single wavefront walking a few hundred items per camera was a serial chain of dependent loads).
-__global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
+template <int NT>
+__global__ __launch_bounds__(NT) void cam_cold_sum(Dp d, int hom) {
   const int done = d.flags[1];  // tested after the first batch of loads is in flight
   __shared__ double sh[4 * 12];
   const int c = blockIdx.x, t = threadIdx.x;
@@ -2667,12 +2671,12 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
   if (done) return;
   // 4 observations per thread in flight: index loads, then the dependent gathers, then the FMAs
   constexpr int U = 4;
-  for (int pb = p0 + t; pb < p1; pb += U * 256) {
+  for (int pb = p0 + t; pb < p1; pb += U * NT) {
     double hx[U], hy[U], hz[U], hw[U];
     double4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = pb + u * 256;
+      const int p = pb + u * NT;
       const bool in = p < p1;
       const int pc = in ? p : p0;
       hx[u] = d.cmv.h[pc];
@@ -2690,19 +2694,19 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
   }
   if (d.part_range) {  // e0_lpl: the camera's partial records are one contiguous run
     const int2 rr = d.part_range[c];
-    for (int w = rr.x + t; w < rr.y; w += 256) {
+    for (int w = rr.x + t; w < rr.y; w += NT) {
       const double* ip = d.hot_part + (size_t)w * 12;
 #pragma unroll
       for (int k = 0; k < 12; ++k) acc[k] += ip[k];
     }
   } else if (r > 0 && r <= d.n_hot_acc) {
-    for (int w = t; w < d.n_hot_wg; w += 256) {
+    for (int w = t; w < d.n_hot_wg; w += NT) {
       const double* ip = d.hot_part + ((size_t)(r - 1) * d.n_hot_wg + w) * 12;
 #pragma unroll
       for (int k = 0; k < 12; ++k) acc[k] += ip[k];
     }
   }
-  block_sum_dpp<12, 256>(acc, sh);
+  block_sum_dpp<12, NT>(acc, sh);
   if (t < 12) {
     double v = 0;
 #pragma unroll
@@ -2733,7 +2737,6 @@ __global__ __launch_bounds__(256) void cam_cold_sum(Dp d, int hom) {
 // has just summed camera c's E0 row applies B_c^-1, the AXPY and the sigma scaling itself, so the term
 // needs one kernel less (the dense y is never materialised).  Norm partials are per camera
 // (series_check then sums n_cams entries).
-constexpr int CCS_THREADS = 128;  // threads per camera of the fused per-camera kernels of the term loop
 template <int NT>
 __global__ __launch_bounds__(NT) void cam_cold_sum_binv(Dp d, int want_norms) {
   const int done = d.flags[1];  // tested after the first batch of loads is in flight
@@ -2743,6 +2746,7 @@ __global__ __launch_bounds__(NT) void cam_cold_sum_binv(Dp d, int want_norms) {
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0;
   const int2 pr = d.cmv.cam_range[c];  // one load instead of the two-level item index
+  const int2 rr = d.part_range ? d.part_range[c] : make_int2(0, 0);  // requested with it: the partial loop does not wait a round trip of its own
   const int p0 = pr.x, p1 = pr.y;
   const int r = d.hot_part ? d.cam_hot[c] : 0;
   // everything the tail needs that depends on c only is requested now, off the critical path
@@ -2780,7 +2784,6 @@ __global__ __launch_bounds__(NT) void cam_cold_sum_binv(Dp d, int want_norms) {
     }
   }
   if (d.part_range) {  // e0_lpl: the camera's partial records are one contiguous run
-    const int2 rr = d.part_range[c];
     for (int w = rr.x + t; w < rr.y; w += NT) {
       const double* ip = d.hot_part + (size_t)w * 12;
 #pragma unroll

@@ -494,9 +494,10 @@ __global__ __launch_bounds__(256) void cm_gram_h(Dp d, int gather) {
 // per camera after the Gram sums: diag2 / sigma (get_Jp_diag2_projective_space,
 // linearization_varproj.hpp:225-264; linearizor_power_varproj.cpp:97-105) and the Householder
 // vector of vec(P_c) for the tangent basis N_c
-__global__ __launch_bounds__(1024) void cam_finish_linearize_h(Dp d, const double* G_in, double* ncw) {
+__global__ __launch_bounds__(CFL_THREADS) void cam_finish_linearize_h(Dp d, const double* G_in, double* ncw) {
   const int c = blockIdx.x;
-  __shared__ double part[16][40];
+  constexpr int NQ = CFL_THREADS / 64;
+  __shared__ double part[NQ][40];
   __shared__ double g[40];
   if (G_in) {
     if (threadIdx.x < 40) g[threadIdx.x] = G_in[40 * (size_t)c + threadIdx.x];
@@ -504,14 +505,14 @@ __global__ __launch_bounds__(1024) void cam_finish_linearize_h(Dp d, const doubl
     const int e = threadIdx.x % 64, q = threadIdx.x / 64;
     if (e < 40) {
       double s = 0;
-      for (int it = d.cam_item_off[c] + q; it < d.cam_item_off[c + 1]; it += 16) s += d.item_partG[40 * (size_t)it + e];
+      for (int it = d.cam_item_off[c] + q; it < d.cam_item_off[c + 1]; it += NQ) s += d.item_partG[40 * (size_t)it + e];
       part[q][e] = s;
     }
     __syncthreads();
     if (threadIdx.x < 40) {
       double sum = 0;  // fixed order
 #pragma unroll
-      for (int k = 0; k < 16; ++k) sum += part[k][threadIdx.x];
+      for (int k = 0; k < NQ; ++k) sum += part[k][threadIdx.x];
       g[threadIdx.x] = sum;
     }
   }
