@@ -5,17 +5,20 @@ set -eu
 tag=${1:-r03}
 cd "$(dirname "$0")/.."
 R=gpurun_out/$tag; P=profiles
-cp $R/e0/kt/*/*kernel_stats.csv $P/${tag}_kernel_stats_default_cmd.csv
-cp $R/e0/sq/*/*counter_collection.csv $P/${tag}_pmc_sq.csv
-cp $R/e0/fetch/*/*counter_collection.csv $P/${tag}_pmc_fetch_size.csv
-cp $R/e0/write/*/*counter_collection.csv $P/${tag}_pmc_write_size.csv
+# gpurun merges a new run into gpurun_out/ without deleting what an earlier run of the same tag left there (the
+# rocprofv3 output files carry the process id): always take the newest match
+newest() { ls -t $@ | head -1; }
+cp $(newest $R/e0/kt/*/*kernel_stats.csv) $P/${tag}_kernel_stats_default_cmd.csv
+cp $(newest $R/e0/sq/*/*counter_collection.csv) $P/${tag}_pmc_sq.csv
+cp $(newest $R/e0/fetch/*/*counter_collection.csv) $P/${tag}_pmc_fetch_size.csv
+cp $(newest $R/e0/write/*/*counter_collection.csv) $P/${tag}_pmc_write_size.csv
 cp $R/e0/summary.json $P/${tag}_profile_summary.json
 cp $R/e0/kt_bench.json $P/${tag}_bench_under_trace.json
 cp $R/bench_default.json $P/${tag}_bench.json
 for n in step2 huber ladybug trafalgar final_huber local final_local_huber; do cp $R/bench_$n.json $P/${tag}_bench_$n.json; done
 for n in step2 huber final_huber local final_local_huber; do
-  cp $R/e0_$n/fetch/*/*counter_collection.csv $P/${tag}_pmc_fetch_size_$n.csv
-  cp $R/e0_$n/write/*/*counter_collection.csv $P/${tag}_pmc_write_size_$n.csv
+  cp $(newest $R/e0_$n/fetch/*/*counter_collection.csv) $P/${tag}_pmc_fetch_size_$n.csv
+  cp $(newest $R/e0_$n/write/*/*counter_collection.csv) $P/${tag}_pmc_write_size_$n.csv
 done
 for n in venice_step1 venice_step2 final_huber_step1; do
   cp $R/stages_$n.md $P/${tag}_stages_$n.md
@@ -34,7 +37,7 @@ for k in ("iteration_time", "jacobian_evaluation_time", "prepare_time", "solve_r
           "back_substitution_time", "residual_evaluation_time"):
     print(k, [round(x * 1e3, 3) for x in d[k]])
 PY
-t() { python3 tools/pmc_to_traffic.py $R/$1/fetch/*/*counter_collection.csv $R/$1/write/*/*counter_collection.csv $2 $P/traffic.json; }
+t() { python3 tools/pmc_to_traffic.py $(newest $R/$1/fetch/*/*counter_collection.csv) $(newest $R/$1/write/*/*counter_collection.csv) $2 $P/traffic.json; }
 t e0 venice-1778:ldsacc:1
 t e0_step2 venice-1778:ldsacc:1:step2
 t e0_huber venice-1778:ldsacc:1:HUBER

@@ -14,7 +14,7 @@ PEAK = 8000.0
 
 def find(d, pat):
     fs = glob.glob(os.path.join(d, "**", pat), recursive=True)
-    return fs[0] if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None  # the newest run (gpurun merges runs of one tag)
 
 
 def pmc(path, counter):
