@@ -68,6 +68,29 @@ def test_linearize_prepare_buffers(norm, small_problem):
     ctx.close()
 
 
+@pytest.mark.parametrize("force_lpl", ["0", None])
+def test_exports_belong_to_the_linearisation_alpha(force_lpl, small_problem, monkeypatch):
+    """The lazily rebuilt per-slot arrays behind the exports (and the POBA back-substitution, the SC solvers) are built
+    with the alpha of povar_linearize_pose, also when a cost evaluation at ANOTHER alpha ran in between (ADVICE r02:
+    ensure_legacy used whatever alpha the last call left in the context)."""
+    from povar_amd import capi
+    if force_lpl is not None:
+        monkeypatch.setenv("POVAR_E0_V1", force_lpl)   # the small problem through the lane-per-landmark kernels: lazy arrays
+    p = small_problem
+    orc, ctx = _setup(p, "HUBER", huber=30.0, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    ctx.set_cameras(p.cams)
+    ctx.set_landmarks(lms)
+    assert ctx.linearize_pose(ALPHA)
+    st, diag2, jls, sigma, hll, b, binv = _oracle_stage(orc, p.cams, lms, LAM)
+    ctx.prepare_pose(LAM)
+    ctx.error_pose(0.37)                                 # leaves another alpha in the context
+    assert rel(ctx.get_buffer(capi.BUF_STORAGE), st.ravel()) < 1e-13
+    assert rel(ctx.get_buffer(capi.BUF_JL_COL_SCALE), jls.ravel()) < 1e-13
+    assert rel(ctx.get_buffer(capi.BUF_HLL_INV), hll.ravel()) < 1e-11
+    ctx.close()
+
+
 @pytest.mark.parametrize("e0_mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("which", ["small", "medium"])
 def test_power_series_term_by_term(which, e0_mode, small_problem, medium_problem):
