@@ -208,17 +208,64 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     }
   }
   int G = std::min(n_cams, n_acc), Tn = 0;
+  double cov_grid = (double)n_obs_all;  // observations the chosen (G, Tn) keeps LDS-resident (counted estimate)
   if (n_cams > n_acc && std::getenv("POVAR_LPL_NOGRID") == nullptr) {
-    double best = -1;
-    for (int g = 0; g <= n_acc; g += 4) {
+    // Candidates g (global cameras) with the grid cameras the remaining slots allow; the cover of each is COUNTED per
+    // landmark: its observations of global cameras, its first two grid observations (always resident, whichever the
+    // cameras), and every further grid observation with the probability that its camera happens to sit in the chosen
+    // workgroup's column or row.  (Round 2 scored the grid observations with a flat 0.85: right for venice-1778,
+    // 5 observations per landmark, too optimistic for final-13682 with 6.5 -- it took 84 global cameras where 240 leave
+    // 23.5 % instead of 26.2 % of the observations cold.)
+    std::vector<int> cand_g, cand_tn;
+    for (int g = 0; g <= n_acc; g += 20) {
       const int cap = n_acc - g;
       // slots a workgroup needs: its column (<= Tn/A + 1 cameras) and its row (<= Tn/B + A: blocks of A ranks)
       int tn = (int)std::max(0.0, (cap - A - 2) / (1.0 / A + 1.0 / B));
-      tn = std::min(tn, n_cams - g);
-      // a landmark's first two tail observations are always resident; count later ones as half covered
-      const double score = (double)S[g] + 0.85 * (double)(S[g + tn] - S[g]);
-      if (score > best) { best = score; G = g; Tn = tn; }
+      cand_g.push_back(g);
+      cand_tn.push_back(std::min(tn, n_cams - g));
     }
+    const int n_cand = (int)cand_g.size();
+    const double p_extra = 1.0 / A + 1.0 / B - 1.0 / ((double)A * B);
+    // g_k ascends and g_k + tn_k descends with k, so a camera of rank r is global for the candidates k >= kg[r] and a
+    // grid camera for k < min(kg[r], kt[r]): two table lookups per observation, the counts per candidate by prefix sums
+    std::vector<int> kg(n_cams), kt(n_cams);
+    for (int r = 0; r < n_cams; ++r) {
+      int a = 0;
+      while (a < n_cand && cand_g[a] <= r) ++a;
+      kg[r] = a;
+      int b = 0;
+      while (b < n_cand && r < cand_g[b] + cand_tn[b]) ++b;
+      kt[r] = b;
+    }
+    std::vector<std::vector<double>> cov_q(n_chunks, std::vector<double>(n_cand, 0.0));
+    lpl_parallel(n_chunks, n_threads, [&](int q) {
+      std::vector<double>& cov = cov_q[q];
+      std::vector<int> dg(n_cand + 1), dt(n_cand + 1);
+      for (int l = chunk_lm[q]; l < chunk_lm[q + 1]; ++l) {
+        std::fill(dg.begin(), dg.end(), 0);
+        std::fill(dt.begin(), dt.end(), 0);
+        for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) {
+          const int r0 = rank1[cam_idx[i]] - 1;
+          dg[kg[r0]]++;                       // global for k >= kg
+          dt[std::min(kg[r0], kt[r0])]++;     // grid for k < min(kg, kt)
+        }
+        int ng = 0, nt = lm_off[l + 1] - lm_off[l];  // nt: observations that are grid cameras for candidate k
+        int below = 0;
+        for (int k = 0; k < n_cand; ++k) {
+          ng += dg[k];
+          below += dt[k];                     // observations whose grid range ended before k
+          const int ntk = nt - below;
+          cov[k] += ng + std::min(ntk, 2) + p_extra * std::max(ntk - 2, 0);
+        }
+      }
+    });
+    double best = -1;
+    for (int k = 0; k < n_cand; ++k) {
+      double c = 0;
+      for (int q = 0; q < n_chunks; ++q) c += cov_q[q][k];
+      if (c > best) { best = c; G = cand_g[k]; Tn = cand_tn[k]; }
+    }
+    cov_grid = best;
     if (const char* e = std::getenv("POVAR_LPL_G")) {  // measurement knob: force the number of global cameras
       G = std::min(std::max(0, std::atoi(e)), n_acc);
       Tn = std::min((int)std::max(0.0, (n_acc - G - A - 2) / (1.0 / A + 1.0 / B)), n_cams - G);
@@ -267,9 +314,6 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     });
     int64_t cov_range = 0;
     for (int w = 0; w < grid; ++w) cov_range += cov[w];
-    // the grid's cover: global cameras, and the first two grid observations of a landmark (counted below exactly by
-    // the assignment; here the same estimate that chose (G, Tn))
-    const double cov_grid = (double)S[G] + 0.85 * (double)(S[G + Tn] - S[G]);
     use_range = (double)cov_range > cov_grid;
     if (const char* e = std::getenv("POVAR_LPL_STRATEGY")) use_range = e[0] == 'r';
     if (timing) std::fprintf(stderr, "[build_lpl] cover: ranges %.4f, grid (estimate) %.4f -> %s\n", (double)cov_range / n_obs_all,
