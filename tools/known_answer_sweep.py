@@ -52,6 +52,7 @@ SETS = {
     "p49": [((49, 2000, 8200), 7, {})],
     "ladybug": [("ladybug-49", None, {})],
     "gt": [((49, 2000, 8200), 7, {"init": "gt", "init_noise": 0.05}), ("trafalgar-257", None, {"init": "gt", "init_noise": 0.02})],
+    "venice": [("venice-1778", None, {"init": "gt", "init_noise": 0.02})],
 }
 
 
