@@ -58,9 +58,7 @@ constexpr int HOT_REC = 11;         // double2 per cached camera: z (6) + P[:, :
 #define POVAR_E0C_BLOCK 1024
 #endif
 constexpr int E0C_BLOCK = POVAR_E0C_BLOCK;  // one workgroup per CU
-#ifndef POVAR_NT
-#define POVAR_NT 0  // experiment mask: 1 backward-pass rows non-temporal, 2 landmark records non-temporal
-#endif
+
 constexpr int E0_SLOT_BYTES = 32;   // e0_lm_cached<true> per-slot stream: uv 16 + meta 4 + cam 4 + lm 4 + cold_pos 4
 constexpr int E0_LMREC_BYTES = 96;  // packed landmark record read by the per-term kernel
 
@@ -1244,32 +1242,28 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   double* acc = reinterpret_cast<double*>(hot + n_hot * HOT_REC);
   int* grab_ctr = reinterpret_cast<int*>(acc + n_slots * 12);
   for (int i = threadIdx.x; i < n_slots * 12; i += E0C_BLOCK) acc[i] = 0;
-  if (threadIdx.x == 0) *grab_ctr = 0;
+  // the first tile of every wavefront is dealt statically (tiles are sorted longest first: the same tiles the first
+  // sixteen grabs would return), the counter serves the later ones
+  if (threadIdx.x == 0) *grab_ctr = E0C_BLOCK / WAVE;
   const double2* rec_img = reinterpret_cast<const double2*>(d.hot_rec);
-  {
-    // staging: slot -> camera rank -> record, two dependent L2 round trips; every thread first requests all its
-    // ranks, then all its record pieces, then writes LDS (a plain loop pays the two latencies once per pass)
-    constexpr int PASSES = (HOT_ACC_MAX * HOT_REC + E0C_BLOCK - 1) / E0C_BLOCK;
-    int rk[PASSES];
-    double2 piece[PASSES];
+  // staging, part 1: slot -> camera rank (the record pieces, a second dependent round trip, are requested further down:
+  // the wavefront's first rows and landmark record go out in between, so the three latencies overlap instead of adding
+  // up -- they are the fixed cost of a launch, a third of the kernel on an 8-GPU shard)
+  constexpr int PASSES = (HOT_ACC_MAX * HOT_REC + E0C_BLOCK - 1) / E0C_BLOCK;
+  int rk[PASSES];
 #pragma unroll
-    for (int u = 0; u < PASSES; ++u) {
-      const int i = threadIdx.x + u * E0C_BLOCK;
-      rk[u] = i < n_hot * HOT_REC ? v.wg_cams[cam0 + i / HOT_REC] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < PASSES; ++u) {
-      const int i = threadIdx.x + u * E0C_BLOCK;
-      piece[u] = rec_img[(size_t)rk[u] * (HOT_REC_STRIDE / 2) + i % HOT_REC];
-    }
-#pragma unroll
-    for (int u = 0; u < PASSES; ++u) {
-      const int i = threadIdx.x + u * E0C_BLOCK;
-      if (i < n_hot * HOT_REC) hot[i] = piece[u];
-    }
+  for (int u = 0; u < PASSES; ++u) {
+    const int i = threadIdx.x + u * E0C_BLOCK;
+    rk[u] = i < n_hot * HOT_REC ? v.wg_cams[cam0 + i / HOT_REC] : 0;
   }
-  __syncthreads();
-  if (done) return;
+  // where the accumulators go at the end (partial record of each slot): requested now, used after the last tile
+  constexpr int FPASSES = (HOT_ACC_MAX * 6 + E0C_BLOCK - 1) / E0C_BLOCK;
+  int frec[FPASSES];
+#pragma unroll
+  for (int u = 0; u < FPASSES; ++u) {
+    const int i = threadIdx.x + u * E0C_BLOCK;
+    frec[u] = i < n_hot * 6 ? v.wg_slot_rec[cam0 + i / 6] : 0;
+  }
   const int lane = threadIdx.x & 63;
   // The workgroup's tiles are sorted longest first; its wavefronts take them on demand (one LDS counter), so a
   // wavefront's last tile is a short one.  The workgroups carry equal observation totals (lpl_layout.hpp).
@@ -1294,40 +1288,32 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
     fl = tiles[4 * t + 3];
   };
   LplCursor pc;
-  pc.t = grab();
+  {
+    const long long t0 = (long long)t_begin + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    pc.t = t0 < t_end ? (int)t0 : t_end;
+  }
   pc.pass = 0;
   pc.j = 0;
   pc.row0 = 0;
   pc.k = 1;
   int c_t = pc.t, c_row0 = 0, c_k = 0, c_nh = 0, c_fl = 0;
-  // the tile after the one being consumed, taken when the consumer enters a tile: the prefetch cursor runs at most
-  // LPL_DEPTH = 3 rows ahead and a tile has at least 4 row steps, so it never needs more than this one
+  // the tile after the one being consumed, taken when the consumer enters a tile (the first one after the staging
+  // barrier below: the counter lives in LDS): the prefetch cursor runs at most LPL_DEPTH = 3 rows ahead and a tile has
+  // at least 4 row steps, so it never needs more than this one -- and not before the consumer has started
   int nx_t = t_end;
   if (c_t < t_end) {
     tile_info(c_t, c_row0, c_k, c_nh, c_fl);
     pc.row0 = c_row0;
     pc.k = c_k;
-    nx_t = grab();
   }
   // request the row under the prefetch cursor and advance it
   auto issue = [&](LplRow& r) {
     if (pc.t < t_end) {
       // the backward pass walks the rows in reverse: the rows read last are the ones most likely still in L2
       const size_t i = ((size_t)pc.row0 + (pc.pass ? pc.k - 1 - pc.j : pc.j)) * WAVE + lane;
-#if POVAR_NT & 1
-      if (pc.pass) {  // last use of the row: do not keep it in L2
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(v.uv) + i);
-        r.uv = make_double2(t.x, t.y);
-        r.cw = __builtin_nontemporal_load(v.cw + i);
-        if (ROBUST) r.w = __builtin_nontemporal_load(v.w + i);
-      } else
-#endif
-      {
-        r.uv = v.uv[i];
-        r.cw = v.cw[i];
-        if (ROBUST) r.w = v.w[i];
-      }
+      r.uv = v.uv[i];
+      r.cw = v.cw[i];
+      if (ROBUST) r.w = v.w[i];
       if (++pc.j == pc.k) {
         pc.j = 0;
         if (++pc.pass == 2) {
@@ -1351,14 +1337,26 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   double hx = 0, hy = 0, hz = 0, G00 = 0, G01 = 0, G02 = 0, G11 = 0, G12 = 0, G22 = 0;
   if (c_t < t_end) {
     const double* rp = v.lmrec + ((size_t)c_t * 9) * WAVE + lane;
-#if POVAR_NT & 2
-#define LPL_LD(p) __builtin_nontemporal_load(p)
-#else
-#define LPL_LD(p) (*(p))
-#endif
-    hx = LPL_LD(rp); hy = LPL_LD(rp + WAVE); hz = LPL_LD(rp + 2 * WAVE);
-    G00 = LPL_LD(rp + 3 * WAVE); G01 = LPL_LD(rp + 4 * WAVE); G02 = LPL_LD(rp + 5 * WAVE); G11 = LPL_LD(rp + 6 * WAVE); G12 = LPL_LD(rp + 7 * WAVE); G22 = LPL_LD(rp + 8 * WAVE);
+    hx = rp[0]; hy = rp[WAVE]; hz = rp[2 * WAVE];
+    G00 = rp[3 * WAVE]; G01 = rp[4 * WAVE]; G02 = rp[5 * WAVE]; G11 = rp[6 * WAVE]; G12 = rp[7 * WAVE]; G22 = rp[8 * WAVE];
   }
+  {
+    // staging, part 2: the record pieces into LDS
+    double2 piece[PASSES];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      piece[u] = rec_img[(size_t)rk[u] * (HOT_REC_STRIDE / 2) + i % HOT_REC];
+    }
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int i = threadIdx.x + u * E0C_BLOCK;
+      if (i < n_hot * HOT_REC) hot[i] = piece[u];
+    }
+  }
+  __syncthreads();
+  if (done) return;
+  if (c_t < t_end) nx_t = grab();
   while (c_t < t_end) {
     double red[3] = {0, 0, 0};
     for (int j = 0; j < c_k; ++j) {
@@ -1398,9 +1396,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
     double nhx = 0, nhy = 0, nhz = 0;
     if (n_t < t_end) {
       const double* rp = v.lmrec + ((size_t)n_t * 9) * WAVE + lane;
-      nhx = LPL_LD(rp); nhy = LPL_LD(rp + WAVE); nhz = LPL_LD(rp + 2 * WAVE);
-      G00 = LPL_LD(rp + 3 * WAVE); G01 = LPL_LD(rp + 4 * WAVE); G02 = LPL_LD(rp + 5 * WAVE); G11 = LPL_LD(rp + 6 * WAVE); G12 = LPL_LD(rp + 7 * WAVE); G22 = LPL_LD(rp + 8 * WAVE);
-#undef LPL_LD
+      nhx = rp[0]; nhy = rp[WAVE]; nhz = rp[2 * WAVE];
+      G00 = rp[3 * WAVE]; G01 = rp[4 * WAVE]; G02 = rp[5 * WAVE]; G11 = rp[6 * WAVE]; G12 = rp[7 * WAVE]; G22 = rp[8 * WAVE];
     }
     const size_t base = (size_t)c_row0 * WAVE + lane;
     for (int jj = 0; jj < c_k; ++jj) {
@@ -1438,17 +1435,10 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
   }
   __syncthreads();
   // accumulators -> this workgroup's partial records (camera-major in hot_out: the per-camera kernel reads one run);
-  // 16-byte stores, all record indices requested first (one L2 round trip, not one per pass)
+  // 16-byte stores; the record indices were requested in the prologue
   {
-    constexpr int PASSES = (HOT_ACC_MAX * 6 + E0C_BLOCK - 1) / E0C_BLOCK;
-    int rec[PASSES];
 #pragma unroll
-    for (int u = 0; u < PASSES; ++u) {
-      const int i = threadIdx.x + u * E0C_BLOCK;
-      rec[u] = i < n_hot * 6 ? v.wg_slot_rec[cam0 + i / 6] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < PASSES; ++u) {
+    for (int u = 0; u < FPASSES; ++u) {
       const int i = threadIdx.x + u * E0C_BLOCK;
       if (i < n_hot * 6) {
         const int r = i / 6, m = 2 * (i % 6);
@@ -1462,7 +1452,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
           s.x = a0[r + 3 * hubs];
           s.y = a1[r + 3 * hubs];
         }
-        reinterpret_cast<double2*>(hot_out + (size_t)rec[u] * 12)[i % 6] = s;
+        reinterpret_cast<double2*>(hot_out + (size_t)frec[u] * 12)[i % 6] = s;
       }
     }
   }
