@@ -177,7 +177,7 @@ int main(int argc, char** argv) {
     extra_r /= (double)L.rows * 4;
     // lower bound of extra_a for the given tile membership and lane halves: a bank hit by deg observations in a
     // half-tile of R rows repeats at least ceil(deg / R) - 1 times in some row (printed to stderr)
-    double bound = 0, bound_mean = 0;
+    double bound = 0, bound_mean = 0, bm_R[32] = {}, rows_R[32] = {};
     for (size_t t = 0; t < L.tile.size(); ++t) {
       const int R = L.tile[t].y;
       for (int hlf = 0; hlf < 2; ++hlf) {
@@ -192,9 +192,12 @@ int main(int argc, char** argv) {
         // the best any placement can do: the heaviest bank spread evenly; averaged over the rows
         bound += (double)std::max(0, (mx + R - 1) / R - 1) ;
         bound_mean += std::max(0.0, (double)mx / R - 1.0);
+        if (R < 32) { bm_R[R] += std::max(0.0, (double)mx / R - 1.0) * R; rows_R[R] += R; }
       }
     }
     std::fprintf(stderr, "lower bound of the MEAN extra atomic lanes per row half for this tile membership: %.3f\n", bound_mean / (L.tile.size() * 2));
+    for (int R = 2; R < 32; ++R)
+      if (rows_R[R] > 0) std::fprintf(stderr, "  tiles of %d rows: bound %.3f (row-weighted)\n", R, bm_R[R] / rows_R[R]);
     std::fprintf(stderr, "lower bound of the worst row per half-tile (max over rows, not the mean): %.3f\n", bound / (L.tile.size() * 2));
   }
   int64_t mx = 0, mn = 1LL << 60;
