@@ -643,6 +643,8 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   const bool no_place = std::getenv("POVAR_LPL_NOPLACE") != nullptr;  // measurement knob: natural order
   int max_tiles_tried = 1 << 30;
   if (const char* e = std::getenv("POVAR_LPL_TILES_TRIED")) max_tiles_tried = std::max(1, std::atoi(e));
+  long good_enough = 0;
+  if (const char* e = std::getenv("POVAR_LPL_EXIT")) good_enough = std::atol(e);
   auto place_wg = [&](int w) {
     std::vector<int> slot_of_rank(n_cams, -1);
     std::vector<int> hot_idx, cold_idx, assign, assign2;
@@ -818,11 +820,11 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
             long best = -1;
             int best_t = -1, best_lane = -1;
             int tiles_tried = 0;
-            for (int t = ta; t <= tb && best != 0 && tiles_tried < max_tiles_tried; ++t) {
+            for (int t = ta; t <= tb && (best < 0 || best > good_enough) && tiles_tried < max_tiles_tried; ++t) {
               if (!free_mask[t - ta]) continue;
               ++tiles_tried;
               unsigned seen = 0;
-              for (unsigned long long m = free_mask[t - ta]; m && best != 0; m &= m - 1) {
+              for (unsigned long long m = free_mask[t - ta]; m && (best < 0 || best > good_enough); m &= m - 1) {
                 const int lane = __builtin_ctzll(m), cls = (lane >> 5) * 2 + (read_group(lane) & 1);
                 if (seen & (1u << cls)) continue;
                 seen |= 1u << cls;

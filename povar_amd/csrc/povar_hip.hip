@@ -164,6 +164,20 @@ struct povar_ctx {
   uint64_t lms_ver = 1, lmx_ver = 0;
   int64_t lml_lin_id = -1, lsc_lin_id = -1;
   int64_t jls_lin_id = -1;  // linearisation whose Jl column scale the landmark-order master jl_scale4 holds
+  int64_t lmslin_lin_id = -1;  // ... and whose landmarks the landmark-order master lms_lin4 holds (lazily, from lml)
+  // compute_error_* of an unchanged state (the LM loop asks again at the top of every iteration,
+  // bal_bundle_adjustment.cpp:302-310 / 600-605): cams_ver counts the writes to cams4 as lms_ver does for lms4
+  uint64_t cams_ver = 1;
+  struct ErrMemo {
+    bool valid = false;
+    uint64_t lms_ver = 0, cams_ver = 0;
+    double alpha = 0;
+    int kind = 0, mode = 0;
+    povar_residual_info ri{};
+  } err_memo;
+  bool no_err_memo = false;   // POVAR_NO_ERR_MEMO=1: evaluate every compute_error call (timing the kernel itself)
+  bool has_empty_lm = false;  // a landmark without observations has no lane: lms_lin4 is then copied eagerly
+  bool flag0_clean = false;  // flags[0] is known to be zero on the device (read back as zero, no writer launched since)
   hipGraphExec_t series_graph = nullptr;
   Dp series_graph_d{};
   int series_graph_key[6] = {0, 0, 0, 0, 0, 0};
@@ -535,9 +549,21 @@ void ensure_jl_scale4(povar_ctx* c) {
   c->jls_lin_id = c->lin_id;
 }
 
+// the landmark-order copy of the linearisation point: the lane-per-landmark linearisation keeps only the lane-ordered
+// one (V2::lml); the lane-per-observation kernels and the exports read lms_lin4
+void ensure_lms_lin(povar_ctx* c) {
+  if (c->lmslin_lin_id == c->lin_id) return;
+  const int64_t n = (int64_t)c->d.v2.n_tiles * WAVE;
+  if (n > 0) hipLaunchKernelGGL(lanes_to_lm, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d.v2.lm_of, c->d.v2.seg,
+                                (const double4*)c->v2_lml.p, c->lms_lin4.p, n);
+  c->lmslin_lin_id = c->lin_id;
+}
+
 void ensure_legacy(povar_ctx* c) {
   if (!(c->linearized || c->linearized_h)) return;
   ensure_jl_scale4(c);
+  ensure_lms_lin(c);
+  c->flag0_clean = false;  // the auxiliary linearisation below may raise the finiteness flag
   if (c->views_lin_id != c->lin_id) build_views(c);
   // the lazily rebuilt sqrt(w) / residual arrays and landmark records belong to the LINEARISATION: they are built
   // with its alpha, whatever alpha the caller (apply_pose, error_pose) has put into the context meanwhile
@@ -581,6 +607,32 @@ void ensure_legacy(povar_ctx* c) {
     }
     c->aux_prep_id = c->prep_id;
   }
+}
+
+// flags[0] (finiteness / p2p time-out bits) is reset before every entry point that reads it back; when the last
+// read-back was zero and nothing that can raise it has been enqueued since, the reset is skipped
+int clear_flag0(povar_ctx* c) {
+  if (c->flag0_clean) return 0;
+  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  return 0;
+}
+bool err_memo_hit(const povar_ctx* c, int kind, double alpha, povar_residual_info* out) {
+  const auto& m = c->err_memo;
+  if (!m.valid || m.kind != kind || m.alpha != alpha || m.lms_ver != c->lms_ver || m.cams_ver != c->cams_ver ||
+      m.mode != c->opt.e0_mode * 4 + (c->use_lpl ? 2 : 0) + (c->use_lpl_prepare ? 1 : 0))
+    return false;
+  *out = m.ri;
+  return true;
+}
+void err_memo_store(povar_ctx* c, int kind, double alpha, const povar_residual_info& ri) {
+  auto& m = c->err_memo;
+  m.valid = !c->no_err_memo;
+  m.kind = kind;
+  m.alpha = alpha;
+  m.lms_ver = c->lms_ver;
+  m.cams_ver = c->cams_ver;
+  m.mode = c->opt.e0_mode * 4 + (c->use_lpl ? 2 : 0) + (c->use_lpl_prepare ? 1 : 0);
+  m.ri = ri;
 }
 
 // OR of a per-rank failure flag over the ranks (is_numerically_valid, linearisation failure)
@@ -855,8 +907,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   c->n_lms = n_lms;
   c->n_obs = n_obs;
   c->lm_off.assign(lm_offsets, lm_offsets + n_lms + 1);
+  for (int l = 0; l < n_lms; ++l) c->has_empty_lm |= lm_offsets[l + 1] == lm_offsets[l];
   HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
+  if (const char* g = std::getenv("POVAR_NO_ERR_MEMO")) c->no_err_memo = g[0] == '1';
   if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
   if (const char* g = std::getenv("POVAR_NO_FUSE")) c->fuse_binv = !(g[0] == '1');
   // A problem that gives the 256 x 16 wavefronts of the lane-per-landmark kernels less than a row each is bound by the
@@ -1143,6 +1197,7 @@ int povar_synchronize(povar_ctx* c) {
 int povar_set_cameras(povar_ctx* c, const double* cams) {
   if (int rc = check_ctx(c)) return rc;
   HIP_TRY(hipMemcpyAsync(c->cams4.p, cams, sizeof(double) * 12 * c->n_cams, hipMemcpyHostToDevice, c->stream));
+  ++c->cams_ver;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1185,6 +1240,7 @@ int povar_restore_pose(povar_ctx* c) {
   HIP_TRY(hipMemcpyAsync(c->cams4.p, c->cams_bak4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->lms4.p, c->lms_bak4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   ++c->lms_ver;
+  ++c->cams_ver;
   return 0;
 }
 
@@ -1213,7 +1269,8 @@ int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
   if (!out) return fail(-1, "null argument");
   TimeScope ts(c, 4);
   set_alpha(c, alpha);
-  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  if (err_memo_hit(c, 1, alpha, out)) return 0;
+  if (int rc = clear_flag0(c)) return rc;
   if (c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
     ensure_lmx(c);
     hipLaunchKernelGGL(lpl_pass<1>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
@@ -1227,6 +1284,7 @@ int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
   double h[3];
   int f[4];
   if (int rc = read_scal_flags(c, h, 3, f)) return rc;
+  c->flag0_clean = f[0] == 0;
   if (int rc = combine_flag(c, &f[0])) return rc;
   out->all_num_obs = (int64_t)std::llround(h[2]);
   out->all_error = h[0];
@@ -1235,6 +1293,7 @@ int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
   out->valid_error = h[0];
   out->valid_residual_sum = h[1];
   out->is_numerically_valid = f[0] ? 0 : 1;
+  err_memo_store(c, 1, alpha, *out);
   return 0;
 }
 
@@ -1244,28 +1303,37 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   set_alpha(c, alpha);
   c->alpha_lin = alpha;
   TimeScope ts(c, 0);
-  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  if (int rc = clear_flag0(c)) return rc;
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   ++c->lin_id;
   c->linearized = true;
   // lane-per-landmark mode: one forward walk over the row stream; the per-slot arrays and the camera-major landmark
   // copies of the lane-per-observation kernels are built when one of them asks (ensure_legacy)
   const bool lazy = lpl_only(c);
+  Dp dl = c->d;  // the camera-major kernels of this call read the linearisation point where it is now
   if (lazy) {
-    // the linearisation point in lane order is a plain copy of the current mirror; the kernel writes the scale mirror
+    // the kernel reads the current lane-ordered mirror and leaves the linearisation point (V2::lml) and the scale
+    // mirror behind; the landmark-order copy lms_lin4 follows when a lane-per-observation kernel asks
+    // (ensure_lms_lin): until then the current landmarks ARE the linearisation point
     ensure_lmx(c);
-    HIP_TRY(hipMemcpyAsync(c->v2_lml.p, c->v2_lmx.p, sizeof(double4) * (size_t)c->d.v2.n_tiles * WAVE, hipMemcpyDeviceToDevice, c->stream));
     c->lml_lin_id = c->lsc_lin_id = c->lin_id;
     hipLaunchKernelGGL(lpl_pass<0>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
+    if (c->has_empty_lm) {
+      HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
+      c->lmslin_lin_id = c->lin_id;
+    } else {
+      dl.lms_lin4 = c->lms4.p;
+    }
   } else {
+    HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
+    c->lmslin_lin_id = c->lin_id;
     launch_lm(c, OpLinearize{});
     c->aux_lin_id = c->jls_lin_id = c->lin_id;
     build_views(c);
   }
   if (c->n_cold3 > 0)
-    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 0);
-  hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, dl, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 0);
+  hipLaunchKernelGGL(cm_gram, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, dl, lazy ? 1 : 0);
   if (sharded(c)) {
     // per-camera Gram moments are partial sums over this rank's landmarks: sum, all-reduce, finish
     hipLaunchKernelGGL(cam_finish_linearize, dim3(c->n_cams), dim3(CFL_THREADS), 0, c->stream, c->d, (const double*)nullptr);
@@ -1277,6 +1345,7 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   HIP_TRY(hipGetLastError());
   int f[4];
   if (int rc = read_flags(c, f)) return rc;
+  c->flag0_clean = f[0] == 0;
   if (int rc = combine_flag(c, &f[0])) return rc;
   c->new_linearization_point = true;
   c->linearized = true;
@@ -1402,6 +1471,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   }
   HIP_TRY(hipGetLastError());
   int iters = m, status = POVAR_LINEAR_SOLVER_NO_CONVERGENCE;
+  if (p2p_terms) c->flag0_clean = false;  // the waits of the exchange kernels raise bit 1 of flags[0] on a time-out
   if (p2p_terms) {
     int f[4];
     if (int rc = read_flags(c, f)) return rc;
@@ -1496,6 +1566,7 @@ int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const doub
     hipLaunchKernelGGL(cam_apply_inc, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->d, 2);
   }
   ++c->lms_ver;
+  ++c->cams_ver;
   if (lpl_back) c->lmx_ver = c->lms_ver;  // backsub_lpl wrote the new landmarks into the lane-ordered mirror too
   if (lpl_back)
     hipLaunchKernelGGL((reduce_partials<1>), dim3(1), dim3(1024), 0, c->stream, c->part.p, c->e0c_grid, c->scal.p);
@@ -1534,7 +1605,8 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
   if (int rc = check_ctx(c)) return rc;
   if (!out) return fail(-1, "null argument");
   TimeScope ts(c, 4);
-  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  if (err_memo_hit(c, 2, 0.0, out)) return 0;
+  if (int rc = clear_flag0(c)) return rc;
   if (c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
     ensure_lmx(c);
     hipLaunchKernelGGL(lpl_pass_h<1>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
@@ -1548,6 +1620,7 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
   double h[6];
   int f[4];
   if (int rc = read_scal_flags(c, h, 6, f)) return rc;
+  c->flag0_clean = f[0] == 0;
   if (int rc = combine_flag(c, &f[0])) return rc;
   out->all_error = h[0];
   out->all_residual_sum = h[1];
@@ -1556,31 +1629,41 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
   out->valid_residual_sum = h[4];
   out->valid_num_obs = (int64_t)std::llround(h[5]);
   out->is_numerically_valid = f[0] ? 0 : 1;
+  err_memo_store(c, 2, 0.0, *out);
   return 0;
 }
 
 int povar_linearize_homogeneous(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
   TimeScope ts(c, 0);
-  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  if (int rc = clear_flag0(c)) return rc;
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
   ++c->lin_id;
   c->linearized_h = true;
   const bool lazy = lpl_only(c);
+  Dp dl = c->d;
   if (lazy) {
+    // as in povar_linearize_pose: the kernel leaves the lane-ordered linearisation point and scale mirror behind,
+    // jl_scale4 and lms_lin4 follow on demand
     ensure_lmx(c);
-    HIP_TRY(hipMemcpyAsync(c->v2_lml.p, c->v2_lmx.p, sizeof(double4) * (size_t)c->d.v2.n_tiles * WAVE, hipMemcpyDeviceToDevice, c->stream));
-    c->lml_lin_id = c->lsc_lin_id = c->lin_id;  // the kernel writes the scale mirror; jl_scale4 follows on demand
+    c->lml_lin_id = c->lsc_lin_id = c->lin_id;
     hipLaunchKernelGGL(lpl_pass_h<0>, dim3(c->e0c_grid), dim3(E0C_BLOCK), pass_lds_bytes(c->v2_max_slots), c->stream, c->d, c->part.p);
+    if (c->has_empty_lm) {
+      HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
+      c->lmslin_lin_id = c->lin_id;
+    } else {
+      dl.lms_lin4 = c->lms4.p;
+    }
   } else {
+    HIP_TRY(hipMemcpyAsync(c->lms_lin4.p, c->lms4.p, sizeof(double4) * c->n_lms, hipMemcpyDeviceToDevice, c->stream));
+    c->lmslin_lin_id = c->lin_id;
     launch_lm(c, OpLinearizeH{});
     c->aux_lin_id = c->jls_lin_id = c->lin_id;
     build_views(c);
   }
   if (c->n_cold3 > 0)
-    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, c->d, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 1);
-  hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, c->d, lazy ? 1 : 0);
+    hipLaunchKernelGGL(cm_build_h, dim3(grid_for(c->n_cold3, 256)), dim3(256), 0, c->stream, dl, (const int*)c->c3_lm.p, c->c3_h.p, c->n_cold3, 1);
+  hipLaunchKernelGGL(cm_gram_h, dim3(grid_for(c->n_items, 4)), dim3(256), 0, c->stream, dl, lazy ? 1 : 0);
   hipLaunchKernelGGL(cam_finish_linearize_h, dim3(c->n_cams), dim3(CFL_THREADS), 0, c->stream, c->d, (const double*)nullptr, c->ncw.p);
   if (sharded(c)) {
     if (int rc = allreduce(c, c->d.G, 40 * (size_t)c->n_cams)) return rc;
@@ -1589,6 +1672,7 @@ int povar_linearize_homogeneous(povar_ctx* c) {
   HIP_TRY(hipGetLastError());
   int f[4];
   if (int rc = read_flags(c, f)) return rc;
+  c->flag0_clean = f[0] == 0;
   if (int rc = combine_flag(c, &f[0])) return rc;
   c->new_linearization_point = true;
   c->linearized = false;  // the step-1 linearisation is gone
@@ -1672,6 +1756,7 @@ int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
     launch_lm(c, OpBackJoint{});
   }
   ++c->lms_ver;
+  ++c->cams_ver;
   if (lpl_back) c->lmx_ver = c->lms_ver;  // backsub_lpl_h keeps the lane-ordered mirror current
   hipLaunchKernelGGL(cam_apply_inc_h, dim3(grid_for(c->n_cams, 256)), dim3(256), 0, c->stream, c->d, 2, (const double*)c->ncw.p);
   if (lpl_back)
@@ -1688,8 +1773,14 @@ int povar_apply_joint(povar_ctx* c, const double* inc, double* l_diff) {
 
 int povar_normalize_joint(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
-  hipLaunchKernelGGL(normalize_joint, dim3(grid_for(std::max(c->n_cams, c->n_lms), 256)), dim3(256), 0, c->stream, c->d);
+  // the lane-ordered mirror of the landmarks, when current, is normalised along (same division, same operands)
+  const bool mirror = c->use_lpl && c->lmx_ver == c->lms_ver && c->d.v2.n_tiles > 0;
+  const int64_t n_lanes = mirror ? (int64_t)c->d.v2.n_tiles * WAVE : 0;
+  hipLaunchKernelGGL(normalize_joint, dim3(grid_for(std::max<int64_t>(std::max(c->n_cams, c->n_lms), n_lanes), 256)), dim3(256), 0,
+                     c->stream, c->d, n_lanes);
   ++c->lms_ver;
+  ++c->cams_ver;
+  if (mirror) c->lmx_ver = c->lms_ver;
   HIP_TRY(hipGetLastError());
   return 0;
 }

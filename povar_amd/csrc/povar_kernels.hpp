@@ -1942,7 +1942,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
   int bad = 0;
   while (c_t < t_end) {
     const int c_row0 = tiles[4 * c_t], c_k = tiles[4 * c_t + 1], c_fl = tiles[4 * c_t + 3];
-    const double4 h = (MODE == 0 ? v.lml : v.lmx)[(size_t)c_t * WAVE + lane];
+    const double4 h = v.lmx[(size_t)c_t * WAVE + lane];
+    if (MODE == 0) v.lml[(size_t)c_t * WAVE + lane] = h;  // the linearisation point, lane-ordered, is left behind
     double red[3] = {0, 0, 0};
     for (int j = 0; j < c_k; ++j) {
       const LplRow cur = n1;

@@ -1226,7 +1226,8 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
   int bad = 0;
   while (c_t < t_end) {
     const int c_row0 = tiles[4 * c_t], c_k = tiles[4 * c_t + 1], c_fl = tiles[4 * c_t + 3];
-    const double4 X = (MODE == 0 ? v.lml : v.lmx)[(size_t)c_t * WAVE + lane];
+    const double4 X = v.lmx[(size_t)c_t * WAVE + lane];
+    if (MODE == 0) v.lml[(size_t)c_t * WAVE + lane] = X;  // the linearisation point, lane-ordered, is left behind
     double red[4] = {0, 0, 0, 0};
     for (int j = 0; j < c_k; ++j) {
       const LplRow cur = n1;
@@ -1565,8 +1566,14 @@ __global__ __launch_bounds__(256) void cam_apply_inc_h(Dp d, int mode, const dou
 }
 
 // K15: P_c /= |P_c|_F, X_l /= X_l[3]  (bal_bundle_adjustment.cpp:700-705)
-__global__ __launch_bounds__(256) void normalize_joint(Dp d) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void normalize_joint(Dp d, int64_t n_lanes) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_lanes && d.v2.lm_of[i] >= 0) {  // lane-ordered mirror (V2::lmx), kept current
+    double4 X = d.v2.lmx[i];
+    const double w = X.w;
+    X.x /= w; X.y /= w; X.z /= w; X.w /= w;
+    d.v2.lmx[i] = X;
+  }
   if (i < d.n_cams) {
     double* P = reinterpret_cast<double*>(d.cams4) + 12 * (size_t)i;
     double s = 0;
