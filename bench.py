@@ -279,6 +279,11 @@ def main():
     ctx = capi.Context(n_c, prob.lm_off[lb : le + 1] - prob.lm_off[lb], prob.cam_idx[ob:oe],
                        prob.obs[ob:oe], device=device, e0_mode=mode, robust_norm=args.robust_norm,
                        huber=args.huber)
+    # steady-state rate: wait for the row placement a host thread of povar_create is still working on (the library
+    # starts on the natural row order and swaps at a later linearisation by itself; POVAR_BENCH_NO_WAIT=1 measures that)
+    t_wait = time.perf_counter()
+    placed = os.environ.get("POVAR_BENCH_NO_WAIT") == "1" or ctx.layout_finalize(wait=True)
+    placement_wait_ms = (time.perf_counter() - t_wait) * 1e3
     comm_used = "none"
     if world > 1 or os.environ.get("POVAR_FORCE_COMM"):
         # POVAR_FORCE_COMM=1 exercises the RCCL path with a 1-rank communicator (1-GPU boxes)
@@ -568,6 +573,10 @@ def main():
                                   "assignment": "contiguous landmark ranges, per-workgroup camera sets" if li.strategy else
                                   "rank-based camera grid",
                                   "layout_build_ms": li.create_ms,
+                                  "row_placement": {0: "none (natural row order)", 1: "inside povar_create",
+                                                    2: "pending on a host thread (kernels on the natural order)",
+                                                    3: "on a host thread, swapped in before the timed region"}[li.placement],
+                                  "row_placement_ms": li.placement_ms, "row_placement_waited_ms": placement_wait_ms,
                                   "term_kernels": "lane per landmark" if li.lane_per_landmark else
                                   "lane per observation (round-1 kernels: under 65 536 observations or POVAR_E0_V1=1)"}
     if not bal_path and (args.popularity != "zipf1" or args.long_track_frac > 0):

@@ -253,8 +253,20 @@ typedef struct {
                            locality), 1 contiguous landmark ranges with per-workgroup camera sets (the file's landmark
                            order carries the locality, as for the reference: bal/bal_problem.cpp:183-303) */
   int32_t hubs;         /* camera slots per workgroup with four accumulator replicas */
+  int32_t placement;    /* LDS bank placement of the rows: 0 natural order (none), 1 placed inside povar_create,
+                           2 being placed on a host thread (the kernels run on the natural order meanwhile),
+                           3 placed rows swapped in */
+  double placement_ms;  /* host wall time of the background placement (0 until it has finished) */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
+/* The reference's constructor is a trivial allocation (sc/linearization_varproj.hpp:44-60); this library's builds the
+ * lane-per-landmark row stream, and the LDS bank placement of its rows is two thirds of that time while it only buys
+ * 10 % of the term rate.  From 2^20 observations on (POVAR_LPL_PLACE=sync|async|none overrides) povar_create therefore
+ * returns on the natural row order and a host thread places the rows; they are swapped in by the first
+ * povar_linearize_* call that finds them ready.  povar_layout_finalize(ctx, 1) waits for the thread and swaps at
+ * once (benchmarks; a linearisation taken before is dropped: linearise again), (ctx, 0) swaps only if ready.
+ * Returns 1 if the placed rows are in use after the call, 0 if not (yet), < 0 on error. */
+int povar_layout_finalize(povar_ctx* ctx, int32_t wait);
 
 /* ---- multi-GPU: landmarks sharded over ranks, one RCCL all-reduce per exchange step ---- */
 /* host-only: contiguous landmark range of `rank`, balanced by observation count */

@@ -46,7 +46,8 @@ class ProfileInfo(C.Structure):
 class LayoutInfo(C.Structure):
     _fields_ = [("grid", C.c_int32), ("lds_slots", C.c_int32), ("n_global", C.c_int32), ("n_tail", C.c_int32),
                 ("n_tiles", C.c_int64), ("n_rows", C.c_int64), ("n_cold", C.c_int64), ("n_obs", C.c_int64), ("lane_per_landmark", C.c_int64),
-                ("create_ms", C.c_double), ("strategy", C.c_int32), ("hubs", C.c_int32)]
+                ("create_ms", C.c_double), ("strategy", C.c_int32), ("hubs", C.c_int32), ("placement", C.c_int32),
+                ("placement_ms", C.c_double)]
 
 
 class TimingsInfo(C.Structure):
@@ -344,6 +345,14 @@ class Context:
         li = LayoutInfo()
         self._chk(self.L.povar_get_layout_info(self.h, C.byref(li)))
         return li
+
+    def layout_finalize(self, wait=True):
+        """Swap the rows placed on the host thread in (wait: block until they are ready).  True when placed rows are
+        in use afterwards.  A linearisation taken before the swap is dropped."""
+        rc = self.L.povar_layout_finalize(self.h, C.c_int32(1 if wait else 0))
+        if rc < 0:
+            raise PovarError(f"povar_hip rc={rc}: {self.L.povar_last_error().decode()}")
+        return rc == 1
 
     def comm_ranks(self):
         n = self.L.povar_comm_ranks(self.h)

@@ -156,7 +156,7 @@ inline void lpl_assign(int h, const std::vector<long>& cost, std::vector<int>& a
 // rank1[c]: 1-based popularity rank of camera c; cnt_sorted[r]: observation count of the camera with rank r (0-based)
 inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx, const double* obs,
                       const std::vector<int>& rank1, const std::vector<int>& slot_of_obs, size_t n_slots, int grid,
-                      int n_acc, LplLayout& L) {
+                      int n_acc, LplLayout& L, bool place = true) {
   // Rows per tile are capped by dealing longer landmarks over several lanes (K0 rows: at most 2 K0 row steps per
   // tile, the unit of load balance).  A wavefront walks its tile's rows one after the other, so on a problem too small
   // to give every wavefront a tile the cap sets the latency of the launch (ladybug-49: 2 rows 106 k, 8 rows 76 k
@@ -640,11 +640,12 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     return g + 2 * (lane >> 5);
   };
   const int hubs = L.hubs;
-  const bool no_place = std::getenv("POVAR_LPL_NOPLACE") != nullptr;  // measurement knob: natural order
+  // place = false: rows in their natural order.  Everything but the six row-order arrays (uv, cw, cpos, lm_pos, lm_of,
+  // of_slot) is the same as with placement: povar_create starts on the natural order and swaps the placed rows in when
+  // a host thread has finished them (lpl_row_arrays_only_differ in the layout checker holds the two against each other)
+  const bool no_place = !place;
   int max_tiles_tried = 1 << 30;
   if (const char* e = std::getenv("POVAR_LPL_TILES_TRIED")) max_tiles_tried = std::max(1, std::atoi(e));
-  long good_enough = 0;
-  if (const char* e = std::getenv("POVAR_LPL_EXIT")) good_enough = std::atol(e);
   auto place_wg = [&](int w) {
     std::vector<int> slot_of_rank(n_cams, -1);
     std::vector<int> hot_idx, cold_idx, assign, assign2;
@@ -820,11 +821,11 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
             long best = -1;
             int best_t = -1, best_lane = -1;
             int tiles_tried = 0;
-            for (int t = ta; t <= tb && (best < 0 || best > good_enough) && tiles_tried < max_tiles_tried; ++t) {
+            for (int t = ta; t <= tb && best != 0 && tiles_tried < max_tiles_tried; ++t) {
               if (!free_mask[t - ta]) continue;
               ++tiles_tried;
               unsigned seen = 0;
-              for (unsigned long long m = free_mask[t - ta]; m && (best < 0 || best > good_enough); m &= m - 1) {
+              for (unsigned long long m = free_mask[t - ta]; m && best != 0; m &= m - 1) {
                 const int lane = __builtin_ctzll(m), cls = (lane >> 5) * 2 + (read_group(lane) & 1);
                 if (seen & (1u << cls)) continue;
                 seen |= 1u << cls;

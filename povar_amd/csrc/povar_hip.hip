@@ -11,8 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -109,6 +111,16 @@ struct povar_ctx {
   DevBuf<int4> v2_tile;
   DevBuf<double> v2_w, v2_lmrec;
   int64_t v2_rows = 0;
+  // LDS bank placement of the rows (lpl_layout.hpp) on a host thread: povar_create returns on the natural row order,
+  // the placed rows are swapped in at the next linearisation after they are ready (or by povar_layout_finalize).
+  // POVAR_LPL_PLACE = sync | async | none; default: async from 2^20 observations on, sync below
+  std::thread placer;
+  std::atomic<int> placer_state{0};  // 0 no thread, 1 running, 2 rows uploaded and ready, 3 failed
+  DevBuf<double2> pl_uv;
+  DevBuf<int> pl_cw, pl_cpos, pl_lm_pos, pl_lm_of, pl_of_slot;
+  size_t pl_bytes = 0;
+  int placement = 0;          // povar_layout_info::placement: 0 natural order, 1 placed in povar_create, 2 pending, 3 swapped in
+  double placement_ms = 0;    // host wall time of the background build (valid from state 2 on)
   bool use_lpl = true;        // POVAR_E0_V1=1: keep e0_lm_cached<true> (lane per observation) for A/B runs
   bool lpl_forced = false;      // POVAR_E0_V1 set: keep the choice (the peer-to-peer exchange otherwise turns use_lpl on)
   bool use_lpl_prepare = true;  // POVAR_PREPARE_V1=1: keep lm_regular<OpPrepare> + cm_scatter
@@ -609,6 +621,32 @@ void ensure_legacy(povar_ctx* c) {
   }
 }
 
+// The placed rows (povar_ctx::placer) replace the natural order.  Only between linearisations: everything lane-ordered
+// that a linearisation leaves behind (V2::lml / lsc / w, the landmark records) belongs to the row order it was built on;
+// the landmark mirror V2::lmx is regathered on demand.  wait: block until the host thread is done.
+// Returns 1 when the rows were swapped in.
+int swap_in_placed_rows(povar_ctx* c, bool wait) {
+  if (c->placement != 2) return 0;
+  if (!wait && c->placer_state.load(std::memory_order_acquire) < 2) return 0;
+  if (c->placer.joinable()) c->placer.join();
+  if (c->placer_state.load(std::memory_order_acquire) != 2) {  // the build or an upload failed: stay on the natural order
+    c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
+    c->placement = 0;
+    return 0;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));  // nothing in flight reads the old rows
+  std::swap(c->v2_uv, c->pl_uv); std::swap(c->v2_cw, c->pl_cw); std::swap(c->v2_cpos, c->pl_cpos);
+  std::swap(c->v2_lm_pos, c->pl_lm_pos); std::swap(c->v2_lm_of, c->pl_lm_of); std::swap(c->v2_of_slot, c->pl_of_slot);
+  c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
+  V2& v = c->d.v2;
+  v.uv = c->v2_uv.p; v.cw = c->v2_cw.p; v.cpos = c->v2_cpos.p; v.lm_pos = c->v2_lm_pos.p; v.lm_of = c->v2_lm_of.p;
+  v.of_slot = c->v2_of_slot.p;
+  c->lmx_ver = 0;                          // lane-ordered landmark mirror: regather
+  c->lml_lin_id = c->lsc_lin_id = -1;
+  c->placement = 3;
+  return 1;
+}
+
 // flags[0] (finiteness / p2p time-out bits) is reset before every entry point that reads it back; when the last
 // read-back was zero and nothing that can raise it has been enqueued since, the reset is skipped
 int clear_flag0(povar_ctx* c) {
@@ -996,9 +1034,49 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   {
     // lane-per-landmark layout of e0_lpl (lpl_layout.hpp)
     LplLayout V;
+    int place_mode = n_obs >= (1 << 20) ? 2 : 1;  // 0 none, 1 in this call, 2 on a host thread
+    if (std::getenv("POVAR_LPL_NOPLACE")) place_mode = 0;
+    if (const char* e = std::getenv("POVAR_LPL_PLACE")) place_mode = e[0] == 'n' ? 0 : e[0] == 's' ? 1 : e[0] == 'a' ? 2 : place_mode;
     build_lpl(n_cams, n_lms, lm_offsets, cam_idx, obs, L.cam_hot, L.slot_of_obs, (size_t)c->n_slots, c->e0c_grid,
-              c->n_hot_acc, V);
+              c->n_hot_acc, V, place_mode == 1);
     lap("build_lpl (lane/landmark)");
+    c->placement = place_mode;
+    if (place_mode == 2 && !V.tile.empty()) {
+      // the same builder again, with the placement, on copies of the caller's arrays (they need not outlive this call)
+      struct Job {
+        std::vector<int32_t> lm_off, cam_idx;
+        std::vector<double> obs;
+        std::vector<int> rank1, slot_of_obs;
+      };
+      auto job = std::make_shared<Job>();
+      job->lm_off.assign(lm_offsets, lm_offsets + n_lms + 1);
+      job->cam_idx.assign(cam_idx, cam_idx + n_obs);
+      job->obs.assign(obs, obs + 2 * n_obs);
+      job->rank1 = L.cam_hot;
+      job->slot_of_obs = L.slot_of_obs;
+      const int64_t rows = V.rows;
+      const size_t n_tiles = V.tile.size();
+      const int dev = options->device, grid = c->e0c_grid, n_acc = c->n_hot_acc;
+      const size_t n_slots = (size_t)c->n_slots;
+      c->placer_state.store(1);
+      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms]() {
+        const auto t0 = std::chrono::steady_clock::now();
+        LplLayout P;
+        build_lpl(n_cams, n_lms, job->lm_off.data(), job->cam_idx.data(), job->obs.data(), job->rank1, job->slot_of_obs,
+                  n_slots, grid, n_acc, P, true);
+        bool ok = P.rows == rows && P.tile.size() == n_tiles && hipSetDevice(dev) == hipSuccess;
+        auto up = [&](auto& buf, const auto& v) {
+          if (!ok) return;
+          ok = buf.alloc(std::max<size_t>(v.size(), 1), &c->pl_bytes) == hipSuccess &&
+               (v.empty() || hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice) == hipSuccess);
+        };
+        up(c->pl_uv, P.uv); up(c->pl_cw, P.cw); up(c->pl_cpos, P.cpos);
+        up(c->pl_lm_pos, P.lm_pos); up(c->pl_lm_of, P.lm_of); up(c->pl_of_slot, P.of_slot);
+        c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        c->placer_state.store(ok ? 2 : 3, std::memory_order_release);
+      });
+      lap("row placement handed to a host thread");
+    }
     if (V.max_slots > c->n_hot_acc) { povar_destroy(c); return fail(-1, "lpl layout: workgroup camera set exceeds the LDS capacity"); }
     c->v2_rows = V.rows;
     c->v2_max_slots = V.max_slots;
@@ -1151,7 +1229,9 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
 #undef HIP_TRY_C
 void povar_destroy(povar_ctx* c) {
   if (!c) return;
+  if (c->placer.joinable()) c->placer.join();
   (void)hipSetDevice(c->opt.device);
+  c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->pin) (void)hipHostFree(c->pin);
@@ -1302,6 +1382,7 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
   c->linearized_h = false;
   set_alpha(c, alpha);
   c->alpha_lin = alpha;
+  if (int rc = swap_in_placed_rows(c, false); rc < 0) return rc;  // a new linearisation point: the row order may change
   TimeScope ts(c, 0);
   if (int rc = clear_flag0(c)) return rc;
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
@@ -1635,6 +1716,7 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
 
 int povar_linearize_homogeneous(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = swap_in_placed_rows(c, false); rc < 0) return rc;
   TimeScope ts(c, 0);
   if (int rc = clear_flag0(c)) return rc;
   HIP_TRY(hipMemcpyAsync(c->cams_lin4.p, c->cams4.p, sizeof(double4) * 3 * c->n_cams, hipMemcpyDeviceToDevice, c->stream));
@@ -2000,7 +2082,23 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->create_ms = c->create_ms;
   out->strategy = c->v2_strategy;
   out->hubs = c->d.v2.hubs;
+  out->placement = c->placement;
+  out->placement_ms = c->placer_state.load(std::memory_order_acquire) >= 2 ? c->placement_ms : 0.0;
   return 0;
+}
+
+int povar_layout_finalize(povar_ctx* c, int32_t wait) {
+  if (int rc = check_ctx(c)) return rc;
+  if (c->placement == 2) {
+    const int rc = swap_in_placed_rows(c, wait != 0);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      // what the current linearisation left in the old row order is gone with it
+      c->linearized = c->linearized_h = false;
+      c->err_memo.valid = false;
+    }
+  }
+  return c->placement == 1 || c->placement == 3 ? 1 : 0;
 }
 
 int povar_comm_ranks(povar_ctx* c) {

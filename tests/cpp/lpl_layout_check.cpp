@@ -3,6 +3,7 @@
 // one JSON line of statistics.  No HIP runtime call is made (runs without a GPU).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -46,7 +47,27 @@ int main(int argc, char** argv) {
   std::vector<int> slot_of_obs(n_obs);
   std::iota(slot_of_obs.begin(), slot_of_obs.end(), 0);
   LplLayout L;
-  build_lpl(n_cams, n_lms, lm_off.data(), cam_idx.data(), obs.data(), rank1, slot_of_obs, (size_t)n_obs, grid, n_acc, L);
+  const bool place = std::getenv("LPL_CHECK_NOPLACE") == nullptr;  // the natural row order povar_create starts on
+  build_lpl(n_cams, n_lms, lm_off.data(), cam_idx.data(), obs.data(), rank1, slot_of_obs, (size_t)n_obs, grid, n_acc, L, place);
+  int same_but_rows = -1;
+  if (std::getenv("LPL_CHECK_BOTH")) {
+    // the other row order: everything but the six row-order arrays must be the same (povar_create swaps only those)
+    LplLayout M;
+    build_lpl(n_cams, n_lms, lm_off.data(), cam_idx.data(), obs.data(), rank1, slot_of_obs, (size_t)n_obs, grid, n_acc, M, !place);
+    auto eq4 = [](const std::vector<int4>& a, const std::vector<int4>& b) {
+      return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(int4)) == 0;
+    };
+    auto eq2 = [](const std::vector<int2>& a, const std::vector<int2>& b) {
+      return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(int2)) == 0;
+    };
+    same_but_rows = eq4(L.tile, M.tile) && L.seg == M.seg && L.wg_tile_off == M.wg_tile_off && L.wg_cam_off == M.wg_cam_off &&
+                    L.wg_cams == M.wg_cams && L.wg_slot_rec == M.wg_slot_rec && eq2(L.part_range, M.part_range) &&
+                    L.cold_lm == M.cold_lm && eq2(L.cold_range, M.cold_range) && L.rows == M.rows &&
+                    L.n_part_rec == M.n_part_rec && L.max_slots == M.max_slots && L.n_global == M.n_global &&
+                    L.hubs == M.hubs && L.strategy == M.strategy && L.uv.size() == M.uv.size() &&
+                    L.lm_of.size() == M.lm_of.size();
+    CHECK(same_but_rows == 1);
+  }
   // ---- invariants
   CHECK(L.max_slots <= n_acc);
   CHECK((int)L.wg_tile_off.size() == grid + 1 && (int)L.wg_cam_off.size() == grid + 1);
@@ -215,7 +236,8 @@ int main(int argc, char** argv) {
   mix(L.wg_slot_rec.data(), L.wg_slot_rec.size() * sizeof(int)); mix(L.cold_lm.data(), L.cold_lm.size() * sizeof(int));
   mix(L.of_slot.data(), L.of_slot.size() * sizeof(int));
   std::printf("{\"fingerprint\": \"%016llx\", ", fp);
-  std::printf("\"strategy\": \"%s\", \"hubs\": %d, ", L.strategy ? "ranges" : "grid", L.hubs);
+  std::printf("\"strategy\": \"%s\", \"hubs\": %d, \"placed\": %d, \"same_but_rows\": %d, ", L.strategy ? "ranges" : "grid", L.hubs,
+              place ? 1 : 0, same_but_rows);
   std::printf("\"ok\": 1, \"n_global\": %d, \"n_tail\": %d, \"grid\": [%d, %d], \"max_slots\": %d, \"rows\": %lld, "
               "\"tiles\": %zu, \"cold\": %lld, \"cold_frac\": %.5f, \"pad_frac\": %.5f, \"wg_rows_min\": %lld, "
               "\"wg_rows_max\": %lld, \"part_recs\": %d, \"extra_atomic_lanes_per_half\": %.3f, \"extra_records_per_read_group\": %.3f}\n",

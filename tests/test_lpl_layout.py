@@ -85,3 +85,18 @@ def test_layout_strategy_follows_the_graph(tmp_path):
     assert z["ok"] == 1 and z["strategy"] == "grid"
     zr = _run(tmp_path, zipf.n_cams, zipf.lm_off, zipf.cam_idx, zipf.obs, 64, 200, env={"POVAR_LPL_STRATEGY": "range"})
     assert zr["ok"] == 1 and zr["strategy"] == "ranges" and zr["cold_frac"] > z["cold_frac"]
+
+
+@pytest.mark.parametrize("popularity", ["zipf1", "local"])
+def test_natural_and_placed_row_orders_share_everything_but_the_rows(tmp_path, popularity):
+    """povar_create starts on the natural row order and swaps six arrays when a host thread has placed the rows: tiles,
+    workgroup camera sets, partial records and the cold view of the two builds must be identical, and the natural order
+    must satisfy the same invariants."""
+    from povar_amd import synth
+    p = synth.make_problem(300, 20000, 90000, seed=5, popularity=popularity)
+    both = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 64, 200, env={"LPL_CHECK_BOTH": "1"})
+    assert both["ok"] == 1 and both["placed"] == 1 and both["same_but_rows"] == 1
+    nat = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 64, 200, env={"LPL_CHECK_NOPLACE": "1"})
+    assert nat["ok"] == 1 and nat["placed"] == 0
+    assert nat["rows"] == both["rows"] and nat["tiles"] == both["tiles"] and nat["cold"] == both["cold"]
+    assert nat["extra_atomic_lanes_per_half"] > both["extra_atomic_lanes_per_half"]

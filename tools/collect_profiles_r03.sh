@@ -26,16 +26,23 @@ for n in venice_step1 venice_step2 final_huber_step1; do
 done
 cp $R/popularity.txt $P/${tag}_popularity_sweep.txt
 cp $R/shards.txt $P/${tag}_shard_term_times.txt
-grep -E "povar_create|build_lpl" $R/create.txt > $P/${tag}_create_time.txt
+grep -E "povar_create|build_lpl|row placement" $R/create.txt > $P/${tag}_create_time.txt
 cp $R/bal_venice/kernel_stats.txt $P/${tag}_bal_venice_kernel_stats.txt
 (echo "# tools/run_bal_config.py <problem> --power-sc-iterations 20 (both LM steps, defaults otherwise); venice: 6 + 4 iterations, --eta 0"
- cat $R/bal_ladybug-49.json $R/bal_trafalgar-257.json $R/bal_venice/bal_summary.json) > $P/${tag}_bal_end_to_end.txt
-python3 - > $P/${tag}_bal_venice_stage_times_ms.txt <<'PY'
-import json
-d = json.load(open("gpurun_out/ba_log_venice-1778.json"))
-for k in ("iteration_time", "jacobian_evaluation_time", "prepare_time", "solve_reduced_system_time",
-          "back_substitution_time", "residual_evaluation_time"):
-    print(k, [round(x * 1e3, 3) for x in d[k]])
+ cat $R/bal_ladybug-49.json $R/bal_trafalgar-257.json
+ echo "# venice as a caller gets it: povar_create returns on the natural row order, the placed rows would arrive after ~0.4 s"
+ cat $R/bal_venice_default.json
+ echo "# venice with POVAR_LPL_PLACE=sync (placement inside povar_create: the steady state of a long run)"
+ cat $R/bal_venice/bal_summary.json) > $P/${tag}_bal_end_to_end.txt
+python3 - $R > $P/${tag}_bal_venice_stage_times_ms.txt <<'PY'
+import json, sys
+for title, f in (("POVAR_LPL_PLACE=sync (placed rows: the steady state)", "ba_log_venice_sync.json"),
+                 ("default (natural row order: the run ends before the placed rows arrive)", "ba_log_venice_default.json")):
+    d = json.load(open(sys.argv[1] + "/" + f))
+    print("#", title)
+    for k in ("iteration_time", "jacobian_evaluation_time", "prepare_time", "solve_reduced_system_time",
+              "back_substitution_time", "residual_evaluation_time"):
+        print(k, [round(x * 1e3, 3) for x in d[k]])
 PY
 t() { python3 tools/pmc_to_traffic.py $(newest $R/$1/fetch/*/*counter_collection.csv) $(newest $R/$1/write/*/*counter_collection.csv) $2 $P/traffic.json; }
 t e0 venice-1778:ldsacc:1

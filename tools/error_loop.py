@@ -11,6 +11,7 @@ from povar_amd import capi, synth  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 p = synth.make_bal_problem("venice-1778")
 ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+ctx.layout_finalize()  # steady state: the placed rows, not the natural order povar_create starts on
 ctx.set_cameras(p.cams)
 ctx.init_landmarks_pose(0.01)
 for _ in range(3):

@@ -34,6 +34,7 @@ def main():
           f"{int(deg[deg > 64].sum())} observations on them)", flush=True)
     for mode in (capi.E0_IMPLICIT_LDSACC, capi.E0_IMPLICIT):
         ctx = capi.Context(p.n_cams, lm_off.astype(np.int32), cam.astype(np.int32), obs, e0_mode=mode)
+        ctx.layout_finalize()
         ctx.set_cameras(p.cams)
         ctx.init_landmarks_pose(0.01)
         assert ctx.linearize_pose(0.01)

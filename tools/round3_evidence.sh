@@ -40,6 +40,11 @@ python3 tools/create_time.py venice-1778 final-13682 > $out/create.txt 2>&1
 for p in ladybug-49 trafalgar-257; do
   python3 tools/run_bal_config.py $p --power-sc-iterations 20 > $out/bal_$p.json 2> $out/bal_$p.err
 done
-tools/bal_kernel_trace.sh $tag/bal_venice venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0 > $out/bal_venice.log 2>&1
+# venice end to end: as a caller gets it (rows placed on a host thread meanwhile: a ten-iteration run is over before they
+# arrive), then with the placement inside povar_create (POVAR_LPL_PLACE=sync: the steady state of a long run) under the trace
+python3 tools/run_bal_config.py venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0 > $out/bal_venice_default.json 2> $out/bal_venice_default.err
+cp gpurun_out/ba_log_venice-1778.json $out/ba_log_venice_default.json
+POVAR_LPL_PLACE=sync tools/bal_kernel_trace.sh $tag/bal_venice venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0 > $out/bal_venice.log 2>&1
+cp gpurun_out/ba_log_venice-1778.json $out/ba_log_venice_sync.json
 rm -rf $out/bal_venice/kt/*/*kernel_trace.csv $out/e0/kt/*/*kernel_trace.csv
 ls $out

@@ -17,6 +17,7 @@ def main():
     lam = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-4
     p = synth.make_bal_problem(shape)
     ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    ctx.layout_finalize()
     ctx.set_cameras(p.cams)
     ctx.init_landmarks_pose(0.01)
     ctx.set_jl_col_scaling(False)

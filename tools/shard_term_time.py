@@ -22,6 +22,7 @@ def main():
         ctx.comm_init(1, 0, capi.comm_unique_id())
         if os.environ.get("POVAR_P2P"):  # per-term exchange through the push/reduce kernels (world of one)
             ctx.p2p_attach(1, 0, [ctx.p2p_export(1)])
+    ctx.layout_finalize()  # steady state: the placed rows
     ctx.set_cameras(p.cams)
     ctx.init_landmarks_pose(0.01)
     assert ctx.linearize_pose(0.01)

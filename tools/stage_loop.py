@@ -24,6 +24,7 @@ a = ap.parse_args()
 alpha, lam = 0.01, 1e-4
 p = synth.make_bal_problem(a.problem, a.popularity)
 ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC, robust_norm=a.robust_norm, huber=a.huber)
+ctx.layout_finalize()  # steady state: the placed rows, not the natural order povar_create starts on
 ctx.set_cameras(p.cams)
 ctx.init_landmarks_pose(alpha)
 t0 = time.perf_counter()
