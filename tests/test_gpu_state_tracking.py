@@ -214,6 +214,7 @@ def test_rows_placed_on_a_host_thread_are_swapped_in(step, medium_problem, monke
     from povar_amd import capi
     p = medium_problem
     kw = dict(e0_mode=capi.E0_IMPLICIT_LDSACC)
+    monkeypatch.setenv("POVAR_E0_V1", "0")             # the lane-per-landmark kernels also under 65 536 observations
     monkeypatch.setenv("POVAR_LPL_PLACE", "sync")
     ref = _ctx(p, True, **kw)
     assert ref.layout_info().placement == 1 and ref.layout_finalize(wait=False)

@@ -26,14 +26,7 @@ pmc_case final_local_huber --problem final-13682 --popularity local --robust-nor
 tools/stage_rooflines.sh $tag/stages_venice_step1 venice-1778 --step 1 > $out/stages_venice_step1.md 2>&1
 tools/stage_rooflines.sh $tag/stages_venice_step2 venice-1778 --step 2 > $out/stages_venice_step2.md 2>&1
 tools/stage_rooflines.sh $tag/stages_final_huber_step1 final-13682 --step 1 --robust-norm HUBER --huber 20 > $out/stages_final_huber_step1.md 2>&1
-python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
-python3 bench.py --step 2 --no-cpu-baseline --no-secondary > $out/bench_step2.json 2> /dev/null
-python3 bench.py --robust-norm HUBER --no-cpu-baseline --no-secondary > $out/bench_huber.json 2> /dev/null
-python3 bench.py --problem ladybug-49 --no-cpu-baseline --no-secondary > $out/bench_ladybug.json 2> /dev/null
-python3 bench.py --problem trafalgar-257 --no-cpu-baseline --no-secondary > $out/bench_trafalgar.json 2> /dev/null
-python3 bench.py --problem final-13682 --robust-norm HUBER --huber 20 --no-cpu-baseline --no-secondary --steps 5 --warmup 1 > $out/bench_final_huber.json 2> /dev/null
-python3 bench.py --popularity local --no-cpu-baseline --no-secondary > $out/bench_local.json 2> /dev/null
-python3 bench.py --problem final-13682 --popularity local --robust-norm HUBER --huber 20 --no-cpu-baseline --no-secondary --steps 5 --warmup 1 > $out/bench_final_local_huber.json 2> /dev/null
+tools/bench_lines.sh $out   # (lines on model bytes if traffic.json is stale: re-run tools/bench_lines.sh after collecting)
 tools/popularity_sweep.sh $out/popularity > $out/popularity.txt 2>&1
 tools/shard_sweep.sh > $out/shards.txt 2>&1
 python3 tools/create_time.py venice-1778 final-13682 > $out/create.txt 2>&1
