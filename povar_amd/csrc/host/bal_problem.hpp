@@ -1,6 +1,7 @@
 // BalProblem: the data model and loaders of the drop-in surface (bal/bal_problem.hpp:66-339,
 // bal/bal_problem.cpp:183-471, 658-708), restated without Eigen/Sophus.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <map>
 #include <string>
@@ -20,6 +21,36 @@ struct StateMirror {
   virtual void pull_state() = 0;                      // device -> BalProblem
 };
 
+// The reference keeps a landmark's observations in a std::map<int, Observation> (bal_problem.hpp:226): five million tree
+// nodes on venice.  Same interface where this code uses it (emplace with the inserted flag, ordered iteration, size),
+// one contiguous sorted array per landmark.
+class ObsMap {
+ public:
+  using value_type = std::pair<int, std::array<double, 2>>;
+  using iterator = std::vector<value_type>::iterator;
+  using const_iterator = std::vector<value_type>::const_iterator;
+  std::pair<iterator, bool> emplace(int cam, const std::array<double, 2>& uv) {
+    if (v_.empty() || v_.back().first < cam) {  // files list a landmark's cameras in ascending order almost always
+      v_.emplace_back(cam, uv);
+      return {v_.end() - 1, true};
+    }
+    auto it = std::lower_bound(v_.begin(), v_.end(), cam, [](const value_type& a, int c) { return a.first < c; });
+    if (it != v_.end() && it->first == cam) return {it, false};
+    it = v_.insert(it, value_type(cam, uv));
+    return {it, true};
+  }
+  iterator begin() { return v_.begin(); }
+  iterator end() { return v_.end(); }
+  const_iterator begin() const { return v_.begin(); }
+  const_iterator end() const { return v_.end(); }
+  size_t size() const { return v_.size(); }
+  bool empty() const { return v_.empty(); }
+  void clear() { v_.clear(); }
+
+ private:
+  std::vector<value_type> v_;
+};
+
 class BalProblem {
  public:
   struct Camera {
@@ -30,7 +61,7 @@ class BalProblem {
   struct Landmark {
     std::array<double, 3> p_w{};
     std::array<double, 4> p_w_homogeneous{};
-    std::map<int, std::array<double, 2>> obs;  // camera index -> (u, v), v negated on load
+    ObsMap obs;  // camera index -> (u, v), v negated on load; ascending camera index like the reference's std::map
     std::array<double, 3> p_w_backup{};
     std::array<double, 4> p_w_homogeneous_backup{};
   };
