@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -87,6 +88,14 @@ class BalProblem {
 
   StateMirror* mirror = nullptr;
   bool quiet = false;
+  // A device-resident Linearizor leaves its context here when it is destroyed; the next one built on the same problem
+  // with the same options (step 2 after step 1, bal_bundle_adjustment.cpp:283 / 585) takes it over instead of building
+  // the device layout a second time.  key: what the context was built for (sizes, options, a hash of the observations).
+  struct DeviceCache {
+    std::shared_ptr<void> ctx;
+    std::string key;
+  };
+  DeviceCache device_cache;
 
  private:
   std::vector<Camera> cameras_;

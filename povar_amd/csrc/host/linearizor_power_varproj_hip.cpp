@@ -6,6 +6,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <memory>
+#include <cstring>
 #include <cstdlib>
 
 #include "../../../include/povar_hip.h"
@@ -30,6 +32,29 @@ void check(int rc, const char* what) {
   }
 }
 
+// what a device context is built from: sizes, options, every (camera, u, v) in landmark order
+std::string context_key(const BalProblem& p, const povar_options& o) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
+  long n_obs = 0;
+  for (const auto& lm : p.landmarks()) {
+    mix(lm.obs.size());
+    for (const auto& kv : lm.obs) {
+      unsigned long long bu, bv;
+      std::memcpy(&bu, &kv.second[0], 8);
+      std::memcpy(&bv, &kv.second[1], 8);
+      mix((unsigned long long)kv.first);
+      mix(bu);
+      mix(bv);
+    }
+    n_obs += (long)lm.obs.size();
+  }
+  char buf[256];
+  std::snprintf(buf, sizeof buf, "%d/%d/%ld/%016llx/norm%d/%.17g/%.17g/dev%d/e0%d", p.num_cameras(), p.num_landmarks(), n_obs, h,
+                o.robust_norm, o.huber_parameter, o.jacobi_scaling_eps, o.device, o.e0_mode);
+  return buf;
+}
+
 ResidualInfo to_ri(const povar_residual_info& r) {
   ResidualInfo o;
   o.all = {r.all_num_obs, r.all_error, r.all_residual_sum};
@@ -43,9 +68,6 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
   LinearizorPowerVarprojHip(BalProblem& bal_problem, const SolverOptions& options, SolverSummary* summary,
                             bool homogeneous)
       : options_(options), bal_problem_(bal_problem), summary_(summary), homogeneous_(homogeneous) {
-    std::vector<int> lm_off, cam_idx;
-    std::vector<double> obs;
-    bal_problem.flatten(lm_off, cam_idx, obs);
     povar_options o{};
     o.robust_norm = (int)options.residual.robust_norm;
     o.huber_parameter = options.residual.huber_parameter;
@@ -54,13 +76,28 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
     o.device = options.device;
     o.e0_mode = options.e0_mode == "tiles" ? POVAR_E0_TILES
                 : options.e0_mode == "implicit" ? POVAR_E0_IMPLICIT : POVAR_E0_IMPLICIT_LDSACC;
-    check(povar_create(&ctx_, bal_problem.num_cameras(), bal_problem.num_landmarks(), (int64_t)cam_idx.size(),
-                       lm_off.data(), cam_idx.data(), obs.data(), &o), "povar_create");
+    // The reference builds a new linearizor for step 2 (its constructor only allocates: sc/linearization_varproj.hpp:
+    // 44-60); the device context -- observation layout, camera sets, row placement under way -- depends on the
+    // observations and these options only, so the one step 1 left behind is taken over.
+    cache_key_ = context_key(bal_problem, o);
+    if (bal_problem.device_cache.ctx && bal_problem.device_cache.key == cache_key_) {
+      holder_ = std::move(bal_problem.device_cache.ctx);
+      bal_problem.device_cache = BalProblem::DeviceCache();
+      ctx_ = static_cast<povar_ctx*>(holder_.get());
+    } else {
+      bal_problem.device_cache = BalProblem::DeviceCache();  // a context for something else: release it first
+      std::vector<int> lm_off, cam_idx;
+      std::vector<double> obs;
+      bal_problem.flatten(lm_off, cam_idx, obs);
+      check(povar_create(&ctx_, bal_problem.num_cameras(), bal_problem.num_landmarks(), (int64_t)cam_idx.size(),
+                         lm_off.data(), cam_idx.data(), obs.data(), &o), "povar_create");
+      holder_ = std::shared_ptr<void>(ctx_, [](void* c) { povar_destroy(static_cast<povar_ctx*>(c)); });
+    }
     using ST = SolverOptions::SolverType;
     sc_step1_ = !homogeneous && (options.solver_type_step_1 == ST::PCG || options.solver_type_step_1 == ST::CHOLESKY);
     sc_step2_ = homogeneous && options.solver_type_step_2 == SolverOptions::SolverTypeRiemannian::RIPCG;
     // LinearizorSC::linearize_pOSE does not scale the landmark Jacobian columns (linearizor_sc.cpp:163-191)
-    if (sc_step1_) check(povar_set_jl_col_scaling(ctx_, 0), "povar_set_jl_col_scaling");
+    check(povar_set_jl_col_scaling(ctx_, sc_step1_ ? 0 : 1), "povar_set_jl_col_scaling");
     // IterationSummary timings come from the device (hipEvents on the library's stream, povar_timings), not from
     // host clocks around the calls
     check(povar_timings_enable(ctx_, 1), "povar_timings_enable");
@@ -70,7 +107,8 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
   ~LinearizorPowerVarprojHip() override {
     pull_state();
     bal_problem_.mirror = nullptr;
-    povar_destroy(ctx_);
+    bal_problem_.device_cache.ctx = std::move(holder_);  // destroyed with the problem, or taken over by the next linearizor
+    bal_problem_.device_cache.key = cache_key_;
   }
 
   void start_iteration(IterationSummary* it) override { it_summary_ = it; }
@@ -277,6 +315,8 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
   SolverSummary* summary_ = nullptr;
   IterationSummary* it_summary_ = nullptr;
   povar_ctx* ctx_ = nullptr;
+  std::shared_ptr<void> holder_;  // owns ctx_; handed to BalProblem::device_cache by the destructor
+  std::string cache_key_;
   bool homogeneous_;
 };
 

@@ -74,13 +74,14 @@ inline int lpl_effective_cpus() {
 }
 
 // fn(item) for item in [0, n_items) on up to n_threads host threads (items taken on demand; the caller's thread works too)
+// (cancel: when it turns true the remaining items are dropped -- a build whose result nobody waits for any more)
 template <class F>
-inline void lpl_parallel(int n_items, int n_threads, F&& fn) {
+inline void lpl_parallel(int n_items, int n_threads, F&& fn, const std::atomic<bool>* cancel = nullptr) {
   std::atomic<int> next{0};
   auto work = [&]() {
     for (;;) {
       const int i = next.fetch_add(1);
-      if (i >= n_items) break;
+      if (i >= n_items || (cancel && cancel->load(std::memory_order_relaxed))) break;
       fn(i);
     }
   };
@@ -156,7 +157,9 @@ inline void lpl_assign(int h, const std::vector<long>& cost, std::vector<int>& a
 // rank1[c]: 1-based popularity rank of camera c; cnt_sorted[r]: observation count of the camera with rank r (0-based)
 inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx, const double* obs,
                       const std::vector<int>& rank1, const std::vector<int>& slot_of_obs, size_t n_slots, int grid,
-                      int n_acc, LplLayout& L, bool place = true) {
+                      int n_acc, LplLayout& L, bool place = true, const std::atomic<bool>* cancel = nullptr) {
+  // cancel: povar_destroy does not wait for a placement it will not use (the layout is incomplete when it was set)
+  auto cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
   // Rows per tile are capped by dealing longer landmarks over several lanes (K0 rows: at most 2 K0 row steps per
   // tile, the unit of load balance).  A wavefront walks its tile's rows one after the other, so on a problem too small
   // to give every wavefront a tile the cap sets the latency of the launch (ladybug-49: 2 rows 106 k, 8 rows 76 k
@@ -346,6 +349,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     return tx[r0] >= 0 && (tx[r0] == w % A || ty[r0] == w / A);
   };
   lap("grid choice");
+  if (cancelled()) return;
   // ---- landmark -> workgroup
   std::vector<int> wg_of(n_lms, -1);
   std::vector<int64_t> load(grid, 0);
@@ -439,6 +443,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     }
   }
   lap("landmark -> workgroup");
+  if (cancelled()) return;
   // ---- cold view: observations whose camera is not resident in their landmark's workgroup, camera-major
   const int64_t n_obs = lm_off[n_lms];
   std::vector<int> cold_pos_of_obs(n_obs, -1);
@@ -477,6 +482,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     });
   }
   lap("cold view");
+  if (cancelled()) return;
   // ---- per workgroup: camera slots (global cameras in rank order, then the tail cameras its landmarks use), tiles
   std::vector<std::vector<int>> lms_of(grid);
   for (int l = 0; l < n_lms; ++l)
@@ -622,6 +628,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     });
   }
   lap("slots and tiles");
+  if (cancelled()) return;
   L.uv.assign((size_t)L.rows * WAVE, make_double2(0, 0));
   L.cw.assign((size_t)L.rows * WAVE, -1);
   L.cpos.assign((size_t)L.rows * WAVE, -1);
@@ -878,8 +885,9 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       }
     }
   };
-  lpl_parallel(grid, n_threads, place_wg);
+  lpl_parallel(grid, n_threads, place_wg, cancel);
   lap("row placement (threads)");
+  if (cancelled()) return;
   // ---- partial records, camera-major: camera c's slots in the workgroups that hold it form one contiguous run, so
   // the per-camera kernel streams them.  (Workgroup-major records -- one contiguous 53 KB flush per workgroup, the
   // per-camera kernel gathering through an index list -- were measured too: the flush is bound by the 13.5 MB it

@@ -116,6 +116,7 @@ struct povar_ctx {
   // POVAR_LPL_PLACE = sync | async | none; default: async from 2^20 observations on, sync below
   std::thread placer;
   std::atomic<int> placer_state{0};  // 0 no thread, 1 running, 2 rows uploaded and ready, 3 failed
+  std::atomic<bool> placer_cancel{false};  // povar_destroy: do not finish a placement nobody will use
   DevBuf<double2> pl_uv;
   DevBuf<int> pl_cw, pl_cpos, pl_lm_pos, pl_lm_of, pl_of_slot;
   size_t pl_bytes = 0;
@@ -1063,8 +1064,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
         const auto t0 = std::chrono::steady_clock::now();
         LplLayout P;
         build_lpl(n_cams, n_lms, job->lm_off.data(), job->cam_idx.data(), job->obs.data(), job->rank1, job->slot_of_obs,
-                  n_slots, grid, n_acc, P, true);
-        bool ok = P.rows == rows && P.tile.size() == n_tiles && hipSetDevice(dev) == hipSuccess;
+                  n_slots, grid, n_acc, P, true, &c->placer_cancel);
+        bool ok = !c->placer_cancel.load() && P.rows == rows && P.tile.size() == n_tiles && hipSetDevice(dev) == hipSuccess;
         auto up = [&](auto& buf, const auto& v) {
           if (!ok) return;
           ok = buf.alloc(std::max<size_t>(v.size(), 1), &c->pl_bytes) == hipSuccess &&
@@ -1229,6 +1230,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
 #undef HIP_TRY_C
 void povar_destroy(povar_ctx* c) {
   if (!c) return;
+  c->placer_cancel.store(true);
   if (c->placer.joinable()) c->placer.join();
   (void)hipSetDevice(c->opt.device);
   c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
