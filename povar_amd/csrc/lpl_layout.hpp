@@ -43,6 +43,8 @@ struct LplLayout {
   std::vector<int> wg_slot_rec;  // partial record each slot is flushed to
   std::vector<int2> part_range;  // [n_cams] partial records of camera c: [first, end)
   std::vector<int> cold_lm;      // [n_cold] landmark of each cold observation, camera-major
+  std::vector<int> cold_src;     // [n_cold] where the row kernels leave its q: (cold row of its tile) * 64 + lane (CmView::src)
+  int64_t cold_rows = 0;         // rows that may hold cold observations (rows >= tile.z of every tile), numbered tile after tile
   std::vector<int2> cold_range;  // [n_cams] run of each camera in the cold view
   int64_t rows = 0;
   int n_part_rec = 0, max_slots = 0, n_global = 0, n_tail = 0, grid_a = 1, grid_b = 1;
@@ -617,6 +619,12 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       for (int4 ti : o.tile) {
         ti.x = (int)L.rows;
         L.rows += ti.y;
+        // bits 4.. of the flag word: number of the tile's first cold row (a cold observation in row j >= tile.z leaves
+        // its q at ((w >> 4) + j - z) * 64 + lane: the lanes of a wavefront store side by side, the per-camera kernel
+        // gathers -- a scatter of 32-byte stores from the row kernel cost final-13682 a third of its term)
+        ti.z = std::min(ti.z, ti.y);
+        ti.w |= (int)(L.cold_rows << 4);
+        L.cold_rows += ti.y - ti.z;
         L.tile.push_back(ti);
       }
       L.seg.insert(L.seg.end(), o.seg.begin(), o.seg.end());
@@ -632,6 +640,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   L.uv.assign((size_t)L.rows * WAVE, make_double2(0, 0));
   L.cw.assign((size_t)L.rows * WAVE, -1);
   L.cpos.assign((size_t)L.rows * WAVE, -1);
+  L.cold_src.assign(L.cold_lm.size(), -1);
   // ---- row stream with LDS bank placement, workgroups in parallel (disjoint row ranges).
   // ds_add_f64 takes 8 LDS cycles per wavefront when the 32 lanes of each half hit 32 different bank pairs and 8
   // more for every additional lane on a bank (tools/micro/lds_atomic_rates.hip); a ds_read_b128 takes one more
@@ -880,6 +889,7 @@ inline void build_lpl(int n_cams, int n_lms, const int32_t* lm_off, const int32_
           } else {
             L.cw[idx] = -2 - r0;  // cold: the record is gathered from the rank-ordered image
             L.cpos[idx] = cold_pos_of_obs[i];
+            L.cold_src[cold_pos_of_obs[i]] = ((L.tile[t].w >> 4) + (j - L.tile[t].z)) * WAVE + lane;
           }
         }
       }

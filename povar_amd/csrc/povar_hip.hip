@@ -105,6 +105,12 @@ struct povar_ctx {
   DevBuf<int> v2_lm_of;
   DevBuf<int> v2_cw, v2_cpos, v2_lm_pos, v2_of_slot, v2_seg, v2_wg_tile_off, v2_wg_cam_off, v2_wg_cams, v2_wg_slot_rec, c3_lm;
   DevBuf<int2> v2_part_range, c3_range;
+  DevBuf<int> c3_src, pl_c3_src;  // CmView::src of the lane-per-landmark cold view (row-major q: lpl_cold_q)
+  // Cold observations of the lane-per-landmark kernels leave q row-major, side by side with the other lanes of their
+  // row, and the per-camera kernels gather it -- instead of one scattered 32-byte store per lane into the camera-major
+  // view (a third of the term on final-13682 with 24 % cold observations).  The gather costs the per-camera kernel a
+  // dependent load, so graphs with few cold observations keep the direct store: from 8 % on (POVAR_COLD_Q_ROWS=0|1).
+  bool q_rows = false;
   DevBuf<double> c3_h, v2_part;
   int64_t n_cold3 = 0;
   int v2_max_slots = 0, v2_n_global = 0, v2_n_tail = 0, v2_strategy = 0;
@@ -506,6 +512,8 @@ Dp ldsacc_dp(povar_ctx* c, bool long_in_kernel = false) {
     dt.cmv.h = c->c3_h.p;
     dt.cmv.n = c->n_cold3;
     dt.cmv.cam_range = c->c3_range.p;
+    dt.cmv.src = c->q_rows ? c->c3_src.p : nullptr;
+    dt.q_rows = c->q_rows ? 1 : 0;
     dt.hot_part = c->v2_part.p;
     dt.part_range = c->v2_part_range.p;
     dt.cold_pos = nullptr;
@@ -632,13 +640,16 @@ int swap_in_placed_rows(povar_ctx* c, bool wait) {
   if (c->placer.joinable()) c->placer.join();
   if (c->placer_state.load(std::memory_order_acquire) != 2) {  // the build or an upload failed: stay on the natural order
     c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
+    c->pl_c3_src.release();
     c->placement = 0;
     return 0;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));  // nothing in flight reads the old rows
   std::swap(c->v2_uv, c->pl_uv); std::swap(c->v2_cw, c->pl_cw); std::swap(c->v2_cpos, c->pl_cpos);
   std::swap(c->v2_lm_pos, c->pl_lm_pos); std::swap(c->v2_lm_of, c->pl_lm_of); std::swap(c->v2_of_slot, c->pl_of_slot);
+  std::swap(c->c3_src, c->pl_c3_src);  // ldsacc_dp takes it from the context at every launch
   c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
+  c->pl_c3_src.release();
   V2& v = c->d.v2;
   v.uv = c->v2_uv.p; v.cw = c->v2_cw.p; v.cpos = c->v2_cpos.p; v.lm_pos = c->v2_lm_pos.p; v.lm_of = c->v2_lm_of.p;
   v.of_slot = c->v2_of_slot.p;
@@ -1031,7 +1042,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     std::thread& t;
     ~Joiner() { if (t.joinable()) t.join(); }
   } joiner{part_b};
-  size_t n_cold_lpl = 0;
+  size_t n_cold_lpl = 0, n_cold_q = 0;
   {
     // lane-per-landmark layout of e0_lpl (lpl_layout.hpp)
     LplLayout V;
@@ -1073,6 +1084,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
         };
         up(c->pl_uv, P.uv); up(c->pl_cw, P.cw); up(c->pl_cpos, P.cpos);
         up(c->pl_lm_pos, P.lm_pos); up(c->pl_lm_of, P.lm_of); up(c->pl_of_slot, P.of_slot);
+        up(c->pl_c3_src, P.cold_src);
         c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         c->placer_state.store(ok ? 2 : 3, std::memory_order_release);
       });
@@ -1100,6 +1112,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (int rc = upload(c->v2_part_range, V.part_range, c)) { povar_destroy(c); return rc; }
     if (int rc = upload(c->c3_lm, V.cold_lm, c)) { povar_destroy(c); return rc; }
     if (int rc = upload(c->c3_range, V.cold_range, c)) { povar_destroy(c); return rc; }
+    if (int rc = upload(c->c3_src, V.cold_src, c)) { povar_destroy(c); return rc; }
+    n_cold_q = (size_t)V.cold_rows * WAVE;
+    c->q_rows = (double)V.cold_lm.size() >= 0.08 * (double)std::max<int64_t>(n_obs, 1);
+    if (const char* e = std::getenv("POVAR_COLD_Q_ROWS")) c->q_rows = e[0] == '1';
     const int nt = (int)V.tile.size();
     HIP_TRY_C(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * LPL_REC_H * WAVE, &c->bytes));  // 9 entries used by step 1
     HIP_TRY_C(c->v2_lmx.alloc((size_t)std::max(nt, 1) * WAVE, &c->bytes));
@@ -1179,7 +1195,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   }
   lap("uploads, allocations (lane/obs)");
   // scatter scalars of the cold observations: one buffer, sized for the largest of the cold views
-  HIP_TRY_C(c->q4c.alloc(std::max<size_t>(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), n_cold_lpl), 1), &c->bytes));
+  HIP_TRY_C(c->q4c.alloc(std::max<size_t>(std::max(std::max(std::max(L.cc_slot.size(), L.c2_lm.size()), n_cold_lpl), n_cold_q), 1), &c->bytes));
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
   ALLOC(hot_rec, (size_t)std::max(n_cams, HOT_MAX) * HOT_REC_STRIDE);  // every camera, in popularity order
@@ -1234,6 +1250,7 @@ void povar_destroy(povar_ctx* c) {
   if (c->placer.joinable()) c->placer.join();
   (void)hipSetDevice(c->opt.device);
   c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
+  c->pl_c3_src.release(); c->c3_src.release();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->pin) (void)hipHostFree(c->pin);
@@ -2019,10 +2036,11 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
   switch (c->opt.e0_mode) {
     case POVAR_E0_IMPLICIT_LDSACC:
       if (c->use_lpl)  // e0_lpl[_h]: uv + camera slot per row slot, 72 (112)-byte landmark records, cold: position + q out
-        lm = c->v2_rows * WAVE * (20 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * (c->joint ? 112 : 72) + cam_static + n_cold * 36 + hot_flush;
+        lm = c->v2_rows * WAVE * (20 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * (c->joint ? 112 : 72) + cam_static +
+             n_cold * (c->q_rows ? 32 : 36) + hot_flush;  // q_rows: no position load, the per-camera kernel reads the index
       else
           lm = ns * (E0_SLOT_BYTES + robust) + nl * E0_LMREC_BYTES + cam_static + n_cold * 32 + hot_flush;
-      cm = hot_flush + n_cold * (32 + 24) + tail;
+      cm = hot_flush + n_cold * (32 + 24 + (lpl && c->q_rows ? 4 : 0)) + tail;
       break;
     case POVAR_E0_IMPLICIT:
       lm = ns * (28 + robust) + nl * 96 + cam_static + no * 32;   // uv, cam, lm, meta; q4 out

@@ -72,6 +72,8 @@ struct CmView {
   double* part;            // [n_items][12]
   int n_items;
   const int2* cam_range;   // [n_cams] (first, end) position of each camera's run (cold view only, else nullptr)
+  const int* src;          // [n] where q of the p-th observation is in q4c (the lane-per-landmark kernels store row-major:
+                           // lpl_cold_q), nullptr: at p itself (the lane-per-observation kernels store camera-major)
 };
 
 // Lane-per-landmark layout of the per-term E0 kernel (e0_lpl).  Landmarks are sorted by (observation count,
@@ -118,6 +120,7 @@ struct Dp {
   const int* cam;
   const int* lm;
   const int* meta;
+  int q_rows;           // lane-per-landmark kernels: cold observations leave q row-major (lpl_cold_q, gathered through CmView::src)
   int lin_aux_only;     // OpLinearize: write only the per-slot sqrt(w) / weighted residual (legacy arrays, filled lazily)
   int prep_aux_only;    // OpPrepare[H]: leave the lane-per-landmark records alone (called to fill hll_inv / lmrec lazily)
   int prep_lpl_only;    // prepare_lpl[_h]: write only the lane-per-landmark records, not hll_inv / lmrec (filled lazily)
@@ -1221,6 +1224,9 @@ __host__ __device__ inline int lpl_acc_slot(int cw, int hubs) {
 __host__ __device__ inline size_t lpl_lds_bytes(int n_hot) {
   return (size_t)n_hot * HOT_REC * sizeof(double2) + (size_t)(n_hot + 3 * lpl_hubs(n_hot)) * 96 + 16;
 }
+// where a cold observation of row j, lane `lane` leaves its q in Dp::q4c (fl, nh: tile.w, tile.z; lpl_layout.hpp)
+__device__ inline int lpl_cold_q(int fl, int nh, int j, int lane) { return ((fl >> 4) + (j - nh)) * WAVE + lane; }
+
 struct LplRow {
   double2 uv;
   int cw;
@@ -1399,7 +1405,6 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
       nhx = rp[0]; nhy = rp[WAVE]; nhz = rp[2 * WAVE];
       G00 = rp[3 * WAVE]; G01 = rp[4 * WAVE]; G02 = rp[5 * WAVE]; G11 = rp[6 * WAVE]; G12 = rp[7 * WAVE]; G22 = rp[8 * WAVE];
     }
-    const size_t base = (size_t)c_row0 * WAVE + lane;
     for (int jj = 0; jj < c_k; ++jj) {
       const int j = c_k - 1 - jj;
       const LplRow cur = n1;
@@ -1419,8 +1424,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl(Dp d, double* hot_out) {
         for (int m = 0; m < 12; ++m)
           __hip_atomic_fetch_add(a + m * n_slots, val[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (cur.cw < -1) {
-        // the position of q in the cold view is requested together with the record: one round trip, not two
-        const int cold_at = v.cpos[base + (size_t)j * WAVE];
+        // where q goes: row-major next to the other lanes' (graphs with many cold observations: the per-camera kernel
+        // gathers, Dp::q_rows) or straight to its place in the camera-major cold view (few: one 32-byte store per lane)
+        const int cold_at = d.q_rows ? lpl_cold_q(c_fl, c_nh, j, lane) : v.cpos[((size_t)c_row0 + j) * WAVE + lane];
         lpl_read_p3(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2), P3);
         lpl_backward(o, P3, g, q);
         d.q4c[cold_at] = make_double4(q[0], q[1], q[2], 0);
@@ -1636,7 +1642,6 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
         rec[2] = make_double4(Hi[2], Hi[4], Hi[5], Hi[8]);
       }
     }
-    const size_t base = (size_t)c_row0 * WAVE + lane;
     for (int jj = 0; jj < c_k; ++jj) {
       const int j = c_k - 1 - jj;
       const LplRow cur = n1;
@@ -1662,7 +1667,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl(Dp d, double* hot_out) 
         for (int m = 0; m < 12; ++m)
           __hip_atomic_fetch_add(a + m * n_slots, val[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
-        d.q4c[v.cpos[base + (size_t)j * WAVE]] = make_double4(q.x, q.y, q.z, 0);
+        d.q4c[d.q_rows ? lpl_cold_q(c_fl, c_nh, j, lane) : v.cpos[((size_t)c_row0 + j) * WAVE + lane]] = make_double4(q.x, q.y, q.z, 0);
       }
     }
     c_t = nx_t;
@@ -2674,7 +2679,7 @@ __global__ __launch_bounds__(NT) void cam_cold_sum(Dp d, int hom) {
       hy[u] = d.cmv.h[d.cmv.n + pc];
       hz[u] = d.cmv.h[2 * d.cmv.n + pc];
       hw[u] = hom ? d.cmv.h[3 * d.cmv.n + pc] : 1.0;
-      q[u] = in ? d.q4c[pc] : make_double4(0, 0, 0, 0);  // streamed: E0 wrote it in this order
+      q[u] = in ? d.q4c[d.cmv.src ? d.cmv.src[pc] : pc] : make_double4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -2753,7 +2758,7 @@ __global__ __launch_bounds__(NT) void cam_cold_sum_binv(Dp d, int want_norms) {
     acc_old = d.accum[base + t];
   }
   if (done) return;
-  constexpr int U = 4;
+  constexpr int U = 4;  // (8 with the gather through CmView::src: 1499 -> 1470 terms/s on final-13682)
   for (int pb = p0 + t; pb < p1; pb += U * NT) {
     double hx[U], hy[U], hz[U];
     double4 q[U];
@@ -2765,7 +2770,7 @@ __global__ __launch_bounds__(NT) void cam_cold_sum_binv(Dp d, int want_norms) {
       hx[u] = d.cmv.h[pc];
       hy[u] = d.cmv.h[d.cmv.n + pc];
       hz[u] = d.cmv.h[2 * d.cmv.n + pc];
-      q[u] = in ? d.q4c[pc] : make_double4(0, 0, 0, 0);  // streamed: E0 wrote it in this order
+      q[u] = in ? d.q4c[d.cmv.src ? d.cmv.src[pc] : pc] : make_double4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {

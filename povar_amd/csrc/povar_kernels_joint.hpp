@@ -876,7 +876,6 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
     double4 nX = make_double4(0, 0, 0, 1), ns4 = make_double4(1, 1, 1, 1);
     double nHi[6] = {0, 0, 0, 0, 0, 0};
     if (n_t < t_end) load_rec(n_t, nX, ns4, nHi);
-    const size_t base = (size_t)c_row0 * WAVE + lane;
     for (int jj = 0; jj < c_k; ++jj) {
       const int j = c_k - 1 - jj;
       const LplRow cur = n1;
@@ -909,7 +908,9 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lpl_h(Dp d, double* hot_out) {
         read_cam(hot + lpl_cw_slot(cur.cw) * LPL_CAMREC_H, P);
         scatter(bwd(P));
       } else if (cur.cw < -1) {
-        const int cold_at = v.cpos[base + (size_t)j * WAVE];
+        // where q goes: row-major next to the other lanes' (graphs with many cold observations: the per-camera kernel
+        // gathers, Dp::q_rows) or straight to its place in the camera-major cold view (few: one 32-byte store per lane)
+        const int cold_at = d.q_rows ? lpl_cold_q(c_fl, c_nh, j, lane) : v.cpos[((size_t)c_row0 + j) * WAVE + lane];
         read_cam(rec_img + (size_t)(-2 - cur.cw) * (HOT_REC_STRIDE / 2), P);
         d.q4c[cold_at] = bwd(P);
       }
@@ -1094,7 +1095,6 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
         rec[3] = make_double4(Hi[5], Hi[8], 0, 0);
       }
     }
-    const size_t base = (size_t)c_row0 * WAVE + lane;
     for (int jj = 0; jj < c_k; ++jj) {
       const int j = c_k - 1 - jj;
       const LplRow cur = n1;
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
         for (int m = 0; m < 12; ++m)
           __hip_atomic_fetch_add(a + m * n_slots, val[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
-        d.q4c[v.cpos[base + (size_t)j * WAVE]] = q;
+        d.q4c[d.q_rows ? lpl_cold_q(c_fl, c_nh, j, lane) : v.cpos[((size_t)c_row0 + j) * WAVE + lane]] = q;
       }
     }
     c_t = nx_t;
@@ -1478,7 +1478,7 @@ __global__ __launch_bounds__(NT) void cam_cold_sum_binv_h(Dp d, int want_norms, 
       hy[u] = d.cmv.h[d.cmv.n + pc];
       hz[u] = d.cmv.h[2 * d.cmv.n + pc];
       hw[u] = d.cmv.h[3 * d.cmv.n + pc];
-      q[u] = in ? d.q4c[pc] : make_double4(0, 0, 0, 0);
+      q[u] = in ? d.q4c[d.cmv.src ? d.cmv.src[pc] : pc] : make_double4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {

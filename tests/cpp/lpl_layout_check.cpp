@@ -64,7 +64,8 @@ int main(int argc, char** argv) {
                     L.wg_cams == M.wg_cams && L.wg_slot_rec == M.wg_slot_rec && eq2(L.part_range, M.part_range) &&
                     L.cold_lm == M.cold_lm && eq2(L.cold_range, M.cold_range) && L.rows == M.rows &&
                     L.n_part_rec == M.n_part_rec && L.max_slots == M.max_slots && L.n_global == M.n_global &&
-                    L.hubs == M.hubs && L.strategy == M.strategy && L.uv.size() == M.uv.size() &&
+                    L.hubs == M.hubs && L.strategy == M.strategy && L.uv.size() == M.uv.size() && L.cold_rows == M.cold_rows &&
+                    L.cold_src.size() == M.cold_src.size() &&
                     L.lm_of.size() == M.lm_of.size();
     CHECK(same_but_rows == 1);
   }
@@ -102,6 +103,9 @@ int main(int argc, char** argv) {
           } else {
             ++n_cold;
             CHECK(L.cpos[idx] >= 0 && L.cpos[idx] < (int)L.cold_lm.size());
+            // where the row kernels leave this observation's q (lpl_cold_q) and where the per-camera kernel looks for it
+            const int64_t at = ((int64_t)(ti.w >> 4) + (j - ti.z)) * 64 + lane;
+            CHECK(j >= ti.z && at >= 0 && at < L.cold_rows * 64 && L.cold_src[L.cpos[idx]] == (int)at);
           }
         }
     }
@@ -235,6 +239,7 @@ int main(int argc, char** argv) {
   mix(L.tile.data(), L.tile.size() * sizeof(int4)); mix(L.wg_cams.data(), L.wg_cams.size() * sizeof(int));
   mix(L.wg_slot_rec.data(), L.wg_slot_rec.size() * sizeof(int)); mix(L.cold_lm.data(), L.cold_lm.size() * sizeof(int));
   mix(L.of_slot.data(), L.of_slot.size() * sizeof(int));
+  mix(L.cold_src.data(), L.cold_src.size() * sizeof(int));
   std::printf("{\"fingerprint\": \"%016llx\", ", fp);
   std::printf("\"strategy\": \"%s\", \"hubs\": %d, \"placed\": %d, \"same_but_rows\": %d, ", L.strategy ? "ranges" : "grid", L.hubs,
               place ? 1 : 0, same_but_rows);
