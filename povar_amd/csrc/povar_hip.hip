@@ -109,7 +109,9 @@ struct povar_ctx {
   // Cold observations of the lane-per-landmark kernels leave q row-major, side by side with the other lanes of their
   // row, and the per-camera kernels gather it -- instead of one scattered 32-byte store per lane into the camera-major
   // view (a third of the term on final-13682 with 24 % cold observations).  The gather costs the per-camera kernel a
-  // dependent load, so graphs with few cold observations keep the direct store: from 8 % on (POVAR_COLD_Q_ROWS=0|1).
+  // dependent load, so graphs with fewer cold observations keep the direct store: from 20 % on (POVAR_COLD_Q_ROWS=0|1).
+  // venice-1778 shape, cold share -> terms/s direct / row-major: Zipf(1) 3 % 14.8 / 14.3 k, 25 % long tracks 11 % 8.5 / 8.1 k,
+  // Zipf(0.5) 18 % 9.76 / 9.77 k, uniform 31 % 6.46 / 7.11 k; final-13682 24 % 1.34 / 1.50 k.
   bool q_rows = false;
   DevBuf<double> c3_h, v2_part;
   int64_t n_cold3 = 0;
@@ -1114,7 +1116,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (int rc = upload(c->c3_range, V.cold_range, c)) { povar_destroy(c); return rc; }
     if (int rc = upload(c->c3_src, V.cold_src, c)) { povar_destroy(c); return rc; }
     n_cold_q = (size_t)V.cold_rows * WAVE;
-    c->q_rows = (double)V.cold_lm.size() >= 0.08 * (double)std::max<int64_t>(n_obs, 1);
+    c->q_rows = (double)V.cold_lm.size() >= 0.20 * (double)std::max<int64_t>(n_obs, 1);
     if (const char* e = std::getenv("POVAR_COLD_Q_ROWS")) c->q_rows = e[0] == '1';
     const int nt = (int)V.tile.size();
     HIP_TRY_C(c->v2_lmrec.alloc((size_t)std::max(nt, 1) * LPL_REC_H * WAVE, &c->bytes));  // 9 entries used by step 1

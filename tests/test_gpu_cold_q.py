@@ -1,5 +1,5 @@
 """Cold observations of the lane-per-landmark kernels (camera not in the workgroup's LDS set): where they leave their
-scatter scalars q.  Two addressings of Dp::q4c, chosen by the share of cold observations (POVAR_COLD_Q_ROWS overrides):
+scatter scalars q.  Two addressings of Dp::q4c, chosen by the share of cold observations (from 20 % on; POVAR_COLD_Q_ROWS overrides):
 straight into the camera-major cold view (one scattered 32-byte store per lane) or row-major next to the other lanes of
 the row (lpl_cold_q), gathered by the per-camera kernels through CmView::src.  Both against the oracle, term by term,
 steps 1 and 2, b of prepare_Hb included, with camera sets of 4 / 8 slots so that most observations are cold."""
