@@ -1548,8 +1548,12 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
     // the whole loop (memset, B^-1, m x {E0 kernels, [all-reduce], B^-1 + AXPY, [check]}) is one graph
     // launch; it is re-captured only when a kernel argument changes
     const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode, (sharded(c) ? 1 : 0) | (p2p_terms ? 2 : 0), norms ? 1 : 0, r_tol > 0 ? 1 : 0};
+    // (the landmark damping is an argument of the prepare / back-substitution kernels only: no kernel of the loop reads
+    // it, and step 2 changes it with every LM iteration -- a capture + instantiation of 0.25 ms each time)
+    Dp key_d = c->d;
+    key_d.lambda_lm = 0;
     const bool same = c->series_graph && std::memcmp(key, c->series_graph_key, sizeof(key)) == 0 &&
-                      std::memcmp(&c->d, &c->series_graph_d, sizeof(Dp)) == 0 &&
+                      std::memcmp(&key_d, &c->series_graph_d, sizeof(Dp)) == 0 &&
                       c->series_graph_tol[0] == q_tol && c->series_graph_tol[1] == r_tol;
     if (!same) {
       if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
@@ -1563,7 +1567,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
       HIP_TRY(hipGraphInstantiate(&c->series_graph, g, nullptr, nullptr, 0));
       (void)hipGraphDestroy(g);
       std::memcpy(c->series_graph_key, key, sizeof(key));
-      c->series_graph_d = c->d;
+      c->series_graph_d = key_d;
       c->series_graph_tol[0] = q_tol;
       c->series_graph_tol[1] = r_tol;
     }
