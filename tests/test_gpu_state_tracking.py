@@ -252,3 +252,40 @@ def test_rows_placed_on_a_host_thread_are_swapped_in(step, medium_problem, monke
     assert auto.layout_info().placement == 3 and np.array_equal(got, want)
     for c in (ref, nat, ctx, auto):
         c.close()
+
+
+def _free_device_bytes():
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
+def test_destroy_does_not_wait_for_a_row_placement_nobody_will_use(monkeypatch):
+    """povar_destroy cancels the host thread (checked between its work items) and joins it: a context dropped right
+    after povar_create, at any point of the placement, neither hangs nor leaks the thread's device buffers."""
+    import time
+    from povar_amd import capi, synth
+    monkeypatch.setenv("POVAR_LPL_PLACE", "async")
+    p = synth.make_problem(300, 60000, 300000, seed=4)
+    t_create = t_close = 0.0
+    free0 = None
+    for k in range(12):
+        t0 = time.perf_counter()
+        ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+        t1 = time.perf_counter()
+        assert ctx.layout_info().placement == 2
+        time.sleep(0.004 * (k % 4))                     # drop it at different stages of the background build
+        if k % 3 == 2:
+            ctx.set_cameras(p.cams)
+            ctx.init_landmarks_pose(ALPHA)
+            assert ctx.linearize_pose(ALPHA)            # may or may not swap
+        t2 = time.perf_counter()
+        ctx.close()
+        t_create += t1 - t0
+        t_close += time.perf_counter() - t2
+        free = _free_device_bytes()
+        free0 = free if free0 is None else free0
+        assert free >= free0 - (64 << 20), (k, free0, free)   # nothing accumulates from context to context
+    assert t_close < t_create + 1.0
