@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <atomic>
@@ -67,6 +68,8 @@ struct DevBuf {
 };
 
 }  // namespace
+
+static std::mutex g_capture_mu;  // see povar_ctx::placer_cancel
 
 struct povar_ctx {
   int n_cams = 0, n_lms = 0;
@@ -125,6 +128,10 @@ struct povar_ctx {
   std::thread placer;
   std::atomic<int> placer_state{0};  // 0 no thread, 1 running, 2 rows uploaded and ready, 3 failed
   std::atomic<bool> placer_cancel{false};  // povar_destroy: do not finish a placement nobody will use
+  // A hipMalloc / hipMemcpy of the host thread while the caller's thread captures the term loop into a hipGraph
+  // invalidates the capture ("operation failed due to a previous error during capture", also in thread-local capture
+  // mode): the thread makes its HIP calls in short pieces under g_capture_mu (one for the process: the check is not
+  // per stream), the capture holds it from begin to end.
   DevBuf<double2> pl_uv;
   DevBuf<int> pl_cw, pl_cpos, pl_lm_pos, pl_lm_of, pl_of_slot;
   size_t pl_bytes = 0;
@@ -1078,11 +1085,22 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
         LplLayout P;
         build_lpl(n_cams, n_lms, job->lm_off.data(), job->cam_idx.data(), job->obs.data(), job->rank1, job->slot_of_obs,
                   n_slots, grid, n_acc, P, true, &c->placer_cancel);
-        bool ok = !c->placer_cancel.load() && P.rows == rows && P.tile.size() == n_tiles && hipSetDevice(dev) == hipSuccess;
+        bool ok = !c->placer_cancel.load() && P.rows == rows && P.tile.size() == n_tiles;
+        if (ok) {
+          std::lock_guard<std::mutex> lk(g_capture_mu);
+          ok = hipSetDevice(dev) == hipSuccess;
+        }
         auto up = [&](auto& buf, const auto& v) {
           if (!ok) return;
-          ok = buf.alloc(std::max<size_t>(v.size(), 1), &c->pl_bytes) == hipSuccess &&
-               (v.empty() || hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice) == hipSuccess);
+          {
+            std::lock_guard<std::mutex> lk(g_capture_mu);
+            ok = buf.alloc(std::max<size_t>(v.size(), 1), &c->pl_bytes) == hipSuccess;
+          }
+          const size_t piece = ((size_t)8 << 20) / sizeof(v[0]);  // 8 MB per copy: a capture waits a millisecond at most
+          for (size_t at = 0; ok && at < v.size() && !c->placer_cancel.load(); at += piece) {
+            std::lock_guard<std::mutex> lk(g_capture_mu);
+            ok = hipMemcpy(buf.p + at, v.data() + at, std::min(piece, v.size() - at) * sizeof(v[0]), hipMemcpyHostToDevice) == hipSuccess;
+          }
         };
         up(c->pl_uv, P.uv); up(c->pl_cw, P.cw); up(c->pl_cpos, P.cpos);
         up(c->pl_lm_pos, P.lm_pos); up(c->pl_lm_of, P.lm_of); up(c->pl_of_slot, P.of_slot);
@@ -1559,6 +1577,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
       if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
       c->series_graph = nullptr;
       hipGraph_t g = nullptr;
+      std::lock_guard<std::mutex> lk(g_capture_mu);  // no HIP call of the row-placement thread inside the capture
       HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       const int rc = enqueue_series(c, m, q_tol, r_tol);
       hipError_t e = hipStreamEndCapture(c->stream, &g);

@@ -289,3 +289,26 @@ def test_destroy_does_not_wait_for_a_row_placement_nobody_will_use(monkeypatch):
         free0 = free if free0 is None else free0
         assert free >= free0 - (64 << 20), (k, free0, free)   # nothing accumulates from context to context
     assert t_close < t_create + 1.0
+
+
+def test_graph_capture_while_the_placement_thread_uploads(monkeypatch):
+    """A hipMalloc / hipMemcpy of the row-placement thread inside the caller's capture of the term loop invalidated the
+    capture (error -1901 "operation failed due to a previous error during capture"): the two are serialised now.  First
+    solves (= captures) at a range of delays after povar_create, so that some of them meet the thread's upload phase."""
+    import time
+    from povar_amd import capi, synth
+    monkeypatch.setenv("POVAR_LPL_PLACE", "async")
+    p = synth.make_problem(300, 60000, 300000, seed=4)
+    ref = None
+    for k in range(14):
+        ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+        ctx.set_cameras(p.cams)
+        ctx.init_landmarks_pose(ALPHA)
+        time.sleep(0.003 * k)
+        for _ in range(3):                              # three captures in a row (another m: another graph)
+            assert ctx.linearize_pose(ALPHA)
+            inc, _, _, rc = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M + _)
+            assert rc == 0
+        ref = inc if ref is None else ref
+        assert rel(inc, ref) < 1e-10
+        ctx.close()
