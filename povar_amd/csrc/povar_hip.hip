@@ -2457,6 +2457,11 @@ int povar_solve_joint_sc(povar_ctx* c, double lambda, int32_t min_iterations, in
                          double* inc, int32_t* num_iterations, int32_t* termination) {
   // LinearizorSC::solve_joint (linearizor_sc.cpp:224-303)
   if (int rc = povar_prepare_joint(c, lambda)) return rc;
+  // cm_gram_sc reads the per-slot sqrt(w) and the landmark-order records: after a lane-per-landmark linearisation /
+  // prepare they are rebuilt here (missing until round 3: RIPCG with a robust norm took stale weights on every problem
+  // large enough for the lane-per-landmark kernels -- the parity tests' "lane-per-landmark" halves were not running
+  // those kernels, tests/conftest.py)
+  ensure_legacy(c);
   if (int rc = ensure_sc(c)) return rc;
   if (int rc = build_schur_jacobi<true>(c, lambda)) return rc;
   {
