@@ -34,6 +34,17 @@ def _ri(r):
             r.is_numerically_valid)
 
 
+def _same(a, b, exact):
+    """two logs of tuples of numbers: identical, or equal to 1e-9 (costs of states that went through LM steps whose
+    increments differ in the last bits)"""
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        if exact:
+            assert x == y
+        else:
+            assert len(x) == len(y) and all(abs(u - v) <= 1e-9 * max(abs(u), abs(v), 1e-300) for u, v in zip(x, y)), (x, y)
+
+
 def _step1_sequence(ctx, p, log):
     from povar_amd import capi
     ctx.set_cameras(p.cams)
@@ -75,9 +86,14 @@ def test_error_memo_changes_no_number_step1(which, e0_mode, small_problem, mediu
         states.append(_step1_sequence(ctx, p, log))
         logs.append(log)
         ctx.close()
-    assert logs[0] == logs[1]
+    # e0_mode 0 is bit-reproducible from context to context; the LDS-accumulating mode sums in the order its atomics
+    # arrive (same numbers to rounding).  Inside ONE context an unchanged state must give the identical answer either way.
+    _same(logs[0], logs[1], exact=e0_mode == 0)
     assert logs[0][0] == logs[0][1] and logs[0][-1] != logs[0][-2]
-    assert np.array_equal(states[0][0], states[1][0]) and np.array_equal(states[0][1], states[1][1])
+    if e0_mode == 0:
+        assert np.array_equal(states[0][0], states[1][0]) and np.array_equal(states[0][1], states[1][1])
+    else:
+        assert rel(states[0][0], states[1][0]) < 1e-11 and rel(states[0][1], states[1][1]) < 1e-9
     # the values move when the state moves (a memo that never invalidates would pass the comparison above only if
     # the other context were broken the same way: check against the sequence itself)
     errs = [e[0] for e in logs[0]]
@@ -111,7 +127,7 @@ def test_error_memo_changes_no_number_step2(e0_mode, small_problem):
         log.append(tuple(ctx.get_landmarks_homogeneous().ravel()[:64]))
         logs.append(log)
         ctx.close()
-    assert logs[0] == logs[1]
+    _same(logs[0], logs[1], exact=e0_mode == 0)
 
 
 def test_normalize_joint_keeps_the_lane_mirror(medium_problem):
@@ -134,7 +150,7 @@ def test_normalize_joint_keeps_the_lane_mirror(medium_problem):
     b = _ctx(p, False, e0_mode=capi.E0_IMPLICIT_LDSACC)
     b.set_cameras(Pn)
     b.set_landmarks_homogeneous(Xn)
-    assert _ri(b.error_homogeneous()) == ra
+    _same([_ri(b.error_homogeneous())], [ra], exact=False)
     a.close()
     b.close()
 
@@ -209,8 +225,10 @@ def _start(ctx, p, step):
 @pytest.mark.parametrize("step", [1, 2])
 def test_rows_placed_on_a_host_thread_are_swapped_in(step, medium_problem, monkeypatch):
     """POVAR_LPL_PLACE=async (the default from 2^20 observations on): povar_create returns on the natural row order, the
-    placed rows arrive later.  Before the swap the results agree with the placed layout to rounding, after it bit for
-    bit (same rows as POVAR_LPL_PLACE=sync); a linearisation taken before povar_layout_finalize is dropped."""
+    placed rows arrive later.  On either order the results agree with POVAR_LPL_PLACE=sync to rounding (another summation
+    order of the same numbers); the placement state goes 2 -> 3; a linearisation taken before povar_layout_finalize
+    swapped the rows is dropped; povar_linearize_* swaps by itself once the thread has delivered."""
+    import time
     from povar_amd import capi
     p = medium_problem
     kw = dict(e0_mode=capi.E0_IMPLICIT_LDSACC)
@@ -224,32 +242,30 @@ def test_rows_placed_on_a_host_thread_are_swapped_in(step, medium_problem, monke
     nat = _ctx(p, True, **kw)
     assert nat.layout_info().placement == 0 and not nat.layout_finalize(wait=True)
     _start(nat, p, step)
-    natural = _solve_once(nat, p, step)
-    assert 0 < rel(natural, want) < 1e-10            # another summation order, the same numbers
+    assert rel(_solve_once(nat, p, step), want) < 1e-10
     monkeypatch.setenv("POVAR_LPL_PLACE", "async")
     ctx = _ctx(p, True, **kw)
     assert ctx.layout_info().placement == 2
     _start(ctx, p, step)
-    first = _solve_once(ctx, p, step)                  # on either row order, whichever the thread's progress allowed
-    assert rel(first, want) < 1e-10
+    assert rel(_solve_once(ctx, p, step), want) < 1e-10      # on either row order, whichever the thread's progress allowed
+    swapped_by_linearize = ctx.layout_info().placement == 3
     assert ctx.layout_finalize(wait=True)
     li = ctx.layout_info()
     assert li.placement == 3 and li.placement_ms > 0
-    if np.array_equal(first, natural):                 # the swap happened in povar_layout_finalize: linearise again
+    if not swapped_by_linearize:                       # the swap happened in povar_layout_finalize: linearise again
         with pytest.raises(capi.PovarError):
             ctx.prepare_pose(LAM) if step == 1 else ctx.prepare_joint(LAM)
-    assert np.array_equal(_solve_once(ctx, p, step), want)
+    assert rel(_solve_once(ctx, p, step), want) < 1e-10
     # the swap inside povar_linearize_*: keep linearising until the thread has delivered
-    import time
     auto = _ctx(p, True, **kw)
     _start(auto, p, step)
     for _ in range(400):
         got = _solve_once(auto, p, step)
+        assert rel(got, want) < 1e-10
         if auto.layout_info().placement == 3:
             break
-        assert np.array_equal(got, natural)
         time.sleep(0.01)
-    assert auto.layout_info().placement == 3 and np.array_equal(got, want)
+    assert auto.layout_info().placement == 3
     for c in (ref, nat, ctx, auto):
         c.close()
 
