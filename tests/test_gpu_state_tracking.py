@@ -34,15 +34,15 @@ def _ri(r):
             r.is_numerically_valid)
 
 
-def _same(a, b, exact):
-    """two logs of tuples of numbers: identical, or equal to 1e-9 (costs of states that went through LM steps whose
-    increments differ in the last bits)"""
+def _same(a, b, exact, tol=1e-9):
+    """two logs of tuples of numbers: identical, or equal to tol (costs of states that went through LM steps whose
+    increments differ in the last bits; step 2 amplifies them: SURVEY 8(c) asks 1e-6 of an end-to-end cost)"""
     assert len(a) == len(b)
     for x, y in zip(a, b):
         if exact:
             assert x == y
         else:
-            assert len(x) == len(y) and all(abs(u - v) <= 1e-9 * max(abs(u), abs(v), 1e-300) for u, v in zip(x, y)), (x, y)
+            assert len(x) == len(y) and all(abs(u - v) <= tol * max(abs(u), abs(v), 1e-300) for u, v in zip(x, y)), (x, y)
 
 
 def _step1_sequence(ctx, p, log):
@@ -127,7 +127,7 @@ def test_error_memo_changes_no_number_step2(e0_mode, small_problem):
         log.append(tuple(ctx.get_landmarks_homogeneous().ravel()[:64]))
         logs.append(log)
         ctx.close()
-    _same(logs[0], logs[1], exact=e0_mode == 0)
+    _same(logs[0], logs[1], exact=e0_mode == 0, tol=1e-6)
 
 
 def test_normalize_joint_keeps_the_lane_mirror(medium_problem):
