@@ -257,6 +257,15 @@ typedef struct {
                            2 being placed on a host thread (the kernels run on the natural order meanwhile),
                            3 placed rows swapped in */
   double placement_ms;  /* host wall time of the background placement (0 until it has finished) */
+  int32_t e0_kernel;    /* per-term E0 kernel of step 1: 0 e0_lpl (lane = landmark, cameras in LDS), > 0: the e0_ck
+                           instantiation in use (lane = camera chunk, landmarks in LDS; povar_set_e0_kernel) */
+  int32_t ck_ready;     /* 1: the camera-chunk layout of the rows in use exists (with the rows placed on a host thread
+                           it arrives together with them) */
+  int32_t ck_batches, ck_slots;  /* landmark batches per workgroup, landmark slots per batch */
+  int32_t ck_tiles_max; /* most chunk tiles of one (workgroup, batch) */
+  int32_t ck_part_rec;  /* partial records of the camera-chunk kernel (workgroup slots + chunks of cameras without one) */
+  int64_t ck_rows, ck_chunks, ck_cold_chunks;
+  double ck_build_ms;   /* host time of the derivation from the lane-per-landmark layout */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 /* The reference's constructor is a trivial allocation (sc/linearization_varproj.hpp:44-60); this library's builds the
@@ -267,6 +276,11 @@ int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
  * once (benchmarks; a linearisation taken before is dropped: linearise again), (ctx, 0) swaps only if ready.
  * Returns 1 if the placed rows are in use after the call, 0 if not (yet), < 0 on error. */
 int povar_layout_finalize(povar_ctx* ctx, int32_t wait);
+/* Per-term E0 kernel of step 1 (replaces right_mul_e0_pOSE, sc/linearization_power_varproj.hpp:364-406, either way):
+ * 0 = e0_lpl, 1.. = e0_ck instantiations (povar_kernels_ck.hpp; table POVAR_CK_VARIANTS in povar_hip.hip: wavefronts per
+ * workgroup, register-resident tiles, rows in flight).  Environment: POVAR_E0_CK=<n> sets the initial choice, which also
+ * decides how the camera-chunk layout is cut (chunk cap, wavefronts the tiles are scheduled over). */
+int povar_set_e0_kernel(povar_ctx* ctx, int32_t kernel);
 
 /* ---- multi-GPU: landmarks sharded over ranks, one RCCL all-reduce per exchange step ---- */
 /* host-only: contiguous landmark range of `rank`, balanced by observation count */

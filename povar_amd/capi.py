@@ -47,7 +47,9 @@ class LayoutInfo(C.Structure):
     _fields_ = [("grid", C.c_int32), ("lds_slots", C.c_int32), ("n_global", C.c_int32), ("n_tail", C.c_int32),
                 ("n_tiles", C.c_int64), ("n_rows", C.c_int64), ("n_cold", C.c_int64), ("n_obs", C.c_int64), ("lane_per_landmark", C.c_int64),
                 ("create_ms", C.c_double), ("strategy", C.c_int32), ("hubs", C.c_int32), ("placement", C.c_int32),
-                ("placement_ms", C.c_double)]
+                ("placement_ms", C.c_double), ("e0_kernel", C.c_int32), ("ck_ready", C.c_int32), ("ck_batches", C.c_int32),
+                ("ck_slots", C.c_int32), ("ck_tiles_max", C.c_int32), ("ck_part_rec", C.c_int32), ("ck_rows", C.c_int64),
+                ("ck_chunks", C.c_int64), ("ck_cold_chunks", C.c_int64), ("ck_build_ms", C.c_double)]
 
 
 class TimingsInfo(C.Structure):
@@ -65,7 +67,8 @@ def build(force: bool = False) -> str:
     """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_PKG, "csrc")
     srcs = [os.path.join(src_dir, f) for f in ("povar_hip.hip", "povar_kernels.hpp", "povar_kernels_joint.hpp",
-                                               "povar_kernels_sc.hpp", "povar_kernels_chol.hpp", "lpl_layout.hpp")] + [HEADER]
+                                               "povar_kernels_sc.hpp", "povar_kernels_chol.hpp", "lpl_layout.hpp",
+                                               "ck_layout.hpp", "povar_kernels_ck.hpp")] + [HEADER]
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)
@@ -353,6 +356,10 @@ class Context:
         if rc < 0:
             raise PovarError(f"povar_hip rc={rc}: {self.L.povar_last_error().decode()}")
         return rc == 1
+
+    def set_e0_kernel(self, kernel):
+        """Per-term E0 kernel of step 1: 0 = e0_lpl, 1..5 = e0_ck instantiations (include/povar_hip.h)."""
+        self._chk(self.L.povar_set_e0_kernel(self.h, C.c_int32(int(kernel))))
 
     def comm_ranks(self):
         n = self.L.povar_comm_ranks(self.h)

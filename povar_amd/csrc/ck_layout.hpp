@@ -1,0 +1,332 @@
+// ck_layout.hpp -- host-side construction of the camera-chunk layout of the per-term E0 kernel e0_ck
+// (povar_kernels_ck.hpp: struct CkP).  Pure host C++, no device code.
+//
+// e0_lpl (lane = landmark, camera records + accumulators in LDS) is bound by the LDS pipe: 240 bytes of record reads
+// and twelve fp64 atomics per observation.  e0_ck turns the split round: lane = a CHUNK of at most CK_HMAX
+// observations of ONE camera (its record Z, P3 and its accumulator y_c live in registers), and the LANDMARKS of a
+// batch live in LDS (h~ 24 bytes, u / g 24 bytes): per observation 24 bytes read + three atomics on the way forward,
+// 48 bytes read on the way back.  The layout is derived from the lane-per-landmark layout, which has already decided
+//   * which workgroup owns which landmark and which cameras have an accumulator slot in which workgroup (the camera
+//     grid / range strategy of lpl_layout.hpp: a camera's observations are concentrated in the workgroups that hold it,
+//     which is what makes the chunks long),
+//   * the lane of every landmark (V2::lmrec is in that order: a batch is a set of lane-per-landmark tiles, so the
+//     landmark records of a batch are loaded with coalesced reads and nothing per landmark has to be permuted).
+// Per workgroup the tiles are dealt round-robin over NB batches (NB: what the LDS holds); the observations of a batch
+// are grouped by camera, every camera's run is cut into near-equal chunks of at most H observations (H per batch: what
+// the longest-first schedule of the chunk tiles over the wavefronts likes best), chunks are sorted by (length, camera)
+// and cut into tiles of 64 chunks; row j of a tile holds observation j of every chunk ([row][lane]: coalesced).
+// Chunks of cameras WITHOUT an accumulator slot in the workgroup ("cold" in the lane-per-landmark layout) are ordinary
+// chunks here -- their record comes from the rank-ordered image like every other -- and leave their twelve sums in a
+// partial record of their own instead of the LDS accumulator: no per-observation scatter, no cold view.
+#pragma once
+
+#include <climits>
+
+#include "lpl_layout.hpp"
+
+namespace povar {
+
+constexpr int CK_HMAX = 16;        // rows per chunk tile at most (observations per chunk)
+constexpr int CK_LDS_BYTES = 160 * 1024;
+constexpr int CK_FLAG_DUP = 1;     // lanes of the tile share accumulators: segmented wavefront sum before the flush
+constexpr int CK_FLAG_COLD = 2;    // some chunk of the tile writes its own partial record
+constexpr uint32_t CK_NONE = 0xffffu;  // 16-bit landmark slot of a row without observation
+
+struct CkLayout {
+  std::vector<double2> uv;       // [rows][64]
+  std::vector<uint32_t> li;      // [li_rows][64] landmark slots (16 bits each) of rows 2q | 2q+1 << 16 of a tile
+  std::vector<int> src;          // [rows][64] row slot of the lane-per-landmark layout this entry is (-1: none)
+  std::vector<int4> tile;        // x: first row, y: height, z: flags, w: first li row
+  std::vector<int> lane_cam;     // [tiles][64] popularity rank of the lane's camera (-1: empty lane)
+  std::vector<int> lane_acc;     // [tiles][64] >= 0: accumulator slot of the workgroup; < 0: ~(partial record) of a cold chunk
+  std::vector<int> lane_seg;     // [tiles][64] first | last << 8 lane of the run that shares this lane's accumulator
+  std::vector<int> bt_off;       // [grid * nb + 1] tiles of (workgroup, batch)
+  std::vector<int> slot_rec;     // [lpl wg_cams.size()] partial record each workgroup slot is flushed to
+  std::vector<int2> part_range;  // [n_cams] partial records of camera c (by camera index): [first, end)
+  int nb = 1;                    // batches per workgroup
+  int slots = 64;                // landmark slots of a batch (multiple of 64; the same for every workgroup)
+  int n_part_rec = 0, max_acc = 0;
+  int64_t rows = 0, li_rows = 0;
+  // statistics
+  int64_t n_chunks = 0, n_cold_chunks = 0, n_obs = 0;
+  int max_tiles_bt = 0;          // most tiles of a (workgroup, batch)
+  double extra_lanes = 0;        // bank collisions left: extra lanes per (row, half), summed over the rows
+};
+
+inline size_t ck_lds_bytes(int slots, int n_acc) { return (size_t)slots * 48 + (size_t)n_acc * 104 + 64; }  // = ck_lds_bytes_dev
+
+// cost of one batch for chunk cap H: longest-first schedule of its tiles over n_waves wavefronts, every tile charged
+// its height plus a fixed overhead (record gather, flush); also returns the tile count
+inline int ck_schedule_cost(const std::vector<int>& counts, int H, int n_waves, int tile_overhead, int* n_tiles_out) {
+  std::vector<int> len;
+  for (int n : counts) {
+    const int k = (n + H - 1) / H, base = n / k, rem = n % k;
+    for (int q = 0; q < k; ++q) len.push_back(base + (q < rem ? 1 : 0));
+  }
+  std::sort(len.begin(), len.end(), std::greater<int>());
+  const int n_tiles = ((int)len.size() + WAVE - 1) / WAVE;
+  std::priority_queue<int, std::vector<int>, std::greater<int>> heap;
+  for (int w = 0; w < n_waves; ++w) heap.push(0);
+  int makespan = 0;
+  for (int t = 0; t < n_tiles; ++t) {
+    const int load = heap.top() + len[(size_t)t * WAVE] + tile_overhead;
+    heap.pop();
+    heap.push(load);
+    makespan = std::max(makespan, load);
+  }
+  if (n_tiles_out) *n_tiles_out = n_tiles;
+  return makespan;
+}
+
+// L: the lane-per-landmark layout (rows in the order the device will use); rank -> camera index through cam_of_rank
+// n_waves, hmax: wavefronts per workgroup of the kernel instantiation that will run the layout, and the tallest tile it
+// keeps in registers (CK_HMAX: none / whatever schedules best)
+inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector<int>& cam_of_rank, int n_waves,
+                     CkLayout& K, bool place = true, int hmax = CK_HMAX) {
+  int n_threads = std::min(lpl_effective_cpus(), 128);
+  if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
+  hmax = std::min(CK_HMAX, std::max(1, hmax));
+  int tile_overhead = 3;
+  if (const char* e = std::getenv("POVAR_CK_TILE_COST")) tile_overhead = std::max(0, std::atoi(e));
+  // ---- batches: the smallest count whose landmark slots fit next to the accumulators
+  int max_tiles_w = 1, max_acc = 1;
+  for (int w = 0; w < grid; ++w) {
+    max_tiles_w = std::max(max_tiles_w, L.wg_tile_off[w + 1] - L.wg_tile_off[w]);
+    max_acc = std::max(max_acc, L.wg_cam_off[w + 1] - L.wg_cam_off[w]);
+  }
+  int nb = 1;
+  while (ck_lds_bytes(WAVE * ((max_tiles_w + nb - 1) / nb), max_acc) > (size_t)CK_LDS_BYTES && nb < max_tiles_w) ++nb;
+  if (const char* e = std::getenv("POVAR_CK_NB")) nb = std::max(nb, std::atoi(e));
+  K.nb = nb;
+  K.slots = WAVE * ((max_tiles_w + nb - 1) / nb);
+  K.max_acc = max_acc;
+  struct WgOut {
+    std::vector<double2> uv;
+    std::vector<uint32_t> li;
+    std::vector<int> src, lane_cam, lane_acc, lane_seg, bt_tiles;  // bt_tiles[b]: tiles of batch b
+    std::vector<int4> tile;  // x, w: local row / li-row numbers
+    std::vector<int> cold_rank;  // rank of every cold chunk, in the order their lanes say ~(index)
+    int64_t chunks = 0, obs = 0;
+    double extra = 0;
+  };
+  std::vector<WgOut> out(grid);
+  lpl_parallel(grid, n_threads, [&](int w) {
+    WgOut& o = out[w];
+    o.bt_tiles.assign(nb, 0);
+    const int t0 = L.wg_tile_off[w], t1 = L.wg_tile_off[w + 1];
+    struct Ob { int key, li, src; };  // key: accumulator slot, or n_acc_w + rank for a camera without one
+    const int n_acc_w = L.wg_cam_off[w + 1] - L.wg_cam_off[w];
+    std::vector<Ob> obs;
+    std::vector<int> counts, first_of;
+    struct Chunk { int key, first, len; };
+    std::vector<Chunk> chunks;
+    std::vector<int> assign;
+    std::vector<long> cost;
+    for (int b = 0; b < nb; ++b) {
+      obs.clear();
+      for (int t = t0 + b; t < t1; t += nb) {
+        const int4 ti = L.tile[t];
+        const int slot0 = ((t - t0) / nb) * WAVE;
+        for (int j = 0; j < ti.y; ++j)
+          for (int lane = 0; lane < WAVE; ++lane) {
+            const size_t idx = ((size_t)ti.x + j) * WAVE + lane;
+            const int cw = L.cw[idx];
+            if (cw == -1) continue;
+            Ob ob;
+            ob.key = cw >= 0 ? lpl_cw_slot(cw) : n_acc_w + (-2 - cw);
+            ob.li = slot0 + (L.seg[(size_t)t * WAVE + lane] & 255);  // a landmark dealt over several lanes: its first lane's slot
+            ob.src = (int)idx;
+            obs.push_back(ob);
+          }
+      }
+      o.obs += (int64_t)obs.size();
+      std::stable_sort(obs.begin(), obs.end(), [](const Ob& a, const Ob& c) { return a.key < c.key; });
+      counts.clear();
+      first_of.clear();
+      for (size_t i = 0; i < obs.size();) {
+        size_t j = i;
+        while (j < obs.size() && obs[j].key == obs[i].key) ++j;
+        counts.push_back((int)(j - i));
+        first_of.push_back((int)i);
+        i = j;
+      }
+      // chunk cap of this batch
+      int H = hmax, best = INT_MAX;
+      for (int h = std::min(2, hmax); h <= hmax; ++h) {
+        const int c = ck_schedule_cost(counts, h, n_waves, tile_overhead, nullptr);
+        if (c <= best) { best = c; H = h; }  // ties: the larger cap (fewer chunks)
+      }
+      chunks.clear();
+      for (size_t g = 0; g < counts.size(); ++g) {
+        const int n = counts[g], k = (n + H - 1) / H, base = n / k, rem = n % k;
+        int at = first_of[g];
+        for (int q = 0; q < k; ++q) {
+          const int len = base + (q < rem ? 1 : 0);
+          chunks.push_back(Chunk{obs[at].key, at, len});
+          at += len;
+        }
+      }
+      // inside a length: by popularity rank -- the lanes of a tile gather their camera records from the rank-ordered
+      // image, and neighbouring ranks share cache lines (in slot order every lane of a gather hit a line of its own)
+      auto rank_of = [&](int key) { return key >= n_acc_w ? key - n_acc_w : L.wg_cams[L.wg_cam_off[w] + key]; };
+      std::stable_sort(chunks.begin(), chunks.end(), [&](const Chunk& a, const Chunk& c) {
+        if (a.len != c.len) return a.len > c.len;
+        const int ra = rank_of(a.key), rc = rank_of(c.key);
+        return ra != rc ? ra < rc : a.key < c.key;
+      });
+      o.chunks += (int64_t)chunks.size();
+      const int n_tiles = ((int)chunks.size() + WAVE - 1) / WAVE;
+      o.bt_tiles[b] = n_tiles;
+      for (int tt = 0; tt < n_tiles; ++tt) {
+        const int c0 = tt * WAVE, c1 = std::min((int)chunks.size(), c0 + WAVE);
+        const int T = chunks[c0].len;
+        int4 ti = make_int4((int)(o.uv.size() / WAVE), T, 0, (int)(o.li.size() / WAVE));
+        const size_t r0 = o.uv.size(), q0 = o.li.size();
+        o.uv.resize(r0 + (size_t)T * WAVE, make_double2(0, 0));
+        o.src.resize(r0 + (size_t)T * WAVE, -1);
+        o.li.resize(q0 + (size_t)((T + 1) / 2) * WAVE, CK_NONE | (CK_NONE << 16));
+        const size_t l0 = o.lane_cam.size();
+        o.lane_cam.resize(l0 + WAVE, -1);
+        o.lane_acc.resize(l0 + WAVE, 0);
+        o.lane_seg.resize(l0 + WAVE, 0);
+        for (int lane = 0; lane < WAVE; ++lane) o.lane_seg[l0 + lane] = lane | (lane << 8);
+        // bank occupancy of the tile: [row][half][32]
+        uint16_t occ[CK_HMAX][2][32] = {};
+        uint16_t mx[CK_HMAX][2];
+        for (int j = 0; j < CK_HMAX; ++j) mx[j][0] = mx[j][1] = 1;
+        for (int q = c0; q < c1; ++q) {
+          const int lane = q - c0, half = lane >> 5;
+          const Chunk& ck = chunks[q];
+          const bool cold = ck.key >= n_acc_w;
+          o.lane_cam[l0 + lane] = cold ? ck.key - n_acc_w : L.wg_cams[L.wg_cam_off[w] + ck.key];
+          if (cold) {
+            o.lane_acc[l0 + lane] = ~(int)o.cold_rank.size();
+            o.cold_rank.push_back(ck.key - n_acc_w);
+            ti.z |= CK_FLAG_COLD;
+          } else {
+            o.lane_acc[l0 + lane] = ck.key;
+            if (lane > 0 && chunks[q - 1].key == ck.key) ti.z |= CK_FLAG_DUP;
+          }
+          // rows of the chunk's observations: an assignment problem against the banks already taken in this half of
+          // the tile (a lane with fewer observations than the tile has rows may leave any rows empty)
+          const int h = ck.len;
+          assign.resize(h);
+          if (place && T > 1) {
+            cost.assign((size_t)T * T, 0);
+            for (int a = 0; a < h; ++a) {
+              const int cls = obs[ck.first + a].li & 31;
+              for (int j = 0; j < T; ++j) {
+                const int v = occ[j][half][cls];
+                cost[(size_t)a * T + j] = 1000L * std::max(0, v + 1 - (int)mx[j][half]) + v;
+              }
+            }
+            std::vector<int> full;
+            lpl_assign(T, cost, full);  // items h..T-1 are dummies (zero cost everywhere)
+            for (int a = 0; a < h; ++a) assign[a] = full[a];
+          } else {
+            for (int a = 0; a < h; ++a) assign[a] = a;
+          }
+          for (int a = 0; a < h; ++a) {
+            const Ob& ob = obs[ck.first + a];
+            const int j = assign[a];
+            const size_t idx = r0 + (size_t)j * WAVE + lane;
+            const size_t s = (size_t)ob.src;
+            o.uv[idx] = L.uv[s];
+            o.src[idx] = ob.src;
+            uint32_t& word = o.li[q0 + (size_t)(j >> 1) * WAVE + lane];
+            word = (j & 1) ? ((word & 0xffffu) | ((uint32_t)ob.li << 16)) : ((word & 0xffff0000u) | (uint32_t)ob.li);
+            const uint16_t v = ++occ[j][half][ob.li & 31];
+            mx[j][half] = std::max(mx[j][half], v);
+          }
+        }
+        for (int j = 0; j < T; ++j) o.extra += (mx[j][0] - 1) + (mx[j][1] - 1);
+        // runs of lanes with the same accumulator (resident chunks of one camera are adjacent: sorted by key)
+        if (ti.z & CK_FLAG_DUP) {
+          int lane = 0;
+          const int nl = c1 - c0;
+          while (lane < nl) {
+            int e = lane;
+            if (o.lane_acc[l0 + lane] >= 0)
+              while (e + 1 < nl && o.lane_acc[l0 + e + 1] == o.lane_acc[l0 + lane]) ++e;
+            for (int x = lane; x <= e; ++x) o.lane_seg[l0 + x] = lane | (e << 8);
+            lane = e + 1;
+          }
+        }
+        o.tile.push_back(ti);
+      }
+    }
+  });
+  // ---- global numbering
+  K.bt_off.assign((size_t)grid * nb + 1, 0);
+  std::vector<int64_t> row0_of(grid), li0_of(grid);
+  std::vector<int> tile0_of(grid), cold0_of(grid);
+  int n_cold_chunks = 0;
+  for (int w = 0; w < grid; ++w) {
+    const WgOut& o = out[w];
+    row0_of[w] = K.rows;
+    li0_of[w] = K.li_rows;
+    tile0_of[w] = (int)K.tile.size();
+    cold0_of[w] = n_cold_chunks;
+    n_cold_chunks += (int)o.cold_rank.size();
+    int t = (int)K.tile.size();
+    for (int b = 0; b < nb; ++b) {
+      K.bt_off[(size_t)w * nb + b] = t;
+      t += o.bt_tiles[b];
+      K.max_tiles_bt = std::max(K.max_tiles_bt, o.bt_tiles[b]);
+    }
+    for (int4 ti : o.tile) {
+      ti.x += (int)K.rows;
+      ti.w += (int)K.li_rows;
+      K.tile.push_back(ti);
+    }
+    K.rows += (int64_t)(o.uv.size() / WAVE);
+    K.li_rows += (int64_t)(o.li.size() / WAVE);
+    K.n_chunks += o.chunks;
+    K.n_obs += o.obs;
+    K.extra_lanes += o.extra;
+  }
+  K.bt_off[(size_t)grid * nb] = (int)K.tile.size();
+  K.n_cold_chunks = n_cold_chunks;
+  // ---- partial records, camera-major: a camera's workgroup slots first, then its cold chunks
+  std::vector<int> n_rec(n_cams, 0);  // by rank
+  for (size_t s = 0; s < L.wg_cams.size(); ++s) n_rec[L.wg_cams[s]]++;
+  std::vector<int> n_slot_rec(n_rec);
+  for (int w = 0; w < grid; ++w)
+    for (int r0 : out[w].cold_rank) n_rec[r0]++;
+  std::vector<int> first(n_cams + 1, 0);
+  for (int r0 = 0; r0 < n_cams; ++r0) first[r0 + 1] = first[r0] + n_rec[r0];
+  K.n_part_rec = first[n_cams];
+  K.part_range.assign(n_cams, make_int2(0, 0));
+  for (int r0 = 0; r0 < n_cams; ++r0) K.part_range[cam_of_rank[r0]] = make_int2(first[r0], first[r0 + 1]);
+  K.slot_rec.assign(L.wg_cams.size(), 0);
+  {
+    std::vector<int> next(first.begin(), first.end() - 1);
+    for (size_t s = 0; s < L.wg_cams.size(); ++s) K.slot_rec[s] = next[L.wg_cams[s]]++;
+    // cold chunks: record numbers in workgroup order (deterministic whatever the thread count)
+    std::vector<int> cold_rec((size_t)n_cold_chunks);
+    for (int w = 0; w < grid; ++w)
+      for (size_t i = 0; i < out[w].cold_rank.size(); ++i) cold_rec[(size_t)cold0_of[w] + i] = next[out[w].cold_rank[i]]++;
+    // ---- concatenate the per-workgroup arrays
+    // (+ CK_HMAX rows of padding: the register-resident tiles of e0_ck load CK_HMAX rows whatever the tile's height)
+    K.uv.assign((size_t)(K.rows + CK_HMAX) * WAVE, make_double2(0, 0));
+    K.src.assign((size_t)(K.rows + CK_HMAX) * WAVE, -1);
+    K.li.assign((size_t)(K.li_rows + CK_HMAX) * WAVE, CK_NONE | (CK_NONE << 16));
+    K.lane_cam.resize(K.tile.size() * WAVE);
+    K.lane_acc.resize(K.tile.size() * WAVE);
+    K.lane_seg.resize(K.tile.size() * WAVE);
+    lpl_parallel(grid, n_threads, [&](int w) {
+      const WgOut& o = out[w];
+      std::copy(o.uv.begin(), o.uv.end(), K.uv.begin() + row0_of[w] * WAVE);
+      std::copy(o.src.begin(), o.src.end(), K.src.begin() + row0_of[w] * WAVE);
+      std::copy(o.li.begin(), o.li.end(), K.li.begin() + li0_of[w] * WAVE);
+      std::copy(o.lane_cam.begin(), o.lane_cam.end(), K.lane_cam.begin() + (size_t)tile0_of[w] * WAVE);
+      std::copy(o.lane_seg.begin(), o.lane_seg.end(), K.lane_seg.begin() + (size_t)tile0_of[w] * WAVE);
+      for (size_t i = 0; i < o.lane_acc.size(); ++i) {
+        const int a = o.lane_acc[i];
+        K.lane_acc[(size_t)tile0_of[w] * WAVE + i] = a >= 0 ? a : ~cold_rec[(size_t)cold0_of[w] + (size_t)(~a)];
+      }
+    });
+  }
+}
+
+}  // namespace povar

@@ -24,6 +24,8 @@
 #include "povar_kernels_sc.hpp"
 #include "povar_kernels_chol.hpp"
 #include "lpl_layout.hpp"
+#include "ck_layout.hpp"
+#include "povar_kernels_ck.hpp"
 
 using namespace povar;
 
@@ -140,6 +142,30 @@ struct povar_ctx {
   bool use_lpl = true;        // POVAR_E0_V1=1: keep e0_lm_cached<true> (lane per observation) for A/B runs
   bool lpl_forced = false;      // POVAR_E0_V1 set: keep the choice (the peer-to-peer exchange otherwise turns use_lpl on)
   bool use_lpl_prepare = true;  // POVAR_PREPARE_V1=1: keep lm_regular<OpPrepare> + cm_scatter
+  // camera-chunk layout of e0_ck (ck_layout.hpp): derived from the lane-per-landmark rows in use, so it is rebuilt
+  // with them (pl_ck: built by the placement thread from the placed rows, swapped in together with them)
+  struct CkDev {
+    DevBuf<double2> uv;
+    DevBuf<uint32_t> li;
+    DevBuf<int> src, lane_cam, lane_acc, lane_seg, bt_off, slot_rec;
+    DevBuf<int4> tile;
+    DevBuf<int2> part_range;
+    DevBuf<double> part, w;
+    int nb = 0, slots = 0, n_part_rec = 0, max_acc = 0, max_tiles_bt = 0;
+    int64_t rows = 0, li_rows = 0, n_chunks = 0, n_cold_chunks = 0;
+    double build_ms = 0;
+    bool ready = false;
+    void release() {
+      uv.release(); li.release(); src.release(); lane_cam.release(); lane_acc.release(); lane_seg.release(); bt_off.release();
+      slot_rec.release(); tile.release(); part_range.release(); part.release(); w.release();
+      ready = false;
+    }
+  } ck, pl_ck;
+  DevBuf<double> ck_img;         // [21][ck_pad] structure-of-arrays record image (Dp::ck_img)
+  DevBuf<int2> ck_zero_range;    // [n_cams] empty runs: e0_ck leaves no per-observation cold view to the per-camera kernels
+  int ck_pad = 0;
+  int ck_variant = 0;            // 0: e0_lpl; 1..CK_VARIANTS: e0_ck instantiation (POVAR_CK_VARIANTS)
+  int64_t ckw_lin_id = -1;       // linearisation whose robust weights CkDev::w holds
   DevBuf<double4> q4c;        // scatter scalars of the cold observations, in cold camera-major order
   DevBuf<int> lm_slot0, lm_cnt_dev;
   bool k1_qr = true;          // POVAR_K1_NORMAL_EQ=1: the round-1 normal-equation kernels (A/B accuracy runs)
@@ -425,6 +451,107 @@ int upload(DevBuf<T>& buf, const std::vector<T>& v, povar_ctx* c) {
 inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
 
 // ------------------------------------------------------------------------------------------
+// camera-chunk layout of e0_ck: upload, kernel parameters, launch
+// ------------------------------------------------------------------------------------------
+// locked: called by the row-placement thread -- its HIP calls go in short pieces under g_capture_mu (povar_ctx::placer_cancel)
+bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked, size_t* bytes) {
+  bool ok = true;
+  auto guarded = [&](auto&& fn) {
+    if (locked) {
+      std::lock_guard<std::mutex> lk(g_capture_mu);
+      fn();
+    } else {
+      fn();
+    }
+  };
+  auto up = [&](auto& buf, const auto& v) {
+    if (!ok) return;
+    guarded([&] { ok = buf.alloc(std::max<size_t>(v.size(), 1), bytes) == hipSuccess; });
+    const size_t piece = ((size_t)8 << 20) / sizeof(v[0]);  // 8 MB per copy: a capture waits a millisecond at most
+    for (size_t at = 0; ok && at < v.size() && !(locked && c->placer_cancel.load()); at += piece)
+      guarded([&] {
+        ok = hipMemcpy(buf.p + at, v.data() + at, std::min(piece, v.size() - at) * sizeof(v[0]), hipMemcpyHostToDevice) == hipSuccess;
+      });
+  };
+  up(D.uv, K.uv); up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_cam, K.lane_cam); up(D.lane_acc, K.lane_acc);
+  up(D.lane_seg, K.lane_seg); up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
+  if (ok) guarded([&] { ok = D.part.alloc((size_t)std::max(K.n_part_rec, 1) * 12, bytes) == hipSuccess; });
+  if (ok && c->opt.robust_norm)
+    guarded([&] { ok = D.w.alloc(std::max<size_t>(K.uv.size(), 1), bytes) == hipSuccess; });  // (padded like uv)
+  D.nb = K.nb; D.slots = K.slots; D.n_part_rec = K.n_part_rec; D.max_acc = K.max_acc; D.max_tiles_bt = K.max_tiles_bt;
+  D.rows = K.rows; D.li_rows = K.li_rows; D.n_chunks = K.n_chunks; D.n_cold_chunks = K.n_cold_chunks;
+  D.ready = ok && !(locked && c->placer_cancel.load());
+  return D.ready;
+}
+CkP ck_params(const povar_ctx* c) {
+  const auto& D = c->ck;
+  return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_cam.p, D.lane_acc.p, D.lane_seg.p, D.bt_off.p, D.slot_rec.p, c->ck_img.p,
+             D.nb, D.slots, c->ck_pad};
+}
+// e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight
+#define POVAR_CK_VARIANTS(X) X(1, 16, 2) X(2, 16, 4) X(3, 16, 6) X(4, 12, 4) X(5, 12, 8) X(6, 8, 8)
+constexpr int CK_VARIANTS = 6;
+struct CkVariant { int nw, sd; };
+CkVariant ck_variant_info(int variant) {
+  switch (variant) {
+#define X(id, nw, sd) case id: return CkVariant{nw, sd};
+    POVAR_CK_VARIANTS(X)
+#undef X
+    default: return CkVariant{16, 2};
+  }
+}
+bool ck_active(const povar_ctx* c) {
+  return c->ck_variant > 0 && c->ck.ready && c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+}
+// the per-camera kernels behind e0_ck: partial records only (its own table), no per-observation cold view
+void ck_dp(const povar_ctx* c, Dp& da) {
+  da.hot_part = c->ck.part.p;
+  da.part_range = c->ck.part_range.p;
+  da.cmv.cam_range = c->ck_zero_range.p;
+  da.cmv.n = 0;
+  da.cmv.src = nullptr;
+  da.q_rows = 0;
+}
+template <int NW, int SD>
+void launch_e0_ck_t(povar_ctx* c, const Dp& da) {
+  const CkP k = ck_params(c);
+  const size_t lds = ck_lds_bytes(c->ck.slots, c->ck.max_acc);
+  if (c->opt.robust_norm)
+    hipLaunchKernelGGL((e0_ck<NW, SD, true>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+  else
+    hipLaunchKernelGGL((e0_ck<NW, SD, false>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+}
+void launch_e0_ck(povar_ctx* c, const Dp& da) {
+  switch (c->ck_variant) {
+#define X(id, nw, sd) case id: launch_e0_ck_t<nw, sd>(c, da); break;
+    POVAR_CK_VARIANTS(X)
+#undef X
+    default: break;
+  }
+}
+template <int NW, int SD>
+hipError_t ck_set_lds_t() {
+  hipError_t e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)e0_ck<NW, SD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+}
+hipError_t ck_set_lds_all() {
+  hipError_t e = hipSuccess;
+#define X(id, nw, sd) if (e == hipSuccess) e = ck_set_lds_t<nw, sd>();
+  POVAR_CK_VARIANTS(X)
+#undef X
+  return e;
+}
+// robust weights in chunk order (V2::w is written by the linearisation walk in lane-per-landmark order)
+void ensure_ck_w(povar_ctx* c) {
+  if (!c->opt.robust_norm || !c->ck.ready || !c->ck.w.p || !c->v2_w.p || c->ckw_lin_id == c->lin_id) return;
+  const int64_t n = (int64_t)c->ck.src.n;  // every row, the padding included (weight 0)
+  hipLaunchKernelGGL(ck_gather_w, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const int*)c->ck.src.p, (const double*)c->v2_w.p,
+                     c->ck.w.p, n);
+  c->ckw_lin_id = c->lin_id;
+}
+
+// ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
 template <class Op>
@@ -650,6 +777,7 @@ int swap_in_placed_rows(povar_ctx* c, bool wait) {
   if (c->placer_state.load(std::memory_order_acquire) != 2) {  // the build or an upload failed: stay on the natural order
     c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
     c->pl_c3_src.release();
+    c->pl_ck.release();
     c->placement = 0;
     return 0;
   }
@@ -664,6 +792,11 @@ int swap_in_placed_rows(povar_ctx* c, bool wait) {
   v.of_slot = c->v2_of_slot.p;
   c->lmx_ver = 0;                          // lane-ordered landmark mirror: regather
   c->lml_lin_id = c->lsc_lin_id = -1;
+  // the camera-chunk layout belongs to the row order it was derived from
+  c->ck.release();
+  if (c->pl_ck.ready) std::swap(c->ck, c->pl_ck);
+  c->pl_ck.release();
+  c->ckw_lin_id = -1;
   c->placement = 3;
   return 1;
 }
@@ -714,6 +847,7 @@ int combine_flag(povar_ctx* c, int* flag) {
 int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
   prof_mark(c, 0);
   if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // cm_scatter / legacy cold views
+  if (ck_active(c)) ensure_ck_w(c);  // (a no-op inside the graph capture: povar_power_series_pose has called it before)
   if (c->joint) {
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
     if (acc && c->use_lpl) {
@@ -754,6 +888,8 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
     // long landmarks inside e0_lm_cached (its own cold view)
     const bool lik = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->long_in_kernel;
     Dp da = acc ? ldsacc_dp(c, lik) : c->d;
+    const bool ck_now = ck_active(c);
+    if (ck_now) ck_dp(c, da);
     // peer-to-peer exchange: only inside the term loop (fuse_norms >= 0) of the lane-per-landmark kernels; every other
     // caller (right_mul_e0, PCG) wants the dense, all-reduced y
     const bool p2p_now = c->p2p && fuse_norms >= 0 && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
@@ -766,6 +902,8 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
       if (c->n_long > 0)
         hipLaunchKernelGGL((lm_long<OpE0Tiles>), dim3(c->n_long), dim3(LM_BLOCK), 0, c->stream, da, OpE0Tiles{}, c->part.p);
     }
+    else if (ck_now)
+      launch_e0_ck(c, da);
     else if (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->use_lpl && c->opt.robust_norm)
       hipLaunchKernelGGL(e0_lpl<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK),
                          lpl_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
@@ -1042,7 +1180,15 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY_C(hipFuncSetAttribute((const void*)prepare_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
+    HIP_TRY_C(ck_set_lds_all());
   }
+  // per-term E0 kernel of step 1: e0_lpl (0) or an e0_ck instantiation (POVAR_E0_CK=<variant>, povar_set_e0_kernel)
+  if (const char* g = std::getenv("POVAR_E0_CK")) c->ck_variant = std::max(0, std::min(CK_VARIANTS, std::atoi(g)));
+  const bool want_ck = c->use_lpl && std::getenv("POVAR_NO_CK") == nullptr;
+  // the camera-chunk layout is cut for the instantiation that will run it (its tiles are scheduled over its wavefronts)
+  const CkVariant ckv = ck_variant_info(c->ck_variant > 0 ? c->ck_variant : 1);
+  int ck_nw = ckv.nw, ck_hmax = CK_HMAX;
+  if (const char* e = std::getenv("POVAR_CK_HMAX")) ck_hmax = std::min(CK_HMAX, std::max(1, std::atoi(e)));
 
   // The arrays of the lane-per-observation kernels (part B) are built on a second host thread while this one builds
   // and uploads the lane-per-landmark layout: the two only share the slot numbers and camera ranks of part A.
@@ -1067,7 +1213,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       struct Job {
         std::vector<int32_t> lm_off, cam_idx;
         std::vector<double> obs;
-        std::vector<int> rank1, slot_of_obs;
+        std::vector<int> rank1, slot_of_obs, cam_of_rank;
       };
       auto job = std::make_shared<Job>();
       job->lm_off.assign(lm_offsets, lm_offsets + n_lms + 1);
@@ -1075,17 +1221,23 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       job->obs.assign(obs, obs + 2 * n_obs);
       job->rank1 = L.cam_hot;
       job->slot_of_obs = L.slot_of_obs;
+      job->cam_of_rank = L.hot_cams;
       const int64_t rows = V.rows;
       const size_t n_tiles = V.tile.size();
       const int dev = options->device, grid = c->e0c_grid, n_acc = c->n_hot_acc;
       const size_t n_slots = (size_t)c->n_slots;
       c->placer_state.store(1);
-      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms]() {
+      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax]() {
         const auto t0 = std::chrono::steady_clock::now();
         LplLayout P;
-        build_lpl(n_cams, n_lms, job->lm_off.data(), job->cam_idx.data(), job->obs.data(), job->rank1, job->slot_of_obs,
-                  n_slots, grid, n_acc, P, true, &c->placer_cancel);
-        bool ok = !c->placer_cancel.load() && P.rows == rows && P.tile.size() == n_tiles;
+        bool built = true;
+        try {  // an allocation failure of this thread must not terminate the caller's process: stay on the natural order
+          build_lpl(n_cams, n_lms, job->lm_off.data(), job->cam_idx.data(), job->obs.data(), job->rank1, job->slot_of_obs,
+                    n_slots, grid, n_acc, P, true, &c->placer_cancel);
+        } catch (...) {
+          built = false;
+        }
+        bool ok = built && !c->placer_cancel.load() && P.rows == rows && P.tile.size() == n_tiles;
         if (ok) {
           std::lock_guard<std::mutex> lk(g_capture_mu);
           ok = hipSetDevice(dev) == hipSuccess;
@@ -1105,6 +1257,17 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
         up(c->pl_uv, P.uv); up(c->pl_cw, P.cw); up(c->pl_cpos, P.cpos);
         up(c->pl_lm_pos, P.lm_pos); up(c->pl_lm_of, P.lm_of); up(c->pl_of_slot, P.of_slot);
         up(c->pl_c3_src, P.cold_src);
+        if (ok && want_ck) {  // the camera-chunk layout of the placed rows (a failure here only leaves e0_lpl in charge)
+          try {
+            const auto tk = std::chrono::steady_clock::now();
+            CkLayout K;
+            build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, true, ck_hmax);
+            c->pl_ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
+            if (!c->placer_cancel.load()) ck_upload(c, c->pl_ck, K, true, &c->pl_bytes);
+          } catch (...) {
+            c->pl_ck.ready = false;
+          }
+        }
         c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         c->placer_state.store(ok ? 2 : 3, std::memory_order_release);
       });
@@ -1145,6 +1308,20 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     HIP_TRY_C(c->c3_h.alloc(4 * std::max<size_t>(V.cold_lm.size(), 1), &c->bytes));
     if (options->robust_norm) HIP_TRY_C(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
     n_cold_lpl = V.cold_lm.size();
+    if (want_ck && !V.tile.empty()) {
+      c->ck_pad = (n_cams + 63) & ~63;
+      HIP_TRY_C(c->ck_img.alloc((size_t)21 * c->ck_pad, &c->bytes));
+      HIP_TRY_C(hipMemset(c->ck_img.p, 0, sizeof(double) * 21 * c->ck_pad));
+      if (int rc = upload(c->ck_zero_range, std::vector<int2>((size_t)n_cams, make_int2(0, 0)), c)) { povar_destroy(c); return rc; }
+      if (place_mode != 2) {  // (else: built from the placed rows by the host thread, swapped in with them)
+        const auto tk = std::chrono::steady_clock::now();
+        CkLayout K;
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, true, ck_hmax);
+        c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
+        if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
+        lap("camera-chunk layout");
+      }
+    }
     c->d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
                  c->v2_lm_of.p, c->v2_lmx.p, c->v2_lml.p, c->v2_lsc.p, c->v2_lm_pos.p, c->v2_of_slot.p, c->v2_wg_tile_off.p, c->v2_wg_cam_off.p, c->v2_wg_cams.p,
                  c->v2_wg_slot_rec.p, nt, V.hubs};
@@ -1246,6 +1423,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.cmv = CmView{c->cm_slot.p, c->cm_h.p, n_obs, c->item_off.p, c->cam_item_off.p, c->item_part.p, c->n_items, nullptr};
   d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
   d.hot_rec = c->hot_rec.p;
+  d.ck_img = c->ck_img.p; d.ck_pad = c->ck_pad;
   d.hot_cams = c->hot_cams.p; d.n_hot = std::min(n_cams, HOT_MAX);
   d.part_range = nullptr;
   d.p2p_peer = nullptr; d.p2p_epoch = nullptr; d.p2p_world = 1; d.p2p_rank = 0;
@@ -1271,6 +1449,7 @@ void povar_destroy(povar_ctx* c) {
   (void)hipSetDevice(c->opt.device);
   c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
   c->pl_c3_src.release(); c->c3_src.release();
+  c->ck.release(); c->pl_ck.release(); c->ck_img.release(); c->ck_zero_range.release();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->pin) (void)hipHostFree(c->pin);
@@ -1486,6 +1665,8 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   c->new_linearization_point = false;
   c->d.lambda_lm = solver_type == POVAR_POWER_SCHUR_COMPLEMENT ? lambda : 0.0;  // cpp:197-200
   hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_cams * 12, 256)), dim3(256), 0, c->stream, c->d, 0);
+  if (c->ck_img.p)
+    hipLaunchKernelGGL(ck_build_img_p3, dim3(grid_for((int64_t)c->n_cams * 9, 256)), dim3(256), 0, c->stream, c->d, c->ck_img.p, c->ck_pad);
   if (c->use_lpl && c->use_lpl_prepare && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
     // lane-per-landmark K7: Hll^-1, landmark records and the per-camera partial sums of b in one kernel, then the
     // per-camera sum of the partials and the cold observations (same kernel as the per-term one, output b)
@@ -1558,6 +1739,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (m < 0) return fail(-1, "power_sc_iterations < 0");
   TimeScope ts(c, 2);
   if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // not inside the graph capture
+  if (ck_active(c)) ensure_ck_w(c);
   const bool norms = q_tol > 0 || r_tol > 0;
   // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
   // RCCL-in-capture is not something a 1-GPU box can validate); POVAR_GRAPH_COMM=1 opts in
@@ -1565,7 +1747,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (c->use_graph && !c->profile && m > 0 && (p2p_terms || (!c->host_fn && (!c->comm || c->graph_with_comm)))) {
     // the whole loop (memset, B^-1, m x {E0 kernels, [all-reduce], B^-1 + AXPY, [check]}) is one graph
     // launch; it is re-captured only when a kernel argument changes
-    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode, (sharded(c) ? 1 : 0) | (p2p_terms ? 2 : 0), norms ? 1 : 0, r_tol > 0 ? 1 : 0};
+    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode + 16 * (ck_active(c) ? c->ck_variant : 0), (sharded(c) ? 1 : 0) | (p2p_terms ? 2 : 0), norms ? 1 : 0, r_tol > 0 ? 1 : 0};
     // (the landmark damping is an argument of the prepare / back-substitution kernels only: no kernel of the loop reads
     // it, and step 2 changes it with every LM iteration -- a capture + instantiation of 0.25 ms each time)
     Dp key_d = c->d;
@@ -2129,6 +2311,16 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->hubs = c->d.v2.hubs;
   out->placement = c->placement;
   out->placement_ms = c->placer_state.load(std::memory_order_acquire) >= 2 ? c->placement_ms : 0.0;
+  out->e0_kernel = c->ck_variant > 0 && c->ck.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC ? c->ck_variant : 0;
+  out->ck_ready = c->ck.ready ? 1 : 0;
+  out->ck_batches = c->ck.nb;
+  out->ck_slots = c->ck.slots;
+  out->ck_tiles_max = c->ck.max_tiles_bt;
+  out->ck_rows = c->ck.rows;
+  out->ck_chunks = c->ck.n_chunks;
+  out->ck_cold_chunks = c->ck.n_cold_chunks;
+  out->ck_part_rec = c->ck.n_part_rec;
+  out->ck_build_ms = c->ck.build_ms;
   return 0;
 }
 
@@ -2144,6 +2336,14 @@ int povar_layout_finalize(povar_ctx* c, int32_t wait) {
     }
   }
   return c->placement == 1 || c->placement == 3 ? 1 : 0;
+}
+
+int povar_set_e0_kernel(povar_ctx* c, int32_t kernel) {
+  if (int rc = check_ctx(c)) return rc;
+  if (kernel < 0 || kernel > CK_VARIANTS) return fail(-1, "unknown E0 kernel");
+  if (kernel > 0 && !c->ck_img.p) return fail(-1, "the camera-chunk layout was not built for this context");
+  c->ck_variant = kernel;
+  return 0;
 }
 
 int povar_comm_ranks(povar_ctx* c) {

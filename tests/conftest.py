@@ -18,6 +18,9 @@ def pytest_configure(config):
 # modules use small problems: they run twice, once as the library would ("auto") and once with the lane-per-landmark
 # kernels forced (POVAR_E0_V1=0), so that both families stay compared with the oracle on every case.
 _BOTH_KERNEL_FAMILIES = {"test_gpu_step1", "test_gpu_step2", "test_gpu_fuzz", "test_gpu_sharded", "test_gpu_sc_solvers"}
+# ... and a third time with the camera-chunk form of the step-1 E0 operator (e0_ck, round 4) on the lane-per-landmark
+# layout: every small-problem case of these modules (term by term, early exit, long landmarks, fuzz, shards, PCG)
+_WITH_CAMERA_CHUNKS = {"test_gpu_step1", "test_gpu_fuzz", "test_gpu_sharded", "test_gpu_sc_solvers"}
 
 
 def pytest_generate_tests(metafunc):
@@ -25,14 +28,20 @@ def pytest_generate_tests(metafunc):
     # effect -- appending its name to metafunc.fixturenames, as rounds 2 and 3 did, produced the two ids but never ran
     # the fixture: `--setup-show` did not list it, and the "lane-per-landmark" halves ran the automatic choice)
     if metafunc.definition.get_closest_marker("gpu") and metafunc.module.__name__.split(".")[-1] in _BOTH_KERNEL_FAMILIES:
-        metafunc.parametrize("_term_kernels", ["auto", "lane-per-landmark"], indirect=True)
+        which = ["auto", "lane-per-landmark"]
+        if metafunc.module.__name__.split(".")[-1] in _WITH_CAMERA_CHUNKS:
+            which.append("camera-chunk")
+        metafunc.parametrize("_term_kernels", which, indirect=True)
 
 
 @pytest.fixture(autouse=True)
 def _term_kernels(request, monkeypatch):
     which = getattr(request, "param", "auto")
-    if which == "lane-per-landmark":
+    if which in ("lane-per-landmark", "camera-chunk"):
         monkeypatch.setenv("POVAR_E0_V1", "0")
+    if which == "camera-chunk":
+        monkeypatch.setenv("POVAR_E0_CK", "1")
+        monkeypatch.setenv("POVAR_LPL_PLACE", "sync")  # the chunk layout belongs to the row order: have it from the start
     return which
 
 

@@ -1,0 +1,133 @@
+// Host-only check of the camera-chunk layout builder (povar_amd/csrc/ck_layout.hpp): reads a problem dumped by
+// tests/test_ck_layout.py, builds the lane-per-landmark layout and the camera-chunk layout derived from it, verifies
+// the invariants e0_ck relies on and prints one JSON line of statistics.  No HIP runtime call (runs without a GPU).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../povar_amd/csrc/ck_layout.hpp"
+
+using namespace povar;
+
+template <class T>
+static std::vector<T> read_vec(const char* path) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { std::perror(path); std::exit(2); }
+  std::fseek(f, 0, SEEK_END);
+  const long n = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  std::vector<T> v(n / sizeof(T));
+  if (std::fread(v.data(), sizeof(T), v.size(), f) != v.size()) std::exit(2);
+  std::fclose(f);
+  return v;
+}
+
+#define CHECK(c)                                                      \
+  do {                                                                \
+    if (!(c)) { std::printf("FAILED %s line %d\n", #c, __LINE__); return 1; } \
+  } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 8) return 2;
+  const int n_cams = std::atoi(argv[1]), grid = std::atoi(argv[5]), n_acc = std::atoi(argv[6]), n_waves = std::atoi(argv[7]);
+  const auto lm_off = read_vec<int32_t>(argv[2]);
+  const auto cam_idx = read_vec<int32_t>(argv[3]);
+  const auto obs = read_vec<double>(argv[4]);
+  const int n_lms = (int)lm_off.size() - 1;
+  const int64_t n_obs = lm_off[n_lms];
+  std::vector<int64_t> cnt(n_cams, 0);
+  for (int64_t i = 0; i < n_obs; ++i) cnt[cam_idx[i]]++;
+  std::vector<int> order(n_cams), rank1(n_cams);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });
+  for (int r = 0; r < n_cams; ++r) rank1[order[r]] = r + 1;
+  std::vector<int> slot_of_obs(n_obs);
+  std::iota(slot_of_obs.begin(), slot_of_obs.end(), 0);
+  LplLayout L;
+  build_lpl(n_cams, n_lms, lm_off.data(), cam_idx.data(), obs.data(), rank1, slot_of_obs, (size_t)n_obs, grid, n_acc, L,
+            std::getenv("LPL_CHECK_NOPLACE") == nullptr);
+  CkLayout K;
+  const auto t0 = std::chrono::steady_clock::now();
+  build_ck(L, n_cams, grid, order, n_waves, K, std::getenv("CK_CHECK_NOPLACE") == nullptr);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  // ---- invariants
+  CHECK((int)K.bt_off.size() == grid * K.nb + 1 && K.bt_off.back() == (int)K.tile.size());
+  CHECK((int64_t)K.uv.size() == (K.rows + CK_HMAX) * 64 && K.src.size() == K.uv.size() && (int64_t)K.li.size() == (K.li_rows + CK_HMAX) * 64);
+  CHECK(ck_lds_bytes(K.slots, K.max_acc) <= (size_t)CK_LDS_BYTES);
+  std::vector<int> lm_of_obs(n_obs);
+  for (int l = 0; l < n_lms; ++l)
+    for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) lm_of_obs[i] = l;
+  // observation of every lane-per-landmark row slot
+  std::vector<int> obs_of_slot(L.uv.size(), -1);
+  for (int64_t i = 0; i < n_obs; ++i) obs_of_slot[L.of_slot[i]] = (int)i;
+  std::vector<char> seen(n_obs, 0), rec_used(K.n_part_rec, 0);
+  int64_t n_placed = 0, hist[CK_HMAX + 1] = {};
+  for (int w = 0; w < grid; ++w) {
+    const int nw = L.wg_cam_off[w + 1] - L.wg_cam_off[w];
+    const int t0w = L.wg_tile_off[w];
+    for (int b = 0; b < K.nb; ++b)
+      for (int t = K.bt_off[(size_t)w * K.nb + b]; t < K.bt_off[(size_t)w * K.nb + b + 1]; ++t) {
+        const int4 ti = K.tile[t];
+        CHECK(ti.y >= 1 && ti.y <= CK_HMAX);
+        hist[ti.y]++;
+        if (t > K.bt_off[(size_t)w * K.nb + b]) CHECK(K.tile[t - 1].y >= ti.y);  // longest first inside a batch
+        for (int lane = 0; lane < 64; ++lane) {
+          const int rank = K.lane_cam[(size_t)t * 64 + lane], acc = K.lane_acc[(size_t)t * 64 + lane];
+          const int sg = K.lane_seg[(size_t)t * 64 + lane], s_first = sg & 255, s_last = sg >> 8;
+          CHECK(s_first <= lane && lane <= s_last && s_last < 64);
+          int n_lane = 0;
+          for (int j = 0; j < ti.y; ++j) {
+            const size_t idx = ((size_t)ti.x + j) * 64 + lane;
+            const uint32_t word = K.li[((size_t)ti.w + (j >> 1)) * 64 + lane];
+            const uint32_t li = (j & 1) ? word >> 16 : word & 0xffffu;
+            const int s = K.src[idx];
+            if (s < 0) { CHECK(li == CK_NONE); continue; }
+            ++n_lane;
+            CHECK(rank >= 0 && (int)li < K.slots);
+            const int i = obs_of_slot[s];
+            CHECK(i >= 0 && !seen[i]);
+            seen[i] = 1;
+            ++n_placed;
+            CHECK(K.uv[idx].x == obs[2 * (size_t)i] && K.uv[idx].y == obs[2 * (size_t)i + 1]);
+            CHECK(rank1[cam_idx[i]] - 1 == rank);
+            // the landmark slot: tile (slot / 64) of this batch, a lane of the landmark
+            const int lt = t0w + b + K.nb * (int)(li / 64);
+            CHECK(lt < L.wg_tile_off[w + 1] && L.lm_of[(size_t)lt * 64 + (li & 63)] == lm_of_obs[i]);
+            CHECK((L.seg[(size_t)lt * 64 + (li & 63)] & 255) == (int)(li & 63));
+          }
+          if (rank < 0) { CHECK(n_lane == 0); continue; }
+          CHECK(n_lane >= 1);
+          if (acc >= 0) {
+            CHECK(acc < nw && L.wg_cams[L.wg_cam_off[w] + acc] == rank);
+            for (int x = s_first; x <= s_last; ++x) CHECK(K.lane_acc[(size_t)t * 64 + x] == acc);
+            if (s_first != s_last) CHECK(ti.z & CK_FLAG_DUP);
+          } else {
+            CHECK(ti.z & CK_FLAG_COLD);
+            const int rec = ~acc, cam = order[rank];
+            CHECK(rec >= K.part_range[cam].x && rec < K.part_range[cam].y && !rec_used[rec]);
+            rec_used[rec] = 1;
+            CHECK(s_first == lane && s_last == lane);
+          }
+        }
+      }
+    for (int s = L.wg_cam_off[w]; s < L.wg_cam_off[w + 1]; ++s) {
+      const int rec = K.slot_rec[s], cam = order[L.wg_cams[s]];
+      CHECK(rec >= K.part_range[cam].x && rec < K.part_range[cam].y && !rec_used[rec]);
+      rec_used[rec] = 1;
+    }
+  }
+  CHECK(n_placed == n_obs);
+  for (int r = 0; r < K.n_part_rec; ++r) CHECK(rec_used[r]);
+  for (int h = 1; h <= CK_HMAX; ++h)
+    if (hist[h]) std::fprintf(stderr, "tiles of %2d rows: %lld\n", h, (long long)hist[h]);
+  std::printf("{\"ok\": 1, \"nb\": %d, \"slots\": %d, \"tiles\": %zu, \"rows\": %lld, \"chunks\": %lld, \"cold_chunks\": %lld, "
+              "\"obs_per_chunk\": %.3f, \"pad_frac\": %.4f, \"max_tiles_bt\": %d, \"part_rec\": %d, \"lpl_part_rec\": %d, "
+              "\"extra_lanes_per_half_row\": %.4f, \"lds_bytes\": %zu, \"build_ms\": %.1f, \"lpl_rows\": %lld}\n",
+              K.nb, K.slots, K.tile.size(), (long long)K.rows, (long long)K.n_chunks, (long long)K.n_cold_chunks,
+              (double)n_obs / std::max<int64_t>(K.n_chunks, 1), 1.0 - (double)n_obs / ((double)K.rows * 64), K.max_tiles_bt,
+              K.n_part_rec, L.n_part_rec, K.extra_lanes / (2.0 * std::max<int64_t>(K.rows, 1)), ck_lds_bytes(K.slots, K.max_acc), ms,
+              (long long)L.rows);
+  return 0;
+}

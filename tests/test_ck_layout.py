@@ -1,0 +1,64 @@
+"""Host-only invariants of the camera-chunk layout builder (povar_amd/csrc/ck_layout.hpp: the layout of e0_ck, derived
+from the lane-per-landmark layout) through tests/cpp/ck_layout_check.cpp: every observation in exactly one chunk of its
+camera, landmark slots that name its landmark inside the batch, accumulator slots / own partial records consistent with
+the workgroup's camera set, partial records camera-major and used once, LDS capacity respected.  Runs without a GPU."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "build", "ck_layout_check")
+
+
+def _run(tmp_path, n_cams, lm_off, cam_idx, obs, grid, n_acc, n_waves=16, env=None):
+    src = [os.path.join(ROOT, "tests", "cpp", "ck_layout_check.cpp"), os.path.join(ROOT, "povar_amd", "csrc", "ck_layout.hpp"),
+           os.path.join(ROOT, "povar_amd", "csrc", "lpl_layout.hpp")]
+    if not os.path.exists(BIN) or any(os.path.getmtime(BIN) < os.path.getmtime(s) for s in src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-B", "../../build/ck_layout_check"],
+                              stdout=subprocess.DEVNULL)
+    f = [str(tmp_path / n) for n in ("lm_off.bin", "cam_idx.bin", "obs.bin")]
+    np.ascontiguousarray(lm_off, dtype=np.int32).tofile(f[0])
+    np.ascontiguousarray(cam_idx, dtype=np.int32).tofile(f[1])
+    np.ascontiguousarray(obs, dtype=np.float64).tofile(f[2])
+    r = subprocess.run([BIN, str(n_cams)] + f + [str(grid), str(n_acc), str(n_waves)], capture_output=True, text=True,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout + r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("grid,n_acc,n_waves", [(256, 520, 16), (256, 64, 16), (7, 40, 8), (1, 520, 16), (12, 16, 12)])
+def test_ck_layout_invariants_medium(tmp_path, grid, n_acc, n_waves):
+    from povar_amd import synth
+    p = synth.make_problem(300, 20000, 90000, seed=5)
+    s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, grid, n_acc, n_waves)
+    assert s["ok"] == 1 and s["lds_bytes"] <= 160 * 1024
+    if p.n_cams <= n_acc:
+        assert s["cold_chunks"] == 0
+
+
+def test_ck_layout_long_tracks_and_single_observation_landmarks(tmp_path):
+    """Landmarks dealt over several lanes (one landmark slot for all of them), 1-observation landmarks, a 650-observation
+    track, natural and placed row orders of the parent layout."""
+    rng = np.random.default_rng(3)
+    n_c = 700
+    ks = np.concatenate([[1, 1, 2, 650, 130, 64, 65, 9, 8], rng.integers(1, 12, size=3000)])
+    lm_off = np.concatenate([[0], np.cumsum(ks)]).astype(np.int32)
+    w = 1.0 / np.arange(1, n_c + 1)
+    cam_idx = np.concatenate([np.sort(rng.choice(n_c, k, replace=False, p=w / w.sum())) for k in ks]).astype(np.int32)
+    obs = rng.normal(size=(cam_idx.shape[0], 2))
+    for env in (None, {"LPL_CHECK_NOPLACE": "1"}, {"CK_CHECK_NOPLACE": "1"}):
+        s = _run(tmp_path, n_c, lm_off, cam_idx, obs, 16, 100, env=env)
+        assert s["ok"] == 1
+
+
+def test_ck_layout_venice_shape(tmp_path):
+    """The BASELINE shape: two landmark batches per workgroup, chunks of 7-9 observations on average, a few per cent of
+    padding, the bank placement of the rows at most one extra lane per row half."""
+    from povar_amd import synth
+    p = synth.make_bal_problem("venice-1778")
+    s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 256, 520, env={"LPL_CHECK_NOPLACE": "1"})
+    assert s["ok"] == 1 and s["nb"] == 2 and s["pad_frac"] < 0.06 and s["obs_per_chunk"] > 6.5
+    assert s["extra_lanes_per_half_row"] < 1.1

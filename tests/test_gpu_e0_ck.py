@@ -1,0 +1,137 @@
+"""e0_ck -- the camera-chunk form of right_mul_e0_pOSE (sc/linearization_power_varproj.hpp:364-406; lane = a chunk of one
+camera's observations, landmarks of a batch in LDS, povar_kernels_ck.hpp) -- against the CPU oracle at the BASELINE sizes,
+every instantiation against e0_lpl, robust norms, and the hand-over between the two kernels when the placed rows (and
+with them the chunk layout) arrive from the host thread.
+
+Tolerances as for e0_lpl: E0 x 1e-12, 20-term increment 1e-10, relative 2-norms.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel
+
+pytestmark = pytest.mark.gpu
+ALPHA, LAM, M = 0.01, 1e-4, 20
+NT = min(os.cpu_count() or 1, 16)
+N_VARIANTS = 6
+
+
+def _problem(name):
+    from povar_amd import synth
+    if name == "local-900":
+        return synth.make_problem(900, 40000, 200000, seed=9, popularity="local")
+    return synth.make_bal_problem(name)
+
+
+def _prepared(p, robust="NONE", **kw):
+    from povar_amd import capi
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm=robust, e0_mode=capi.E0_IMPLICIT_LDSACC, **kw)
+    assert ctx.layout_finalize(True) or p.n_obs < (1 << 20)
+    ctx.set_cameras(p.cams)
+    ctx.init_landmarks_pose(ALPHA)
+    assert ctx.linearize_pose(ALPHA)
+    ctx.prepare_pose(LAM)
+    return ctx
+
+
+@pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778", "local-900"])
+def test_e0_ck_oracle_parity_at_size(name):
+    """E0 x and the 20-term increment of the camera-chunk kernel against the oracle (same linearisation point)."""
+    from povar_amd import capi
+    from oracle import povar_oracle as O
+    p = _problem(name)
+    orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    ctx.layout_finalize(True)
+    li = ctx.layout_info()
+    assert li.ck_ready == 1 and li.ck_batches >= 1
+    lms = orc.init_landmarks_pose(ALPHA, p.cams)
+    ctx.set_cameras(p.cams)
+    ctx.set_landmarks(lms)
+    assert ctx.linearize_pose(ALPHA)
+    st, diag2, jls, sigma, ok = orc.stage1_pose(ALPHA, p.cams, lms)
+    assert ok
+    orc.scale_jp_cols_pose(st, sigma)
+    hll, b, binv = orc.prepare_hb_pose(st, LAM)
+    ctx.prepare_pose(LAM)
+    x = np.random.default_rng(5).normal(size=12 * p.n_cams)
+    e0_ref = orc.right_mul_e0_pose(st, hll, x, n_threads=NT)
+    ref, it, status, _ = orc.solve_pose(st, hll, binv, b, M, n_threads=NT)
+    for kernel in (1, 2):
+        ctx.set_e0_kernel(kernel)
+        assert ctx.layout_info().e0_kernel == kernel
+        assert rel(ctx.right_mul_e0_pose(x), e0_ref) < 1e-12, kernel
+        inc, it2, st2, rc = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)
+        assert rc == 0 and (it2, st2) == (it, status) and rel(inc, ref) < 1e-10, kernel
+    del st
+    ctx.close()
+
+
+@pytest.mark.parametrize("robust", ["NONE", "HUBER", "CAUCHY"])
+def test_every_e0_ck_instantiation_against_e0_lpl(robust):
+    """trafalgar-257 (one landmark batch per workgroup), every instantiation, every robust norm: the same E0 x, the same
+    20 terms and the same early exit as the lane-per-landmark kernel (itself held against the oracle elsewhere)."""
+    from povar_amd import capi
+    p = _problem("trafalgar-257")
+    ctx = _prepared(p, robust)
+    x = np.random.default_rng(7).normal(size=12 * p.n_cams)
+    ctx.set_e0_kernel(0)
+    y0 = ctx.right_mul_e0_pose(x)
+    inc0, it0, st0, _ = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M, q_tol=0.0, r_tol=1e-3)
+    for kernel in range(1, N_VARIANTS + 1):
+        ctx.set_e0_kernel(kernel)
+        assert rel(ctx.right_mul_e0_pose(x), y0) < 1e-12, kernel
+        inc, it, st, rc = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M, q_tol=0.0, r_tol=1e-3)
+        assert rc == 0 and (it, st) == (it0, st0) and rel(inc, inc0) < 1e-10, kernel
+    ctx.close()
+
+
+def test_e0_ck_several_batches_and_cold_chunks(monkeypatch):
+    """A small LDS budget for cameras (64 accumulator slots) and many landmark batches per workgroup (POVAR_CK_NB=5):
+    chunks of cameras without a slot (their own partial records), batches of different sizes, tiles of every height."""
+    from povar_amd import capi, synth
+    monkeypatch.setenv("POVAR_E0_V1", "0")
+    monkeypatch.setenv("POVAR_HOT_ACC", "64")
+    monkeypatch.setenv("POVAR_CK_NB", "5")
+    monkeypatch.setenv("POVAR_LPL_PLACE", "sync")
+    p = synth.make_problem(300, 20000, 90000, seed=5)
+    ctx = _prepared(p)
+    li = ctx.layout_info()
+    assert li.ck_ready == 1 and li.ck_batches >= 5 and li.ck_cold_chunks > 0
+    x = np.random.default_rng(3).normal(size=12 * p.n_cams)
+    ctx.set_e0_kernel(0)
+    y0 = ctx.right_mul_e0_pose(x)
+    inc0 = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0]
+    for kernel in (1, 4, 6):
+        ctx.set_e0_kernel(kernel)
+        assert rel(ctx.right_mul_e0_pose(x), y0) < 1e-12
+        assert rel(ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0], inc0) < 1e-10
+    ctx.close()
+
+
+def test_e0_ck_arrives_with_the_placed_rows(monkeypatch):
+    """Rows placed on a host thread (POVAR_LPL_PLACE=async): until they are swapped in the context has no chunk layout and
+    the term loop runs e0_lpl whatever kernel is asked for; afterwards e0_ck runs on the layout derived from the placed
+    rows.  Same increment before and after (to the summation order)."""
+    from povar_amd import capi, synth
+    monkeypatch.setenv("POVAR_E0_V1", "0")
+    monkeypatch.setenv("POVAR_LPL_PLACE", "async")
+    monkeypatch.setenv("POVAR_E0_CK", "1")
+    p = synth.make_problem(300, 20000, 90000, seed=5)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    ctx.set_cameras(p.cams)
+    ctx.init_landmarks_pose(ALPHA)
+    before = ctx.layout_info()
+    if before.placement == 2:  # not swapped in yet (the thread may already have finished: then the swap is pending too)
+        assert before.ck_ready == 0 and before.e0_kernel == 0
+    assert ctx.linearize_pose(ALPHA)
+    inc_a = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0]
+    assert ctx.layout_finalize(True)
+    after = ctx.layout_info()
+    assert after.placement == 3 and after.ck_ready == 1 and after.e0_kernel == 1
+    assert ctx.linearize_pose(ALPHA)
+    inc_b = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0]
+    assert rel(inc_b, inc_a) < 1e-10
+    ctx.close()
