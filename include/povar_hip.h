@@ -281,6 +281,9 @@ int povar_layout_finalize(povar_ctx* ctx, int32_t wait);
  * workgroup, register-resident tiles, rows in flight).  Environment: POVAR_E0_CK=<n> sets the initial choice, which also
  * decides how the camera-chunk layout is cut (chunk cap, wavefronts the tiles are scheduled over). */
 int povar_set_e0_kernel(povar_ctx* ctx, int32_t kernel);
+/* Diagnostic builds only (-DPOVAR_CK_STAMPS, tools/ck_stamps.py): in-kernel s_memtime stamps of e0_ck's phases,
+ * [workgroups][2 wavefronts][40]; the first call arms the collection.  The shipped library returns an error. */
+int povar_debug_ck_stamps(povar_ctx* ctx, uint64_t* out, int64_t n);
 
 /* ---- multi-GPU: landmarks sharded over ranks, one RCCL all-reduce per exchange step ---- */
 /* host-only: contiguous landmark range of `rank`, balanced by observation count */

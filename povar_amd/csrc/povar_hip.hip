@@ -147,7 +147,8 @@ struct povar_ctx {
   struct CkDev {
     DevBuf<double2> uv;
     DevBuf<uint32_t> li;
-    DevBuf<int> src, lane_cam, lane_acc, lane_seg, bt_off, slot_rec;
+    DevBuf<int> src, bt_off, slot_rec;
+    DevBuf<int2> lane_meta;
     DevBuf<int4> tile;
     DevBuf<int2> part_range;
     DevBuf<double> part, w;
@@ -156,11 +157,12 @@ struct povar_ctx {
     double build_ms = 0;
     bool ready = false;
     void release() {
-      uv.release(); li.release(); src.release(); lane_cam.release(); lane_acc.release(); lane_seg.release(); bt_off.release();
+      uv.release(); li.release(); src.release(); lane_meta.release(); bt_off.release();
       slot_rec.release(); tile.release(); part_range.release(); part.release(); w.release();
       ready = false;
     }
   } ck, pl_ck;
+  DevBuf<unsigned long long> ck_stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): CkP::stamps
   DevBuf<double> ck_img;         // [21][ck_pad] structure-of-arrays record image (Dp::ck_img)
   DevBuf<int2> ck_zero_range;    // [n_cams] empty runs: e0_ck leaves no per-observation cold view to the per-camera kernels
   int ck_pad = 0;
@@ -473,8 +475,13 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
         ok = hipMemcpy(buf.p + at, v.data() + at, std::min(piece, v.size() - at) * sizeof(v[0]), hipMemcpyHostToDevice) == hipSuccess;
       });
   };
-  up(D.uv, K.uv); up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_cam, K.lane_cam); up(D.lane_acc, K.lane_acc);
-  up(D.lane_seg, K.lane_seg); up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
+  std::vector<int2> meta(K.lane_cam.size());
+  for (size_t i = 0; i < meta.size(); ++i) {
+    const int sg = K.lane_seg[i];
+    meta[i] = make_int2(K.lane_cam[i] < 0 ? -1 : (K.lane_cam[i] | ((sg & 63) << 16) | (((sg >> 8) & 63) << 22)), K.lane_acc[i]);
+  }
+  up(D.uv, K.uv); up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_meta, meta);
+  up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
   if (ok) guarded([&] { ok = D.part.alloc((size_t)std::max(K.n_part_rec, 1) * 12, bytes) == hipSuccess; });
   if (ok && c->opt.robust_norm)
     guarded([&] { ok = D.w.alloc(std::max<size_t>(K.uv.size(), 1), bytes) == hipSuccess; });  // (padded like uv)
@@ -485,19 +492,20 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
 }
 CkP ck_params(const povar_ctx* c) {
   const auto& D = c->ck;
-  return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_cam.p, D.lane_acc.p, D.lane_seg.p, D.bt_off.p, D.slot_rec.p, c->ck_img.p,
-             D.nb, D.slots, c->ck_pad};
+  return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p, c->ck_img.p,
+             D.nb, D.slots, c->ck_pad, c->ck_stamps.p};
 }
-// e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight
-#define POVAR_CK_VARIANTS(X) X(1, 16, 2) X(2, 16, 4) X(3, 16, 6) X(4, 12, 4) X(5, 12, 8) X(6, 8, 8)
+// e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight, double-buffered
+// tile records (povar_kernels_ck.hpp)
+#define POVAR_CK_VARIANTS(X) X(1, 16, 2, false) X(2, 16, 4, false) X(3, 12, 2, true) X(4, 12, 4, false) X(5, 8, 4, true) X(6, 8, 2, true)
 constexpr int CK_VARIANTS = 6;
-struct CkVariant { int nw, sd; };
+struct CkVariant { int nw, sd; bool db; };
 CkVariant ck_variant_info(int variant) {
   switch (variant) {
-#define X(id, nw, sd) case id: return CkVariant{nw, sd};
+#define X(id, nw, sd, db) case id: return CkVariant{nw, sd, db};
     POVAR_CK_VARIANTS(X)
 #undef X
-    default: return CkVariant{16, 2};
+    default: return CkVariant{16, 2, false};
   }
 }
 bool ck_active(const povar_ctx* c) {
@@ -512,32 +520,32 @@ void ck_dp(const povar_ctx* c, Dp& da) {
   da.cmv.src = nullptr;
   da.q_rows = 0;
 }
-template <int NW, int SD>
+template <int NW, int SD, bool DB>
 void launch_e0_ck_t(povar_ctx* c, const Dp& da) {
   const CkP k = ck_params(c);
   const size_t lds = ck_lds_bytes(c->ck.slots, c->ck.max_acc);
   if (c->opt.robust_norm)
-    hipLaunchKernelGGL((e0_ck<NW, SD, true>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+    hipLaunchKernelGGL((e0_ck<NW, SD, DB, true>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
   else
-    hipLaunchKernelGGL((e0_ck<NW, SD, false>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+    hipLaunchKernelGGL((e0_ck<NW, SD, DB, false>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
 }
 void launch_e0_ck(povar_ctx* c, const Dp& da) {
   switch (c->ck_variant) {
-#define X(id, nw, sd) case id: launch_e0_ck_t<nw, sd>(c, da); break;
+#define X(id, nw, sd, db) case id: launch_e0_ck_t<nw, sd, db>(c, da); break;
     POVAR_CK_VARIANTS(X)
 #undef X
     default: break;
   }
 }
-template <int NW, int SD>
+template <int NW, int SD, bool DB>
 hipError_t ck_set_lds_t() {
-  hipError_t e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)e0_ck<NW, SD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  return hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
 }
 hipError_t ck_set_lds_all() {
   hipError_t e = hipSuccess;
-#define X(id, nw, sd) if (e == hipSuccess) e = ck_set_lds_t<nw, sd>();
+#define X(id, nw, sd, db) if (e == hipSuccess) e = ck_set_lds_t<nw, sd, db>();
   POVAR_CK_VARIANTS(X)
 #undef X
   return e;
@@ -1449,7 +1457,7 @@ void povar_destroy(povar_ctx* c) {
   (void)hipSetDevice(c->opt.device);
   c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
   c->pl_c3_src.release(); c->c3_src.release();
-  c->ck.release(); c->pl_ck.release(); c->ck_img.release(); c->ck_zero_range.release();
+  c->ck.release(); c->pl_ck.release(); c->ck_img.release(); c->ck_zero_range.release(); c->ck_stamps.release();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->pin) (void)hipHostFree(c->pin);
@@ -2344,6 +2352,25 @@ int povar_set_e0_kernel(povar_ctx* c, int32_t kernel) {
   if (kernel > 0 && !c->ck_img.p) return fail(-1, "the camera-chunk layout was not built for this context");
   c->ck_variant = kernel;
   return 0;
+}
+
+int povar_debug_ck_stamps(povar_ctx* c, uint64_t* out, int64_t n) {
+  if (int rc = check_ctx(c)) return rc;
+#ifdef POVAR_CK_STAMPS
+  const size_t want = (size_t)c->e0c_grid * 16 * CK_N_STAMPS;
+  if (!c->ck_stamps.p) {  // first call: allocate; the stamps of the launches from now on are returned by the next call
+    HIP_TRY(c->ck_stamps.alloc(want, &c->bytes));
+    HIP_TRY(hipMemset(c->ck_stamps.p, 0, want * sizeof(unsigned long long)));
+    if (c->series_graph) { (void)hipGraphExecDestroy(c->series_graph); c->series_graph = nullptr; }
+    return 0;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(out, c->ck_stamps.p, std::min<size_t>((size_t)n, want) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return (int)std::min<size_t>((size_t)n, want);
+#else
+  (void)out; (void)n;
+  return fail(-1, "library built without POVAR_CK_STAMPS");
+#endif
 }
 
 int povar_comm_ranks(povar_ctx* c) {

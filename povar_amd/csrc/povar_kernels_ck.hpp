@@ -30,28 +30,67 @@ struct CkP {
   const uint32_t* li;    // [li_rows][64] two 16-bit landmark slots per word
   const double* w;       // [rows][64] robust weights (only with a robust norm)
   const int4* tile;      // first row, height, flags, first li row
-  const int* lane_cam;   // [tiles][64] rank of the lane's camera (-1: empty lane)
-  const int* lane_acc;   // [tiles][64] >= 0 accumulator slot, < 0: ~(partial record of a cold chunk)
-  const int* lane_seg;   // [tiles][64] first | last << 8 lane sharing the accumulator
+  const int2* lane_meta; // [tiles][64] x: rank of the lane's camera | first << 16 | last << 22 lane sharing its accumulator
+                         // (x < 0: empty lane); y: >= 0 accumulator slot, < 0: ~(partial record of a cold chunk)
   const int* bt_off;     // [grid * nb + 1]
   const int* slot_rec;   // partial record of each workgroup slot
   const double* img;     // [21][pad] structure-of-arrays record image by rank: z (12), then P3 row-major (9)
   int nb, slots, pad;
+  unsigned long long* stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): [grid][16][CK_N_STAMPS] s_memtime stamps, else nullptr
 };
+constexpr int CK_N_STAMPS = 40;
+#ifdef POVAR_CK_STAMPS
+#define CK_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    if (k.stamps && lane0 == 0 && (i) < CK_N_STAMPS)                                                  \
+      k.stamps[((size_t)blockIdx.x * 16 + wave) * CK_N_STAMPS + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define CK_STAMP(i)
+#endif
 
 constexpr int CK_ACC_STRIDE = 13;  // doubles per accumulator slot in LDS (12 used)
 __host__ __device__ inline size_t ck_lds_bytes_dev(int slots, int n_acc) { return (size_t)slots * 48 + (size_t)n_acc * CK_ACC_STRIDE * 8 + 64; }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release + acquire fence around s_barrier and
+// waits for EVERY outstanding vector memory operation (s_waitcnt vmcnt(0)) first -- including the loads this kernel
+// issues ahead of its barriers precisely so that they are in flight while the wavefront waits.  What the phases hand
+// over through the barriers is in LDS (h~, u, g, the accumulators): lgkmcnt(0) is all the ordering they need; the
+// global loads stay in flight and the compiler waits for each where its registers are first used.
+__device__ inline void ck_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// lane metadata word: rank | first << 16 | last << 22 (negative: empty lane); seg comes out as first | last << 8
+__host__ __device__ inline int ck_rank(int x) { return x < 0 ? -1 : (x & 0xffff); }
+__host__ __device__ inline int ck_seg(int x) { return ((x >> 16) & 63) | (((x >> 22) & 63) << 8); }
+
+// lpl_forward without the accumulation (red = ..., not red += ...: three fp64 adds per observation less)
+__device__ inline void ck_forward_math(const LplObs& o, const double* zz, const double* P3, double hx, double hy, double hz,
+                                       double* red) {
+  const double d0 = hx * zz[0] + hy * zz[1] + hz * zz[2] + zz[3];
+  const double d1 = hx * zz[4] + hy * zz[5] + hz * zz[6] + zz[7];
+  const double d2 = hx * zz[8] + hy * zz[9] + hz * zz[10] + zz[11];
+  const double a0 = o.w * (d0 - o.cu * d2);
+  const double a1 = o.w * (d1 - o.cv * d2);
+  const double a2 = o.w * (o.cuv * d2 - o.cu * d0 - o.cv * d1);
+  red[0] = P3[0] * a0 + P3[3] * a1 + P3[6] * a2;
+  red[1] = P3[1] * a0 + P3[4] * a1 + P3[7] * a2;
+  red[2] = P3[2] * a0 + P3[5] * a1 + P3[8] * a2;
+}
 
 // One observation forward: u_l += P3^T (w C (Z h~_l)); backward: y_c += h~_l (x) (w C (P3 g_l))
 __device__ inline void ck_obs_forward(const Dp& d, double2 uv, double w, const double* zz, const double* P3, double hx, double hy,
                                       double hz, double* lu, int S, uint32_t s) {
   LplObs o;
   o.set(d, uv, w);
-  double red[3] = {0, 0, 0};
-  lpl_forward(o, zz, P3, hx, hy, hz, red);
+  double red[3];
+  ck_forward_math(o, zz, P3, hx, hy, hz, red);
+#ifdef POVAR_CK_EXP_NOATOMIC  // timing-only experiment: plain stores instead of the three LDS atomics
+  lu[s] = red[0]; lu[S + s] = red[1]; lu[2 * S + s] = red[2];
+#else
   __hip_atomic_fetch_add(lu + s, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __hip_atomic_fetch_add(lu + S + s, red[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __hip_atomic_fetch_add(lu + 2 * S + s, red[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 __device__ inline void ck_obs_backward(const Dp& d, double2 uv, double w, const double* P3, double hx, double hy, double hz,
                                        const double* g, double* y) {
@@ -68,22 +107,17 @@ __device__ inline void ck_obs_backward(const Dp& d, double2 uv, double w, const 
   }
 }
 
-// Streamed tile (rows read where they are used): D rows are in flight ahead of the row being worked on (the kernel is
-// bound by the bytes it keeps in flight: 16 wavefronts x 2 rows x 1.1 KB per CU sustain 4 TB/s, not 6).  A rolled loop
-// over the rows with a shift register of D row buffers (D - 1 register moves per row: the unrolled-by-D form with
-// statically indexed buffers made the compiler hoist and spill 160 VGPRs).
+// Streamed tile (rows read where they are used): D rows are in flight ahead of the row being worked on.  The D row
+// buffers are statically indexed -- the loop over the rows is unrolled by D -- so that a row's loads really have D
+// iterations to land.  (A rolled loop with a shift register of D buffers was built first: the register moves of
+// iteration j + 1 touch what iteration j has just requested, so every row waited for its predecessor's loads whatever
+// D was -- s_waitcnt vmcnt(0) at the top of the loop, 1400 cycles per row on the way back.)  D is even: the two
+// landmark slots of an li word then sit at a static shift.
 template <int D, bool ROBUST>
 struct CkStream {
   double2 uv[D];
   uint32_t w[D];
   double rw[D];
-  __device__ inline void load(const CkP& k, int row0, int li0, int j, int h, int lane, int i) {
-    if (j < h) {
-      uv[i] = k.uv[((size_t)row0 + j) * WAVE + lane];
-      w[i] = k.li[((size_t)li0 + (j >> 1)) * WAVE + lane];
-      if (ROBUST) rw[i] = k.w[((size_t)row0 + j) * WAVE + lane];
-    }
-  }
   __device__ inline void clear() {
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -92,65 +126,109 @@ struct CkStream {
       rw[i] = 1.0;
     }
   }
-  __device__ inline void start(const CkP& k, int row0, int li0, int h, int lane) {
-    clear();
-#pragma unroll
-    for (int i = 0; i < D; ++i) load(k, row0, li0, i, h, lane, i);
+  // buffer i <- row j of the tile (j clamped into the tile: a request past its end re-reads its last row -- a cache hit --
+  // so that every step issues the same loads and the wait counters can be exact: with loads under `if (j < h)` the
+  // compiler waited for all but the newest load, i.e. for the row it had requested one step earlier)
+  __device__ inline void load(const CkP& k, int row0, int li0, int j, int h, int lane, int i) {
+    j = j < 0 ? 0 : (j >= h ? h - 1 : j);
+    uv[i] = k.uv[((size_t)row0 + j) * WAVE + lane];
+    w[i] = k.li[((size_t)li0 + (j >> 1)) * WAVE + lane];
+    if (ROBUST) rw[i] = k.w[((size_t)row0 + j) * WAVE + lane];
   }
-  // row j leaves the register, row j + D is requested
-  __device__ inline void next(const CkP& k, int row0, int li0, int j, int h, int lane, double2& uv_j, uint32_t& s_j, double& rw_j) {
-    uv_j = uv[0];
-    s_j = (w[0] >> (16 * (j & 1))) & 0xffffu;
-    rw_j = rw[0];
+  // step n of the walk is row n (DIR = +1) or row h - 1 - n (DIR = -1: the way back starts with the rows the way forward
+  // read last, the ones most likely still in the XCD's L2); buffer n % D holds it
+  template <int DIR>
+  __device__ inline void start(const CkP& k, int row0, int li0, int h, int lane) {
 #pragma unroll
-    for (int i = 0; i + 1 < D; ++i) {
-      uv[i] = uv[i + 1];
-      w[i] = w[i + 1];
-      if (ROBUST) rw[i] = rw[i + 1];
-    }
-    load(k, row0, li0, j + D, h, lane, D - 1);
+    for (int i = 0; i < D; ++i) load(k, row0, li0, DIR > 0 ? i : h - 1 - i, h, lane, i);
   }
 };
-// the rows of one tile, forward / backward; st has been started on the tile (its first D rows are in flight)
+#ifdef POVAR_CK_EXP_NOBWDROWS  // timing-only experiment: the way back re-reads ONE row of the tile (what rows kept on chip would cost)
+#define CK_BWD_ROW(j) 0
+#else
+#define CK_BWD_ROW(j) (j)
+#endif
+// the rows of one tile (h >= 1); st has been started on the tile (steps 0 .. D-1 are in flight)
+template <int D, bool ROBUST>
+__device__ inline void ck_forward_step(const Dp& d, const CkP& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+                                       const double* zz, const double* P3, const double* lh, double* lu, int S, int j, int i) {
+  const double2 uv = st.uv[i];
+  const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
+  const double rw = ROBUST ? st.rw[i] : 1.0;
+  st.load(k, row0, li0, j + D, h, lane, i);
+  if (s != 0xffffu) {
+    const double hx = lh[s], hy = lh[S + s], hz = lh[2 * S + s];
+    ck_obs_forward(d, uv, rw, zz, P3, hx, hy, hz, lu, S, s);
+  }
+}
 template <int D, bool ROBUST>
 __device__ inline void ck_forward_rows(const Dp& d, const CkP& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
                                        const double* zz, const double* P3, const double* lh, double* lu, int S) {
+  int n0 = 0;
 #pragma nounroll
-  for (int j = 0; j < h; ++j) {
-    double2 uv;
-    uint32_t s;
-    double rw;
-    st.next(k, row0, li0, j, h, lane, uv, s, rw);
-    if (s != 0xffffu) {
-      const double hx = lh[s], hy = lh[S + s], hz = lh[2 * S + s];
-      ck_obs_forward(d, uv, ROBUST ? rw : 1.0, zz, P3, hx, hy, hz, lu, S, s);
-    }
+  for (; n0 + D <= h; n0 += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) ck_forward_step<D, ROBUST>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S, n0 + i, i);
+  }
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)  // the last h % D rows
+    if (n0 + i < h) ck_forward_step<D, ROBUST>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S, n0 + i, i);
+}
+template <int D, bool ROBUST>
+__device__ inline void ck_backward_step(const Dp& d, const CkP& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+                                        const double* P3, const double* lh, const double* lg, int S, double* y, int j, int i) {
+  const double2 uv = st.uv[i];
+  const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
+  const double rw = ROBUST ? st.rw[i] : 1.0;
+  st.load(k, row0, li0, CK_BWD_ROW(j - D), h, lane, i);
+  if (s != 0xffffu) {
+#ifdef POVAR_CK_EXP_NOBWDLDS  // timing-only experiment: the way back without its six LDS reads per observation
+    const double hx = uv.x, hy = uv.y, hz = rw;
+    const double g[3] = {uv.y, uv.x, rw};
+#else
+    const double hx = lh[s], hy = lh[S + s], hz = lh[2 * S + s];
+    const double g[3] = {lg[s], lg[S + s], lg[2 * S + s]};
+#endif
+    ck_obs_backward(d, uv, rw, P3, hx, hy, hz, g, y);
   }
 }
 template <int D, bool ROBUST>
 __device__ inline void ck_backward_rows(const Dp& d, const CkP& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
                                         const double* P3, const double* lh, const double* lg, int S, double* y) {
+  int n0 = 0;
 #pragma nounroll
-  for (int j = 0; j < h; ++j) {
-    double2 uv;
-    uint32_t s;
-    double rw;
-    st.next(k, row0, li0, j, h, lane, uv, s, rw);
-    if (s != 0xffffu) {
-      const double hx = lh[s], hy = lh[S + s], hz = lh[2 * S + s];
-      const double g[3] = {lg[s], lg[S + s], lg[2 * S + s]};
-      ck_obs_backward(d, uv, ROBUST ? rw : 1.0, P3, hx, hy, hz, g, y);
-    }
+  for (; n0 + D <= h; n0 += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) ck_backward_step<D, ROBUST>(d, k, st, row0, li0, h, lane, P3, lh, lg, S, y, h - 1 - (n0 + i), i);
   }
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)
+    if (n0 + i < h) ck_backward_step<D, ROBUST>(d, k, st, row0, li0, h, lane, P3, lh, lg, S, y, h - 1 - (n0 + i), i);
 }
 
-__device__ inline void ck_load_z(const CkP& k, int rank, double* zz) {
+// The lane's camera record, from the rank-ordered image the other E0 kernels stage into LDS (Dp::hot_rec: z (12), then
+// P3 row-major (9), 192-byte stride): 168 contiguous bytes = eleven 16-byte loads that touch two or three cache lines.
+// (A structure-of-arrays image -- one 8-byte load per entry, neighbouring ranks sharing lines -- was built first: the
+// lanes of a tile hold cameras scattered over hundreds of ranks, so each of its 21 + 9 loads per tile touched up to 64
+// lines; the texture addresser's work per tile, not HBM, set the kernel's time.)
+__device__ inline void ck_load_z(const Dp& d, int rank, double* zz) {
+  const double2* r = reinterpret_cast<const double2*>(d.hot_rec + (size_t)rank * HOT_REC_STRIDE);
 #pragma unroll
-  for (int j = 0; j < 12; ++j) zz[j] = k.img[(size_t)j * k.pad + rank];
+  for (int j = 0; j < 6; ++j) {
+    const double2 v = r[j];
+    zz[2 * j] = v.x;
+    zz[2 * j + 1] = v.y;
+  }
 }
-__device__ inline void ck_load_p3(const CkP& k, int rank, double* P3) {
+__device__ inline void ck_load_p3(const Dp& d, int rank, double* P3) {
+  const double2* r = reinterpret_cast<const double2*>(d.hot_rec + (size_t)rank * HOT_REC_STRIDE) + 6;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) P3[j] = k.img[(size_t)(12 + j) * k.pad + rank];
+  for (int j = 0; j < 4; ++j) {
+    const double2 v = r[j];
+    P3[2 * j] = v.x;
+    P3[2 * j + 1] = v.y;
+  }
+  P3[8] = d.hot_rec[(size_t)rank * HOT_REC_STRIDE + 20];
 }
 
 // end of a tile's backward pass: the chunk sums go to the camera's accumulator in LDS (lanes that share one are summed
@@ -174,12 +252,23 @@ __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int r
 }
 
 // NW wavefronts per workgroup; SD: rows a tile keeps in flight ahead of the row being worked on.
-// A wavefront's time line is a chain of round trips -- tile metadata (which camera is in which lane), then the record
-// gather that depends on it, then the rows -- and with one or two tiles per wavefront and pass nothing else of its own
-// hides them.  So every pass is started BEFORE the workgroup barrier in front of it: the metadata of the wavefront's
-// first tile is requested first, the gather and the first SD rows follow as soon as it is there and are in flight while
-// the wavefront waits at the barrier; the metadata of a wavefront's next tile is requested before it walks the current one.
-template <int NW, int SD, bool ROBUST>
+//
+// What bounds the kernel (in-kernel stamps, tools/ck_stamps.py; profiles/r04_*): the row loops issue ~35 fp64
+// instructions per row and pass and are VALU-bound while all sixteen wavefronts are in them; everything else is the
+// time line of ONE wavefront -- round trips that nothing of its own hides (one or two tiles per wavefront and pass):
+// tile metadata (which camera is in which lane), the record gather that depends on it (64 lanes, 64 different cache
+// lines: ~30 cycles of the texture addresser per load, eleven loads, sixteen wavefronts at once), the first rows.  So:
+//   * a wavefront walks its tiles of a batch forward and then back in REVERSE order: the way back starts with the tile
+//     whose P3 is still in registers (no second gather for the 12 of 16 wavefronts that have one tile) and whose rows
+//     were read last (they come back in reverse too: what the XCD's L2 still holds is read first);
+//   * every pass is started before the workgroup barrier in front of it (gather and first rows of the first tile in
+//     flight while the wavefront waits), the metadata of a wavefront's next tile is requested before it walks the
+//     current one, and the landmark coordinates + first metadata of the NEXT batch are requested before the way back
+//     of the current one;
+//   * the rounds of the tile walk alternate direction (tile_of): the short tiles of the second round go to the
+//     wavefronts with the shortest first tiles -- the longest-first schedule the layout was cut for, without a counter
+//     that would hide which tile comes next.
+template <int NW, int SD, bool DB, bool ROBUST>
 __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) {
   const int done = d.flags[1];
   extern __shared__ double ck_lds[];
@@ -199,18 +288,87 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
   const cint_p tiles = (cint_p)(uintptr_t)k.tile;
   const cint_p bt = (cint_p)(uintptr_t)k.bt_off;
   if (done) return;  // wave-uniform, before any barrier and any side effect
+  auto tile_of = [&](int tb0, int q) { return tb0 + q * NW + ((q & 1) ? NW - 1 - wave : wave); };
+  constexpr int HM = 32 / NW > 0 ? 32 / NW : 1;  // slot tiles per wavefront whose h~ / G are requested a phase ahead
+  double hn[HM][3];
+  auto request_h = [&](int b, int lane) {
+#pragma unroll
+    for (int q = 0; q < HM; ++q) {
+      hn[q][0] = hn[q][1] = hn[q][2] = 0;
+      const int m = wave + q * NW;
+      if (b < k.nb && t0 + b + k.nb * m < t1) {
+        const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9) * WAVE + lane;
+        hn[q][0] = rp[0]; hn[q][1] = rp[WAVE]; hn[q][2] = rp[2 * WAVE];
+      }
+    }
+  };
+  int rank_next = 0;  // camera ranks of the wavefront's first tile of the next batch (requested with hn)
+  auto request_first_meta = [&](int b, int lane) {
+    rank_next = 0;
+    if (b < k.nb) {
+      const int tb0 = bt[blockIdx.x * k.nb + b], tb1 = bt[blockIdx.x * k.nb + b + 1];
+      if (tb0 + wave < tb1) rank_next = ck_rank(k.lane_meta[(size_t)(tb0 + wave) * WAVE + lane].x);
+    }
+  };
+  request_first_meta(0, lane0);
+  request_h(0, lane0);
   for (int b = 0; b < k.nb; ++b) {
-    // The lane number is made opaque per batch: every per-lane address of the body (a dozen 64-bit pointers into the row,
-    // metadata and record arrays) is otherwise hoisted out of the batch loop as loop-invariant and held in registers
-    // through all of it -- 30-40 VGPRs the row loops then lack (their camera record went to scratch: 8 reloads per row).
+    // The lane number is made opaque per batch (and again per pass): every per-lane address of the body (a dozen 64-bit
+    // pointers into the row, metadata and record arrays) is otherwise hoisted out of the batch loop as loop-invariant and
+    // held in registers through all of it.  And every array is initialised on the path that does not load it: an
+    // undefined value makes the compiler carry the PREVIOUS iteration's registers through the whole body instead (42
+    // VGPRs held across the way back; the row loop's camera record went to scratch: 8 reloads per row).
     int lane = lane0;
     asm volatile("" : "+v"(lane));
+    CK_STAMP(8 * b + 0);
     const int tb0 = bt[blockIdx.x * k.nb + b], tb1 = bt[blockIdx.x * k.nb + b + 1];
-    int t = tb0 + wave;
-    int rank = 0;
-    if (t < tb1) rank = k.lane_cam[(size_t)t * WAVE + lane];
-    // ---- landmark coordinates of the batch into LDS, u = 0
-    for (int m = wave; t0 + b + k.nb * m < t1; m += NW) {
+    int q_t = 0;  // round of the tile walk
+    int t = tile_of(tb0, 0);
+    int rank = rank_next;
+    double zz[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, P3[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    CkStream<SD, ROBUST> st;
+    st.clear();
+    int row0 = 0, h = 0, fl = 0, li0 = 0;
+    // (Order of the requests: the rows of a tile are requested after everything else of its phase.  The wait counters
+    // retire in issue order; with younger loads pending behind the rows, the compiler's merge of the loop-entry and
+    // back-edge states at the head of the row loop came out as s_waitcnt vmcnt(0): every row waited for the row
+    // requested one step earlier.)
+    //
+    // DB (double buffering, for instantiations with registers to spare: 12 wavefronts, 168 VGPRs): record and first rows
+    // of the tile AFTER the current one are requested before the current one is walked -- a wavefront's second tile
+    // then starts without the 8-9 thousand cycles (gather + rows, one dependent round trip under load) that made the
+    // four wavefronts with a second tile the tail of every pass.
+    int tn = tile_of(tb0, 1);
+    int rank_n = 0, rank_nn = 0;
+    double zn[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, Pn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    CkStream<SD, ROBUST> stn;
+    stn.clear();
+    int row0n = 0, hnx = 0, fln = 0, li0n = 0;
+    // ---- the way forward starts: record and first rows of the first tile (the metadata came with the last phase)
+    if (t < tb1) {
+      row0 = tiles[4 * t]; h = tiles[4 * t + 1]; li0 = tiles[4 * t + 3];
+      if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
+      const int rk = rank < 0 ? 0 : rank;
+      ck_load_z(d, rk, zz);
+      ck_load_p3(d, rk, P3);
+      st.template start<1>(k, row0, li0, h, lane);
+    }
+    CK_STAMP(8 * b + 1);
+    // ---- landmark coordinates of the batch into LDS (requested a phase ago), u = 0
+#pragma unroll
+    for (int q = 0; q < HM; ++q) {
+      const int m = wave + q * NW;
+      if (t0 + b + k.nb * m < t1) {
+        const int s = m * WAVE + lane;
+        lh[s] = hn[q][0];
+        lh[S + s] = hn[q][1];
+        lh[2 * S + s] = hn[q][2];
+        lu[s] = 0;
+        lu[S + s] = 0;
+        lu[2 * S + s] = 0;
+      }
+    }
+    for (int m = wave + HM * NW; t0 + b + k.nb * m < t1; m += NW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9) * WAVE + lane;
       const int s = m * WAVE + lane;
       lh[s] = rp[0];
@@ -220,78 +378,91 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       lu[S + s] = 0;
       lu[2 * S + s] = 0;
     }
+    // the tile after the first: its record and first rows (DB), the metadata of the one after that
+    auto request_next_fwd = [&]() {
+      if (DB && tn < tb1) {
+        const int tnn = tile_of(tb0, q_t + 2);
+        row0n = tiles[4 * tn]; hnx = tiles[4 * tn + 1]; li0n = tiles[4 * tn + 3];
+        if (tnn < tb1) rank_nn = ck_rank(k.lane_meta[(size_t)tnn * WAVE + lane].x);
+        const int rk = rank_n < 0 ? 0 : rank_n;
+        ck_load_z(d, rk, zn);
+        ck_load_p3(d, rk, Pn);
+        stn.template start<1>(k, row0n, li0n, hnx, lane);
+      }
+    };
+    request_next_fwd();
+    CK_STAMP(8 * b + 2);
+    ck_barrier();
+    CK_STAMP(8 * b + 3);
     // ---- forward
-    {
-      // (every array below is initialised on the path that does not load it: an undefined value makes the compiler carry
-      // the PREVIOUS batch iteration's registers through the whole loop body instead -- 42 VGPRs held across the way back)
-      double zz[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, P3[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      CkStream<SD, ROBUST> st;
-      st.clear();
-      int row0 = 0, h = 0, li0 = 0;
-      if (t < tb1) {
-        row0 = tiles[4 * t]; h = tiles[4 * t + 1]; li0 = tiles[4 * t + 3];
-        const int rk = rank < 0 ? 0 : rank;
-        ck_load_z(k, rk, zz);
-        ck_load_p3(k, rk, P3);
-        st.start(k, row0, li0, h, lane);
-      }
-      __syncthreads();
-      while (t < tb1) {
-        const int tn = t + NW;
-        int rank_n = 0;
-        if (tn < tb1) rank_n = k.lane_cam[(size_t)tn * WAVE + lane];
-        ck_forward_rows<SD, ROBUST>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S);
-        t = tn;
-        if (t < tb1) {
-          row0 = tiles[4 * t]; h = tiles[4 * t + 1]; li0 = tiles[4 * t + 3];
-          const int rk = rank_n < 0 ? 0 : rank_n;
-          ck_load_z(k, rk, zz);
-          ck_load_p3(k, rk, P3);
-          st.start(k, row0, li0, h, lane);
-        }
-      }
-    }
-    // ---- the way back is started before the barriers in front of it: metadata, P3 and first rows of the wavefront's
-    // first tile, and G of its landmark slots (NW x GM slot tiles without a loop, the rest in the loop below)
-    asm volatile("" : "+v"(lane));  // (again: the two passes share no per-lane address register)
-    t = tb0 + wave;
-    int acc_slot = 0, seg = 0;
-    if (t < tb1) {
-      rank = k.lane_cam[(size_t)t * WAVE + lane];
-      acc_slot = k.lane_acc[(size_t)t * WAVE + lane];
-      seg = k.lane_seg[(size_t)t * WAVE + lane];
-    }
-#ifndef CK_GM
-#define CK_GM (32 / NW > 0 ? 32 / NW : 1)
-#endif
-    constexpr int GM = CK_GM > 0 ? CK_GM : 1;
-    double G[GM][6];
+    while (t < tb1) {
+      ck_forward_rows<SD, ROBUST>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S);
+      if (b == 0) CK_STAMP(20 + 2 * q_t);
+      if (tn >= tb1) break;  // (t, q_t, rank, P3 stay on the last tile: the way back starts there)
+      t = tn;
+      ++q_t;
+      rank = rank_n;
+      tn = tile_of(tb0, q_t + 1);
+      if (DB) {
 #pragma unroll
-    for (int q = 0; q < GM; ++q) {
+        for (int e = 0; e < 12; ++e) zz[e] = zn[e];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) P3[e] = Pn[e];
+        st = stn;
+        row0 = row0n; h = hnx; li0 = li0n;
+        rank_n = rank_nn;
+        request_next_fwd();
+      } else {
+        row0 = tiles[4 * t]; h = tiles[4 * t + 1]; li0 = tiles[4 * t + 3];
+        if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
+        const int rk = rank < 0 ? 0 : rank;
+        ck_load_z(d, rk, zz);
+        ck_load_p3(d, rk, P3);
+        st.template start<1>(k, row0, li0, h, lane);
+      }
+      if (b == 0) CK_STAMP(19 + 2 * q_t);
+    }
+    CK_STAMP(8 * b + 4);
+    // ---- the way back starts before the barriers in front of it: accumulator metadata and last rows of the tile the
+    // wavefront has just left (its P3 is in registers), G of its landmark slots, and the next batch's first requests
+    asm volatile("" : "+v"(lane));  // (the two passes share no per-lane address register)
+    int acc_slot = 0, seg = 0;
+    int tp = q_t > 0 ? tile_of(tb0, q_t - 1) : tb1;
+    int rank_p = 0, acc_p = 0, seg_p = 0, rank_pp = 0, acc_pp = 0, seg_pp = 0;
+    double G[HM][6];
+#pragma unroll
+    for (int q = 0; q < HM; ++q) {
 #pragma unroll
       for (int e = 0; e < 6; ++e) G[q][e] = 0;
       const int m = wave + q * NW;
-      if (CK_GM > 0 && t0 + b + k.nb * m < t1) {
+      if (t0 + b + k.nb * m < t1) {
         const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9 + 3) * WAVE + lane;
 #pragma unroll
         for (int e = 0; e < 6; ++e) G[q][e] = rp[e * WAVE];
       }
     }
-    double P3[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    CkStream<SD, ROBUST> st;
-    st.clear();
-    int row0 = 0, h = 0, fl = 0, li0 = 0;
+    request_first_meta(b + 1, lane);  // the next batch is started from here: its coordinates and first metadata are in
+    request_h(b + 1, lane);           // flight during the way back
     if (t < tb1) {
-      row0 = tiles[4 * t]; h = tiles[4 * t + 1]; fl = tiles[4 * t + 2]; li0 = tiles[4 * t + 3];
-      ck_load_p3(k, rank < 0 ? 0 : rank, P3);
-      st.start(k, row0, li0, h, lane);
+      const int2 me = k.lane_meta[(size_t)t * WAVE + lane];
+      seg = ck_seg(me.x);
+      acc_slot = me.y;
+      fl = tiles[4 * t + 2];
+      if (tp < tb1) {
+        const int2 mp = k.lane_meta[(size_t)tp * WAVE + lane];
+        rank_p = ck_rank(mp.x);
+        seg_p = ck_seg(mp.x);
+        acc_p = mp.y;
+      }
+      st.template start<-1>(k, row0, li0, h, lane);
     }
-    __syncthreads();
+    ck_barrier();
+    CK_STAMP(8 * b + 5);
     // ---- g = G u per landmark slot (over u)
 #pragma unroll
-    for (int q = 0; q < GM; ++q) {
+    for (int q = 0; q < HM; ++q) {
       const int m = wave + q * NW;
-      if (CK_GM > 0 && t0 + b + k.nb * m < t1) {
+      if (t0 + b + k.nb * m < t1) {
         const int s = m * WAVE + lane;
         const double u0 = lu[s], u1 = lu[S + s], u2 = lu[2 * S + s];
         lu[s] = G[q][0] * u0 + G[q][1] * u1 + G[q][2] * u2;
@@ -299,7 +470,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         lu[2 * S + s] = G[q][2] * u0 + G[q][4] * u1 + G[q][5] * u2;
       }
     }
-    for (int m = wave + CK_GM * NW; t0 + b + k.nb * m < t1; m += NW) {
+    for (int m = wave + HM * NW; t0 + b + k.nb * m < t1; m += NW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9 + 3) * WAVE + lane;
       const double g0 = rp[0], g1 = rp[WAVE], g2 = rp[2 * WAVE], g3 = rp[3 * WAVE], g4 = rp[4 * WAVE], g5 = rp[5 * WAVE];
       const int s = m * WAVE + lane;
@@ -308,37 +479,66 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       lu[S + s] = g1 * u0 + g3 * u1 + g4 * u2;
       lu[2 * S + s] = g2 * u0 + g4 * u1 + g5 * u2;
     }
-    __syncthreads();
-    // ---- backward
-    while (t < tb1) {
-      const int tn = t + NW;
-      int rank_n = 0, acc_n = 0, seg_n = 0;
-      if (tn < tb1) {
-        rank_n = k.lane_cam[(size_t)tn * WAVE + lane];
-        acc_n = k.lane_acc[(size_t)tn * WAVE + lane];
-        seg_n = k.lane_seg[(size_t)tn * WAVE + lane];
+    // the tile before the current one on the way back: its P3 and last rows (DB), the metadata of the one before that
+    auto request_next_bwd = [&]() {
+      if (DB && tp < tb1) {
+        const int tpp = q_t > 1 ? tile_of(tb0, q_t - 2) : tb1;
+        row0n = tiles[4 * tp]; hnx = tiles[4 * tp + 1]; fln = tiles[4 * tp + 2]; li0n = tiles[4 * tp + 3];
+        if (tpp < tb1) {
+          const int2 mp = k.lane_meta[(size_t)tpp * WAVE + lane];
+          rank_pp = ck_rank(mp.x);
+          seg_pp = ck_seg(mp.x);
+          acc_pp = mp.y;
+        }
+        ck_load_p3(d, rank_p < 0 ? 0 : rank_p, Pn);
+        stn.template start<-1>(k, row0n, li0n, hnx, lane);
       }
+    };
+    request_next_bwd();
+    ck_barrier();
+    CK_STAMP(8 * b + 6);
+    // ---- backward: the wavefront's tiles in reverse
+    while (t < tb1) {
       double y[12];
 #pragma unroll
       for (int m = 0; m < 12; ++m) y[m] = 0;
       ck_backward_rows<SD, ROBUST>(d, k, st, row0, li0, h, lane, P3, lh, lu, S, y);
       ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, part_out);
-      t = tn;
-      if (t < tb1) {
-        rank = rank_n; acc_slot = acc_n; seg = seg_n;
+      if (tp >= tb1) break;
+      t = tp;
+      --q_t;
+      rank = rank_p; acc_slot = acc_p; seg = seg_p;
+      tp = q_t > 0 ? tile_of(tb0, q_t - 1) : tb1;
+      if (DB) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) P3[e] = Pn[e];
+        st = stn;
+        row0 = row0n; h = hnx; fl = fln; li0 = li0n;
+        rank_p = rank_pp; acc_p = acc_pp; seg_p = seg_pp;
+        request_next_bwd();
+      } else {
         row0 = tiles[4 * t]; h = tiles[4 * t + 1]; fl = tiles[4 * t + 2]; li0 = tiles[4 * t + 3];
-        ck_load_p3(k, rank < 0 ? 0 : rank, P3);
-        st.start(k, row0, li0, h, lane);
+        if (tp < tb1) {
+          const int2 mp = k.lane_meta[(size_t)tp * WAVE + lane];
+          rank_p = ck_rank(mp.x);
+          seg_p = ck_seg(mp.x);
+          acc_p = mp.y;
+        }
+        ck_load_p3(d, rank < 0 ? 0 : rank, P3);
+        st.template start<-1>(k, row0, li0, h, lane);
       }
     }
-    __syncthreads();  // the next batch overwrites h~ and u; after the last one: the accumulators are complete
+    CK_STAMP(8 * b + 7);
+    ck_barrier();  // the next batch overwrites h~ and u; after the last one: the accumulators are complete
   }
+  CK_STAMP(8 * k.nb);
   // ---- accumulators -> this workgroup's partial records (camera-major in part_out)
   for (int i = threadIdx.x; i < n_acc * 6; i += NW * 64) {
     const int r = i / 6, m = 2 * (i % 6);
     const int rec = k.slot_rec[cam0 + r];
     reinterpret_cast<double2*>(part_out + (size_t)rec * 12)[i % 6] = make_double2(acc[r * CK_ACC_STRIDE + m], acc[r * CK_ACC_STRIDE + m + 1]);
   }
+  CK_STAMP(8 * k.nb + 1);
   if (d.p2p_epoch && blockIdx.x == 0 && threadIdx.x == 0) *d.p2p_epoch += 1;  // one tick per term (as e0_lpl)
 }
 

@@ -1,0 +1,54 @@
+"""Where the time of e0_ck goes, phase by phase: in-kernel s_memtime stamps of a diagnostic build of the library
+(-DPOVAR_CK_STAMPS; the shipped library executes no stamp).
+
+    make -C povar_amd/csrc stamps && POVAR_LIB=build/libpovar_hip_stamps.so python tools/ck_stamps.py venice-1778 --variant 1
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from povar_amd import capi, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("problem", nargs="?", default="venice-1778")
+ap.add_argument("--variant", type=int, default=1)
+a = ap.parse_args()
+p = synth.make_bal_problem(a.problem)
+ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+ctx.layout_finalize(True)
+ctx.set_cameras(p.cams)
+ctx.init_landmarks_pose(0.01)
+assert ctx.linearize_pose(0.01)
+ctx.prepare_pose(1e-4)
+ctx.set_e0_kernel(a.variant)
+li = ctx.layout_info()
+NS = 40
+buf = np.zeros(li.grid * 16 * NS, dtype=np.uint64)
+assert ctx.L.povar_debug_ck_stamps(ctx.h, C.c_void_p(buf.ctypes.data), C.c_int64(buf.size)) == 0
+for _ in range(3):
+    ctx.power_series_pose(20)
+ctx.synchronize()
+n = ctx.L.povar_debug_ck_stamps(ctx.h, C.c_void_p(buf.ctypes.data), C.c_int64(buf.size))
+assert n == buf.size, n
+s = buf.reshape(li.grid, 16, NS).astype(np.float64)
+nw = int((s[:, :, 0] > 0).any(axis=0).sum())
+nb = li.ck_batches
+names = ["start", "h in LDS", "gather issued", "barrier1", "fwd done", "barrier2", "Gu+barrier3", "bwd done"]
+t0 = s[:, :nw, 0].min(axis=1, keepdims=True)  # the workgroup's first wavefront to start
+print(f"cycles since the workgroup's start, median over {li.grid} workgroups; columns: wavefronts 0..{nw - 1}")
+for b in range(nb):
+    for i, nm in enumerate(names):
+        v = np.median(s[:, :nw, 8 * b + i] - t0, axis=0)
+        print(f"b{b} {nm:14s}" + "".join(f"{x / 1000:7.1f}" for x in v))
+for i, nm in ((8 * nb, "last barrier"), (8 * nb + 1, "flushed")):
+    v = np.median(s[:, :nw, i] - t0, axis=0)
+    print(f"   {nm:14s}" + "".join(f"{x / 1000:7.1f}" for x in v))
+for i, nm in ((20, 'b0 fwd tile0 done'), (21, 'b0 tile1 issued'), (22, 'b0 fwd tile1 done')):
+    v = np.median(s[:, :nw, i] - t0, axis=0)
+    print(f"   {nm:14s}" + "".join(f"{x / 1000:7.1f}" for x in v))
+hs = np.zeros((nw, 3))
+ctx.close()
