@@ -57,7 +57,7 @@ def kernel_source_sha():
     """Stamp of the device code the PMC traffic figures in profiles/traffic.json were measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_hip.hip", "lpl_layout.hpp"):
+    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_kernels_ck.hpp", "povar_hip.hip", "lpl_layout.hpp", "ck_layout.hpp"):
         with open(os.path.join(ROOT, "povar_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -492,7 +492,8 @@ def main():
             key = f"{args.problem}:{args.e0_mode}:{world}" + (":step2" if args.step == 2 else "") + \
                 (f":{args.robust_norm}" if args.robust_norm != "NONE" else "") + \
                 (f":{args.popularity}" if args.popularity != "zipf1" else "") + \
-                (f":ltf{args.long_track_frac:g}" if args.long_track_frac > 0 else "") + (":file" if bal_path else "")
+                (f":ltf{args.long_track_frac:g}" if args.long_track_frac > 0 else "") + (":file" if bal_path else "") + \
+                (f":ck{ctx.layout_info().e0_kernel}" if args.step == 1 and ctx.layout_info().e0_kernel > 0 else "")
             if key in tj:
                 if tj.get("_source_sha", {}).get(key) == kernel_source_sha():
                     traffic, traffic_note = tj[key], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/"
@@ -536,6 +537,7 @@ def main():
             "bound": "hbm",
             "kernel": {capi.E0_IMPLICIT: "E0 x (e0_lm_cached<false> + cm_scatter)",
                        capi.E0_IMPLICIT_LDSACC: (("E0 x (e0_lpl_h + cam_cold_sum[_binv]_h)" if args.step == 2
+                                                  else "E0 x (e0_ck + cam_cold_sum[_binv])" if ctx.layout_info().e0_kernel > 0
                                                   else "E0 x (e0_lpl + cam_cold_sum[_binv])")
                                                  if ctx.layout_info().lane_per_landmark else
                                                  "E0 x (e0_lm_cached<true>[_h] + cam_cold_sum[_binv])"),
@@ -577,6 +579,16 @@ def main():
                                                     2: "pending on a host thread (kernels on the natural order)",
                                                     3: "on a host thread, swapped in before the timed region"}[li.placement],
                                   "row_placement_ms": li.placement_ms, "row_placement_waited_ms": placement_wait_ms,
+                                  # which step-1 E0 kernel ran the timed loop (0: e0_lpl, lane = landmark; > 0: an e0_ck
+                                  # instantiation, lane = camera chunk) and how it was chosen
+                                  "e0_kernel": li.e0_kernel,
+                                  "e0_kernel_choice": {0: "forced", 1: "automatic (not timed yet)",
+                                                       2: "automatic: both kernels timed on this problem"}[li.e0_auto],
+                                  "e0_tune_us": {"e0_lpl": round(li.tune_lpl_us, 2), "e0_ck": round(li.tune_ck_us, 2)},
+                                  "camera_chunks": {"batches": li.ck_batches, "landmark_slots": li.ck_slots, "rows": li.ck_rows,
+                                                    "chunks": li.ck_chunks, "own_record_chunks": li.ck_cold_chunks,
+                                                    "partial_records": li.ck_part_rec, "build_ms": round(li.ck_build_ms, 1)}
+                                  if li.ck_ready else None,
                                   "term_kernels": "lane per landmark" if li.lane_per_landmark else
                                   "lane per observation (round-1 kernels: under 65 536 observations or POVAR_E0_V1=1)"}
     if not bal_path and (args.popularity != "zipf1" or args.long_track_frac > 0):

@@ -266,6 +266,9 @@ typedef struct {
   int32_t ck_part_rec;  /* partial records of the camera-chunk kernel (workgroup slots + chunks of cameras without one) */
   int64_t ck_rows, ck_chunks, ck_cold_chunks;
   double ck_build_ms;   /* host time of the derivation from the lane-per-landmark layout */
+  int32_t e0_auto;      /* 0: the E0 kernel was forced (POVAR_E0_CK, povar_set_e0_kernel); 1: the library will time e0_lpl and e0_ck
+                           on this problem at the next power series; 2: it has (e0_kernel is its choice) */
+  float tune_lpl_us, tune_ck_us;  /* what that timing saw, microseconds per launch */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 /* The reference's constructor is a trivial allocation (sc/linearization_varproj.hpp:44-60); this library's builds the
@@ -279,7 +282,9 @@ int povar_layout_finalize(povar_ctx* ctx, int32_t wait);
 /* Per-term E0 kernel of step 1 (replaces right_mul_e0_pOSE, sc/linearization_power_varproj.hpp:364-406, either way):
  * 0 = e0_lpl, 1.. = e0_ck instantiations (povar_kernels_ck.hpp; table POVAR_CK_VARIANTS in povar_hip.hip: wavefronts per
  * workgroup, register-resident tiles, rows in flight).  Environment: POVAR_E0_CK=<n> sets the initial choice, which also
- * decides how the camera-chunk layout is cut (chunk cap, wavefronts the tiles are scheduled over). */
+ * decides how the camera-chunk layout is cut (chunk cap, wavefronts the tiles are scheduled over).  kernel = -1 (the
+ * default when nothing is forced): the library times both kernels once per layout on the prepared problem and keeps the
+ * faster one (povar_layout_info.e0_auto, tune_*_us). */
 int povar_set_e0_kernel(povar_ctx* ctx, int32_t kernel);
 /* Diagnostic builds only (-DPOVAR_CK_STAMPS, tools/ck_stamps.py): in-kernel s_memtime stamps of e0_ck's phases,
  * [workgroups][2 wavefronts][40]; the first call arms the collection.  The shipped library returns an error. */

@@ -49,7 +49,8 @@ class LayoutInfo(C.Structure):
                 ("create_ms", C.c_double), ("strategy", C.c_int32), ("hubs", C.c_int32), ("placement", C.c_int32),
                 ("placement_ms", C.c_double), ("e0_kernel", C.c_int32), ("ck_ready", C.c_int32), ("ck_batches", C.c_int32),
                 ("ck_slots", C.c_int32), ("ck_tiles_max", C.c_int32), ("ck_part_rec", C.c_int32), ("ck_rows", C.c_int64),
-                ("ck_chunks", C.c_int64), ("ck_cold_chunks", C.c_int64), ("ck_build_ms", C.c_double)]
+                ("ck_chunks", C.c_int64), ("ck_cold_chunks", C.c_int64), ("ck_build_ms", C.c_double), ("e0_auto", C.c_int32),
+                ("tune_lpl_us", C.c_float), ("tune_ck_us", C.c_float)]
 
 
 class TimingsInfo(C.Structure):

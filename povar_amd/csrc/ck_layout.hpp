@@ -44,6 +44,7 @@ struct CkLayout {
   std::vector<int> slot_rec;     // [lpl wg_cams.size()] partial record each workgroup slot is flushed to
   std::vector<int2> part_range;  // [n_cams] partial records of camera c (by camera index): [first, end)
   int nb = 1;                    // batches per workgroup
+  int ng = 1;                    // of which ng are in LDS at the same time (groups of wavefronts)
   int slots = 64;                // landmark slots of a batch (multiple of 64; the same for every workgroup)
   int n_part_rec = 0, max_acc = 0;
   int64_t rows = 0, li_rows = 0;
@@ -53,7 +54,7 @@ struct CkLayout {
   double extra_lanes = 0;        // bank collisions left: extra lanes per (row, half), summed over the rows
 };
 
-inline size_t ck_lds_bytes(int slots, int n_acc) { return (size_t)slots * 48 + (size_t)n_acc * 104 + 64; }  // = ck_lds_bytes_dev
+inline size_t ck_lds_bytes(int slots, int n_acc, int ng = 1) { return 16 + (size_t)ng * slots * 48 + (size_t)n_acc * 104 + 64; }  // = ck_lds_bytes_dev
 
 // cost of one batch for chunk cap H: longest-first schedule of its tiles over n_waves wavefronts, every tile charged
 // its height plus a fixed overhead (record gather, flush); also returns the tile count
@@ -81,8 +82,10 @@ inline int ck_schedule_cost(const std::vector<int>& counts, int H, int n_waves, 
 // L: the lane-per-landmark layout (rows in the order the device will use); rank -> camera index through cam_of_rank
 // n_waves, hmax: wavefronts per workgroup of the kernel instantiation that will run the layout, and the tallest tile it
 // keeps in registers (CK_HMAX: none / whatever schedules best)
+// ng: groups of wavefronts that work on different batches at the same time (the LDS holds ng batches; the batch count is a
+// multiple of ng; n_waves = wavefronts of ONE group)
 inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector<int>& cam_of_rank, int n_waves,
-                     CkLayout& K, bool place = true, int hmax = CK_HMAX) {
+                     CkLayout& K, bool place = true, int hmax = CK_HMAX, int ng = 1) {
   int n_threads = std::min(lpl_effective_cpus(), 128);
   if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
   hmax = std::min(CK_HMAX, std::max(1, hmax));
@@ -94,10 +97,12 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     max_tiles_w = std::max(max_tiles_w, L.wg_tile_off[w + 1] - L.wg_tile_off[w]);
     max_acc = std::max(max_acc, L.wg_cam_off[w + 1] - L.wg_cam_off[w]);
   }
-  int nb = 1;
-  while (ck_lds_bytes(WAVE * ((max_tiles_w + nb - 1) / nb), max_acc) > (size_t)CK_LDS_BYTES && nb < max_tiles_w) ++nb;
-  if (const char* e = std::getenv("POVAR_CK_NB")) nb = std::max(nb, std::atoi(e));
+  ng = std::max(ng, 1);
+  int nb = ng;
+  while (ck_lds_bytes(WAVE * ((max_tiles_w + nb - 1) / nb), max_acc, ng) > (size_t)CK_LDS_BYTES && nb < max_tiles_w) nb += ng;
+  if (const char* e = std::getenv("POVAR_CK_NB")) nb = std::max(nb, (std::atoi(e) + ng - 1) / ng * ng);
   K.nb = nb;
+  K.ng = ng;
   K.slots = WAVE * ((max_tiles_w + nb - 1) / nb);
   K.max_acc = max_acc;
   struct WgOut {

@@ -168,6 +168,9 @@ struct povar_ctx {
   int ck_pad = 0;
   int ck_variant = 0;            // 0: e0_lpl; 1..CK_VARIANTS: e0_ck instantiation (POVAR_CK_VARIANTS)
   int64_t ckw_lin_id = -1;       // linearisation whose robust weights CkDev::w holds
+  bool ck_auto = true;           // the library picks e0_lpl or e0_ck by timing both on this problem (ck_autotune); false: forced
+  bool ck_tuned = false;
+  float ck_tune_us[2] = {0, 0};  // what the timing saw: e0_lpl, e0_ck (microseconds per launch)
   DevBuf<double4> q4c;        // scatter scalars of the cold observations, in cold camera-major order
   DevBuf<int> lm_slot0, lm_cnt_dev;
   bool k1_qr = true;          // POVAR_K1_NORMAL_EQ=1: the round-1 normal-equation kernels (A/B accuracy runs)
@@ -496,20 +499,23 @@ CkP ck_params(const povar_ctx* c) {
              D.nb, D.slots, c->ck_pad, c->ck_stamps.p};
 }
 // e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight, double-buffered
-// tile records (povar_kernels_ck.hpp)
-#define POVAR_CK_VARIANTS(X) X(1, 16, 2, false) X(2, 16, 4, false) X(3, 12, 2, true) X(4, 12, 4, false) X(5, 8, 4, true) X(6, 8, 2, true)
+// tile records, groups of wavefronts working on different batches (povar_kernels_ck.hpp)
+#define POVAR_CK_VARIANTS(X) \
+  X(1, 16, 2, false, 1) X(2, 16, 4, false, 1) X(3, 12, 2, true, 1) X(4, 16, 2, false, 2) X(5, 16, 4, false, 2) X(6, 8, 2, true, 1)
 constexpr int CK_VARIANTS = 6;
-struct CkVariant { int nw, sd; bool db; };
+struct CkVariant { int nw, sd; bool db; int ng; };
 CkVariant ck_variant_info(int variant) {
   switch (variant) {
-#define X(id, nw, sd, db) case id: return CkVariant{nw, sd, db};
+#define X(id, nw, sd, db, ng) case id: return CkVariant{nw, sd, db, ng};
     POVAR_CK_VARIANTS(X)
 #undef X
-    default: return CkVariant{16, 2, false};
+    default: return CkVariant{16, 2, false, 1};
   }
 }
+bool ck_variant_fits(const povar_ctx* c, int variant);
 bool ck_active(const povar_ctx* c) {
-  return c->ck_variant > 0 && c->ck.ready && c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+  return c->ck_variant > 0 && c->ck.ready && c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
+         ck_variant_fits(c, c->ck_variant);
 }
 // the per-camera kernels behind e0_ck: partial records only (its own table), no per-observation cold view
 void ck_dp(const povar_ctx* c, Dp& da) {
@@ -520,36 +526,47 @@ void ck_dp(const povar_ctx* c, Dp& da) {
   da.cmv.src = nullptr;
   da.q_rows = 0;
 }
-template <int NW, int SD, bool DB>
+template <int NW, int SD, bool DB, int NG>
 void launch_e0_ck_t(povar_ctx* c, const Dp& da) {
   const CkP k = ck_params(c);
-  const size_t lds = ck_lds_bytes(c->ck.slots, c->ck.max_acc);
+  const size_t lds = ck_lds_bytes(c->ck.slots, c->ck.max_acc, NG);
   if (c->opt.robust_norm)
-    hipLaunchKernelGGL((e0_ck<NW, SD, DB, true>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+    hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, true>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
   else
-    hipLaunchKernelGGL((e0_ck<NW, SD, DB, false>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+    hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, false>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+}
+// an instantiation runs a layout whose batches fit its groups: the LDS holds ng batches at once
+bool ck_variant_fits(const povar_ctx* c, int variant) {
+  const CkVariant v = ck_variant_info(variant);
+  return c->ck.ready && c->ck.nb % v.ng == 0 && ck_lds_bytes(c->ck.slots, c->ck.max_acc, v.ng) <= (size_t)CK_LDS_BYTES;
 }
 void launch_e0_ck(povar_ctx* c, const Dp& da) {
   switch (c->ck_variant) {
-#define X(id, nw, sd, db) case id: launch_e0_ck_t<nw, sd, db>(c, da); break;
+#define X(id, nw, sd, db, ng) case id: launch_e0_ck_t<nw, sd, db, ng>(c, da); break;
     POVAR_CK_VARIANTS(X)
 #undef X
     default: break;
   }
 }
-template <int NW, int SD, bool DB>
+template <int NW, int SD, bool DB, int NG>
 hipError_t ck_set_lds_t() {
-  hipError_t e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, NG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  return hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, NG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
 }
 hipError_t ck_set_lds_all() {
   hipError_t e = hipSuccess;
-#define X(id, nw, sd, db) if (e == hipSuccess) e = ck_set_lds_t<nw, sd, db>();
+#define X(id, nw, sd, db, ng) if (e == hipSuccess) e = ck_set_lds_t<nw, sd, db, ng>();
   POVAR_CK_VARIANTS(X)
 #undef X
   return e;
 }
+// Which of the two step-1 E0 kernels is faster depends on the graph (e0_ck: venice-like camera counts, any share of
+// observations whose camera has no LDS slot; e0_lpl: many cameras and few observations per (camera, batch), where a chunk
+// is a single observation -- final-13682).  Unless the caller has forced one, both are timed once per layout on the
+// problem itself: a warm-up and three launches each on the prepared system (they only write their partial records).
+int ck_autotune(povar_ctx* c);
+
 // robust weights in chunk order (V2::w is written by the linearisation walk in lane-per-landmark order)
 void ensure_ck_w(povar_ctx* c) {
   if (!c->opt.robust_norm || !c->ck.ready || !c->ck.w.p || !c->v2_w.p || c->ckw_lin_id == c->lin_id) return;
@@ -805,6 +822,7 @@ int swap_in_placed_rows(povar_ctx* c, bool wait) {
   if (c->pl_ck.ready) std::swap(c->ck, c->pl_ck);
   c->pl_ck.release();
   c->ckw_lin_id = -1;
+  c->ck_tuned = false;  // (the choice between the two E0 kernels is timed again on the new rows)
   c->placement = 3;
   return 1;
 }
@@ -971,6 +989,50 @@ void launch_binv(povar_ctx* c, int mode, int want_norms) {
     hipLaunchKernelGGL(cam_binv_axpy, dim3(c->n_cam_blocks), dim3(K9_CAMS * 64), 0, c->stream, dt, mode == 3 ? 1 : mode,
                        want_norms);
   }
+}
+
+int ck_autotune(povar_ctx* c) {
+  if (!c->ck_auto || c->ck_tuned || !c->ck.ready || !c->use_lpl || c->joint || c->opt.e0_mode != POVAR_E0_IMPLICIT_LDSACC ||
+      !ck_variant_fits(c, 1))
+    return 0;
+  c->ck_tuned = true;
+  ensure_ck_w(c);
+  HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));  // (a series that ended early leaves "done" set)
+  hipEvent_t ev[4];
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  Dp da = ldsacc_dp(c, true);
+  da.p2p_peer = nullptr;
+  da.p2p_epoch = nullptr;
+  Dp dk = da;
+  ck_dp(c, dk);
+  const int keep = c->ck_variant;
+  c->ck_variant = 1;
+  auto run_lpl = [&]() {
+    if (c->opt.robust_norm)
+      hipLaunchKernelGGL(e0_lpl<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
+    else
+      hipLaunchKernelGGL(e0_lpl<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
+  };
+  constexpr int REPS = 3;
+  run_lpl();
+  HIP_TRY(hipEventRecord(ev[0], c->stream));
+  for (int i = 0; i < REPS; ++i) run_lpl();
+  HIP_TRY(hipEventRecord(ev[1], c->stream));
+  launch_e0_ck(c, dk);
+  HIP_TRY(hipEventRecord(ev[2], c->stream));
+  for (int i = 0; i < REPS; ++i) launch_e0_ck(c, dk);
+  HIP_TRY(hipEventRecord(ev[3], c->stream));
+  c->ck_variant = keep;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipGetLastError());
+  float ms_lpl = 0, ms_ck = 0;
+  HIP_TRY(hipEventElapsedTime(&ms_lpl, ev[0], ev[1]));
+  HIP_TRY(hipEventElapsedTime(&ms_ck, ev[2], ev[3]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  c->ck_tune_us[0] = 1e3f * ms_lpl / REPS;
+  c->ck_tune_us[1] = 1e3f * ms_ck / REPS;
+  c->ck_variant = ms_ck < 0.98f * ms_lpl ? 1 : 0;
+  return 0;
 }
 
 int ensure_tiles(povar_ctx* c) {
@@ -1191,11 +1253,15 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     HIP_TRY_C(ck_set_lds_all());
   }
   // per-term E0 kernel of step 1: e0_lpl (0) or an e0_ck instantiation (POVAR_E0_CK=<variant>, povar_set_e0_kernel)
-  if (const char* g = std::getenv("POVAR_E0_CK")) c->ck_variant = std::max(0, std::min(CK_VARIANTS, std::atoi(g)));
+  if (const char* g = std::getenv("POVAR_E0_CK")) {
+    c->ck_variant = std::max(0, std::min(CK_VARIANTS, std::atoi(g)));
+    c->ck_auto = false;
+  }
   const bool want_ck = c->use_lpl && std::getenv("POVAR_NO_CK") == nullptr;
   // the camera-chunk layout is cut for the instantiation that will run it (its tiles are scheduled over its wavefronts)
   const CkVariant ckv = ck_variant_info(c->ck_variant > 0 ? c->ck_variant : 1);
-  int ck_nw = ckv.nw, ck_hmax = CK_HMAX;
+  int ck_nw = ckv.nw / ckv.ng, ck_hmax = CK_HMAX;  // (wavefronts of one group)
+  const int ck_ng = ckv.ng;
   if (const char* e = std::getenv("POVAR_CK_HMAX")) ck_hmax = std::min(CK_HMAX, std::max(1, std::atoi(e)));
 
   // The arrays of the lane-per-observation kernels (part B) are built on a second host thread while this one builds
@@ -1235,7 +1301,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       const int dev = options->device, grid = c->e0c_grid, n_acc = c->n_hot_acc;
       const size_t n_slots = (size_t)c->n_slots;
       c->placer_state.store(1);
-      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax]() {
+      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax, ck_ng]() {
         const auto t0 = std::chrono::steady_clock::now();
         LplLayout P;
         bool built = true;
@@ -1269,7 +1335,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
           try {
             const auto tk = std::chrono::steady_clock::now();
             CkLayout K;
-            build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, true, ck_hmax);
+            build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, true, ck_hmax, ck_ng);
             c->pl_ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
             if (!c->placer_cancel.load()) ck_upload(c, c->pl_ck, K, true, &c->pl_bytes);
           } catch (...) {
@@ -1324,7 +1390,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       if (place_mode != 2) {  // (else: built from the placed rows by the host thread, swapped in with them)
         const auto tk = std::chrono::steady_clock::now();
         CkLayout K;
-        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, true, ck_hmax);
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, true, ck_hmax, ck_ng);
         c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
         if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
         lap("camera-chunk layout");
@@ -1747,6 +1813,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (m < 0) return fail(-1, "power_sc_iterations < 0");
   TimeScope ts(c, 2);
   if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // not inside the graph capture
+  if (int rc = ck_autotune(c)) return rc;
   if (ck_active(c)) ensure_ck_w(c);
   const bool norms = q_tol > 0 || r_tol > 0;
   // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
@@ -2250,6 +2317,16 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
   int64_t lm = 0, cm = 0;
   switch (c->opt.e0_mode) {
     case POVAR_E0_IMPLICIT_LDSACC:
+      if (ck_active(c)) {
+        // e0_ck: the chunk rows (uv 16 + landmark slot 2 bytes) on BOTH passes -- the kernel as built reads them twice --,
+        // the 72-byte landmark records once, 8 bytes of lane metadata per chunk lane and pass, the partial records out
+        // (one per workgroup slot + one per chunk of a camera without a slot); the per-camera kernel reads those back
+        const int64_t part = (int64_t)c->ck.n_part_rec * 96;
+        lm = 2 * c->ck.rows * WAVE * (18 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * 72 + cam_static +
+             2 * (int64_t)(c->ck.lane_meta.n) * 8 + part;
+        cm = part + tail;
+        break;
+      }
       if (c->use_lpl)  // e0_lpl[_h]: uv + camera slot per row slot, 72 (112)-byte landmark records, cold: position + q out
         lm = c->v2_rows * WAVE * (20 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * (c->joint ? 112 : 72) + cam_static +
              n_cold * (c->q_rows ? 32 : 36) + hot_flush;  // q_rows: no position load, the per-camera kernel reads the index
@@ -2319,7 +2396,7 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->hubs = c->d.v2.hubs;
   out->placement = c->placement;
   out->placement_ms = c->placer_state.load(std::memory_order_acquire) >= 2 ? c->placement_ms : 0.0;
-  out->e0_kernel = c->ck_variant > 0 && c->ck.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC ? c->ck_variant : 0;
+  out->e0_kernel = c->ck_variant > 0 && c->ck.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && ck_variant_fits(c, c->ck_variant) ? c->ck_variant : 0;
   out->ck_ready = c->ck.ready ? 1 : 0;
   out->ck_batches = c->ck.nb;
   out->ck_slots = c->ck.slots;
@@ -2329,6 +2406,9 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->ck_cold_chunks = c->ck.n_cold_chunks;
   out->ck_part_rec = c->ck.n_part_rec;
   out->ck_build_ms = c->ck.build_ms;
+  out->e0_auto = c->ck_auto ? (c->ck_tuned ? 2 : 1) : 0;
+  out->tune_lpl_us = c->ck_tune_us[0];
+  out->tune_ck_us = c->ck_tune_us[1];
   return 0;
 }
 
@@ -2348,8 +2428,15 @@ int povar_layout_finalize(povar_ctx* c, int32_t wait) {
 
 int povar_set_e0_kernel(povar_ctx* c, int32_t kernel) {
   if (int rc = check_ctx(c)) return rc;
-  if (kernel < 0 || kernel > CK_VARIANTS) return fail(-1, "unknown E0 kernel");
+  if (kernel < -1 || kernel > CK_VARIANTS) return fail(-1, "unknown E0 kernel");
   if (kernel > 0 && !c->ck_img.p) return fail(-1, "the camera-chunk layout was not built for this context");
+  if (kernel < 0) {  // back to the library's own choice
+    c->ck_auto = true;
+    c->ck_tuned = false;
+    c->ck_variant = 0;
+    return 0;
+  }
+  c->ck_auto = false;
   c->ck_variant = kernel;
   return 0;
 }

@@ -43,14 +43,14 @@ constexpr int CK_N_STAMPS = 40;
 #define CK_STAMP(i)                                                                                   \
   do {                                                                                                \
     if (k.stamps && lane0 == 0 && (i) < CK_N_STAMPS)                                                  \
-      k.stamps[((size_t)blockIdx.x * 16 + wave) * CK_N_STAMPS + (i)] = __builtin_amdgcn_s_memtime(); \
+      k.stamps[((size_t)blockIdx.x * 16 + wave_all) * CK_N_STAMPS + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define CK_STAMP(i)
 #endif
 
 constexpr int CK_ACC_STRIDE = 13;  // doubles per accumulator slot in LDS (12 used)
-__host__ __device__ inline size_t ck_lds_bytes_dev(int slots, int n_acc) { return (size_t)slots * 48 + (size_t)n_acc * CK_ACC_STRIDE * 8 + 64; }
+__host__ __device__ inline size_t ck_lds_bytes_dev(int slots, int n_acc, int ng) { return 16 + (size_t)ng * slots * 48 + (size_t)n_acc * CK_ACC_STRIDE * 8 + 64; }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release + acquire fence around s_barrier and
 // waits for EVERY outstanding vector memory operation (s_waitcnt vmcnt(0)) first -- including the loads this kernel
@@ -58,6 +58,19 @@ __host__ __device__ inline size_t ck_lds_bytes_dev(int slots, int n_acc) { retur
 // over through the barriers is in LDS (h~, u, g, the accumulators): lgkmcnt(0) is all the ordering they need; the
 // global loads stay in flight and the compiler waits for each where its registers are first used.
 __device__ inline void ck_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Barrier of ONE group of wavefronts of the workgroup (NG > 1: the workgroup's wavefronts work as NG independent groups on
+// different landmark batches, so that one group's latency phases -- record gathers, second tiles, barrier waits --
+// overlap the other's fp64-bound row phases on the same SIMDs).  s_barrier is workgroup-wide, so this one is a counter
+// in LDS: every wavefront adds one (after its own LDS traffic has drained) and sleeps until the group's count reaches
+// its generation.  LDS is one coherent memory for the CU: what the other wavefronts wrote before their add is visible.
+__device__ inline void ck_group_barrier(int* cnt, int& gen, int group_waves, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  gen += group_waves;
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) __builtin_amdgcn_s_sleep(2);
+  asm volatile("" ::: "memory");
+}
 
 // lane metadata word: rank | first << 16 | last << 22 (negative: empty lane); seg comes out as first | last << 8
 __host__ __device__ inline int ck_rank(int x) { return x < 0 ? -1 : (x & 0xffff); }
@@ -268,34 +281,48 @@ __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int r
 //   * the rounds of the tile walk alternate direction (tile_of): the short tiles of the second round go to the
 //     wavefronts with the shortest first tiles -- the longest-first schedule the layout was cut for, without a counter
 //     that would hide which tile comes next.
-template <int NW, int SD, bool DB, bool ROBUST>
+// NG groups of NW / NG wavefronts each (batch b belongs to group b % NG; the layout's batch count is a multiple of NG and the
+// LDS holds NG batches of landmark slots).
+template <int NW, int SD, bool DB, int NG, bool ROBUST>
 __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) {
   const int done = d.flags[1];
   extern __shared__ double ck_lds[];
-  const V2& v = d.v2;
+  constexpr int GW = NW / NG;  // wavefronts of a group
   const int S = k.slots;
-  double* lh = ck_lds;            // [3][S] landmark coordinates of the batch
-  double* lu = ck_lds + 3 * S;    // [3][S] u = Jl^T Jp x, then g = G u
-  double* acc = ck_lds + 6 * S;   // [n_acc][13] per-camera accumulators of the workgroup
+  const int lane0 = threadIdx.x & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int grp = NG > 1 ? wave_all / GW : 0;   // (consecutive wavefronts go to the SIMDs in turn: every SIMD hosts both groups)
+  const int wave = NG > 1 ? wave_all % GW : wave_all;  // number inside the group
+  int* gbase = reinterpret_cast<int*>(ck_lds);            // [NG] barrier counters of the groups (16 bytes reserved)
+  double* lh = ck_lds + 2 + (size_t)grp * 6 * S;  // [3][S] landmark coordinates of the group's batch
+  double* lu = lh + 3 * S;                    // [3][S] u = Jl^T Jp x, then g = G u
+  double* acc = ck_lds + 2 + (size_t)NG * 6 * S;  // [n_acc][13] per-camera accumulators of the workgroup
+  int* gcnt = gbase + grp;
+  int ggen = 0;
+  const V2& v = d.v2;
   const int cam0 = v.wg_cam_off[blockIdx.x];
   const int n_acc = v.wg_cam_off[blockIdx.x + 1] - cam0;
-  const int lane0 = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int t0 = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
   const int t1 = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
   for (int i = threadIdx.x; i < n_acc * CK_ACC_STRIDE; i += NW * 64) acc[i] = 0;
+  if (NG > 1 && threadIdx.x < NG) gbase[threadIdx.x] = 0;
   typedef const int __attribute__((address_space(4))) * cint_p;
   const cint_p tiles = (cint_p)(uintptr_t)k.tile;
   const cint_p bt = (cint_p)(uintptr_t)k.bt_off;
   if (done) return;  // wave-uniform, before any barrier and any side effect
-  auto tile_of = [&](int tb0, int q) { return tb0 + q * NW + ((q & 1) ? NW - 1 - wave : wave); };
+  if (NG > 1) ck_barrier();  // accumulators and counters are zero before any group goes on (NG = 1: the first batch barrier)
+  auto group_barrier = [&]() {
+    if (NG > 1) ck_group_barrier(gcnt, ggen, GW, lane0);
+    else ck_barrier();
+  };
+  auto tile_of = [&](int tb0, int q) { return tb0 + q * GW + ((q & 1) ? GW - 1 - wave : wave); };
   constexpr int HM = 32 / NW > 0 ? 32 / NW : 1;  // slot tiles per wavefront whose h~ / G are requested a phase ahead
   double hn[HM][3];
   auto request_h = [&](int b, int lane) {
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
       hn[q][0] = hn[q][1] = hn[q][2] = 0;
-      const int m = wave + q * NW;
+      const int m = wave + q * GW;
       if (b < k.nb && t0 + b + k.nb * m < t1) {
         const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9) * WAVE + lane;
         hn[q][0] = rp[0]; hn[q][1] = rp[WAVE]; hn[q][2] = rp[2 * WAVE];
@@ -310,9 +337,9 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       if (tb0 + wave < tb1) rank_next = ck_rank(k.lane_meta[(size_t)(tb0 + wave) * WAVE + lane].x);
     }
   };
-  request_first_meta(0, lane0);
-  request_h(0, lane0);
-  for (int b = 0; b < k.nb; ++b) {
+  request_first_meta(grp, lane0);
+  request_h(grp, lane0);
+  for (int b = grp; b < k.nb; b += NG) {
     // The lane number is made opaque per batch (and again per pass): every per-lane address of the body (a dozen 64-bit
     // pointers into the row, metadata and record arrays) is otherwise hoisted out of the batch loop as loop-invariant and
     // held in registers through all of it.  And every array is initialised on the path that does not load it: an
@@ -320,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     // VGPRs held across the way back; the row loop's camera record went to scratch: 8 reloads per row).
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    CK_STAMP(8 * b + 0);
+    CK_STAMP(8 * (b / NG) + 0);
     const int tb0 = bt[blockIdx.x * k.nb + b], tb1 = bt[blockIdx.x * k.nb + b + 1];
     int q_t = 0;  // round of the tile walk
     int t = tile_of(tb0, 0);
@@ -353,11 +380,11 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       ck_load_p3(d, rk, P3);
       st.template start<1>(k, row0, li0, h, lane);
     }
-    CK_STAMP(8 * b + 1);
+    CK_STAMP(8 * (b / NG) + 1);
     // ---- landmark coordinates of the batch into LDS (requested a phase ago), u = 0
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
-      const int m = wave + q * NW;
+      const int m = wave + q * GW;
       if (t0 + b + k.nb * m < t1) {
         const int s = m * WAVE + lane;
         lh[s] = hn[q][0];
@@ -368,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         lu[2 * S + s] = 0;
       }
     }
-    for (int m = wave + HM * NW; t0 + b + k.nb * m < t1; m += NW) {
+    for (int m = wave + HM * GW; t0 + b + k.nb * m < t1; m += GW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9) * WAVE + lane;
       const int s = m * WAVE + lane;
       lh[s] = rp[0];
@@ -391,13 +418,13 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       }
     };
     request_next_fwd();
-    CK_STAMP(8 * b + 2);
-    ck_barrier();
-    CK_STAMP(8 * b + 3);
+    CK_STAMP(8 * (b / NG) + 2);
+    group_barrier();
+    CK_STAMP(8 * (b / NG) + 3);
     // ---- forward
     while (t < tb1) {
       ck_forward_rows<SD, ROBUST>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S);
-      if (b == 0) CK_STAMP(20 + 2 * q_t);
+      if (b < NG) CK_STAMP(20 + 2 * q_t);
       if (tn >= tb1) break;  // (t, q_t, rank, P3 stay on the last tile: the way back starts there)
       t = tn;
       ++q_t;
@@ -420,9 +447,9 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         ck_load_p3(d, rk, P3);
         st.template start<1>(k, row0, li0, h, lane);
       }
-      if (b == 0) CK_STAMP(19 + 2 * q_t);
+      if (b < NG) CK_STAMP(19 + 2 * q_t);
     }
-    CK_STAMP(8 * b + 4);
+    CK_STAMP(8 * (b / NG) + 4);
     // ---- the way back starts before the barriers in front of it: accumulator metadata and last rows of the tile the
     // wavefront has just left (its P3 is in registers), G of its landmark slots, and the next batch's first requests
     asm volatile("" : "+v"(lane));  // (the two passes share no per-lane address register)
@@ -434,15 +461,15 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     for (int q = 0; q < HM; ++q) {
 #pragma unroll
       for (int e = 0; e < 6; ++e) G[q][e] = 0;
-      const int m = wave + q * NW;
+      const int m = wave + q * GW;
       if (t0 + b + k.nb * m < t1) {
         const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9 + 3) * WAVE + lane;
 #pragma unroll
         for (int e = 0; e < 6; ++e) G[q][e] = rp[e * WAVE];
       }
     }
-    request_first_meta(b + 1, lane);  // the next batch is started from here: its coordinates and first metadata are in
-    request_h(b + 1, lane);           // flight during the way back
+    request_first_meta(b + NG, lane);  // the next batch is started from here: its coordinates and first metadata are in
+    request_h(b + NG, lane);           // flight during the way back
     if (t < tb1) {
       const int2 me = k.lane_meta[(size_t)t * WAVE + lane];
       seg = ck_seg(me.x);
@@ -456,12 +483,12 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       }
       st.template start<-1>(k, row0, li0, h, lane);
     }
-    ck_barrier();
-    CK_STAMP(8 * b + 5);
+    group_barrier();
+    CK_STAMP(8 * (b / NG) + 5);
     // ---- g = G u per landmark slot (over u)
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
-      const int m = wave + q * NW;
+      const int m = wave + q * GW;
       if (t0 + b + k.nb * m < t1) {
         const int s = m * WAVE + lane;
         const double u0 = lu[s], u1 = lu[S + s], u2 = lu[2 * S + s];
@@ -470,7 +497,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         lu[2 * S + s] = G[q][2] * u0 + G[q][4] * u1 + G[q][5] * u2;
       }
     }
-    for (int m = wave + HM * NW; t0 + b + k.nb * m < t1; m += NW) {
+    for (int m = wave + HM * GW; t0 + b + k.nb * m < t1; m += GW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9 + 3) * WAVE + lane;
       const double g0 = rp[0], g1 = rp[WAVE], g2 = rp[2 * WAVE], g3 = rp[3 * WAVE], g4 = rp[4 * WAVE], g5 = rp[5 * WAVE];
       const int s = m * WAVE + lane;
@@ -495,8 +522,8 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       }
     };
     request_next_bwd();
-    ck_barrier();
-    CK_STAMP(8 * b + 6);
+    group_barrier();
+    CK_STAMP(8 * (b / NG) + 6);
     // ---- backward: the wavefront's tiles in reverse
     while (t < tb1) {
       double y[12];
@@ -528,17 +555,18 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         st.template start<-1>(k, row0, li0, h, lane);
       }
     }
-    CK_STAMP(8 * b + 7);
-    ck_barrier();  // the next batch overwrites h~ and u; after the last one: the accumulators are complete
+    CK_STAMP(8 * (b / NG) + 7);
+    group_barrier();  // the next batch overwrites h~ and u; after the last one: the accumulators are complete
   }
-  CK_STAMP(8 * k.nb);
+  if (NG > 1) ck_barrier();  // every group is done: the accumulators are complete
+  CK_STAMP(8 * (k.nb / NG));
   // ---- accumulators -> this workgroup's partial records (camera-major in part_out)
   for (int i = threadIdx.x; i < n_acc * 6; i += NW * 64) {
     const int r = i / 6, m = 2 * (i % 6);
     const int rec = k.slot_rec[cam0 + r];
     reinterpret_cast<double2*>(part_out + (size_t)rec * 12)[i % 6] = make_double2(acc[r * CK_ACC_STRIDE + m], acc[r * CK_ACC_STRIDE + m + 1]);
   }
-  CK_STAMP(8 * k.nb + 1);
+  CK_STAMP(8 * (k.nb / NG) + 1);
   if (d.p2p_epoch && blockIdx.x == 0 && threadIdx.x == 0) *d.p2p_epoch += 1;  // one tick per term (as e0_lpl)
 }
 

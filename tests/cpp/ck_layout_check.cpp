@@ -50,12 +50,13 @@ int main(int argc, char** argv) {
             std::getenv("LPL_CHECK_NOPLACE") == nullptr);
   CkLayout K;
   const auto t0 = std::chrono::steady_clock::now();
-  build_ck(L, n_cams, grid, order, n_waves, K, std::getenv("CK_CHECK_NOPLACE") == nullptr);
+  const int ng = std::getenv("CK_CHECK_NG") ? std::atoi(std::getenv("CK_CHECK_NG")) : 1;
+  build_ck(L, n_cams, grid, order, n_waves, K, std::getenv("CK_CHECK_NOPLACE") == nullptr, CK_HMAX, ng);
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   // ---- invariants
   CHECK((int)K.bt_off.size() == grid * K.nb + 1 && K.bt_off.back() == (int)K.tile.size());
   CHECK((int64_t)K.uv.size() == (K.rows + CK_HMAX) * 64 && K.src.size() == K.uv.size() && (int64_t)K.li.size() == (K.li_rows + CK_HMAX) * 64);
-  CHECK(ck_lds_bytes(K.slots, K.max_acc) <= (size_t)CK_LDS_BYTES);
+  CHECK(ck_lds_bytes(K.slots, K.max_acc, K.ng) <= (size_t)CK_LDS_BYTES && K.nb % K.ng == 0);
   std::vector<int> lm_of_obs(n_obs);
   for (int l = 0; l < n_lms; ++l)
     for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) lm_of_obs[i] = l;
@@ -127,7 +128,7 @@ int main(int argc, char** argv) {
               "\"extra_lanes_per_half_row\": %.4f, \"lds_bytes\": %zu, \"build_ms\": %.1f, \"lpl_rows\": %lld}\n",
               K.nb, K.slots, K.tile.size(), (long long)K.rows, (long long)K.n_chunks, (long long)K.n_cold_chunks,
               (double)n_obs / std::max<int64_t>(K.n_chunks, 1), 1.0 - (double)n_obs / ((double)K.rows * 64), K.max_tiles_bt,
-              K.n_part_rec, L.n_part_rec, K.extra_lanes / (2.0 * std::max<int64_t>(K.rows, 1)), ck_lds_bytes(K.slots, K.max_acc), ms,
+              K.n_part_rec, L.n_part_rec, K.extra_lanes / (2.0 * std::max<int64_t>(K.rows, 1)), ck_lds_bytes(K.slots, K.max_acc, K.ng), ms,
               (long long)L.rows);
   return 0;
 }

@@ -104,7 +104,7 @@ def test_e0_ck_several_batches_and_cold_chunks(monkeypatch):
     ctx.set_e0_kernel(0)
     y0 = ctx.right_mul_e0_pose(x)
     inc0 = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0]
-    for kernel in (1, 3, 6):
+    for kernel in (1, 3, 4, 6):
         ctx.set_e0_kernel(kernel)
         assert rel(ctx.right_mul_e0_pose(x), y0) < 1e-12
         assert rel(ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0], inc0) < 1e-10
@@ -134,4 +134,32 @@ def test_e0_ck_arrives_with_the_placed_rows(monkeypatch):
     assert ctx.linearize_pose(ALPHA)
     inc_b = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0]
     assert rel(inc_b, inc_a) < 1e-10
+    ctx.close()
+
+
+def test_e0_kernel_is_chosen_by_timing_both():
+    """Nothing forced: the first power series of a layout times e0_lpl and e0_ck on the prepared problem and keeps the faster
+    one; forcing a kernel and handing the choice back both work; the increment is the same either way."""
+    from povar_amd import capi
+    p = _problem("trafalgar-257")
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    ctx.layout_finalize(True)
+    ctx.set_cameras(p.cams)
+    ctx.init_landmarks_pose(ALPHA)
+    assert ctx.linearize_pose(ALPHA)
+    li = ctx.layout_info()
+    assert li.e0_auto == 1 and li.e0_kernel == 0 and li.ck_ready == 1
+    inc_auto = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0]
+    li = ctx.layout_info()
+    assert li.e0_auto == 2 and li.e0_kernel in (0, 1) and li.tune_lpl_us > 0 and li.tune_ck_us > 0
+    assert (li.e0_kernel == 1) == (li.tune_ck_us < 0.98 * li.tune_lpl_us)
+    for forced in (0, 1):
+        ctx.set_e0_kernel(forced)
+        li = ctx.layout_info()
+        assert li.e0_auto == 0 and li.e0_kernel == forced
+        assert rel(ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0], inc_auto) < 1e-10
+    ctx.set_e0_kernel(-1)
+    assert ctx.layout_info().e0_auto == 1
+    assert rel(ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0], inc_auto) < 1e-10
+    assert ctx.layout_info().e0_auto == 2
     ctx.close()
