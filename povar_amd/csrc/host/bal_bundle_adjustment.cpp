@@ -337,6 +337,8 @@ void bundle_adjust_manual(BalProblem& bal_problem, const SolverOptions& so, Solv
   create_homogeneous_landmark(bal_problem);                    // :861
   optimize_lm(bal_problem, so, summary, timer_total, true);    // second step: Riemannian manifold optimisation, :864
   if (timing) timing->optimize_time = summary.total_time_in_seconds;  // :868-870
+  // the device context the last linearizor left behind for a successor (step 2 takes over step 1's): nobody comes after
+  bal_problem.device_cache.clear();
 }
 
 bool get_memory_info(unsigned long long& resident, unsigned long long& resident_peak) {

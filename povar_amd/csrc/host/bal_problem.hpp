@@ -91,9 +91,20 @@ class BalProblem {
   // A device-resident Linearizor leaves its context here when it is destroyed; the next one built on the same problem
   // with the same options (step 2 after step 1, bal_bundle_adjustment.cpp:283 / 585) takes it over instead of building
   // the device layout a second time.  key: what the context was built for (sizes, options, a hash of the observations).
+  // The cache is not copied with the problem (a copy would share ONE live device context with the original: two
+  // linearizors could adopt it under the same key) -- a copied problem starts without one; moves keep it.
   struct DeviceCache {
     std::shared_ptr<void> ctx;
     std::string key;
+    DeviceCache() = default;
+    DeviceCache(const DeviceCache&) {}
+    DeviceCache& operator=(const DeviceCache& o) {
+      if (this != &o) { ctx.reset(); key.clear(); }
+      return *this;
+    }
+    DeviceCache(DeviceCache&&) = default;
+    DeviceCache& operator=(DeviceCache&&) = default;
+    void clear() { ctx.reset(); key.clear(); }
   };
   DeviceCache device_cache;
 

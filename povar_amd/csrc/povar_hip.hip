@@ -835,6 +835,9 @@ int clear_flag0(povar_ctx* c) {
   return 0;
 }
 bool err_memo_hit(const povar_ctx* c, int kind, double alpha, povar_residual_info* out) {
+  // (not while sharded: a hit returns before the all-reduce of the failure flag, and whether a rank's memo is valid
+  // depends on rank-local events -- a rank that recomputes would enter the collective alone.  ADVICE r03.)
+  if (sharded(c)) return false;
   const auto& m = c->err_memo;
   if (!m.valid || m.kind != kind || m.alpha != alpha || m.lms_ver != c->lms_ver || m.cams_ver != c->cams_ver ||
       m.mode != c->opt.e0_mode * 4 + (c->use_lpl ? 2 : 0) + (c->use_lpl_prepare ? 1 : 0))
@@ -1266,7 +1269,14 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
 
   // The arrays of the lane-per-observation kernels (part B) are built on a second host thread while this one builds
   // and uploads the lane-per-landmark layout: the two only share the slot numbers and camera ranks of part A.
-  std::thread part_b([&]() { build_layout_b(n_cams, n_lms, lm_offsets, cam_idx, obs, L, LT); });
+  std::atomic<bool> part_b_failed{false};
+  std::thread part_b([&]() {
+    try {
+      build_layout_b(n_cams, n_lms, lm_offsets, cam_idx, obs, L, LT);
+    } catch (...) {  // (an allocation failure of this thread must not terminate the caller's process)
+      part_b_failed.store(true);
+    }
+  });
   struct Joiner {  // every early return below must wait for the thread
     std::thread& t;
     ~Joiner() { if (t.joinable()) t.join(); }
@@ -1402,6 +1412,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   }
   lap("uploads (lane/landmark)");
   part_b.join();
+  if (part_b_failed.load()) { povar_destroy(c); return fail(-4, "out of host memory while building the lane-per-observation layout"); }
   lap("wait for the lane/obs arrays");
   int rc = 0;
   if ((rc = upload(c->uv, L.uv, c)) || (rc = upload(c->cam, L.cam, c)) || (rc = upload(c->lm, L.lm, c)) ||

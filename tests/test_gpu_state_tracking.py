@@ -21,7 +21,13 @@ def _ctx(p, memo, **kw):
     old = os.environ.get("POVAR_NO_ERR_MEMO")
     os.environ["POVAR_NO_ERR_MEMO"] = "0" if memo else "1"
     try:
-        return capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, **kw)
+        ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, **kw)
+        # Two contexts are compared number by number below: both run on the placed rows from the start.  (With the rows
+        # placed on a host thread -- POVAR_LPL_PLACE=async -- each context would otherwise swap them in at whichever
+        # linearisation finds them ready: a different summation order from a different iteration on, which is timing, not
+        # the memo.  ADVICE r03.)
+        ctx.layout_finalize(True)
+        return ctx
     finally:
         if old is None:
             del os.environ["POVAR_NO_ERR_MEMO"]
@@ -127,7 +133,7 @@ def test_error_memo_changes_no_number_step2(e0_mode, small_problem):
         log.append(tuple(ctx.get_landmarks_homogeneous().ravel()[:64]))
         logs.append(log)
         ctx.close()
-    _same(logs[0], logs[1], exact=e0_mode == 0, tol=1e-6)
+    _same(logs[0], logs[1], exact=e0_mode == 0, tol=1e-9 if e0_mode == 0 else 1e-6)
 
 
 def test_normalize_joint_keeps_the_lane_mirror(medium_problem):

@@ -1,11 +1,12 @@
 #!/bin/bash
 # The `-m gpu` suite under forced library modes: each knob routes EVERY context of every test through a path the
 # defaults only take for some problem sizes (round 3 found a stale-weights defect of RIPCG and a capture/upload race this
-# way).  Expected: all green except the assertions about the layout the library picks BY DEFAULT
-# (test_step1_oracle_parity_at_size::_check_strategy under forced camera sets / strategies).
+# way).  Expected: all green (the test of the layout the library picks BY DEFAULT skips itself when the
+# environment forces the layout; the at-size oracle comparison runs in every mode).
 #   tools/forced_mode_suite.sh            (about 2.5 GPU-minutes per mode)
 cd "$(dirname "$0")/.." || exit 1
-run() { echo "== $*"; env "$@" python3 -m pytest tests -q -m gpu 2>&1 | grep "FAILED\|passed\|failed"; }
+# -rf --tb=line: every failure with the assertion that failed, not only the test name
+run() { echo "== $*"; env "$@" python3 -m pytest tests -q -m gpu -rf --tb=line 2>&1 | grep "FAILED\|Error\|assert\|passed\|failed"; }
 run POVAR_E0_V1=0
 run POVAR_E0_V1=0 POVAR_LPL_PLACE=async POVAR_COLD_Q_ROWS=1
 run POVAR_E0_V1=0 POVAR_HOT_ACC=8
@@ -15,3 +16,4 @@ run POVAR_E0_V1=0 POVAR_LPL_STRATEGY=range POVAR_HOT_ACC=24 POVAR_LPL_PLACE=asyn
 run POVAR_E0_V1=0 POVAR_LPL_NOGRID=1 POVAR_LONG_SEPARATE=1 POVAR_HOT_ACC=40 POVAR_NO_ERR_MEMO=1
 run POVAR_PREPARE_V1=1 POVAR_NO_FUSE=1
 run POVAR_NO_GRAPH=1
+run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_LPL_PLACE=sync
