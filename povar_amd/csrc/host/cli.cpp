@@ -84,6 +84,7 @@ bool parse_bal_app_arguments(int argc, char** argv, BalAppOptions& o) {
   dbl("vee-factor", &o.solver.vee_factor);
   str("e0-mode", &o.solver.e0_mode);
   integer("device", &o.solver.device);
+  integer("gpus", &o.solver.gpus);
 
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];

@@ -3,8 +3,13 @@
 // include/povar_hip.h: the two reference classes differ in solve()/solve_joint() and in the Jl column
 // scaling of step 1 only, so one class serves both.  The device context owns cameras and landmarks
 // between calls; BalProblem forwards backup/restore/normalise through StateMirror.
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <memory>
 #include <cstring>
@@ -320,10 +325,333 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
   bool homogeneous_;
 };
 
+// ------------------------------------------------------------------------------------------
+// N landmark shards in one process (BASELINE configs 4 / 5; SURVEY 8(b): "one context per process drives all local
+// GPUs").  The reference's caller is ONE thread calling the eleven virtuals (solver/linearizor.hpp:65-81,
+// bal_bundle_adjustment.cpp:283-284, 585-586); the library's sharded entry points are collectives -- every rank must be
+// inside the same call at the same time -- so each shard context has a host thread of its own and every virtual hands
+// the same call to all of them and waits.  Cameras and every per-camera result are replicated (identical on all ranks
+// after the library's exchange steps: rank 0's copy is returned), landmarks live on the shard that owns them.
+// Exchange: RCCL (povar_comm_init) when the shards sit on distinct devices; an in-process all-reduce through the
+// library's host hook (povar_comm_init_host) when they share one (RCCL refuses duplicate devices) or POVAR_HOST_COMM=1.
+// ------------------------------------------------------------------------------------------
+class ShardTeam {
+ public:
+  explicit ShardTeam(int n) : n_(n), slab_(n) {
+    for (int r = 0; r < n; ++r) workers_.emplace_back([this, r] { loop(r); });
+  }
+  ~ShardTeam() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+      ++gen_;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  int size() const { return n_; }
+  // fn(rank) on every shard's thread, concurrently; returns when all are done
+  void run(const std::function<void(int)>& fn) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn;
+      pending_ = n_;
+      ++gen_;
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+  // in-process all-reduce (sum, in place, fixed rank order on every rank): the host hook of povar_comm_init_host
+  static void allreduce_hook(double* buf, int64_t n, void* user) {
+    auto* a = static_cast<std::pair<ShardTeam*, int>*>(user);
+    a->first->allreduce(a->second, buf, n);
+  }
+  std::vector<std::pair<ShardTeam*, int>> hook_args;
+
+ private:
+  void loop(int r) {
+    long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* fn = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (quit_) return;
+        fn = fn_;
+      }
+      (*fn)(r);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        --pending_;
+      }
+      done_cv_.notify_all();
+    }
+  }
+  void barrier() {
+    std::unique_lock<std::mutex> lk(bar_mu_);
+    const long g = bar_gen_;
+    if (++bar_count_ == n_) {
+      bar_count_ = 0;
+      ++bar_gen_;
+      bar_cv_.notify_all();
+    } else {
+      bar_cv_.wait(lk, [&] { return bar_gen_ != g; });
+    }
+  }
+  void allreduce(int rank, double* buf, int64_t n) {
+    slab_[rank].assign(buf, buf + n);
+    barrier();
+    for (int64_t i = 0; i < n; ++i) {
+      double s = 0;
+      for (int r = 0; r < n_; ++r) s += slab_[r][i];
+      buf[i] = s;
+    }
+    barrier();
+  }
+  int n_;
+  std::vector<std::thread> workers_;
+  std::mutex mu_, bar_mu_;
+  std::condition_variable cv_, done_cv_, bar_cv_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int pending_ = 0, bar_count_ = 0;
+  long gen_ = 0, bar_gen_ = 0;
+  bool quit_ = false;
+  std::vector<std::vector<double>> slab_;
+};
+
+class LinearizorPowerVarprojHipMulti : public Linearizor, public StateMirror {
+ public:
+  LinearizorPowerVarprojHipMulti(BalProblem& bal_problem, const SolverOptions& options, SolverSummary* summary, bool homogeneous)
+      : options_(options), bal_problem_(bal_problem), summary_(summary), homogeneous_(homogeneous), team_(options.gpus) {
+    using ST = SolverOptions::SolverType;
+    if (options.solver_type_step_1 == ST::PCG || options.solver_type_step_1 == ST::CHOLESKY ||
+        options.solver_type_step_2 == SolverOptions::SolverTypeRiemannian::RIPCG) {
+      std::fprintf(stderr, "FATAL: --gpus > 1 serves the power-series solvers (POWER_VARPROJ, POWER_SCHUR_COMPLEMENT, RIPOBA)\n");
+      std::abort();
+    }
+    const int world = options.gpus;
+    povar_options o{};
+    o.robust_norm = (int)options.residual.robust_norm;
+    o.huber_parameter = options.residual.huber_parameter;
+    o.jacobi_scaling_eps = options.jacobi_scaling_epsilon > 0 ? options.jacobi_scaling_epsilon : 1e-5;
+    o.e0_mode = options.e0_mode == "tiles" ? POVAR_E0_TILES
+                : options.e0_mode == "implicit" ? POVAR_E0_IMPLICIT : POVAR_E0_IMPLICIT_LDSACC;
+    std::vector<int> lm_off, cam_idx;
+    std::vector<double> obs;
+    bal_problem.flatten(lm_off, cam_idx, obs);
+    const int n_lms = bal_problem.num_landmarks();
+    const int n_dev = std::max(povar_device_count(), 1);
+    const bool distinct = world <= n_dev;
+    const char* force_host = std::getenv("POVAR_HOST_COMM");
+    use_rccl_ = distinct && !(force_host && force_host[0] == '1');
+    uint8_t uid[128] = {0};
+    if (use_rccl_) check(povar_comm_unique_id(uid), "povar_comm_unique_id");
+    shards_.resize(world);
+    team_.hook_args.resize(world);
+    for (int r = 0; r < world; ++r) team_.hook_args[r] = {&team_, r};
+    team_.run([&](int r) {
+      Shard& s = shards_[r];
+      check(povar_shard_range(n_lms, lm_off.data(), world, r, &s.lb, &s.le), "povar_shard_range");
+      std::vector<int> off(lm_off.begin() + s.lb, lm_off.begin() + s.le + 1);
+      const int ob = off.front();
+      for (int& v : off) v -= ob;
+      povar_options or_ = o;
+      or_.device = (options.device + r) % n_dev;
+      check(povar_create(&s.ctx, bal_problem.num_cameras(), s.le - s.lb, (int64_t)off.back(), off.data(), cam_idx.data() + ob,
+                         obs.data() + 2 * (size_t)ob, &or_), "povar_create");
+      if (use_rccl_) check(povar_comm_init(s.ctx, world, r, uid), "povar_comm_init");
+      else check(povar_comm_init_host(s.ctx, world, r, &ShardTeam::allreduce_hook, &team_.hook_args[r]), "povar_comm_init_host");
+      check(povar_set_jl_col_scaling(s.ctx, 1), "povar_set_jl_col_scaling");
+      if (r == 0) check(povar_timings_enable(s.ctx, 1), "povar_timings_enable");
+    });
+    push_state();
+    bal_problem_.mirror = this;
+  }
+  ~LinearizorPowerVarprojHipMulti() override {
+    pull_state();
+    bal_problem_.mirror = nullptr;
+    team_.run([&](int r) { povar_destroy(shards_[r].ctx); });
+  }
+  bool uses_rccl() const { return use_rccl_; }
+
+  void start_iteration(IterationSummary* it) override { it_summary_ = it; }
+  void finish_iteration() override {}
+  void initialize_varproj_lm_pOSE(double alpha, bool initialization_varproj) override {
+    if (initialization_varproj) all([&](Shard& s, int) { check(povar_init_landmarks_pose(s.ctx, alpha), "povar_init_landmarks_pose"); });
+  }
+  void compute_error_pOSE(ResidualInfo& ri, bool) override {
+    std::vector<povar_residual_info> r(shards_.size());
+    all([&](Shard& s, int k) { check(povar_error_pose(s.ctx, options_.alpha, &r[k]), "povar_error_pose"); });
+    ri = to_ri(r[0]);  // (all-reduced inside the library: the same on every rank)
+    IF_SET(it_summary_)->residual_evaluation_time_in_seconds += device_seconds(4);
+    IF_SET(summary_)->num_residual_evaluations += 1;
+  }
+  void compute_error_homogeneous(ResidualInfo& ri, bool) override {
+    std::vector<povar_residual_info> r(shards_.size());
+    all([&](Shard& s, int k) { check(povar_error_homogeneous(s.ctx, &r[k]), "povar_error_homogeneous"); });
+    ri = to_ri(r[0]);
+    IF_SET(it_summary_)->residual_evaluation_time_in_seconds += device_seconds(4);
+    IF_SET(summary_)->num_residual_evaluations += 1;
+  }
+  void linearize_pOSE(double alpha) override {
+    std::atomic<int> failed{0};
+    all([&](Shard& s, int) {
+      const int rc = povar_linearize_pose(s.ctx, alpha);
+      check(rc, "povar_linearize_pose");
+      if (rc == POVAR_NUMERIC_FAILURE) failed.store(1);
+    });
+    after_linearize(failed.load());
+  }
+  void linearize_projective_space_homogeneous() override {
+    std::atomic<int> failed{0};
+    all([&](Shard& s, int) {
+      const int rc = povar_linearize_homogeneous(s.ctx);
+      check(rc, "povar_linearize_homogeneous");
+      if (rc == POVAR_NUMERIC_FAILURE) failed.store(1);
+    });
+    after_linearize(failed.load());
+  }
+  VecX solve(const SolverOptions& so, double lambda, double) override {
+    const size_t n = 12 * (size_t)bal_problem_.num_cameras();
+    std::vector<VecX> inc(shards_.size(), VecX(n));
+    std::vector<int32_t> iters(shards_.size(), 0), term(shards_.size(), 0);
+    const int st = so.solver_type_step_1 == SolverOptions::SolverType::POWER_SCHUR_COMPLEMENT
+                       ? POVAR_POWER_SCHUR_COMPLEMENT : POVAR_POWER_VARPROJ;
+    all([&](Shard& s, int k) {
+      check(povar_prepare_pose(s.ctx, lambda, st), "povar_prepare_pose");
+      check(povar_power_series_pose(s.ctx, options_.power_sc_iterations, options_.eta, options_.r_tolerance, &iters[k], &term[k]),
+            "povar_power_series_pose");
+      check(povar_get_increment(s.ctx, inc[k].data()), "povar_get_increment");
+    });
+    IF_SET(it_summary_)->prepare_time_in_seconds = device_seconds(1);
+    fill_solver_summary(device_seconds(2), iters[0], term[0]);
+    return std::move(inc[0]);
+  }
+  VecX solve_joint(double lambda, double) override {
+    const size_t n = 11 * (size_t)bal_problem_.num_cameras();
+    std::vector<VecX> inc(shards_.size(), VecX(n));
+    std::vector<int32_t> iters(shards_.size(), 0), term(shards_.size(), 0);
+    all([&](Shard& s, int k) {
+      check(povar_solve_joint(s.ctx, lambda, options_.power_sc_iterations, options_.eta, options_.r_tolerance, inc[k].data(),
+                              &iters[k], &term[k]), "povar_solve_joint");
+    });
+    IF_SET(it_summary_)->prepare_time_in_seconds = device_seconds(1);
+    fill_solver_summary(device_seconds(2), iters[0], term[0]);
+    return std::move(inc[0]);
+  }
+  double apply(const SolverOptions& so, double alpha, VecX&& inc) override {
+    std::vector<double> l_diff(shards_.size(), 0.0);
+    const int st = so.solver_type_step_1 == SolverOptions::SolverType::POWER_SCHUR_COMPLEMENT
+                       ? POVAR_POWER_SCHUR_COMPLEMENT : POVAR_POWER_VARPROJ;
+    all([&](Shard& s, int k) { check(povar_apply_pose(s.ctx, st, alpha, inc.data(), &l_diff[k]), "povar_apply_pose"); });
+    IF_SET(it_summary_)->back_substitution_time_in_seconds = device_seconds(3);
+    return l_diff[0];
+  }
+  double apply_joint(VecX&& inc) override {
+    std::vector<double> l_diff(shards_.size(), 0.0);
+    all([&](Shard& s, int k) { check(povar_apply_joint(s.ctx, inc.data(), &l_diff[k]), "povar_apply_joint"); });
+    IF_SET(it_summary_)->back_substitution_time_in_seconds = device_seconds(3);
+    return l_diff[0];
+  }
+
+  // StateMirror
+  void backup_pOSE() override { all([&](Shard& s, int) { check(povar_backup_pose(s.ctx), "povar_backup_pose"); }); }
+  void restore_pOSE() override { all([&](Shard& s, int) { check(povar_restore_pose(s.ctx), "povar_restore_pose"); }); }
+  void backup_joint() override { all([&](Shard& s, int) { check(povar_backup_joint(s.ctx), "povar_backup_joint"); }); }
+  void restore_joint() override { all([&](Shard& s, int) { check(povar_restore_joint(s.ctx), "povar_restore_joint"); }); }
+  void normalize_joint() override { all([&](Shard& s, int) { check(povar_normalize_joint(s.ctx), "povar_normalize_joint"); }); }
+  void pull_state() override {
+    const int nc = bal_problem_.num_cameras();
+    const int w = homogeneous_ ? 4 : 3;
+    std::vector<double> cams(12 * (size_t)nc);
+    all([&](Shard& s, int k) {
+      if (k == 0) check(povar_get_cameras(s.ctx, cams.data()), "povar_get_cameras");
+      std::vector<double> lms((size_t)w * (s.le - s.lb));
+      if (homogeneous_) check(povar_get_landmarks_homogeneous(s.ctx, lms.data()), "povar_get_landmarks_homogeneous");
+      else check(povar_get_landmarks(s.ctx, lms.data()), "povar_get_landmarks");
+      for (int l = s.lb; l < s.le; ++l)
+        for (int q = 0; q < w; ++q) {
+          const double v = lms[(size_t)w * (l - s.lb) + q];
+          if (homogeneous_) bal_problem_.landmarks()[l].p_w_homogeneous[q] = v;
+          else bal_problem_.landmarks()[l].p_w[q] = v;
+        }
+    });
+    for (int c = 0; c < nc; ++c)
+      for (int q = 0; q < 12; ++q) bal_problem_.cameras()[c].space_matrix[q] = cams[12 * (size_t)c + q];
+  }
+
+ private:
+  struct Shard {
+    povar_ctx* ctx = nullptr;
+    int32_t lb = 0, le = 0;
+  };
+  template <class F>
+  void all(F&& f) {
+    team_.run([&](int r) { f(shards_[r], r); });
+  }
+  void after_linearize(int failed) {
+    if (failed) {
+      std::fprintf(stderr, "FATAL: did not expect numerical failure during linearization\n");
+      std::abort();
+    }
+    const double e = device_seconds(0);
+    IF_SET(it_summary_)->jacobian_evaluation_time_in_seconds = e;
+    IF_SET(it_summary_)->stage1_time_in_seconds = e;
+    IF_SET(summary_)->num_jacobian_evaluations += 1;
+  }
+  double device_seconds(int kind) {  // rank 0's device time (the ranks run the same calls side by side)
+    povar_timings_info t;
+    check(povar_timings(shards_[0].ctx, &t), "povar_timings");
+    const double now[5] = {t.linearize_ms, t.prepare_ms, t.solve_ms, t.apply_ms, t.other_ms};
+    const double d = (now[kind] - seen_[kind]) * 1e-3;
+    seen_[kind] = now[kind];
+    return d;
+  }
+  void push_state() {
+    const int nc = bal_problem_.num_cameras();
+    const int w = homogeneous_ ? 4 : 3;
+    std::vector<double> cams(12 * (size_t)nc);
+    for (int c = 0; c < nc; ++c)
+      for (int q = 0; q < 12; ++q) cams[12 * (size_t)c + q] = bal_problem_.cameras()[c].space_matrix[q];
+    all([&](Shard& s, int) {
+      check(povar_set_cameras(s.ctx, cams.data()), "povar_set_cameras");
+      std::vector<double> lms((size_t)w * (s.le - s.lb));
+      for (int l = s.lb; l < s.le; ++l)
+        for (int q = 0; q < w; ++q)
+          lms[(size_t)w * (l - s.lb) + q] = homogeneous_ ? bal_problem_.landmarks()[l].p_w_homogeneous[q] : bal_problem_.landmarks()[l].p_w[q];
+      if (homogeneous_) check(povar_set_landmarks_homogeneous(s.ctx, lms.data()), "povar_set_landmarks_homogeneous");
+      else check(povar_set_landmarks(s.ctx, lms.data()), "povar_set_landmarks");
+    });
+  }
+  void fill_solver_summary(double seconds, int iters, int term) {
+    IF_SET(it_summary_)->solve_reduced_system_time_in_seconds = seconds;
+    IF_SET(it_summary_)->linear_solver_iterations = iters;
+    IF_SET(it_summary_)->linear_solver_message =
+        term == POVAR_LINEAR_SOLVER_SUCCESS ? "Iteration: " + std::to_string(iters) + " Convergence."
+                                            : "Maximum number of iterations reached.";
+    IF_SET(it_summary_)->linear_solver_type = "bal_power_sc";
+    IF_SET(summary_)->num_linear_solves += 1;
+  }
+
+  SolverOptions options_;
+  BalProblem& bal_problem_;
+  SolverSummary* summary_ = nullptr;
+  IterationSummary* it_summary_ = nullptr;
+  bool homogeneous_;
+  bool use_rccl_ = false;
+  ShardTeam team_;
+  std::vector<Shard> shards_;
+  double seen_[5] = {0, 0, 0, 0, 0};
+};
+
 LinearizorFactory g_factory = nullptr;
 
 std::unique_ptr<Linearizor> make(BalProblem& p, const SolverOptions& o, SolverSummary* s, bool hom) {
   if (g_factory) return g_factory(p, o, s, hom);
+  if (o.gpus > 1) return std::make_unique<LinearizorPowerVarprojHipMulti>(p, o, s, hom);
   return std::make_unique<LinearizorPowerVarprojHip>(p, o, s, hom);
 }
 

@@ -53,6 +53,10 @@ struct SolverOptions {
   // MI355X build: which E0 operator form the device uses (not a reference option)
   std::string e0_mode = "ldsacc";  // "ldsacc" (fastest), "implicit" (bit-reproducible), "tiles" (stored tiles)
   int device = 0;
+  // landmark shards = device contexts of ONE process (BASELINE configs 4 / 5: "landmarks sharded across 8 x MI355X"):
+  // shard r runs on device (device + r) mod device count; one exchange step per power-series term (RCCL, or an in-process
+  // all-reduce when shards share a device)
+  int gpus = 1;
 
   // solver_options.cpp:41-51
   bool use_projection_validity_check() const { return optimized_cost != OptimizedCost::ERROR; }

@@ -61,3 +61,28 @@ def test_bal_hip_matches_bal_oracle(tmp_path, extra):
     assert np.allclose(a["trust_region_radius"][:n1], b["trust_region_radius"][:n1], rtol=1e-5)
     assert a["_static"]["solver"]["termination_type"] == b["_static"]["solver"]["termination_type"]
     assert "Final Cost" in out_a and a["_type"] == "rootba_povar"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_bal_gpus_n_matches_one_device(tmp_path, gpus):
+    """`bal --gpus N`: the single-process N-shard Linearizor (host/linearizor_power_varproj_hip.cpp: one host thread per
+    shard context, landmark shards from povar_shard_range, one exchange step per power-series term) against `bal` on one
+    context, trafalgar-257 shape from a start inside the basin, both LM steps run to convergence: identical accept/reject
+    sequences and inner iteration counts, every cost to 1e-6, the same trust-region schedule, the same final state file.
+    On a one-GPU box the shards share device 0 and the exchange is the in-process all-reduce through the library's host
+    hook (RCCL refuses duplicate devices); on a multi-GPU node the same command runs RCCL over the devices."""
+    from povar_amd import synth
+    p = synth.make_bal_problem("trafalgar-257", init="gt", init_noise=0.02)
+    f = str(tmp_path / "problem-257-65132-gt.txt")
+    synth.write_data_custom(f, p)
+    extra = ["--max-num-iterations-step-1", "30", "--max-num-iterations-step-2", "30", "--power-sc-iterations", "20"]
+    one, _ = _run("bin/bal", f, str(tmp_path / "one.json"), extra)
+    many, _ = _run("bin/bal", f, str(tmp_path / "many.json"), extra + ["--gpus", str(gpus)])
+    assert one["iteration"] == many["iteration"] and len(one["iteration"]) > 6
+    assert one["step_is_successful"] == many["step_is_successful"]
+    assert one["linear_solver_iterations"] == many["linear_solver_iterations"]
+    ca, cb = np.array(one["cost"]), np.array(many["cost"])
+    assert np.abs(ca / cb - 1).max() <= 1e-6, np.abs(ca / cb - 1).max()
+    assert np.allclose(one["trust_region_radius"], many["trust_region_radius"], rtol=1e-4)
+    assert one["_static"]["solver"]["termination_type"] == many["_static"]["solver"]["termination_type"]

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ALPHA, LAM, M = 0.01, 1e-4, 6
 
 
-def _ctx(p, memo, **kw):
+def _ctx(p, memo, finalize=True, **kw):
     from povar_amd import capi
     old = os.environ.get("POVAR_NO_ERR_MEMO")
     os.environ["POVAR_NO_ERR_MEMO"] = "0" if memo else "1"
@@ -26,7 +26,8 @@ def _ctx(p, memo, **kw):
         # placed on a host thread -- POVAR_LPL_PLACE=async -- each context would otherwise swap them in at whichever
         # linearisation finds them ready: a different summation order from a different iteration on, which is timing, not
         # the memo.  ADVICE r03.)
-        ctx.layout_finalize(True)
+        if finalize:
+            ctx.layout_finalize(True)
         return ctx
     finally:
         if old is None:
@@ -250,7 +251,7 @@ def test_rows_placed_on_a_host_thread_are_swapped_in(step, medium_problem, monke
     _start(nat, p, step)
     assert rel(_solve_once(nat, p, step), want) < 1e-10
     monkeypatch.setenv("POVAR_LPL_PLACE", "async")
-    ctx = _ctx(p, True, **kw)
+    ctx = _ctx(p, True, finalize=False, **kw)
     assert ctx.layout_info().placement == 2
     _start(ctx, p, step)
     assert rel(_solve_once(ctx, p, step), want) < 1e-10      # on either row order, whichever the thread's progress allowed
