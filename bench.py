@@ -107,6 +107,7 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
     max_obs and scale by the observation ratio -- said in `sample`."""
     from oracle import povar_oracle as O
 
+    build_note = O.use_native_build()  # the reference's flags, for this host (VERDICT r03: the portable build is -O3 / x86-64-v3)
     n_l, n_o, scale = prob.n_lms, prob.n_obs, 1.0
     if n_o > max_obs:
         n_l = max(int(np.searchsorted(prob.lm_off, max_obs)), 1)
@@ -131,16 +132,23 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
     tried = {"1": v1 * scale}
     best = (v1, 1, 0)
     grain_dyn = max(64, n_l // (64 * ncpu))
+    # ... and each of them again with per-thread private sums joined after the loop instead of the per-camera mutex
+    # ("-private": NOT the reference's scheme for this loop -- its Reductor does that for the column norms,
+    # linearization_varproj.hpp:184-209 -- reported so that the mutex's share of the multithreaded slowdown shows)
     for nt in sorted({ncpu, max(ncpu // 4, 1), min(16, ncpu), min(4, ncpu)} - {1}):
-        for grain in (0, grain_dyn):
-            O.set_e0_schedule(grain)
-            orc.solve_pose(st, hll, binv, b, 1, n_threads=nt)
-            t0 = time.perf_counter()
-            orc.solve_pose(st, hll, binv, b, 2, n_threads=nt)
-            v = 2.0 / (time.perf_counter() - t0)
-            tried[f"{nt}" + ("-dynamic" if grain else "")] = v * scale
-            if v > best[0]:
-                best = (v, nt, grain)
+        for private in (False, True):
+            O.set_e0_scatter(private)
+            for grain in (0, grain_dyn):
+                O.set_e0_schedule(grain)
+                orc.solve_pose(st, hll, binv, b, 1, n_threads=nt)
+                t0 = time.perf_counter()
+                orc.solve_pose(st, hll, binv, b, 2, n_threads=nt)
+                v = 2.0 / (time.perf_counter() - t0)
+                tried[f"{nt}" + ("-dynamic" if grain else "") + ("-private" if private else "")] = v * scale
+                if v > best[0] and not private:  # the headline baseline stays the reference's scheme
+                    best = (v, nt, grain)
+    O.set_e0_scatter(False)
+    best_private = max([v for k, v in tried.items() if k.endswith("-private")], default=0.0)
     cores, grain = best[1], best[2]
     O.set_e0_schedule(grain)
     t0 = time.perf_counter()
@@ -166,6 +174,8 @@ def cpu_baseline(prob, alpha, lam, m, max_obs=8_000_000):
         "kind": "port",
         "value_1_thread": v1 * scale,
         "threads_tried": {k: round(v, 3) for k, v in tried.items()},
+        "value_private_sums": round(best_private, 3),  # best multithreaded rate WITHOUT the per-camera mutex (see threads_tried)
+        "build": build_note,
         "value_all_cores": max(tried.get(str(ncpu), 0.0), tried.get(f"{ncpu}-dynamic", 0.0)) if ncpu > 1 else v1 * scale,
         "host_cpus": os.cpu_count() or 1,
         "usable_cpus": ncpu,

@@ -492,6 +492,13 @@ static void* e0_worker(void* arg) {
  * g > 0: chunks of g landmarks on demand (auto_partitioner analogue, LPV:402-403 uses TBB's default). */
 static int g_e0_grain = 0;
 void orc_set_e0_schedule(int32_t grain) { g_e0_grain = grain > 0 ? grain : 0; }
+/* How the threads combine their `res += Jp^T s`.  0: the reference's scheme -- one std::mutex per camera, taken per
+ * observation (LPV:393-397).  1: every thread adds into a result vector of its own and the vectors are summed after the
+ * join -- what the reference's Reductor does for the per-camera column norms (linearization_varproj.hpp:184-209), NOT
+ * what it does here; a second baseline that shows how much of the multithreaded slowdown on a hub-heavy graph is the
+ * mutex and how much is this restatement (bench.py cpu_baseline.threads_tried). */
+static int g_e0_private = 0;
+void orc_set_e0_scatter(int32_t private_sums) { g_e0_private = private_sums != 0; }
 
 /* persistent worker pool (the reference runs on TBB's pool: thread creation is not part of its
  * per-term cost).  Workers park on a barrier pair; one pool per thread count, never torn down. */
@@ -561,16 +568,28 @@ void orc_right_mul_e0_pose_mt(const orc_problem* p, const double* storage, const
   int l = 0;
   static int cursor;
   cursor = 0;
+  const size_t n = 12 * (size_t)p->n_cams;
+  static double* priv = NULL;  /* [n_threads][n] private sums (scatter scheme 1) */
+  static size_t priv_size = 0;
+  if (g_e0_private && priv_size < n * (size_t)n_threads) {
+    priv = (double*)realloc(priv, sizeof(double) * n * (size_t)n_threads);
+    priv_size = n * (size_t)n_threads;
+  }
+  if (g_e0_private) memset(priv, 0, sizeof(double) * n * (size_t)n_threads);
   for (int t = 0; t < n_threads; ++t) {
     const int64_t target = p->n_obs * (int64_t)(t + 1) / n_threads;
     int l1 = l;
     while (l1 < p->n_lms && p->lm_off[l1 + 1] <= target) ++l1;
     if (t == n_threads - 1) l1 = p->n_lms;
-    pool->jobs[t] = (e0_job){p, storage, hll_inv, x, y, l, l1, locks, g_e0_grain > 0 ? &cursor : NULL, g_e0_grain};
+    pool->jobs[t] = (e0_job){p, storage, hll_inv, x, g_e0_private ? priv + n * (size_t)t : y, l, l1,
+                             g_e0_private ? NULL : locks, g_e0_grain > 0 ? &cursor : NULL, g_e0_grain};
     l = l1;
   }
   pthread_barrier_wait(&pool->start);
   pthread_barrier_wait(&pool->done);
+  if (g_e0_private)
+    for (int t = 0; t < n_threads; ++t)
+      for (size_t i = 0; i < n; ++i) y[i] += priv[n * (size_t)t + i];
 }
 
 static double norm2(const double* v, size_t n) {

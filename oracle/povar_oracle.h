@@ -100,6 +100,8 @@ void orc_right_mul_e0_pose(const orc_problem* p, const double* storage, const do
  * orc_set_e0_schedule(0): one contiguous landmark range per thread, balanced by observations (static partitioner);
  * orc_set_e0_schedule(g > 0): chunks of g landmarks taken on demand (TBB's default auto_partitioner analogue). */
 void orc_set_e0_schedule(int32_t grain);
+/* 0: per-camera mutex (the reference, LPV:393-397); 1: per-thread private sums joined afterwards (a second CPU baseline) */
+void orc_set_e0_scatter(int32_t private_sums);
 void orc_right_mul_e0_pose_mt(const orc_problem* p, const double* storage, const double* hll_inv,
                               const double* x, double* y, int32_t n_threads);
 int orc_solve_pose(const orc_problem* p, const double* storage, const double* hll_inv,

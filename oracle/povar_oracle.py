@@ -44,10 +44,46 @@ def build(force: bool = False) -> str:
     return so
 
 
-def lib():
+def use_native_build() -> str:
+    """bench.py's cpu_baseline only: compile the oracle for THIS host with the reference's own optimisation flags
+    (CMakeLists.txt: -Ofast -march=native; the library the tests use is -O3 -march=x86-64-v3 so that one binary runs
+    on every box) into a temporary directory and make it the loaded library.  Returns the flags used, or a note
+    why the portable build stays (no compiler)."""
+    global _LIB
+    import tempfile
+    flags = ["-Ofast", "-march=native", "-fPIC", "-std=c11"]
+    out = os.path.join(tempfile.mkdtemp(prefix="povar_oracle_native_"), "libpovar_oracle_native.so")
+    try:
+        subprocess.check_call(["gcc"] + flags + ["-shared", "-o", out, os.path.join(_HERE, "povar_oracle.c"), "-lm", "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError) as e:
+        return f"portable build (-O3 -march=x86-64-v3): native build failed ({e})"
+    # a trial run in a child process first: where the compiler's idea of `native` and what the (virtualised) CPU
+    # executes disagree, the build crashes -- then the portable one stays
+    import sys
+    trial = ("import sys, numpy as np; sys.path.insert(0, %r); from povar_amd import synth; from oracle import povar_oracle as O; "
+             "O.lib(%r); p = synth.make_problem(20, 300, 1300, seed=1); o = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs); "
+             "l = o.init_landmarks_pose(0.01, p.cams); st, d2, jl, sg, ok = o.stage1_pose(0.01, p.cams, l); o.scale_jp_cols_pose(st, sg); "
+             "h, b, bi = o.prepare_hb_pose(st, 1e-4); x = o.solve_pose(st, h, bi, b, 3, n_threads=2)[0]; "
+             "sys.exit(0 if np.all(np.isfinite(x)) else 3)") % (os.path.dirname(_HERE), out)
+    r = subprocess.run([sys.executable, "-c", trial], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if r.returncode != 0:
+        return f"portable build (-O3 -march=x86-64-v3): the native build failed its trial run (exit {r.returncode})"
+    _LIB = None
+    lib(out)
+    return "gcc " + " ".join(flags[:2]) + " (built on this host)"
+
+
+def set_e0_scatter(private_sums: bool) -> None:
+    """Threaded E0: False = the reference's per-camera mutex (LPV:393-397); True = per-thread private sums joined after
+    the loop (a second CPU baseline, not the reference's scheme)."""
+    lib().orc_set_e0_scatter(C.c_int32(1 if private_sums else 0))
+
+
+def lib(path=None):
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(path or build())
         for name in ("orc_back_substitute_pose", "orc_back_substitute_poba",
                      "orc_back_substitute_joint"):
             getattr(_LIB, name).restype = C.c_double
