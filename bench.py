@@ -500,6 +500,9 @@ def main():
     bytes_e0 = algorithmic_bytes_e0(n_c, loc_l, loc_o)
     achieved = model_bytes / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
     effective = bytes_e0 / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
+    li0 = ctx.layout_info()
+    once_bytes = model_bytes - (li0.ck_rows * 64 * (18 + (8 if args.robust_norm != "NONE" else 0))
+                                if args.step == 1 and li0.e0_kernel > 0 else 0)
     traffic, traffic_note = None, "no PMC figure for this workload/mode"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -581,6 +584,10 @@ def main():
             "model_frac": achieved / HBM_PEAK_GBPS,
             "traffic_GBps": (traffic / (e0_ms * 1e-3) / 1e9) if traffic else None,
             "traffic_frac": (traffic / (e0_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            # the same yardstick for both step-1 kernels: every array of the operator ONCE (e0_lpl's design bytes; e0_ck
+            # reads its row stream on the way forward AND on the way back by design: its model bytes carry the rows twice)
+            "once_bytes_per_launch": once_bytes,
+            "once_frac": once_bytes / (e0_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if e0_ms > 0 else 0.0,
             # SURVEY 8(d) stored-tile model (the reference's bytes): an EFFECTIVE rate for the implicit kernels
             "algorithmic_bytes_per_launch": bytes_e0,
             "effective_GBps": effective,

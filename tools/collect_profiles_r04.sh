@@ -1,0 +1,40 @@
+#!/bin/bash
+# Copies what tools/round4_evidence.sh <tag> and tools/round4_traffic.sh <ttag> left under gpurun_out/ into profiles/
+# (tracked) and stamps profiles/traffic.json (one key per measured term loop) with the hash of the kernel sources:
+#   tools/collect_profiles_r04.sh [tag] [ttag]
+set -eu
+tag=${1:-r04A}; ttag=${2:-r04T}
+cd "$(dirname "$0")/.."
+R=gpurun_out/$tag; T=gpurun_out/$ttag; P=profiles
+newest() { ls -t $@ | head -1; }
+# the venice term loop with e0_lpl and e0_ck in one process: kernel trace, FETCH / WRITE / SQ passes, and the summary
+cp $(newest $R/e0/kt/*/*kernel_stats.csv) $P/r04_kernel_stats_e0_lpl_vs_e0_ck.csv
+cp $(newest $R/e0/sq/*/*counter_collection.csv) $P/r04_pmc_sq_e0_lpl_vs_e0_ck.csv
+cp $R/e0_summary.txt $P/r04_e0_lpl_vs_e0_ck_summary.txt
+cp $(newest $R/e0_huber/kt/*/*kernel_stats.csv) $P/r04_kernel_stats_e0_lpl_vs_e0_ck_huber.csv
+cp $R/e0_huber_summary.txt $P/r04_e0_lpl_vs_e0_ck_huber_summary.txt
+cp $R/stamps.txt $P/r04_e0_ck_phase_stamps.txt
+cp $R/sweep.txt $P/r04_e0_ck_graph_families.txt
+cp $R/shards.txt $P/r04_shard_term_times.txt
+cp $R/bench_default.json $P/r04_bench.json
+for n in forced_e0_lpl huber local zipf05 uniform trafalgar ladybug step2 final_huber; do cp $R/bench_$n.json $P/r04_bench_$n.json; done
+(echo "# tools/run_bal_config.py venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0"
+ cat $R/bal_venice.json
+ echo "# the same with --gpus 2: two shard contexts of one process (here: both on the one device of the box)"
+ cat $R/bal_venice_gpus2.json) > $P/r04_bal_end_to_end.txt
+for n in ck1 lpl huber huber_ck1 local_ck1 local zipf05_ck1 uniform_ck1 step2 final_huber final_local_huber; do
+  cp $(newest $T/pmc_$n/fetch/*/*counter_collection.csv) $P/r04_pmc_fetch_size_$n.csv
+  cp $(newest $T/pmc_$n/write/*/*counter_collection.csv) $P/r04_pmc_write_size_$n.csv
+done
+t() { python3 tools/pmc_to_traffic.py $P/r04_pmc_fetch_size_$1.csv $P/r04_pmc_write_size_$1.csv $2 $P/traffic.json; }
+t ck1 venice-1778:ldsacc:1:ck1
+t lpl venice-1778:ldsacc:1
+t huber venice-1778:ldsacc:1:HUBER
+t huber_ck1 venice-1778:ldsacc:1:HUBER:ck1
+t local_ck1 venice-1778:ldsacc:1:local:ck1
+t local venice-1778:ldsacc:1:local
+t zipf05_ck1 venice-1778:ldsacc:1:zipf0.5:ck1
+t uniform_ck1 venice-1778:ldsacc:1:uniform:ck1
+t step2 venice-1778:ldsacc:1:step2
+t final_huber final-13682:ldsacc:1:HUBER
+t final_local_huber final-13682:ldsacc:1:HUBER:local

@@ -44,7 +44,9 @@ def main():
     pr = ctx.profile_get()
     print(f"{shape} world={world}: shard {le - lb} landmarks / {oe - ob} obs; {dt / (k * m) * 1e6:.1f} us per term "
           f"({k * m / dt:.0f} terms/s); e0 {pr.e0_ms / max(pr.e0_launches, 1) * 1e3:.1f} us, "
-          f"binv {pr.binv_ms / max(pr.binv_launches, 1) * 1e3:.1f} us, comm {pr.comm_ms / max(pr.comm_launches, 1) * 1e3:.1f} us")
+          f"binv {pr.binv_ms / max(pr.binv_launches, 1) * 1e3:.1f} us, comm {pr.comm_ms / max(pr.comm_launches, 1) * 1e3:.1f} us; "
+          f"step-1 kernel {'e0_ck' if ctx.layout_info().e0_kernel else 'e0_lpl'} (timed: e0_lpl {ctx.layout_info().tune_lpl_us:.1f}, "
+          f"e0_ck {ctx.layout_info().tune_ck_us:.1f} us)")
     ctx.close()
 
 
