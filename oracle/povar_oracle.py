@@ -50,28 +50,34 @@ def use_native_build() -> str:
     on every box) into a temporary directory and make it the loaded library.  Returns the flags used, or a note
     why the portable build stays (no compiler)."""
     global _LIB
-    import tempfile
-    flags = ["-Ofast", "-march=native", "-fPIC", "-std=c11"]
-    out = os.path.join(tempfile.mkdtemp(prefix="povar_oracle_native_"), "libpovar_oracle_native.so")
-    try:
-        subprocess.check_call(["gcc"] + flags + ["-shared", "-o", out, os.path.join(_HERE, "povar_oracle.c"), "-lm", "-lpthread"],
-                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    except (OSError, subprocess.CalledProcessError) as e:
-        return f"portable build (-O3 -march=x86-64-v3): native build failed ({e})"
-    # a trial run in a child process first: where the compiler's idea of `native` and what the (virtualised) CPU
-    # executes disagree, the build crashes -- then the portable one stays
     import sys
+    import tempfile
+    # a trial run in a child process before the build is loaded: gcc 11.4 -O3/-Ofast -march=native on an AVX-512 host
+    # emits an aligned 32-byte load from a stack array of the const-propagated clones of llt_inverse_upper (n = 11, 12)
+    # that is not 32-byte aligned (general protection fault in prepare_hb_pose; fine with -fno-ipa-cp-clone,
+    # -mno-avx512f or -march=x86-64-v3) -- the second flag set keeps the reference's flags and drops only the cloning
     trial = ("import sys, numpy as np; sys.path.insert(0, %r); from povar_amd import synth; from oracle import povar_oracle as O; "
              "O.lib(%r); p = synth.make_problem(20, 300, 1300, seed=1); o = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs); "
              "l = o.init_landmarks_pose(0.01, p.cams); st, d2, jl, sg, ok = o.stage1_pose(0.01, p.cams, l); o.scale_jp_cols_pose(st, sg); "
              "h, b, bi = o.prepare_hb_pose(st, 1e-4); x = o.solve_pose(st, h, bi, b, 3, n_threads=2)[0]; "
-             "sys.exit(0 if np.all(np.isfinite(x)) else 3)") % (os.path.dirname(_HERE), out)
-    r = subprocess.run([sys.executable, "-c", trial], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    if r.returncode != 0:
-        return f"portable build (-O3 -march=x86-64-v3): the native build failed its trial run (exit {r.returncode})"
-    _LIB = None
-    lib(out)
-    return "gcc " + " ".join(flags[:2]) + " (built on this host)"
+             "sys.exit(0 if np.all(np.isfinite(x)) else 3)")
+    note = ""
+    for extra in ([], ["-fno-ipa-cp-clone"]):
+        flags = ["-Ofast", "-march=native"] + extra
+        out = os.path.join(tempfile.mkdtemp(prefix="povar_oracle_native_"), "libpovar_oracle_native.so")
+        try:
+            subprocess.check_call(["gcc"] + flags + ["-fPIC", "-std=c11", "-shared", "-o", out, os.path.join(_HERE, "povar_oracle.c"),
+                                   "-lm", "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except (OSError, subprocess.CalledProcessError) as e:
+            return f"portable build (-O3 -march=x86-64-v3): native build failed ({e})"
+        r = subprocess.run([sys.executable, "-c", trial % (os.path.dirname(_HERE), out)], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+        if r.returncode == 0:
+            _LIB = None
+            lib(out)
+            return "gcc " + " ".join(flags) + " (built on this host)" + note
+        note = f"; plain -Ofast -march=native failed its trial run (exit {r.returncode})"
+    return "portable build (-O3 -march=x86-64-v3)" + note
 
 
 def set_e0_scatter(private_sums: bool) -> None:
