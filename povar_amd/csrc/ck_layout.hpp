@@ -34,7 +34,7 @@ constexpr uint32_t CK_NONE = 0xffffu;  // 16-bit landmark slot of a row without 
 
 struct CkLayout {
   std::vector<double2> uv;       // [rows][64]
-  std::vector<uint32_t> li;      // [li_rows][64] landmark slots (16 bits each) of rows 2q | 2q+1 << 16 of a tile
+  std::vector<uint32_t> li;      // [li_rows][64] 3 x landmark slot (16 bits each; CK_NONE: none) of rows 2q | 2q+1 << 16 of a tile
   std::vector<int> src;          // [rows][64] row slot of the lane-per-landmark layout this entry is (-1: none)
   std::vector<int4> tile;        // x: first row, y: height, z: flags, w: first li row
   std::vector<int> lane_cam;     // [tiles][64] popularity rank of the lane's camera (-1: empty lane)
@@ -239,7 +239,8 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
             o.uv[idx] = L.uv[s];
             o.src[idx] = ob.src;
             uint32_t& word = o.li[q0 + (size_t)(j >> 1) * WAVE + lane];
-            word = (j & 1) ? ((word & 0xffffu) | ((uint32_t)ob.li << 16)) : ((word & 0xffff0000u) | (uint32_t)ob.li);
+            const uint32_t li3 = 3u * (uint32_t)ob.li;  // the slot's first double in the [slot][3] LDS arrays of the kernel
+            word = (j & 1) ? ((word & 0xffffu) | (li3 << 16)) : ((word & 0xffff0000u) | li3);
             const uint16_t v = ++occ[j][half][ob.li & 31];
             mx[j][half] = std::max(mx[j][half], v);
           }

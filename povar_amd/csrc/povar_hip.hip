@@ -490,13 +490,15 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
     guarded([&] { ok = D.w.alloc(std::max<size_t>(K.uv.size(), 1), bytes) == hipSuccess; });  // (padded like uv)
   D.nb = K.nb; D.slots = K.slots; D.n_part_rec = K.n_part_rec; D.max_acc = K.max_acc; D.max_tiles_bt = K.max_tiles_bt;
   D.rows = K.rows; D.li_rows = K.li_rows; D.n_chunks = K.n_chunks; D.n_cold_chunks = K.n_cold_chunks;
+  // (the kernel reads the rows through 32-bit buffer descriptors: a row array of 4 GiB or more is left to e0_lpl)
+  ok = ok && K.uv.size() * sizeof(double2) < (1ull << 32);
   D.ready = ok && !(locked && c->placer_cancel.load());
   return D.ready;
 }
 CkP ck_params(const povar_ctx* c) {
   const auto& D = c->ck;
   return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p, c->ck_img.p,
-             D.nb, D.slots, c->ck_pad, c->ck_stamps.p};
+             D.nb, D.slots, c->ck_pad, (unsigned)(D.uv.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t)), c->ck_stamps.p};
 }
 // e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight, double-buffered
 // tile records, groups of wavefronts working on different batches (povar_kernels_ck.hpp)

@@ -27,7 +27,7 @@ constexpr int CK_ROWS = 16;  // = CK_HMAX of ck_layout.hpp: rows per chunk tile 
 
 struct CkP {
   const double2* uv;     // [rows][64]
-  const uint32_t* li;    // [li_rows][64] two 16-bit landmark slots per word
+  const uint32_t* li;    // [li_rows][64] two 16-bit words per entry: 3 x the landmark's slot (its first LDS double), 0xffff: none
   const double* w;       // [rows][64] robust weights (only with a robust norm)
   const int4* tile;      // first row, height, flags, first li row
   const int2* lane_meta; // [tiles][64] x: rank of the lane's camera | first << 16 | last << 22 lane sharing its accumulator
@@ -36,6 +36,7 @@ struct CkP {
   const int* slot_rec;   // partial record of each workgroup slot
   const double* img;     // [21][pad] structure-of-arrays record image by rank: z (12), then P3 row-major (9)
   int nb, slots, pad;
+  unsigned uv_bytes, li_bytes;  // sizes of uv (= w's in doubles x 2) and li: the rows are read through buffer descriptors
   unsigned long long* stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): [grid][16][CK_N_STAMPS] s_memtime stamps, else nullptr
 };
 constexpr int CK_N_STAMPS = 40;
@@ -98,11 +99,11 @@ __device__ inline void ck_obs_forward(const Dp& d, double2 uv, double w, const d
   double red[3];
   ck_forward_math(o, zz, P3, hx, hy, hz, red);
 #ifdef POVAR_CK_EXP_NOATOMIC  // timing-only experiment: plain stores instead of the three LDS atomics
-  lu[s] = red[0]; lu[S + s] = red[1]; lu[2 * S + s] = red[2];
+  lu[s] = red[0]; lu[s + 1] = red[1]; lu[s + 2] = red[2];
 #else
-  __hip_atomic_fetch_add(lu + s, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  __hip_atomic_fetch_add(lu + S + s, red[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  __hip_atomic_fetch_add(lu + 2 * S + s, red[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(lu + s, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (s = 3 x slot)
+  __hip_atomic_fetch_add(lu + s + 1, red[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(lu + s + 2, red[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 }
 __device__ inline void ck_obs_backward(const Dp& d, double2 uv, double w, const double* P3, double hx, double hy, double hz,
@@ -126,6 +127,17 @@ __device__ inline void ck_obs_backward(const Dp& d, double2 uv, double w, const 
 // iteration j + 1 touch what iteration j has just requested, so every row waited for its predecessor's loads whatever
 // D was -- s_waitcnt vmcnt(0) at the top of the loop, 1400 cycles per row on the way back.)  D is even: the two
 // landmark slots of an li word then sit at a static shift.
+// buffer descriptors of the row arrays (wave-uniform: built once per kernel from kernel arguments)
+struct CkRows {
+  __amdgpu_buffer_rsrc_t uv, li, w;
+};
+__device__ inline CkRows ck_rows(const CkP& k) {
+  CkRows R;
+  R.uv = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(k.uv), 0, k.uv_bytes, 0x00020000);
+  R.li = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(k.li), 0, k.li_bytes, 0x00020000);
+  R.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(k.w), 0, k.w ? k.uv_bytes / 2 : 0, 0x00020000);
+  return R;
+}
 template <int D, bool ROBUST>
 struct CkStream {
   double2 uv[D];
@@ -141,19 +153,30 @@ struct CkStream {
   }
   // buffer i <- row j of the tile (j clamped into the tile: a request past its end re-reads its last row -- a cache hit --
   // so that every step issues the same loads and the wait counters can be exact: with loads under `if (j < h)` the
-  // compiler waited for all but the newest load, i.e. for the row it had requested one step earlier)
-  __device__ inline void load(const CkP& k, int row0, int li0, int j, int h, int lane, int i) {
+  // compiler waited for all but the newest load, i.e. for the row it had requested one step earlier).
+  // The rows are read through buffer descriptors (CkRows): descriptor in SGPRs + the lane's constant 32-bit byte offset +
+  // the row's byte offset as the scalar offset -- no VALU instruction per load (a flat load took a 64-bit add each, two
+  // per row and pass in loops that are VALU-bound).
+  __device__ inline void load(const CkRows& R, int row0, int li0, int j, int h, int lane, int i) {
     j = j < 0 ? 0 : (j >= h ? h - 1 : j);
-    uv[i] = k.uv[((size_t)row0 + j) * WAVE + lane];
-    w[i] = k.li[((size_t)li0 + (j >> 1)) * WAVE + lane];
-    if (ROBUST) rw[i] = k.w[((size_t)row0 + j) * WAVE + lane];
+    const unsigned ul = (unsigned)lane;
+    const unsigned ro = (unsigned)(row0 + j) * (unsigned)(WAVE * 16), lo = (unsigned)(li0 + (j >> 1)) * (unsigned)(WAVE * 4);
+    typedef unsigned __attribute__((ext_vector_type(4))) u4;
+    typedef unsigned __attribute__((ext_vector_type(2))) u2;
+    const u4 a = __builtin_amdgcn_raw_buffer_load_b128(R.uv, ul * 16u, ro, 0);
+    uv[i] = make_double2(__longlong_as_double(((long long)a.y << 32) | a.x), __longlong_as_double(((long long)a.w << 32) | a.z));
+    w[i] = __builtin_amdgcn_raw_buffer_load_b32(R.li, ul * 4u, lo, 0);
+    if (ROBUST) {
+      const u2 b = __builtin_amdgcn_raw_buffer_load_b64(R.w, ul * 8u, ro >> 1, 0);
+      rw[i] = __longlong_as_double(((long long)b.y << 32) | b.x);
+    }
   }
   // step n of the walk is row n (DIR = +1) or row h - 1 - n (DIR = -1: the way back starts with the rows the way forward
   // read last, the ones most likely still in the XCD's L2); buffer n % D holds it
   template <int DIR>
-  __device__ inline void start(const CkP& k, int row0, int li0, int h, int lane) {
+  __device__ inline void start(const CkRows& R, int row0, int li0, int h, int lane) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) load(k, row0, li0, DIR > 0 ? i : h - 1 - i, h, lane, i);
+    for (int i = 0; i < D; ++i) load(R, row0, li0, DIR > 0 ? i : h - 1 - i, h, lane, i);
   }
 };
 #ifdef POVAR_CK_EXP_NOBWDROWS  // timing-only experiment: the way back re-reads ONE row of the tile (what rows kept on chip would cost)
@@ -163,19 +186,19 @@ struct CkStream {
 #endif
 // the rows of one tile (h >= 1); st has been started on the tile (steps 0 .. D-1 are in flight)
 template <int D, bool ROBUST>
-__device__ inline void ck_forward_step(const Dp& d, const CkP& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+__device__ inline void ck_forward_step(const Dp& d, const CkRows& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
                                        const double* zz, const double* P3, const double* lh, double* lu, int S, int j, int i) {
   const double2 uv = st.uv[i];
   const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
   const double rw = ROBUST ? st.rw[i] : 1.0;
   st.load(k, row0, li0, j + D, h, lane, i);
   if (s != 0xffffu) {
-    const double hx = lh[s], hy = lh[S + s], hz = lh[2 * S + s];
+    const double hx = lh[s], hy = lh[s + 1], hz = lh[s + 2];  // (s = 3 x slot: ck_layout.hpp)
     ck_obs_forward(d, uv, rw, zz, P3, hx, hy, hz, lu, S, s);
   }
 }
 template <int D, bool ROBUST>
-__device__ inline void ck_forward_rows(const Dp& d, const CkP& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+__device__ inline void ck_forward_rows(const Dp& d, const CkRows& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
                                        const double* zz, const double* P3, const double* lh, double* lu, int S) {
   int n0 = 0;
 #pragma nounroll
@@ -188,7 +211,7 @@ __device__ inline void ck_forward_rows(const Dp& d, const CkP& k, CkStream<D, RO
     if (n0 + i < h) ck_forward_step<D, ROBUST>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S, n0 + i, i);
 }
 template <int D, bool ROBUST>
-__device__ inline void ck_backward_step(const Dp& d, const CkP& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+__device__ inline void ck_backward_step(const Dp& d, const CkRows& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
                                         const double* P3, const double* lh, const double* lg, int S, double* y, int j, int i) {
   const double2 uv = st.uv[i];
   const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
@@ -199,14 +222,14 @@ __device__ inline void ck_backward_step(const Dp& d, const CkP& k, CkStream<D, R
     const double hx = uv.x, hy = uv.y, hz = rw;
     const double g[3] = {uv.y, uv.x, rw};
 #else
-    const double hx = lh[s], hy = lh[S + s], hz = lh[2 * S + s];
-    const double g[3] = {lg[s], lg[S + s], lg[2 * S + s]};
+    const double hx = lh[s], hy = lh[s + 1], hz = lh[s + 2];
+    const double g[3] = {lg[s], lg[s + 1], lg[s + 2]};
 #endif
     ck_obs_backward(d, uv, rw, P3, hx, hy, hz, g, y);
   }
 }
 template <int D, bool ROBUST>
-__device__ inline void ck_backward_rows(const Dp& d, const CkP& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+__device__ inline void ck_backward_rows(const Dp& d, const CkRows& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
                                         const double* P3, const double* lh, const double* lg, int S, double* y) {
   int n0 = 0;
 #pragma nounroll
@@ -288,14 +311,18 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
   const int done = d.flags[1];
   extern __shared__ double ck_lds[];
   constexpr int GW = NW / NG;  // wavefronts of a group
+  const CkRows R = ck_rows(k);
   const int S = k.slots;
   const int lane0 = threadIdx.x & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int grp = NG > 1 ? wave_all / GW : 0;   // (consecutive wavefronts go to the SIMDs in turn: every SIMD hosts both groups)
   const int wave = NG > 1 ? wave_all % GW : wave_all;  // number inside the group
   int* gbase = reinterpret_cast<int*>(ck_lds);            // [NG] barrier counters of the groups (16 bytes reserved)
-  double* lh = ck_lds + 2 + (size_t)grp * 6 * S;  // [3][S] landmark coordinates of the group's batch
-  double* lu = lh + 3 * S;                    // [3][S] u = Jl^T Jp x, then g = G u
+  // Slot-major ([S][3], 24-byte stride): the three entries of a landmark are ONE address + immediate offsets (component-
+  // major [3][S] cost six address additions per observation and pass in loops that are VALU-bound at 44 instructions
+  // per row); slot -> bank pair is still a bijection mod 32 (6 s mod 64): the layout's row placement is unchanged.
+  double* lh = ck_lds + 2 + (size_t)grp * 6 * S;  // [S][3] landmark coordinates of the group's batch
+  double* lu = lh + 3 * S;                    // [S][3] u = Jl^T Jp x, then g = G u
   double* acc = ck_lds + 2 + (size_t)NG * 6 * S;  // [n_acc][13] per-camera accumulators of the workgroup
   int* gcnt = gbase + grp;
   int ggen = 0;
@@ -378,7 +405,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       const int rk = rank < 0 ? 0 : rank;
       ck_load_z(d, rk, zz);
       ck_load_p3(d, rk, P3);
-      st.template start<1>(k, row0, li0, h, lane);
+      st.template start<1>(R, row0, li0, h, lane);
     }
     CK_STAMP(8 * (b / NG) + 1);
     // ---- landmark coordinates of the batch into LDS (requested a phase ago), u = 0
@@ -387,23 +414,23 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       const int m = wave + q * GW;
       if (t0 + b + k.nb * m < t1) {
         const int s = m * WAVE + lane;
-        lh[s] = hn[q][0];
-        lh[S + s] = hn[q][1];
-        lh[2 * S + s] = hn[q][2];
-        lu[s] = 0;
-        lu[S + s] = 0;
-        lu[2 * S + s] = 0;
+        lh[3 * s] = hn[q][0];
+        lh[3 * s + 1] = hn[q][1];
+        lh[3 * s + 2] = hn[q][2];
+        lu[3 * s] = 0;
+        lu[3 * s + 1] = 0;
+        lu[3 * s + 2] = 0;
       }
     }
     for (int m = wave + HM * GW; t0 + b + k.nb * m < t1; m += GW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9) * WAVE + lane;
       const int s = m * WAVE + lane;
-      lh[s] = rp[0];
-      lh[S + s] = rp[WAVE];
-      lh[2 * S + s] = rp[2 * WAVE];
-      lu[s] = 0;
-      lu[S + s] = 0;
-      lu[2 * S + s] = 0;
+      lh[3 * s] = rp[0];
+      lh[3 * s + 1] = rp[WAVE];
+      lh[3 * s + 2] = rp[2 * WAVE];
+      lu[3 * s] = 0;
+      lu[3 * s + 1] = 0;
+      lu[3 * s + 2] = 0;
     }
     // the tile after the first: its record and first rows (DB), the metadata of the one after that
     auto request_next_fwd = [&]() {
@@ -414,7 +441,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         const int rk = rank_n < 0 ? 0 : rank_n;
         ck_load_z(d, rk, zn);
         ck_load_p3(d, rk, Pn);
-        stn.template start<1>(k, row0n, li0n, hnx, lane);
+        stn.template start<1>(R, row0n, li0n, hnx, lane);
       }
     };
     request_next_fwd();
@@ -423,7 +450,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     CK_STAMP(8 * (b / NG) + 3);
     // ---- forward
     while (t < tb1) {
-      ck_forward_rows<SD, ROBUST>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S);
+      ck_forward_rows<SD, ROBUST>(d, R, st, row0, li0, h, lane, zz, P3, lh, lu, S);
       if (b < NG) CK_STAMP(20 + 2 * q_t);
       if (tn >= tb1) break;  // (t, q_t, rank, P3 stay on the last tile: the way back starts there)
       t = tn;
@@ -445,7 +472,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         const int rk = rank < 0 ? 0 : rank;
         ck_load_z(d, rk, zz);
         ck_load_p3(d, rk, P3);
-        st.template start<1>(k, row0, li0, h, lane);
+        st.template start<1>(R, row0, li0, h, lane);
       }
       if (b < NG) CK_STAMP(19 + 2 * q_t);
     }
@@ -481,7 +508,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         seg_p = ck_seg(mp.x);
         acc_p = mp.y;
       }
-      st.template start<-1>(k, row0, li0, h, lane);
+      st.template start<-1>(R, row0, li0, h, lane);
     }
     group_barrier();
     CK_STAMP(8 * (b / NG) + 5);
@@ -491,20 +518,20 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       const int m = wave + q * GW;
       if (t0 + b + k.nb * m < t1) {
         const int s = m * WAVE + lane;
-        const double u0 = lu[s], u1 = lu[S + s], u2 = lu[2 * S + s];
-        lu[s] = G[q][0] * u0 + G[q][1] * u1 + G[q][2] * u2;
-        lu[S + s] = G[q][1] * u0 + G[q][3] * u1 + G[q][4] * u2;
-        lu[2 * S + s] = G[q][2] * u0 + G[q][4] * u1 + G[q][5] * u2;
+        const double u0 = lu[3 * s], u1 = lu[3 * s + 1], u2 = lu[3 * s + 2];
+        lu[3 * s] = G[q][0] * u0 + G[q][1] * u1 + G[q][2] * u2;
+        lu[3 * s + 1] = G[q][1] * u0 + G[q][3] * u1 + G[q][4] * u2;
+        lu[3 * s + 2] = G[q][2] * u0 + G[q][4] * u1 + G[q][5] * u2;
       }
     }
     for (int m = wave + HM * GW; t0 + b + k.nb * m < t1; m += GW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9 + 3) * WAVE + lane;
       const double g0 = rp[0], g1 = rp[WAVE], g2 = rp[2 * WAVE], g3 = rp[3 * WAVE], g4 = rp[4 * WAVE], g5 = rp[5 * WAVE];
       const int s = m * WAVE + lane;
-      const double u0 = lu[s], u1 = lu[S + s], u2 = lu[2 * S + s];
-      lu[s] = g0 * u0 + g1 * u1 + g2 * u2;
-      lu[S + s] = g1 * u0 + g3 * u1 + g4 * u2;
-      lu[2 * S + s] = g2 * u0 + g4 * u1 + g5 * u2;
+      const double u0 = lu[3 * s], u1 = lu[3 * s + 1], u2 = lu[3 * s + 2];
+      lu[3 * s] = g0 * u0 + g1 * u1 + g2 * u2;
+      lu[3 * s + 1] = g1 * u0 + g3 * u1 + g4 * u2;
+      lu[3 * s + 2] = g2 * u0 + g4 * u1 + g5 * u2;
     }
     // the tile before the current one on the way back: its P3 and last rows (DB), the metadata of the one before that
     auto request_next_bwd = [&]() {
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
           acc_pp = mp.y;
         }
         ck_load_p3(d, rank_p < 0 ? 0 : rank_p, Pn);
-        stn.template start<-1>(k, row0n, li0n, hnx, lane);
+        stn.template start<-1>(R, row0n, li0n, hnx, lane);
       }
     };
     request_next_bwd();
@@ -529,7 +556,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       double y[12];
 #pragma unroll
       for (int m = 0; m < 12; ++m) y[m] = 0;
-      ck_backward_rows<SD, ROBUST>(d, k, st, row0, li0, h, lane, P3, lh, lu, S, y);
+      ck_backward_rows<SD, ROBUST>(d, R, st, row0, li0, h, lane, P3, lh, lu, S, y);
       ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, part_out);
       if (tp >= tb1) break;
       t = tp;
@@ -552,7 +579,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
           acc_p = mp.y;
         }
         ck_load_p3(d, rank < 0 ? 0 : rank, P3);
-        st.template start<-1>(k, row0, li0, h, lane);
+        st.template start<-1>(R, row0, li0, h, lane);
       }
     }
     CK_STAMP(8 * (b / NG) + 7);

@@ -82,9 +82,11 @@ int main(int argc, char** argv) {
           for (int j = 0; j < ti.y; ++j) {
             const size_t idx = ((size_t)ti.x + j) * 64 + lane;
             const uint32_t word = K.li[((size_t)ti.w + (j >> 1)) * 64 + lane];
-            const uint32_t li = (j & 1) ? word >> 16 : word & 0xffffu;
+            const uint32_t li3 = (j & 1) ? word >> 16 : word & 0xffffu;  // 3 x slot
             const int s = K.src[idx];
-            if (s < 0) { CHECK(li == CK_NONE); continue; }
+            if (s < 0) { CHECK(li3 == CK_NONE); continue; }
+            CHECK(li3 % 3 == 0);
+            const uint32_t li = li3 / 3;
             ++n_lane;
             CHECK(rank >= 0 && (int)li < K.slots);
             const int i = obs_of_slot[s];
