@@ -43,7 +43,8 @@ class Tokens {
       if (got == 0) break;
       n += got;
     }
-    buf_.resize(n);
+    buf_.resize(n + 1);
+    buf_[n] = 0;  // strtod stops here
     p_ = buf_.data();
     end_ = p_ + n;
   }
@@ -52,7 +53,9 @@ class Tokens {
     const char* q = p_ < end_ && *p_ == '+' ? p_ + 1 : p_;
     int v = 0;
     const auto r = std::from_chars(q, end_, v);
-    if (r.ec != std::errc() || r.ptr == q) throw std::runtime_error("parse");
+    // the number must be the whole token ("12.5" where an index is expected is an error, as it is for fscanf("%d") followed
+    // by the next field: consuming a part of it would shift every later field of the piece)
+    if (r.ec != std::errc() || r.ptr == q || (r.ptr < end_ && (unsigned char)*r.ptr > ' ')) throw std::runtime_error("parse");
     p_ = r.ptr;
     return v;
   }
@@ -100,14 +103,12 @@ class Tokens {
       p_ = q;
       return neg ? -v : v;
     }
-    char tmp[64];
-    size_t len = 0;
-    while (p_ + len < end_ && (unsigned char)p_[len] > ' ' && len + 1 < sizeof tmp) { tmp[len] = p_[len]; ++len; }
-    tmp[len] = 0;
+    // everything else: strtod on the buffer itself (NUL-terminated behind end_: the constructor keeps one spare byte),
+    // and the number must be the whole token
     char* e = nullptr;
-    const double v = std::strtod(tmp, &e);
-    if (e == tmp) throw std::runtime_error("parse");
-    p_ += e - tmp;
+    const double v = std::strtod(p_, &e);
+    if (e == p_ || e > end_ || (e < end_ && (unsigned char)*e > ' ')) throw std::runtime_error("parse");
+    p_ = e;
     return v;
   }
 

@@ -5,6 +5,12 @@
 
 #include "../../povar_amd/csrc/host/bal_problem.hpp"
 
+// bal_problem.cpp's load_normalized_bal_problem reports through summarize_problem (bal_bundle_adjustment.cpp, which drags
+// the device library in): this check only loads -- a proper stub instead of letting the linker ignore what is missing
+namespace povar_host {
+void summarize_problem(const BalProblem&, const std::string&, bool, DatasetSummary&) {}
+}  // namespace povar_host
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   povar_host::BalProblem p;

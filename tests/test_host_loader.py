@@ -20,7 +20,8 @@ def _load(path):
     return r.returncode, r.stdout, r.stderr
 
 
-SPELLINGS = ["0", "-0", "7", "-12.5", "+3.25", ".5", "-.125", "3.", "1e-3", "1E+3", "-2.5e-07", "123456.789012",
+LONG = "0." + "123456789" * 9                      # 83 characters: longer than any stack copy of a token
+SPELLINGS = ["0", "-0", "7", LONG, "-12.5", "+3.25", ".5", "-.125", "3.", "1e-3", "1E+3", "-2.5e-07", "123456.789012",
              "0.000001", "999999999999999", "1234567890123456789", "0.1234567890123456789", "1e22", "1e23", "1e-22",
              "1e-23", "4.9e-324", "1.7976931348623157e308", "0x1.8p1", "2.2250738585072014e-308", "123456789.123456789e-5",
              "00012.50", "1e0005"]
@@ -77,10 +78,11 @@ def test_loader_matches_the_python_mirror_on_a_generated_file(tmp_path):
     assert np.array_equal(cams, np.asarray(q.cams).reshape(-1, 12))
 
 
-@pytest.mark.parametrize("damage", ["truncated", "letters", "duplicate", "index"])
+@pytest.mark.parametrize("damage", ["truncated", "letters", "duplicate", "index", "fraction-as-index", "glued"])
 def test_loader_rejects_damaged_files(tmp_path, damage):
     """FATAL like the reference (bal_problem.cpp:227, 297-300): a short file, a non-number, a repeated (camera, landmark)
-    pair, an index out of range."""
+    pair, an index out of range; and a number that is only PART of its token -- a fraction where an index belongs, two
+    values glued together -- which would otherwise shift every later field of the piece without an error."""
     head = "2 2 3\n0 0 1.0 2.0\n1 0 3.0 4.0\n"
     third = {"duplicate": "1 0 5.0 6.0\n", "index": "2 1 5.0 6.0\n"}.get(damage, "0 1 5.0 6.0\n")
     body = head + third + "\n".join(["0.5"] * 30) + "\n" + "\n".join(["1.5"] * 6) + "\n"
@@ -88,6 +90,10 @@ def test_loader_rejects_damaged_files(tmp_path, damage):
         body = body[: len(body) - 20]
     if damage == "letters":
         body = body.replace("3.0", "abc", 1)
+    if damage == "fraction-as-index":
+        body = body.replace("1 0 3.0", "1.5 0 3.0", 1)
+    if damage == "glued":
+        body = body.replace("3.0 4.0", "3.0x4.0 9", 1)
     f = tmp_path / "bad.txt"
     f.write_text(body)
     rc, out, err = _load(str(f))
