@@ -254,6 +254,10 @@ def main():
                          "one all-reduce per term; the once-per-solve exchanges keep the communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the stored-tile comparison leg")
+    ap.add_argument("--with-final", action="store_true",
+                    help="also run the final-13682 shape (HUBER 20, 29 M observations: a term loop whose working set is ten "
+                         "times the Infinity Cache) in a child process and report its rate and measured fraction under "
+                         "`final_13682` (about a minute of problem generation and layout)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -573,8 +577,12 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": ((traffic if traffic else model_bytes) / (e0_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if e0_ms > 0 else 0.0,
-            "basis": "measured HBM bytes (rocprofv3 PMC passes on these kernel sources)" if traffic
-                     else "model bytes of the kernel pair (no PMC figure for these kernel sources / this workload)",
+            "basis": ("measured bytes at the L2's memory side (rocprofv3 PMC passes on these kernel sources; 2 FETCH_SIZE + "
+                      "WRITE_SIZE, calibrated: profiles/r04_fetch_calibration.txt)" if traffic
+                      else "model bytes of the kernel pair (no PMC figure for these kernel sources / this workload)") +
+                     ("; the counters count Infinity-Cache hits and this workload's per-term working set is about the size of "
+                      "the 256 MiB cache: a fraction of the HBM peak in fabric bytes, not all of it from HBM"
+                      if model_bytes < 600e6 else ""),
             "traffic": traffic,
             "traffic_note": traffic_note,
             "model_bytes_per_launch": model_bytes,
@@ -681,6 +689,19 @@ def main():
         out["cpu_baseline"] = None
 
     ctx.close()
+    if rank == 0 and world == 1 and args.with_final:
+        # the one workload of BASELINE.json that is HBM-resident for real (2-3.7 GB per term): its own process, its own line
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--problem", "final-13682", "--robust-norm", "HUBER",
+                            "--huber", "20", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"],
+                           capture_output=True, text=True)
+        try:
+            f = json.loads(r.stdout.strip().splitlines()[-1])
+            out["final_13682"] = {"value": f["value"], "unit": f["unit"], "ms_per_step": f["ms_per_step"],
+                                  "kernel_ms": f["kernel_ms"], "roofline": f["roofline"], "workload": f["config"]["workload"],
+                                  "e0_layout": f["config"].get("e0_layout")}
+        except Exception as e:  # the headline is unaffected
+            out["final_13682"] = {"error": f"{type(e).__name__}: {e}", "stderr_tail": r.stderr[-500:]}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
