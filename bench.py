@@ -286,6 +286,15 @@ def main():
         sys.exit("bench.py needs a HIP device")
     # one rank per GPU; ranks share devices only when there are fewer GPUs than ranks (1-GPU test boxes)
     device = local_rank % n_dev
+    if world > n_dev and "POVAR_CU_MASK" not in os.environ:
+        # ranks that share a device get disjoint ranges of its CUs (two half devices instead of two processes taking turns
+        # on one: a rank that waits inside a kernel for its peer -- the peer-to-peer exchange -- would otherwise keep the peer
+        # off the device until its bounded wait runs out)
+        share = (world + n_dev - 1) // n_dev
+        cus = capi.lib().povar_device_cu_count(device)
+        j = local_rank // n_dev
+        if cus >= 2 * share:
+            os.environ["POVAR_CU_MASK"] = f"{j * (cus // share)}-{(j + 1) * (cus // share) - 1}"
     lb, le = capi.shard_range(prob.lm_off, world, rank)
     ob, oe = int(prob.lm_off[lb]), int(prob.lm_off[le])
     mode = {"implicit": capi.E0_IMPLICIT, "tiles": capi.E0_TILES, "ldsacc": capi.E0_IMPLICIT_LDSACC,

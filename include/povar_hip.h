@@ -82,6 +82,9 @@ typedef struct {
 const char* povar_last_error(void);
 /* number of visible HIP devices (0 without a GPU; < 0 on a runtime error) */
 int povar_device_count(void);
+/* compute units of a device (hipDeviceProp_t::multiProcessorCount; < 0 on a runtime error).  A launcher that puts several
+ * ranks on ONE device gives each a range of them (environment POVAR_CU_MASK=<first>-<last>, read by povar_create). */
+int povar_device_cu_count(int32_t device);
 
 /* LinearizorPowerVarproj ctor (linearizor_power_varproj.cpp:21-38) + LinearizationVarProj ctor /
  * allocate_landmark (linearization_varproj.hpp:42-61, landmark_block.hpp:101-133).

@@ -79,6 +79,7 @@ struct povar_ctx {
   int n_bins = 0, n_slots = 0, n_items = 0, n_long = 0;
   int n_reg_blocks = 0, n_cam_blocks = 0;
   int n_hot = 0, n_hot_acc = 0, e0c_grid = 0, e0c_bins_per_wg = 0;
+  int cu_limit = 0;              // CUs of the stream's mask (POVAR_CU_MASK), 0: the whole device
   int64_t n_cold = 0;
   int n_cold_items = 0;
   povar_options opt{};
@@ -1117,6 +1118,12 @@ int povar_device_count(void) {
   return n;
 }
 
+int povar_device_cu_count(int32_t device) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  return prop.multiProcessorCount;
+}
+
 int povar_shard_range(int32_t n_lms, const int32_t* lm_offsets, int32_t world, int32_t rank,
                       int32_t* lm_begin, int32_t* lm_end) {
   if (!lm_offsets || world < 1 || rank < 0 || rank >= world) return fail(-1, "bad shard arguments");
@@ -1180,7 +1187,25 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   c->n_obs = n_obs;
   c->lm_off.assign(lm_offsets, lm_offsets + n_lms + 1);
   for (int l = 0; l < n_lms; ++l) c->has_empty_lm |= lm_offsets[l + 1] == lm_offsets[l];
-  HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  // POVAR_CU_MASK=<first>-<last>: the context's stream runs on that range of CUs only.  For several contexts that share ONE
+  // device and wait for each other inside kernels (the peer-to-peer term exchange with two ranks on a one-GPU box): an
+  // E0 workgroup takes a CU's whole register file, so the bounded spin of one rank's reduce kernel on every CU kept the
+  // other rank's E0 kernel off the device until the spin timed out.  Disjoint CU ranges make the ranks two half devices.
+  if (const char* g = std::getenv("POVAR_CU_MASK")) {
+    int first = 0, last = -1;
+    hipDeviceProp_t prop;
+    HIP_TRY_C(hipGetDeviceProperties(&prop, options->device));
+    if (std::sscanf(g, "%d-%d", &first, &last) != 2 || first < 0 || last < first || last >= prop.multiProcessorCount) {
+      povar_destroy(c);
+      return fail(-1, "POVAR_CU_MASK: expected <first>-<last> inside the device's CU range");
+    }
+    std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
+    for (int i = first; i <= last; ++i) mask[i / 32] |= 1u << (i % 32);
+    HIP_TRY_C(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()));
+    c->cu_limit = last - first + 1;  // "one workgroup per CU" then means per CU of the range
+  } else {
+    HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  }
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_NO_ERR_MEMO")) c->no_err_memo = g[0] == '1';
   if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
@@ -1210,7 +1235,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     // one 1024-thread workgroup per CU for the LDS-cached E0 kernel
     hipDeviceProp_t prop;
     HIP_TRY_C(hipGetDeviceProperties(&prop, options->device));
-    int cus = std::max(prop.multiProcessorCount, 1);
+    int cus = std::max(c->cu_limit > 0 ? c->cu_limit : prop.multiProcessorCount, 1);
     if (const char* e = std::getenv("POVAR_E0_WGS")) cus = std::max(std::atoi(e), 1);  // tuning knob: E0 workgroups
     c->e0c_bins_per_wg = std::max((c->n_bins + cus - 1) / cus, 1);
     c->e0c_grid = (c->n_bins + c->e0c_bins_per_wg - 1) / c->e0c_bins_per_wg;

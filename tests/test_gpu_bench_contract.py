@@ -91,14 +91,14 @@ def test_bench_two_ranks_p2p_exchange(problem):
     path = os.path.join(ROOT, "gpurun_out", f"inc_p2p_{problem}.npy")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     outs = {}
+    # Two ranks on ONE device: bench.py gives ranks that share a device disjoint halves of its CUs (POVAR_CU_MASK:
+    # the library's stream is created with a CU mask and "one workgroup per CU" follows it), so that both ranks'
+    # term kernels are resident together and a peer's push arrives inside the bounded wait.  Without it the ranks
+    # took turns on the device: an E0 workgroup needs a CU's whole register file, the spinning reduce kernel of
+    # one rank sat on every CU, and its wait timed out before the other rank was scheduled (round 3: skipped on the
+    # driver's box; round 4 with 120 workgroups per rank and no mask: passed or failed with the timing of the day).
     for tag, extra in (("p2p", ["--gpus", "2", "--p2p"]), ("one", ["--no-cpu-baseline"])):
         env = dict(os.environ, POVAR_BENCH_DUMP_INC=path + tag + ".npy")
-        if tag == "p2p" and problem == "venice-1778":
-            # Two ranks on ONE device: each rank's E0 kernels are cut for half of its CUs (120 workgroups of the 256), so
-            # that both ranks' term kernels are resident together and a peer's push arrives inside the bounded wait --
-            # with 256 workgroups each, the ranks took turns on the device and the wait of one could time out while the
-            # other was not even scheduled (round 3: this case fell back to the all-reduce on the driver's box and skipped).
-            env["POVAR_E0_WGS"] = "120"
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--problem", problem, "--steps", "3",
                             "--warmup", "1", "--no-secondary"] + extra, capture_output=True, text=True, timeout=900,
                            cwd=ROOT, env=env)
