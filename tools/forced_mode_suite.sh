@@ -17,3 +17,10 @@ run POVAR_E0_V1=0 POVAR_LPL_NOGRID=1 POVAR_LONG_SEPARATE=1 POVAR_HOT_ACC=40 POVA
 run POVAR_PREPARE_V1=1 POVAR_NO_FUSE=1
 run POVAR_NO_GRAPH=1
 run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_LPL_PLACE=sync
+# the camera-chunk kernel under stress: few accumulators (most chunks write their own record), many batches / short chunks,
+# seven workgroups (dozens of tiles per wavefront), the two-group instantiation, the 12-wavefront one on a layout cut for it
+run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_HOT_ACC=24 POVAR_LPL_STRATEGY=range
+run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_CK_NB=3 POVAR_CK_HMAX=5 POVAR_LPL_PLACE=async
+run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_LPL_K0=2 POVAR_E0_WGS=7
+run POVAR_E0_V1=0 POVAR_E0_CK=4 POVAR_CK_NB=4
+run POVAR_E0_V1=0 POVAR_E0_CK=3 POVAR_NO_GRAPH=1
