@@ -164,9 +164,7 @@ struct povar_ctx {
     }
   } ck, pl_ck;
   DevBuf<unsigned long long> ck_stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): CkP::stamps
-  DevBuf<double> ck_img;         // [21][ck_pad] structure-of-arrays record image (Dp::ck_img)
   DevBuf<int2> ck_zero_range;    // [n_cams] empty runs: e0_ck leaves no per-observation cold view to the per-camera kernels
-  int ck_pad = 0;
   int ck_variant = 0;            // 0: e0_lpl; 1..CK_VARIANTS: e0_ck instantiation (POVAR_CK_VARIANTS)
   int64_t ckw_lin_id = -1;       // linearisation whose robust weights CkDev::w holds
   bool ck_auto = true;           // the library picks e0_lpl or e0_ck by timing both on this problem (ck_autotune); false: forced
@@ -498,8 +496,8 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
 }
 CkP ck_params(const povar_ctx* c) {
   const auto& D = c->ck;
-  return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p, c->ck_img.p,
-             D.nb, D.slots, c->ck_pad, (unsigned)(D.uv.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t)), c->ck_stamps.p};
+  return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p,
+             D.nb, D.slots, (unsigned)(D.uv.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t)), c->ck_stamps.p};
 }
 // e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight, double-buffered
 // tile records, groups of wavefronts working on different batches (povar_kernels_ck.hpp)
@@ -1420,9 +1418,6 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (options->robust_norm) HIP_TRY_C(c->v2_w.alloc((size_t)std::max<int64_t>(c->v2_rows, 1) * WAVE, &c->bytes));
     n_cold_lpl = V.cold_lm.size();
     if (want_ck && !V.tile.empty()) {
-      c->ck_pad = (n_cams + 63) & ~63;
-      HIP_TRY_C(c->ck_img.alloc((size_t)21 * c->ck_pad, &c->bytes));
-      HIP_TRY_C(hipMemset(c->ck_img.p, 0, sizeof(double) * 21 * c->ck_pad));
       if (int rc = upload(c->ck_zero_range, std::vector<int2>((size_t)n_cams, make_int2(0, 0)), c)) { povar_destroy(c); return rc; }
       if (place_mode != 2) {  // (else: built from the placed rows by the host thread, swapped in with them)
         const auto tk = std::chrono::steady_clock::now();
@@ -1535,7 +1530,6 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.cmv = CmView{c->cm_slot.p, c->cm_h.p, n_obs, c->item_off.p, c->cam_item_off.p, c->item_part.p, c->n_items, nullptr};
   d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
   d.hot_rec = c->hot_rec.p;
-  d.ck_img = c->ck_img.p; d.ck_pad = c->ck_pad;
   d.hot_cams = c->hot_cams.p; d.n_hot = std::min(n_cams, HOT_MAX);
   d.part_range = nullptr;
   d.p2p_peer = nullptr; d.p2p_epoch = nullptr; d.p2p_world = 1; d.p2p_rank = 0;
@@ -1561,7 +1555,7 @@ void povar_destroy(povar_ctx* c) {
   (void)hipSetDevice(c->opt.device);
   c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
   c->pl_c3_src.release(); c->c3_src.release();
-  c->ck.release(); c->pl_ck.release(); c->ck_img.release(); c->ck_zero_range.release(); c->ck_stamps.release();
+  c->ck.release(); c->pl_ck.release(); c->ck_zero_range.release(); c->ck_stamps.release();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->pin) (void)hipHostFree(c->pin);
@@ -1777,8 +1771,6 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   c->new_linearization_point = false;
   c->d.lambda_lm = solver_type == POVAR_POWER_SCHUR_COMPLEMENT ? lambda : 0.0;  // cpp:197-200
   hipLaunchKernelGGL(build_hot_rec, dim3(grid_for((int64_t)c->n_cams * 12, 256)), dim3(256), 0, c->stream, c->d, 0);
-  if (c->ck_img.p)
-    hipLaunchKernelGGL(ck_build_img_p3, dim3(grid_for((int64_t)c->n_cams * 9, 256)), dim3(256), 0, c->stream, c->d, c->ck_img.p, c->ck_pad);
   if (c->use_lpl && c->use_lpl_prepare && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC) {
     // lane-per-landmark K7: Hll^-1, landmark records and the per-camera partial sums of b in one kernel, then the
     // per-camera sum of the partials and the cold observations (same kernel as the per-term one, output b)
@@ -2467,7 +2459,7 @@ int povar_layout_finalize(povar_ctx* c, int32_t wait) {
 int povar_set_e0_kernel(povar_ctx* c, int32_t kernel) {
   if (int rc = check_ctx(c)) return rc;
   if (kernel < -1 || kernel > CK_VARIANTS) return fail(-1, "unknown E0 kernel");
-  if (kernel > 0 && !c->ck_img.p) return fail(-1, "the camera-chunk layout was not built for this context");
+  if (kernel > 0 && !c->ck_zero_range.p) return fail(-1, "the camera-chunk layout was not built for this context");
   if (kernel < 0) {  // back to the library's own choice
     c->ck_auto = true;
     c->ck_tuned = false;

@@ -127,8 +127,6 @@ struct Dp {
   const int* hot_cams;  // cameras cached in LDS by e0_lm_cached, most observed first
   double* hot_rec;      // [HOT_MAX][24] contiguous LDS image of the hot cameras' records: z_c (12, rewritten by
                         // every B^-1 kernel) then the static camera part (step 1: P[:, :3] (9), step 2: P (12))
-  double* ck_img;       // [21][ck_pad] structure-of-arrays mirror of the same image by rank (e0_ck gathers one record
-  int ck_pad;           // per lane: neighbouring ranks then share cache lines); nullptr: not kept
   int n_hot;
   const int* long_lm;
   const int* long_first;
@@ -2603,7 +2601,6 @@ __device__ inline void store_z(const Dp& d, int c, int j, double v) {
   d.z[12 * (size_t)c + j] = v;
   const int r = d.cam_hot[c];
   if (r > 0) d.hot_rec[(size_t)(r - 1) * HOT_REC_STRIDE + j] = v;
-  if (r > 0 && d.ck_img) d.ck_img[(size_t)j * d.ck_pad + (r - 1)] = v;
 }
 
 // static part of the hot camera records (per linearisation): P[:, :3] row-major (step 1, hom = 0)

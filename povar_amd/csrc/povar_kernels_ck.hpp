@@ -34,8 +34,7 @@ struct CkP {
                          // (x < 0: empty lane); y: >= 0 accumulator slot, < 0: ~(partial record of a cold chunk)
   const int* bt_off;     // [grid * nb + 1]
   const int* slot_rec;   // partial record of each workgroup slot
-  const double* img;     // [21][pad] structure-of-arrays record image by rank: z (12), then P3 row-major (9)
-  int nb, slots, pad;
+  int nb, slots;
   unsigned uv_bytes, li_bytes;  // sizes of uv (= w's in doubles x 2) and li: the rows are read through buffer descriptors
   unsigned long long* stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): [grid][16][CK_N_STAMPS] s_memtime stamps, else nullptr
 };
@@ -603,15 +602,6 @@ __global__ __launch_bounds__(256) void ck_gather_w(const int* src, const double*
   if (i >= n) return;
   const int s = src[i];
   w_ck[i] = s >= 0 ? w_lpl[s] : 0.0;
-}
-
-// structure-of-arrays mirror of the record image: the static part (P3) per linearisation
-__global__ __launch_bounds__(256) void ck_build_img_p3(Dp d, double* img, int pad) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= d.n_cams * 9) return;
-  const int r = i / 9, e = i % 9;
-  const double* P = reinterpret_cast<const double*>(d.cams_lin4) + 12 * (size_t)d.hot_cams[r];
-  img[(size_t)(12 + e) * pad + r] = P[(e / 3) * 4 + (e % 3)];
 }
 
 }  // namespace povar

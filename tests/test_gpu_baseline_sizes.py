@@ -241,7 +241,7 @@ def test_bal_trafalgar_end_to_end_converged(tmp_path):
 
 
 def test_bal_venice_known_answer(tmp_path):
-    """BASELINE config 4's workload through `bin/bal` on one GPU: VarPro step 1 (m = 20) + RIPOBA step 2 on the
+    """BASELINE config 4's workload through `bin/bal` on one GPU (one context, then sharded over two): VarPro step 1 (m = 20) + RIPOBA step 2 on the
     venice-1778 shape from the perturbed ground-truth cameras must end on the chi-square floor of the 0.5 px noise
     (5 M observations: the floor is known to 0.1 %).  No oracle involved."""
     from povar_amd import synth
@@ -257,6 +257,19 @@ def test_bal_venice_known_answer(tmp_path):
     exp, std = chi2_floor(p.n_cams, p.n_lms, p.n_obs)
     assert abs(d["cost"][-1] - exp) <= 5 * std, (d["cost"][-1], exp, std)
     assert d["_static"]["solver"]["termination_type"] == "CONVERGENCE"
+    # the same run over TWO shard contexts of one process (`bal --gpus 2`: LinearizorPowerVarprojHipMulti, landmark shards of
+    # 2.5 M observations each, one exchange per power-series term; on a one-GPU box through the in-process all-reduce): the
+    # same iterations, every cost to 1e-9, the same floor
+    log2 = str(tmp_path / "hip2.json")
+    r = subprocess.run([os.path.join(ROOT, "bin/bal"), "--input", f, "--log-log-path", log2, "--quiet", "--power-sc-iterations", "20",
+                        "--max-num-iterations-step-1", "100", "--max-num-iterations-step-2", "100", "--gpus", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d2 = json.load(open(log2))
+    assert d2["iteration"] == d["iteration"] and d2["step_is_successful"] == d["step_is_successful"]
+    assert d2["linear_solver_iterations"] == d["linear_solver_iterations"]
+    assert np.abs(np.array(d2["cost"]) / np.array(d["cost"]) - 1).max() <= 1e-9
+    assert d2["_static"]["solver"]["termination_type"] == "CONVERGENCE"
 
 
 def test_final_13682_huber():
