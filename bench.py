@@ -57,7 +57,8 @@ def kernel_source_sha():
     """Stamp of the device code the PMC traffic figures in profiles/traffic.json were measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_kernels_ck.hpp", "povar_hip.hip", "lpl_layout.hpp", "ck_layout.hpp"):
+    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_joint.hpp", "povar_hip.hip",
+              "lpl_layout.hpp", "ck_layout.hpp"):
         with open(os.path.join(ROOT, "povar_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -515,7 +516,7 @@ def main():
     effective = bytes_e0 / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
     li0 = ctx.layout_info()
     once_bytes = model_bytes - (li0.ck_rows * 64 * (18 + (8 if args.robust_norm != "NONE" else 0))
-                                if args.step == 1 and li0.e0_kernel > 0 else 0)
+                                if args.step == 1 and li0.e0_kernel > 0 else 0)  # (step 2's rows are 2-4 bytes: no correction)
     traffic, traffic_note = None, "no PMC figure for this workload/mode"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -528,7 +529,8 @@ def main():
                 (f":{args.robust_norm}" if args.robust_norm != "NONE" else "") + \
                 (f":{args.popularity}" if args.popularity != "zipf1" else "") + \
                 (f":ltf{args.long_track_frac:g}" if args.long_track_frac > 0 else "") + (":file" if bal_path else "") + \
-                (f":ck{ctx.layout_info().e0_kernel}" if args.step == 1 and ctx.layout_info().e0_kernel > 0 else "")
+                (f":ck{ctx.layout_info().e0_kernel}" if args.step == 1 and ctx.layout_info().e0_kernel > 0 else "") + \
+                (":ckh1" if args.step == 2 and ctx.layout_info().e0_kernel_h > 0 else "")
             if key in tj:
                 if tj.get("_source_sha", {}).get(key) == kernel_source_sha():
                     traffic, traffic_note = tj[key], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/"
@@ -571,7 +573,8 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": {capi.E0_IMPLICIT: "E0 x (e0_lm_cached<false> + cm_scatter)",
-                       capi.E0_IMPLICIT_LDSACC: (("E0 x (e0_lpl_h + cam_cold_sum[_binv]_h)" if args.step == 2
+                       capi.E0_IMPLICIT_LDSACC: (("E0 x (e0_ck_h + cam_cold_sum[_binv]_h)" if args.step == 2 and ctx.layout_info().e0_kernel_h > 0
+                                                  else "E0 x (e0_lpl_h + cam_cold_sum[_binv]_h)" if args.step == 2
                                                   else "E0 x (e0_ck + cam_cold_sum[_binv])" if ctx.layout_info().e0_kernel > 0
                                                   else "E0 x (e0_lpl + cam_cold_sum[_binv])")
                                                  if ctx.layout_info().lane_per_landmark else
@@ -628,6 +631,11 @@ def main():
                                   "e0_kernel_choice": {0: "forced", 1: "automatic (not timed yet)",
                                                        2: "automatic: both kernels timed on this problem"}[li.e0_auto],
                                   "e0_tune_us": {"e0_lpl": round(li.tune_lpl_us, 2), "e0_ck": round(li.tune_ck_us, 2)},
+                                  # step 2: 0: e0_lpl_h, 1: e0_ck_h (its own layout instance: more batches, shorter chunks)
+                                  "e0_kernel_step2": li.e0_kernel_h,
+                                  "e0_tune_us_step2": {"e0_lpl_h": round(li.tune_lpl_h_us, 2), "e0_ck_h": round(li.tune_ck_h_us, 2)},
+                                  "camera_chunks_step2": {"batches": li.ckh_batches, "landmark_slots": li.ckh_slots,
+                                                          "chunks": li.ckh_chunks, "own_record_chunks": li.ckh_cold_chunks},
                                   "camera_chunks": {"batches": li.ck_batches, "landmark_slots": li.ck_slots, "rows": li.ck_rows,
                                                     "chunks": li.ck_chunks, "own_record_chunks": li.ck_cold_chunks,
                                                     "partial_records": li.ck_part_rec, "build_ms": round(li.ck_build_ms, 1)}

@@ -272,6 +272,13 @@ typedef struct {
   int32_t e0_auto;      /* 0: the E0 kernel was forced (POVAR_E0_CK, povar_set_e0_kernel); 1: the library will time e0_lpl and e0_ck
                            on this problem at the next power series; 2: it has (e0_kernel is its choice) */
   float tune_lpl_us, tune_ck_us;  /* what that timing saw, microseconds per launch */
+  /* step 2 (solve_joint): the same pair of kernels for the homogeneous operator, on a layout instance of its own
+   * (64 instead of 48 bytes of LDS per landmark slot: more batches, shorter chunks) */
+  int32_t e0_kernel_h;  /* 0: e0_lpl_h, 1: e0_ck_h */
+  int32_t ckh_ready, ckh_batches, ckh_slots;
+  int64_t ckh_chunks, ckh_cold_chunks;
+  int32_t e0_auto_h;    /* as e0_auto: 0 forced, 1 to be timed at the next step-2 power series, 2 timed */
+  float tune_lpl_h_us, tune_ck_h_us;
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 /* The reference's constructor is a trivial allocation (sc/linearization_varproj.hpp:44-60); this library's builds the

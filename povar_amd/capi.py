@@ -50,7 +50,9 @@ class LayoutInfo(C.Structure):
                 ("placement_ms", C.c_double), ("e0_kernel", C.c_int32), ("ck_ready", C.c_int32), ("ck_batches", C.c_int32),
                 ("ck_slots", C.c_int32), ("ck_tiles_max", C.c_int32), ("ck_part_rec", C.c_int32), ("ck_rows", C.c_int64),
                 ("ck_chunks", C.c_int64), ("ck_cold_chunks", C.c_int64), ("ck_build_ms", C.c_double), ("e0_auto", C.c_int32),
-                ("tune_lpl_us", C.c_float), ("tune_ck_us", C.c_float)]
+                ("tune_lpl_us", C.c_float), ("tune_ck_us", C.c_float), ("e0_kernel_h", C.c_int32), ("ckh_ready", C.c_int32),
+                ("ckh_batches", C.c_int32), ("ckh_slots", C.c_int32), ("ckh_chunks", C.c_int64), ("ckh_cold_chunks", C.c_int64),
+                ("e0_auto_h", C.c_int32), ("tune_lpl_h_us", C.c_float), ("tune_ck_h_us", C.c_float)]
 
 
 class TimingsInfo(C.Structure):
@@ -69,7 +71,7 @@ def build(force: bool = False) -> str:
     src_dir = os.path.join(_PKG, "csrc")
     srcs = [os.path.join(src_dir, f) for f in ("povar_hip.hip", "povar_kernels.hpp", "povar_kernels_joint.hpp",
                                                "povar_kernels_sc.hpp", "povar_kernels_chol.hpp", "lpl_layout.hpp",
-                                               "ck_layout.hpp", "povar_kernels_ck.hpp")] + [HEADER]
+                                               "ck_layout.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_joint.hpp")] + [HEADER]
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)

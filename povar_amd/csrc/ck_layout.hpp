@@ -44,6 +44,7 @@ struct CkLayout {
   std::vector<int> slot_rec;     // [lpl wg_cams.size()] partial record each workgroup slot is flushed to
   std::vector<int2> part_range;  // [n_cams] partial records of camera c (by camera index): [first, end)
   int nb = 1;                    // batches per workgroup
+  int li_mul = 3;                // the slot words hold li_mul x slot (CkShape)
   int ng = 1;                    // of which ng are in LDS at the same time (groups of wavefronts)
   int slots = 64;                // landmark slots of a batch (multiple of 64; the same for every workgroup)
   int n_part_rec = 0, max_acc = 0;
@@ -84,8 +85,22 @@ inline int ck_schedule_cost(const std::vector<int>& counts, int H, int n_waves, 
 // keeps in registers (CK_HMAX: none / whatever schedules best)
 // ng: groups of wavefronts that work on different batches at the same time (the LDS holds ng batches; the batch count is a
 // multiple of ng; n_waves = wavefronts of ONE group)
+// shape: what the kernel that runs the layout keeps in LDS per landmark slot and how it addresses it.  Step 1 (e0_ck):
+// 48 bytes, slot-major [slot][3] arrays (the slot words hold 3 x slot).  Step 2 (e0_ck_h): 64 bytes in component-major
+// arrays with a compile-time stride of max_slots (the words hold the slot; the LDS need does not depend on the slot count).
+struct CkShape {
+  int slot_bytes = 48;
+  int li_mul = 3;
+  int max_slots = INT_MAX;
+  bool need_uv = true;   // (step 2's operator does not read the image coordinates)
+};
+inline CkShape ck_shape_step2() { return CkShape{64, 1, 1536, false}; }  // 1536 = CKH_STRIDE (povar_kernels_ck_joint.hpp)
+inline size_t ck_lds_bytes_shape(const CkShape& sh, int slots, int n_acc, int ng) {
+  if (sh.max_slots != INT_MAX) return 16 + (size_t)sh.slot_bytes * sh.max_slots + (size_t)n_acc * 104 + 64;  // = ckh_lds_bytes
+  return 16 + (size_t)ng * slots * sh.slot_bytes + (size_t)n_acc * 104 + 64;
+}
 inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector<int>& cam_of_rank, int n_waves,
-                     CkLayout& K, bool place = true, int hmax = CK_HMAX, int ng = 1) {
+                     CkLayout& K, bool place = true, int hmax = CK_HMAX, int ng = 1, const CkShape& shape = CkShape()) {
   int n_threads = std::min(lpl_effective_cpus(), 128);
   if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
   hmax = std::min(CK_HMAX, std::max(1, hmax));
@@ -99,9 +114,11 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
   }
   ng = std::max(ng, 1);
   int nb = ng;
-  while (ck_lds_bytes(WAVE * ((max_tiles_w + nb - 1) / nb), max_acc, ng) > (size_t)CK_LDS_BYTES && nb < max_tiles_w) nb += ng;
+  while ((ck_lds_bytes_shape(shape, WAVE * ((max_tiles_w + nb - 1) / nb), max_acc, ng) > (size_t)CK_LDS_BYTES ||
+          WAVE * ((max_tiles_w + nb - 1) / nb) > shape.max_slots) && nb < max_tiles_w) nb += ng;
   if (const char* e = std::getenv("POVAR_CK_NB")) nb = std::max(nb, (std::atoi(e) + ng - 1) / ng * ng);
   K.nb = nb;
+  K.li_mul = shape.li_mul;
   K.ng = ng;
   K.slots = WAVE * ((max_tiles_w + nb - 1) / nb);
   K.max_acc = max_acc;
@@ -239,7 +256,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
             o.uv[idx] = L.uv[s];
             o.src[idx] = ob.src;
             uint32_t& word = o.li[q0 + (size_t)(j >> 1) * WAVE + lane];
-            const uint32_t li3 = 3u * (uint32_t)ob.li;  // the slot's first double in the [slot][3] LDS arrays of the kernel
+            const uint32_t li3 = (uint32_t)shape.li_mul * (uint32_t)ob.li;  // step 1: the slot's first double in the [slot][3] LDS arrays
             word = (j & 1) ? ((word & 0xffffu) | (li3 << 16)) : ((word & 0xffff0000u) | li3);
             const uint16_t v = ++occ[j][half][ob.li & 31];
             mx[j][half] = std::max(mx[j][half], v);

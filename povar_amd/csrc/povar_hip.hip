@@ -26,6 +26,7 @@
 #include "lpl_layout.hpp"
 #include "ck_layout.hpp"
 #include "povar_kernels_ck.hpp"
+#include "povar_kernels_ck_joint.hpp"
 
 using namespace povar;
 
@@ -156,17 +157,21 @@ struct povar_ctx {
     int nb = 0, slots = 0, n_part_rec = 0, max_acc = 0, max_tiles_bt = 0;
     int64_t rows = 0, li_rows = 0, n_chunks = 0, n_cold_chunks = 0;
     double build_ms = 0;
+    int64_t w_lin_id = -1;       // linearisation whose robust weights w holds
     bool ready = false;
     void release() {
       uv.release(); li.release(); src.release(); lane_meta.release(); bt_off.release();
       slot_rec.release(); tile.release(); part_range.release(); part.release(); w.release();
       ready = false;
     }
-  } ck, pl_ck;
+  } ck, pl_ck,       // step 1 (e0_ck): the layout in use / the one the placement thread built for the placed rows
+    ckh, pl_ckh;     // step 2 (e0_ck_h): a second instance (64 bytes of LDS per landmark slot: more batches, other chunks)
   DevBuf<unsigned long long> ck_stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): CkP::stamps
   DevBuf<int2> ck_zero_range;    // [n_cams] empty runs: e0_ck leaves no per-observation cold view to the per-camera kernels
   int ck_variant = 0;            // 0: e0_lpl; 1..CK_VARIANTS: e0_ck instantiation (POVAR_CK_VARIANTS)
-  int64_t ckw_lin_id = -1;       // linearisation whose robust weights CkDev::w holds
+  int ckh_variant = 0;           // step 2: 0: e0_lpl_h; 1: e0_ck_h
+  bool ckh_tuned = false;
+  float ckh_tune_us[2] = {0, 0}; // e0_lpl_h, e0_ck_h
   bool ck_auto = true;           // the library picks e0_lpl or e0_ck by timing both on this problem (ck_autotune); false: forced
   bool ck_tuned = false;
   float ck_tune_us[2] = {0, 0};  // what the timing saw: e0_lpl, e0_ck (microseconds per launch)
@@ -458,7 +463,7 @@ inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block
 // camera-chunk layout of e0_ck: upload, kernel parameters, launch
 // ------------------------------------------------------------------------------------------
 // locked: called by the row-placement thread -- its HIP calls go in short pieces under g_capture_mu (povar_ctx::placer_cancel)
-bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked, size_t* bytes) {
+bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked, size_t* bytes, bool need_uv = true) {
   bool ok = true;
   auto guarded = [&](auto&& fn) {
     if (locked) {
@@ -482,7 +487,8 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
     const int sg = K.lane_seg[i];
     meta[i] = make_int2(K.lane_cam[i] < 0 ? -1 : (K.lane_cam[i] | ((sg & 63) << 16) | (((sg >> 8) & 63) << 22)), K.lane_acc[i]);
   }
-  up(D.uv, K.uv); up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_meta, meta);
+  if (need_uv) up(D.uv, K.uv);  // (step 2's operator does not read the image coordinates)
+  up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_meta, meta);
   up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
   if (ok) guarded([&] { ok = D.part.alloc((size_t)std::max(K.n_part_rec, 1) * 12, bytes) == hipSuccess; });
   if (ok && c->opt.robust_norm)
@@ -491,14 +497,17 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
   D.rows = K.rows; D.li_rows = K.li_rows; D.n_chunks = K.n_chunks; D.n_cold_chunks = K.n_cold_chunks;
   // (the kernel reads the rows through 32-bit buffer descriptors: a row array of 4 GiB or more is left to e0_lpl)
   ok = ok && K.uv.size() * sizeof(double2) < (1ull << 32);
+  // the lane metadata keeps a camera's popularity rank in 16 bits
+  ok = ok && c->n_cams <= 65535;
+  D.w_lin_id = -1;
   D.ready = ok && !(locked && c->placer_cancel.load());
   return D.ready;
 }
-CkP ck_params(const povar_ctx* c) {
-  const auto& D = c->ck;
+CkP ck_params(const povar_ctx* c, const povar_ctx::CkDev& D) {
   return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p,
-             D.nb, D.slots, (unsigned)(D.uv.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t)), c->ck_stamps.p};
+             D.nb, D.slots, (unsigned)(D.src.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t)), c->ck_stamps.p};
 }
+CkP ck_params(const povar_ctx* c) { return ck_params(c, c->ck); }
 // e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight, double-buffered
 // tile records, groups of wavefronts working on different batches (povar_kernels_ck.hpp)
 #define POVAR_CK_VARIANTS(X) \
@@ -518,10 +527,15 @@ bool ck_active(const povar_ctx* c) {
   return c->ck_variant > 0 && c->ck.ready && c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
          ck_variant_fits(c, c->ck_variant);
 }
-// the per-camera kernels behind e0_ck: partial records only (its own table), no per-observation cold view
+bool ckh_active(const povar_ctx* c) {
+  return c->joint && c->ckh_variant > 0 && c->ckh.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
+         c->ckh.slots <= CKH_STRIDE && ckh_lds_bytes(c->ckh.max_acc) <= (size_t)CK_LDS_BYTES;
+}
+// the per-camera kernels behind e0_ck / e0_ck_h: partial records only (its own table), no per-observation cold view
 void ck_dp(const povar_ctx* c, Dp& da) {
-  da.hot_part = c->ck.part.p;
-  da.part_range = c->ck.part_range.p;
+  const povar_ctx::CkDev& D = c->joint ? c->ckh : c->ck;
+  da.hot_part = D.part.p;
+  da.part_range = D.part_range.p;
   da.cmv.cam_range = c->ck_zero_range.p;
   da.cmv.n = 0;
   da.cmv.src = nullptr;
@@ -570,12 +584,22 @@ int ck_autotune(povar_ctx* c);
 
 // robust weights in chunk order (V2::w is written by the linearisation walk in lane-per-landmark order)
 void ensure_ck_w(povar_ctx* c) {
-  if (!c->opt.robust_norm || !c->ck.ready || !c->ck.w.p || !c->v2_w.p || c->ckw_lin_id == c->lin_id) return;
-  const int64_t n = (int64_t)c->ck.src.n;  // every row, the padding included (weight 0)
-  hipLaunchKernelGGL(ck_gather_w, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const int*)c->ck.src.p, (const double*)c->v2_w.p,
-                     c->ck.w.p, n);
-  c->ckw_lin_id = c->lin_id;
+  povar_ctx::CkDev& D = c->joint ? c->ckh : c->ck;
+  if (!c->opt.robust_norm || !D.ready || !D.w.p || !c->v2_w.p || D.w_lin_id == c->lin_id) return;
+  const int64_t n = (int64_t)D.src.n;  // every row, the padding included (weight 0)
+  hipLaunchKernelGGL(ck_gather_w, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const int*)D.src.p, (const double*)c->v2_w.p,
+                     D.w.p, n);
+  D.w_lin_id = c->lin_id;
 }
+void launch_e0_ck_h(povar_ctx* c, const Dp& da) {
+  const CkP k = ck_params(c, c->ckh);
+  const size_t lds = ckh_lds_bytes(c->ckh.max_acc);
+  if (c->opt.robust_norm)
+    hipLaunchKernelGGL((e0_ck_h<16, 2, true>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ckh.part.p);
+  else
+    hipLaunchKernelGGL((e0_ck_h<16, 2, false>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ckh.part.p);
+}
+int ckh_autotune(povar_ctx* c);
 
 // ------------------------------------------------------------------------------------------
 // launch helpers
@@ -803,7 +827,7 @@ int swap_in_placed_rows(povar_ctx* c, bool wait) {
   if (c->placer_state.load(std::memory_order_acquire) != 2) {  // the build or an upload failed: stay on the natural order
     c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
     c->pl_c3_src.release();
-    c->pl_ck.release();
+    c->pl_ck.release(); c->pl_ckh.release();
     c->placement = 0;
     return 0;
   }
@@ -822,8 +846,10 @@ int swap_in_placed_rows(povar_ctx* c, bool wait) {
   c->ck.release();
   if (c->pl_ck.ready) std::swap(c->ck, c->pl_ck);
   c->pl_ck.release();
-  c->ckw_lin_id = -1;
-  c->ck_tuned = false;  // (the choice between the two E0 kernels is timed again on the new rows)
+  c->ckh.release();
+  if (c->pl_ckh.ready) std::swap(c->ckh, c->pl_ckh);
+  c->pl_ckh.release();
+  c->ck_tuned = c->ckh_tuned = false;  // (the choice between the E0 kernels is timed again on the new rows)
   c->placement = 3;
   return 1;
 }
@@ -831,8 +857,8 @@ int swap_in_placed_rows(povar_ctx* c, bool wait) {
 // flags[0] (finiteness / p2p time-out bits) is reset before every entry point that reads it back; when the last
 // read-back was zero and nothing that can raise it has been enqueued since, the reset is skipped
 int clear_flag0(povar_ctx* c) {
-  if (c->flag0_clean) return 0;
-  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  if (!c->flag0_clean) HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  c->flag0_clean = false;  // writers follow; clean again only after a read-back of zero (not when that read-back fails: ADVICE r03)
   return 0;
 }
 bool err_memo_hit(const povar_ctx* c, int kind, double alpha, povar_residual_info* out) {
@@ -877,10 +903,15 @@ int combine_flag(povar_ctx* c, int* flag) {
 int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
   prof_mark(c, 0);
   if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // cm_scatter / legacy cold views
-  if (ck_active(c)) ensure_ck_w(c);  // (a no-op inside the graph capture: povar_power_series_pose has called it before)
+  if (ck_active(c) || ckh_active(c)) ensure_ck_w(c);  // (a no-op inside the graph capture: the solve entry points have called it before)
   if (c->joint) {
     const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
-    if (acc && c->use_lpl) {
+    const bool ckh_now = ckh_active(c);
+    Dp dj = ldsacc_dp(c, true);  // what the per-camera kernels below see: e0_ck_h leaves partial records only
+    if (ckh_now) ck_dp(c, dj);
+    if (ckh_now) {
+      launch_e0_ck_h(c, dj);
+    } else if (acc && c->use_lpl) {
       Dp da = ldsacc_dp(c, true);
       if (c->opt.robust_norm)
         hipLaunchKernelGGL(e0_lpl_h<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes_h(c->v2_max_slots), c->stream, da, c->v2_part.p);
@@ -898,11 +929,11 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
       launch_lm(c, OpE0H{});
     }
     if (acc && fuse_norms >= 0 && !sharded(c) && c->fuse_binv) {
-      hipLaunchKernelGGL(cam_cold_sum_binv_h<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, ldsacc_dp(c, true), fuse_norms,
+      hipLaunchKernelGGL(cam_cold_sum_binv_h<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, dj, fuse_norms,
                          (const double*)c->ncw.p);
       *binv_mode = 4;  // B^-1, AXPY and z already done
     } else if (acc) {
-      hipLaunchKernelGGL(cam_cold_sum<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, ldsacc_dp(c, true), 1);
+      hipLaunchKernelGGL(cam_cold_sum<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, dj, 1);
       *binv_mode = 2;  // dense y (sigma applied)
     } else {
       hipLaunchKernelGGL(cm_scatter, dim3(grid_for(std::max(c->n_items, 1), 4)), dim3(256), 0, c->stream, c->d, 1, 1);
@@ -1036,6 +1067,49 @@ int ck_autotune(povar_ctx* c) {
   c->ck_tune_us[0] = 1e3f * ms_lpl / REPS;
   c->ck_tune_us[1] = 1e3f * ms_ck / REPS;
   c->ck_variant = ms_ck < 0.98f * ms_lpl ? 1 : 0;
+  return 0;
+}
+
+// the same choice for step 2: e0_lpl_h against e0_ck_h on the prepared joint system
+int ckh_autotune(povar_ctx* c) {
+  if (!c->ck_auto || c->ckh_tuned || !c->joint || !c->ckh.ready || !c->use_lpl || c->opt.e0_mode != POVAR_E0_IMPLICIT_LDSACC) return 0;
+  c->ckh_tuned = true;
+  c->ckh_variant = 1;
+  if (!ckh_active(c)) {
+    c->ckh_variant = 0;
+    return 0;
+  }
+  ensure_ck_w(c);
+  HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
+  hipEvent_t ev[4];
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  Dp da = ldsacc_dp(c, true);
+  Dp dk = da;
+  ck_dp(c, dk);
+  auto run_lpl = [&]() {
+    if (c->opt.robust_norm)
+      hipLaunchKernelGGL(e0_lpl_h<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes_h(c->v2_max_slots), c->stream, da, c->v2_part.p);
+    else
+      hipLaunchKernelGGL(e0_lpl_h<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes_h(c->v2_max_slots), c->stream, da, c->v2_part.p);
+  };
+  constexpr int REPS = 3;
+  run_lpl();
+  HIP_TRY(hipEventRecord(ev[0], c->stream));
+  for (int i = 0; i < REPS; ++i) run_lpl();
+  HIP_TRY(hipEventRecord(ev[1], c->stream));
+  launch_e0_ck_h(c, dk);
+  HIP_TRY(hipEventRecord(ev[2], c->stream));
+  for (int i = 0; i < REPS; ++i) launch_e0_ck_h(c, dk);
+  HIP_TRY(hipEventRecord(ev[3], c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipGetLastError());
+  float ms_lpl = 0, ms_ck = 0;
+  HIP_TRY(hipEventElapsedTime(&ms_lpl, ev[0], ev[1]));
+  HIP_TRY(hipEventElapsedTime(&ms_ck, ev[2], ev[3]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  c->ckh_tune_us[0] = 1e3f * ms_lpl / REPS;
+  c->ckh_tune_us[1] = 1e3f * ms_ck / REPS;
+  c->ckh_variant = ms_ck < 0.98f * ms_lpl ? 1 : 0;
   return 0;
 }
 
@@ -1279,10 +1353,13 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     HIP_TRY_C(hipFuncSetAttribute((const void*)prepare_lpl_h<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)prep_lds_bytes(HOT_ACC_MAX)));
     HIP_TRY_C(ck_set_lds_all());
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_ck_h<16, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_ck_h<16, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
   }
   // per-term E0 kernel of step 1: e0_lpl (0) or an e0_ck instantiation (POVAR_E0_CK=<variant>, povar_set_e0_kernel)
   if (const char* g = std::getenv("POVAR_E0_CK")) {
     c->ck_variant = std::max(0, std::min(CK_VARIANTS, std::atoi(g)));
+    c->ckh_variant = c->ck_variant > 0 ? 1 : 0;  // (step 2 has one camera-chunk instantiation)
     c->ck_auto = false;
   }
   const bool want_ck = c->use_lpl && std::getenv("POVAR_NO_CK") == nullptr;
@@ -1373,8 +1450,14 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
             build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, true, ck_hmax, ck_ng);
             c->pl_ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
             if (!c->placer_cancel.load()) ck_upload(c, c->pl_ck, K, true, &c->pl_bytes);
+            if (!c->placer_cancel.load()) {  // step 2's instance
+              CkLayout KH;
+              build_ck(P, n_cams, grid, job->cam_of_rank, 16, KH, true, ck_hmax, 1, ck_shape_step2());
+              if (!c->placer_cancel.load()) ck_upload(c, c->pl_ckh, KH, true, &c->pl_bytes, false);
+            }
           } catch (...) {
             c->pl_ck.ready = false;
+            c->pl_ckh.ready = false;
           }
         }
         c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1425,7 +1508,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
         build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, true, ck_hmax, ck_ng);
         c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
         if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
-        lap("camera-chunk layout");
+        CkLayout KH;  // step 2's instance: 64 bytes of LDS per landmark slot, no image coordinates
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, KH, true, ck_hmax, 1, ck_shape_step2());
+        if (!ck_upload(c, c->ckh, KH, false, &c->bytes, false)) { povar_destroy(c); return fail(-1, "camera-chunk layout (step 2): upload failed"); }
+        lap("camera-chunk layouts");
       }
     }
     c->d.v2 = V2{c->v2_uv.p, c->v2_cw.p, c->v2_cpos.p, c->v2_w.p, c->v2_tile.p, c->v2_seg.p, c->v2_lmrec.p,
@@ -1555,7 +1641,7 @@ void povar_destroy(povar_ctx* c) {
   (void)hipSetDevice(c->opt.device);
   c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
   c->pl_c3_src.release(); c->c3_src.release();
-  c->ck.release(); c->pl_ck.release(); c->ck_zero_range.release(); c->ck_stamps.release();
+  c->ck.release(); c->pl_ck.release(); c->ckh.release(); c->pl_ckh.release(); c->ck_zero_range.release(); c->ck_stamps.release();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->pin) (void)hipHostFree(c->pin);
@@ -1844,7 +1930,8 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   TimeScope ts(c, 2);
   if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // not inside the graph capture
   if (int rc = ck_autotune(c)) return rc;
-  if (ck_active(c)) ensure_ck_w(c);
+  if (int rc = ckh_autotune(c)) return rc;
+  if (ck_active(c) || ckh_active(c)) ensure_ck_w(c);
   const bool norms = q_tol > 0 || r_tol > 0;
   // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
   // RCCL-in-capture is not something a 1-GPU box can validate); POVAR_GRAPH_COMM=1 opts in
@@ -1852,7 +1939,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (c->use_graph && !c->profile && m > 0 && (p2p_terms || (!c->host_fn && (!c->comm || c->graph_with_comm)))) {
     // the whole loop (memset, B^-1, m x {E0 kernels, [all-reduce], B^-1 + AXPY, [check]}) is one graph
     // launch; it is re-captured only when a kernel argument changes
-    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode + 16 * (ck_active(c) ? c->ck_variant : 0), (sharded(c) ? 1 : 0) | (p2p_terms ? 2 : 0), norms ? 1 : 0, r_tol > 0 ? 1 : 0};
+    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode + 16 * (c->joint ? (ckh_active(c) ? 1 : 0) : ck_active(c) ? c->ck_variant : 0), (sharded(c) ? 1 : 0) | (p2p_terms ? 2 : 0), norms ? 1 : 0, r_tol > 0 ? 1 : 0};
     // (the landmark damping is an argument of the prepare / back-substitution kernels only: no kernel of the loop reads
     // it, and step 2 changes it with every LM iteration -- a capture + instantiation of 0.25 ms each time)
     Dp key_d = c->d;
@@ -2357,8 +2444,18 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
         cm = part + tail;
         break;
       }
-      if (c->use_lpl)  // e0_lpl[_h]: uv + camera slot per row slot, 72 (112)-byte landmark records, cold: position + q out
-        lm = c->v2_rows * WAVE * (20 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * (c->joint ? 112 : 72) + cam_static +
+      if (ckh_active(c)) {
+        // e0_ck_h: landmark slot (2 bytes) [+ weight] per observation on both passes -- the step-2 operator does not read
+        // the image coordinates --, the 112-byte landmark records once, lane metadata, partial records out and back
+        const int64_t part = (int64_t)c->ckh.n_part_rec * 96;
+        lm = 2 * c->ckh.rows * WAVE * (2 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * 112 + cam_static +
+             2 * (int64_t)(c->ckh.lane_meta.n) * 8 + part;
+        cm = part + tail;
+        break;
+      }
+      if (c->use_lpl)  // e0_lpl: uv + camera slot per row slot, 72-byte landmark records; e0_lpl_h: the camera slot only (its
+                       // operator does not depend on uv: the loads are dead code), 112-byte records; cold: position + q out
+        lm = c->v2_rows * WAVE * ((c->joint ? 4 : 20) + robust) + (int64_t)c->d.v2.n_tiles * WAVE * (c->joint ? 112 : 72) + cam_static +
              n_cold * (c->q_rows ? 32 : 36) + hot_flush;  // q_rows: no position load, the per-camera kernel reads the index
       else
           lm = ns * (E0_SLOT_BYTES + robust) + nl * E0_LMREC_BYTES + cam_static + n_cold * 32 + hot_flush;
@@ -2439,6 +2536,16 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->e0_auto = c->ck_auto ? (c->ck_tuned ? 2 : 1) : 0;
   out->tune_lpl_us = c->ck_tune_us[0];
   out->tune_ck_us = c->ck_tune_us[1];
+  out->e0_kernel_h = c->ckh_variant > 0 && c->ckh.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
+                     c->ckh.slots <= CKH_STRIDE ? 1 : 0;
+  out->ckh_ready = c->ckh.ready ? 1 : 0;
+  out->ckh_batches = c->ckh.nb;
+  out->ckh_slots = c->ckh.slots;
+  out->ckh_chunks = c->ckh.n_chunks;
+  out->ckh_cold_chunks = c->ckh.n_cold_chunks;
+  out->e0_auto_h = c->ck_auto ? (c->ckh_tuned ? 2 : 1) : 0;
+  out->tune_lpl_h_us = c->ckh_tune_us[0];
+  out->tune_ck_h_us = c->ckh_tune_us[1];
   return 0;
 }
 
@@ -2462,12 +2569,13 @@ int povar_set_e0_kernel(povar_ctx* c, int32_t kernel) {
   if (kernel > 0 && !c->ck_zero_range.p) return fail(-1, "the camera-chunk layout was not built for this context");
   if (kernel < 0) {  // back to the library's own choice
     c->ck_auto = true;
-    c->ck_tuned = false;
-    c->ck_variant = 0;
+    c->ck_tuned = c->ckh_tuned = false;
+    c->ck_variant = c->ckh_variant = 0;
     return 0;
   }
   c->ck_auto = false;
   c->ck_variant = kernel;
+  c->ckh_variant = kernel > 0 ? 1 : 0;  // (step 2 has one camera-chunk instantiation)
   return 0;
 }
 

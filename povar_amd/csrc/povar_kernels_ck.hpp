@@ -288,8 +288,8 @@ __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int r
 
 // NW wavefronts per workgroup; SD: rows a tile keeps in flight ahead of the row being worked on.
 //
-// What bounds the kernel (in-kernel stamps, tools/ck_stamps.py; profiles/r04_*): the row loops issue ~35 fp64
-// instructions per row and pass and are VALU-bound while all sixteen wavefronts are in them; everything else is the
+// What bounds the kernel (in-kernel stamps, tools/ck_stamps.py; profiles/r04_*): the row loops issue 38 VALU instructions
+// per row and pass (31 fp64) -- and are not what sets the time: 14 % fewer instructions changed nothing --; the rest is the
 // time line of ONE wavefront -- round trips that nothing of its own hides (one or two tiles per wavefront and pass):
 // tile metadata (which camera is in which lane), the record gather that depends on it (64 lanes, 64 different cache
 // lines: ~30 cycles of the texture addresser per load, eleven loads, sixteen wavefronts at once), the first rows.  So:

@@ -18,9 +18,10 @@ def pytest_configure(config):
 # modules use small problems: they run twice, once as the library would ("auto") and once with the lane-per-landmark
 # kernels forced (POVAR_E0_V1=0), so that both families stay compared with the oracle on every case.
 _BOTH_KERNEL_FAMILIES = {"test_gpu_step1", "test_gpu_step2", "test_gpu_fuzz", "test_gpu_sharded", "test_gpu_sc_solvers"}
-# ... and a third time with the camera-chunk form of the step-1 E0 operator (e0_ck, round 4) on the lane-per-landmark
-# layout: every small-problem case of these modules (term by term, early exit, long landmarks, fuzz, shards, PCG)
-_WITH_CAMERA_CHUNKS = {"test_gpu_step1", "test_gpu_fuzz", "test_gpu_sharded", "test_gpu_sc_solvers"}
+# ... and a third time with the camera-chunk forms of the E0 operators (e0_ck for step 1, e0_ck_h for step 2; round 4) on the
+# lane-per-landmark layout: every small-problem case of these modules (term by term, early exit, long landmarks, fuzz,
+# shards, PCG / RIPCG)
+_WITH_CAMERA_CHUNKS = {"test_gpu_step1", "test_gpu_step2", "test_gpu_fuzz", "test_gpu_sharded", "test_gpu_sc_solvers"}
 
 
 def pytest_generate_tests(metafunc):

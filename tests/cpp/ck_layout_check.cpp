@@ -51,12 +51,14 @@ int main(int argc, char** argv) {
   CkLayout K;
   const auto t0 = std::chrono::steady_clock::now();
   const int ng = std::getenv("CK_CHECK_NG") ? std::atoi(std::getenv("CK_CHECK_NG")) : 1;
-  build_ck(L, n_cams, grid, order, n_waves, K, std::getenv("CK_CHECK_NOPLACE") == nullptr, CK_HMAX, ng);
+  const bool step2 = std::getenv("CK_CHECK_STEP2") != nullptr;  // the shape of e0_ck_h's layout
+  const CkShape shape = step2 ? ck_shape_step2() : CkShape();
+  build_ck(L, n_cams, grid, order, n_waves, K, std::getenv("CK_CHECK_NOPLACE") == nullptr, CK_HMAX, ng, shape);
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   // ---- invariants
   CHECK((int)K.bt_off.size() == grid * K.nb + 1 && K.bt_off.back() == (int)K.tile.size());
   CHECK((int64_t)K.uv.size() == (K.rows + CK_HMAX) * 64 && K.src.size() == K.uv.size() && (int64_t)K.li.size() == (K.li_rows + CK_HMAX) * 64);
-  CHECK(ck_lds_bytes(K.slots, K.max_acc, K.ng) <= (size_t)CK_LDS_BYTES && K.nb % K.ng == 0);
+  CHECK(ck_lds_bytes_shape(shape, K.slots, K.max_acc, K.ng) <= (size_t)CK_LDS_BYTES && K.nb % K.ng == 0 && K.slots <= shape.max_slots);
   std::vector<int> lm_of_obs(n_obs);
   for (int l = 0; l < n_lms; ++l)
     for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) lm_of_obs[i] = l;
@@ -85,8 +87,8 @@ int main(int argc, char** argv) {
             const uint32_t li3 = (j & 1) ? word >> 16 : word & 0xffffu;  // 3 x slot
             const int s = K.src[idx];
             if (s < 0) { CHECK(li3 == CK_NONE); continue; }
-            CHECK(li3 % 3 == 0);
-            const uint32_t li = li3 / 3;
+            CHECK(li3 % (uint32_t)K.li_mul == 0);
+            const uint32_t li = li3 / (uint32_t)K.li_mul;
             ++n_lane;
             CHECK(rank >= 0 && (int)li < K.slots);
             const int i = obs_of_slot[s];
@@ -130,7 +132,7 @@ int main(int argc, char** argv) {
               "\"extra_lanes_per_half_row\": %.4f, \"lds_bytes\": %zu, \"build_ms\": %.1f, \"lpl_rows\": %lld}\n",
               K.nb, K.slots, K.tile.size(), (long long)K.rows, (long long)K.n_chunks, (long long)K.n_cold_chunks,
               (double)n_obs / std::max<int64_t>(K.n_chunks, 1), 1.0 - (double)n_obs / ((double)K.rows * 64), K.max_tiles_bt,
-              K.n_part_rec, L.n_part_rec, K.extra_lanes / (2.0 * std::max<int64_t>(K.rows, 1)), ck_lds_bytes(K.slots, K.max_acc, K.ng), ms,
+              K.n_part_rec, L.n_part_rec, K.extra_lanes / (2.0 * std::max<int64_t>(K.rows, 1)), ck_lds_bytes_shape(shape, K.slots, K.max_acc, K.ng), ms,
               (long long)L.rows);
   return 0;
 }

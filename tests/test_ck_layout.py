@@ -62,3 +62,17 @@ def test_ck_layout_venice_shape(tmp_path):
     s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 256, 520, env={"LPL_CHECK_NOPLACE": "1"})
     assert s["ok"] == 1 and s["nb"] == 2 and s["pad_frac"] < 0.06 and s["obs_per_chunk"] > 6.5
     assert s["extra_lanes_per_half_row"] < 1.1
+
+
+def test_ck_layout_step2_shape(tmp_path):
+    """The instance e0_ck_h (step 2) runs: 64 bytes of LDS per landmark slot in component-major arrays with a compile-time
+    stride of 1536 slots -- more batches than step 1's, at most 1536 slots each, the slot words hold the slot itself."""
+    from povar_amd import synth
+    p = synth.make_problem(300, 20000, 90000, seed=5)
+    for grid, n_acc in ((256, 520), (7, 40), (1, 520)):
+        s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, grid, n_acc, env={"CK_CHECK_STEP2": "1"})
+        assert s["ok"] == 1 and s["slots"] <= 1536 and s["lds_bytes"] <= 160 * 1024
+    p = synth.make_bal_problem("venice-1778")
+    s1 = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 256, 520, env={"LPL_CHECK_NOPLACE": "1"})
+    s2 = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 256, 520, env={"LPL_CHECK_NOPLACE": "1", "CK_CHECK_STEP2": "1"})
+    assert s2["ok"] == 1 and s2["nb"] == 3 > s1["nb"] and s2["slots"] <= 1536 and s2["obs_per_chunk"] > 4.5

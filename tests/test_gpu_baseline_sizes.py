@@ -129,10 +129,12 @@ def test_step1_apply_at_size(name):
     ctx.close()
 
 
+@pytest.mark.parametrize("e0_kernel", ["auto", "camera-chunk"])
 @pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778", "local-900"])
-def test_step2_at_size(name):
-    """solve_joint (RIPOBA inner solve: prepare_lpl_h, e0_lpl_h term by term) and apply_joint against the oracle,
-    bench-default mode."""
+def test_step2_at_size(name, e0_kernel):
+    """solve_joint (RIPOBA inner solve: prepare_lpl_h, the step-2 term kernel term by term) and apply_joint against the
+    oracle, bench-default mode; once with the library's own choice of the term kernel (e0_lpl_h until the solve has timed
+    both) and once with e0_ck_h, the camera-chunk form (povar_kernels_ck_joint.hpp), forced for every term."""
     from povar_amd import capi, synth
     from oracle import povar_oracle as O
     p = _problem(name)
@@ -146,6 +148,11 @@ def test_step2_at_size(name):
     m = 10
     orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, obs)
     ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    if e0_kernel == "camera-chunk":
+        ctx.layout_finalize(True)  # (the chunk layouts belong to the row order in use: have the placed rows first)
+        ctx.set_e0_kernel(1)
+        li = ctx.layout_info()
+        assert li.ckh_ready == 1 and li.e0_kernel_h == 1 and li.ckh_slots <= 1536
     ctx.set_cameras(cams)
     ctx.set_landmarks_homogeneous(lms_h)
     ri, ro = ctx.error_homogeneous(), orc.error_homogeneous(cams, lms_h)

@@ -39,7 +39,7 @@ def main():
     if os.path.exists(out):
         data = json.load(open(out))
     problem, mode, world = key.split(":")[:3]  # further fields (step2, HUBER, local, ...) only qualify the key
-    ck = [f for f in key.split(":") if f.startswith("ck")]
+    ck = [f for f in key.split(":") if f.startswith("ck")]   # ck<variant> (step 1: e0_ck) or ckh1 (step 2: e0_ck_h)
     lm = [k for k in e0 if ((("e0_ck" in k) if ck else ("e0_lpl" in k or "e0_lm_cached" in k)) if mode != "tiles" else "OpE0Tiles" in k)]
     # camera-major half of E0: cm_scatter (deterministic modes) or cam_cold_sum[_binv] (LDSACC modes; the fused
     # kernel also carries the 2 MB of B^-1 reads of the AXPY)
