@@ -80,30 +80,32 @@ __device__ inline void ckh_load_cam(const Dp& d, int rank, Cam& P) {
   P.r2 = make_double4(b4.x, b4.y, b5.x, b5.y);
 }
 
-// one observation forward: U4_l += J4^T t
+// J4 = sw D P with D = [D00 0 D02; 0 D00 D12] (hom_jl4 with unit column scale) is never formed:
+//   J4^T t = P^T (D^T t),   J4 g = D (P g)       (12 + 4 operations each instead of 16 + 8)
+// one observation forward: U4_l += J4^T t,  t = sw D (Z X)
 template <bool ROBUST>
 __device__ inline void ckh_obs_forward(const Cam& P, const double4 (&zz)[3], double w, const double* lx, double* lu, uint32_t s) {
   const double4 X = make_double4(lx[s], lx[CKH_STRIDE + s], lx[2 * CKH_STRIDE + s], lx[3 * CKH_STRIDE + s]);
   const double sw = ROBUST ? sqrt(w) : 1.0;
   const Hom h = hom_project(P, X, 0.0, 0.0);
-  double j4[8], t[2];
-  hom_jl4(P, h, sw, make_double4(1, 1, 1, 1), j4);
+  double t[2];
   hom_jp_x(h, X, sw, zz, t);
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-    __hip_atomic_fetch_add(lu + m * CKH_STRIDE + s, j4[m] * t[0] + j4[4 + m] * t[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const double e0 = sw * h.D00 * t[0], e1 = sw * h.D00 * t[1], e2 = sw * (h.D02 * t[0] + h.D12 * t[1]);
+  __hip_atomic_fetch_add(lu + s, P.r0.x * e0 + P.r1.x * e1 + P.r2.x * e2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(lu + CKH_STRIDE + s, P.r0.y * e0 + P.r1.y * e1 + P.r2.y * e2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(lu + 2 * CKH_STRIDE + s, P.r0.z * e0 + P.r1.z * e1 + P.r2.z * e2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(lu + 3 * CKH_STRIDE + s, P.r0.w * e0 + P.r1.w * e1 + P.r2.w * e2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // one observation backward: y_c += X (x) q,  q = hom_q(J4 G4)
 template <bool ROBUST>
 __device__ inline void ckh_obs_backward(const Cam& P, double w, const double* lx, const double* lg, uint32_t s, double (&y)[12]) {
   const double4 X = make_double4(lx[s], lx[CKH_STRIDE + s], lx[2 * CKH_STRIDE + s], lx[3 * CKH_STRIDE + s]);
-  const double g0 = lg[s], g1 = lg[CKH_STRIDE + s], g2 = lg[2 * CKH_STRIDE + s], g3 = lg[3 * CKH_STRIDE + s];
+  const double4 G = make_double4(lg[s], lg[CKH_STRIDE + s], lg[2 * CKH_STRIDE + s], lg[3 * CKH_STRIDE + s]);
   const double sw = ROBUST ? sqrt(w) : 1.0;
   const Hom h = hom_project(P, X, 0.0, 0.0);
-  double j4[8];
-  hom_jl4(P, h, sw, make_double4(1, 1, 1, 1), j4);
-  const double s0 = j4[0] * g0 + j4[1] * g1 + j4[2] * g2 + j4[3] * g3;
-  const double s1 = j4[4] * g0 + j4[5] * g1 + j4[6] * g2 + j4[7] * g3;
+  const double p0 = dot4(P.r0, G), p1 = dot4(P.r1, G), p2 = dot4(P.r2, G);
+  const double s0 = sw * (h.D00 * p0 + h.D02 * p2);
+  const double s1 = sw * (h.D00 * p1 + h.D12 * p2);
   const double4 q = hom_q(h, sw, s0, s1);
   y[0] += X.x * q.x; y[1] += X.y * q.x; y[2] += X.z * q.x; y[3] += X.w * q.x;
   y[4] += X.x * q.y; y[5] += X.y * q.y; y[6] += X.z * q.y; y[7] += X.w * q.y;
