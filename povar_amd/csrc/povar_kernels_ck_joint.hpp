@@ -80,6 +80,19 @@ __device__ inline void ckh_load_cam(const Dp& d, int rank, Cam& P) {
   P.r2 = make_double4(b4.x, b4.y, b5.x, b5.y);
 }
 
+// D of hom_project with ONE division (1 / z; D02 = -x / z^2 as two multiplications: the three correctly rounded divisions of
+// hom_project cost thirty instructions per observation and pass; the results differ in the last bit or two)
+__device__ inline Hom ckh_project(const Cam& P, const double4& X) {
+  const double x = dot4(P.r0, X), y = dot4(P.r1, X), z = dot4(P.r2, X);
+  Hom h;
+  h.D00 = 1 / z;
+  const double iz2 = h.D00 * h.D00;
+  h.D02 = -x * iz2;
+  h.D12 = -y * iz2;
+  h.r0 = h.r1 = 0;
+  h.valid = true;
+  return h;
+}
 // J4 = sw D P with D = [D00 0 D02; 0 D00 D12] (hom_jl4 with unit column scale) is never formed:
 //   J4^T t = P^T (D^T t),   J4 g = D (P g)       (12 + 4 operations each instead of 16 + 8)
 // one observation forward: U4_l += J4^T t,  t = sw D (Z X)
@@ -87,7 +100,7 @@ template <bool ROBUST>
 __device__ inline void ckh_obs_forward(const Cam& P, const double4 (&zz)[3], double w, const double* lx, double* lu, uint32_t s) {
   const double4 X = make_double4(lx[s], lx[CKH_STRIDE + s], lx[2 * CKH_STRIDE + s], lx[3 * CKH_STRIDE + s]);
   const double sw = ROBUST ? sqrt(w) : 1.0;
-  const Hom h = hom_project(P, X, 0.0, 0.0);
+  const Hom h = ckh_project(P, X);
   double t[2];
   hom_jp_x(h, X, sw, zz, t);
   const double e0 = sw * h.D00 * t[0], e1 = sw * h.D00 * t[1], e2 = sw * (h.D02 * t[0] + h.D12 * t[1]);
@@ -102,7 +115,7 @@ __device__ inline void ckh_obs_backward(const Cam& P, double w, const double* lx
   const double4 X = make_double4(lx[s], lx[CKH_STRIDE + s], lx[2 * CKH_STRIDE + s], lx[3 * CKH_STRIDE + s]);
   const double4 G = make_double4(lg[s], lg[CKH_STRIDE + s], lg[2 * CKH_STRIDE + s], lg[3 * CKH_STRIDE + s]);
   const double sw = ROBUST ? sqrt(w) : 1.0;
-  const Hom h = hom_project(P, X, 0.0, 0.0);
+  const Hom h = ckh_project(P, X);
   const double p0 = dot4(P.r0, G), p1 = dot4(P.r1, G), p2 = dot4(P.r2, G);
   const double s0 = sw * (h.D00 * p0 + h.D02 * p2);
   const double s1 = sw * (h.D00 * p1 + h.D12 * p2);

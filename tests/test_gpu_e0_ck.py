@@ -141,6 +141,8 @@ def test_e0_kernel_is_chosen_by_timing_both():
     """Nothing forced: the first power series of a layout times e0_lpl and e0_ck on the prepared problem and keeps the faster
     one; forcing a kernel and handing the choice back both work; the increment is the same either way."""
     from povar_amd import capi
+    if os.environ.get("POVAR_E0_CK") is not None or os.environ.get("POVAR_NO_CK") is not None:
+        pytest.skip("the environment forces the E0 kernel (tools/forced_mode_suite.sh): this test is about the automatic choice")
     p = _problem("trafalgar-257")
     ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
     ctx.layout_finalize(True)
