@@ -13,16 +13,17 @@ cp $(newest $R/e0/sq/*/*counter_collection.csv) $P/r04_pmc_sq_e0_lpl_vs_e0_ck.cs
 cp $R/e0_summary.txt $P/r04_e0_lpl_vs_e0_ck_summary.txt
 cp $(newest $R/e0_huber/kt/*/*kernel_stats.csv) $P/r04_kernel_stats_e0_lpl_vs_e0_ck_huber.csv
 cp $R/e0_huber_summary.txt $P/r04_e0_lpl_vs_e0_ck_huber_summary.txt
+cp $(newest $R/step2_kt/*/*kernel_stats.csv) $P/r04_kernel_stats_step2_e0_lpl_h_vs_e0_ck_h.csv
 cp $R/stamps.txt $P/r04_e0_ck_phase_stamps.txt
 cp $R/sweep.txt $P/r04_e0_ck_graph_families.txt
 cp $R/shards.txt $P/r04_shard_term_times.txt
 cp $R/bench_default.json $P/r04_bench.json
-for n in forced_e0_lpl huber local zipf05 uniform trafalgar ladybug step2 final_huber; do cp $R/bench_$n.json $P/r04_bench_$n.json; done
+for n in forced_e0_lpl huber local zipf05 uniform trafalgar ladybug step2 step2_forced_e0_lpl_h step2_huber final_huber; do cp $R/bench_$n.json $P/r04_bench_$n.json; done
 (echo "# tools/run_bal_config.py venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0"
  cat $R/bal_venice.json
  echo "# the same with --gpus 2: two shard contexts of one process (here: both on the one device of the box)"
  cat $R/bal_venice_gpus2.json) > $P/r04_bal_end_to_end.txt
-for n in ck1 lpl huber huber_ck1 local_ck1 local zipf05_ck1 uniform_ck1 step2 final_huber final_local_huber; do
+for n in ck1 lpl huber huber_ck1 local_ck1 local zipf05_ck1 uniform_ck1 step2 step2_ckh final_huber final_local_huber; do
   cp $(newest $T/pmc_$n/fetch/*/*counter_collection.csv) $P/r04_pmc_fetch_size_$n.csv
   cp $(newest $T/pmc_$n/write/*/*counter_collection.csv) $P/r04_pmc_write_size_$n.csv
 done
@@ -36,5 +37,6 @@ t local venice-1778:ldsacc:1:local
 t zipf05_ck1 venice-1778:ldsacc:1:zipf0.5:ck1
 t uniform_ck1 venice-1778:ldsacc:1:uniform:ck1
 t step2 venice-1778:ldsacc:1:step2
+t step2_ckh venice-1778:ldsacc:1:step2:ckh1
 t final_huber final-13682:ldsacc:1:HUBER
 t final_local_huber final-13682:ldsacc:1:HUBER:local
