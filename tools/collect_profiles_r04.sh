@@ -22,7 +22,11 @@ for n in forced_e0_lpl huber local zipf05 uniform trafalgar ladybug step2 step2_
 (echo "# tools/run_bal_config.py venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0"
  cat $R/bal_venice.json
  echo "# the same with --gpus 2: two shard contexts of one process (here: both on the one device of the box)"
- cat $R/bal_venice_gpus2.json) > $P/r04_bal_end_to_end.txt
+ cat $R/bal_venice_gpus2.json
+ if [ -f $R/bal_venice_gt_gpus1.json ]; then
+   echo "# venice-1778 from the ground truth perturbed by 2 % (--synth-init-gt), --gpus 1 and --gpus 2"
+   cat $R/bal_venice_gt_gpus1.json $R/bal_venice_gt_gpus2.json
+ fi) > $P/r04_bal_end_to_end.txt
 for n in ck1 lpl huber huber_ck1 local_ck1 local zipf05_ck1 uniform_ck1 step2 step2_ckh final_huber final_local_huber; do
   cp $(newest $T/pmc_$n/fetch/*/*counter_collection.csv) $P/r04_pmc_fetch_size_$n.csv
   cp $(newest $T/pmc_$n/write/*/*counter_collection.csv) $P/r04_pmc_write_size_$n.csv

@@ -37,5 +37,8 @@ bash tools/ck_sweep.sh $out/sweep_raw.txt 1 > $out/sweep.txt 2>&1 < /dev/null
 bash tools/shard_sweep.sh > $out/shards.txt 2>&1 < /dev/null
 python3 tools/run_bal_config.py venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0 > $out/bal_venice.json 2> $out/bal_venice.err < /dev/null
 python3 tools/run_bal_config.py venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0 --gpus 2 > $out/bal_venice_gpus2.json 2> $out/bal_venice_gpus2.err < /dev/null
+for g in 1 2; do
+  python3 tools/run_bal_config.py venice-1778 --synth-init-gt --max-num-iterations-step-1 8 --max-num-iterations-step-2 6 --power-sc-iterations 20 --gpus $g > $out/bal_venice_gt_gpus$g.json 2> $out/bal_venice_gt_gpus$g.err < /dev/null
+done
 rm -rf $out/e0/kt/*/*kernel_trace.csv $out/e0_huber/kt/*/*kernel_trace.csv
 ls $out
