@@ -229,8 +229,9 @@ def self_launch(argv, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps (one step = one m-term solve; 200 x 1.3 ms: long enough for an external utilisation sampler to see)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--problem", default="venice-1778", choices=sorted(synth.BAL_SHAPES))
     ap.add_argument("--e0-mode", default="ldsacc", choices=["ldsacc", "implicit", "tiles", "tiles-ldsacc"],
                     help="E0 operator form: implicit tiles + LDS accumulation of hot cameras (default, fastest), "
