@@ -3,7 +3,8 @@
 # defaults only take for some problem sizes (round 3 found a stale-weights defect of RIPCG and a capture/upload race this
 # way).  Expected: all green (the test of the layout the library picks BY DEFAULT skips itself when the
 # environment forces the layout; the at-size oracle comparison runs in every mode).
-#   tools/forced_mode_suite.sh [ck]       (about 4 GPU-minutes per mode; "ck": only the modes that force the camera-chunk kernels)
+#   tools/forced_mode_suite.sh [ck|base]  (about 4 GPU-minutes per mode; "ck": only the modes that force the camera-chunk kernels,
+#                                          "base": only the others)
 cd "$(dirname "$0")/.." || exit 1
 # -rf --tb=line: every failure with the assertion that failed, not only the test name
 run() { echo "== $*"; env "$@" python3 -m pytest tests -q -m gpu -rf --tb=line 2>&1 | grep "FAILED\|Error\|assert\|passed\|failed"; }
@@ -18,6 +19,7 @@ run POVAR_E0_V1=0 POVAR_LPL_NOGRID=1 POVAR_LONG_SEPARATE=1 POVAR_HOT_ACC=40 POVA
 run POVAR_PREPARE_V1=1 POVAR_NO_FUSE=1
 run POVAR_NO_GRAPH=1
 fi
+[ "${1:-all}" = "base" ] && exit 0
 run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_LPL_PLACE=sync
 # the camera-chunk kernels (e0_ck, and e0_ck_h in every step-2 context) under stress: few accumulators (most chunks write their own record), many batches / short chunks,
 # seven workgroups (dozens of tiles per wavefront), the two-group instantiation, the 12-wavefront one on a layout cut for it
