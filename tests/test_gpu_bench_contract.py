@@ -123,9 +123,15 @@ def test_bench_two_ranks_p2p_is_opt_in_and_falls_back():
     d, inc = _run_bench(base + ["--gpus", "2"], {}, "inc_fb3.npy")
     assert d["config"]["term_exchange"] == "all-reduce"
     assert np.linalg.norm(inc - inc0) <= 1e-11 * np.linalg.norm(inc0)
-    d, inc = _run_bench(base + ["--gpus", "2", "--p2p"], {}, "inc_fb1.npy")
-    assert d["config"]["term_exchange"].startswith("p2p push + local reduce (validated")
-    assert np.linalg.norm(inc - inc0) <= 1e-11 * np.linalg.norm(inc0)
+    # (two PROCESSES on one device: a rank the OS or the device scheduler holds back lets its peer's bounded wait run out,
+    # and the run falls back to the all-reduce -- the designed behaviour, seen once in 33 runs of this test on the shared
+    # box; the exchange has to validate in one of two attempts, the increment has to be right in both)
+    for attempt in range(2):
+        d, inc = _run_bench(base + ["--gpus", "2", "--p2p"], {}, "inc_fb1.npy")
+        assert np.linalg.norm(inc - inc0) <= 1e-11 * np.linalg.norm(inc0)
+        if d["config"]["term_exchange"].startswith("p2p push + local reduce (validated"):
+            break
+    assert d["config"]["term_exchange"].startswith("p2p push + local reduce (validated"), d["config"]["term_exchange"]
     d, inc = _run_bench(base + ["--gpus", "2", "--p2p"], {"POVAR_BENCH_P2P_FAIL": "1"}, "inc_fb2.npy")
     assert d["config"]["term_exchange"].startswith("all-reduce (peer-to-peer exchange not used")
     assert np.linalg.norm(inc - inc0) <= 1e-11 * np.linalg.norm(inc0)
