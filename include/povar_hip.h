@@ -279,6 +279,21 @@ typedef struct {
   int64_t ckh_chunks, ckh_cold_chunks;
   int32_t e0_auto_h;    /* as e0_auto: 0 forced, 1 to be timed at the next step-2 power series, 2 timed */
   float tune_lpl_h_us, tune_ck_h_us;
+  /* resident power series (series_res, povar_kernels_res.hpp): the whole loop of solve_pOSE
+   * (sc/linearization_power_varproj.hpp:191-237) in one launch, observation rows in registers, landmarks and B^-1 in LDS */
+  int32_t res_ready;    /* 1: the layout exists (the context's observations fit the lanes of one workgroup per CU) */
+  int32_t res_active;   /* 1: the next step-1 power series of this context runs as the resident kernel */
+  int32_t res_auto;     /* 0 forced (POVAR_RES, povar_set_series_kernel), 1 to be timed at the next series, 2 timed */
+  int32_t res_wgs, res_waves, res_rows, res_rounds;  /* workgroups, wavefronts per workgroup, rows per chunk, chunks per lane */
+  int32_t res_records;  /* partial records = (workgroup, camera) pairs */
+  int32_t res_max_cams, res_max_lms, res_max_chunks, res_max_acc;  /* of the fullest workgroup: cameras, landmarks, chunks,
+                           cameras whose chunks are several lane runs (accumulator in LDS) */
+  int32_t res_order;    /* landmark order the workgroup ranges were cut from: 0 natural (file) order, 1 by rarest camera */
+  int32_t res_lds_bytes;
+  double res_build_ms;
+  float tune_terms_us, tune_res_us;  /* what the timing saw, microseconds per term: per-term kernels, resident series */
+  int32_t res_failed;   /* 1: a resident series gave up (its workgroups were not all on the device together); the
+                           context repeated that series with the per-term kernels and stays on them */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 /* The reference's constructor is a trivial allocation (sc/linearization_varproj.hpp:44-60); this library's builds the
@@ -297,6 +312,12 @@ int povar_layout_finalize(povar_ctx* ctx, int32_t wait);
  * default when nothing is forced): the library times both kernels of a step once per layout on the prepared problem and
  * keeps the faster one (povar_layout_info.e0_auto[_h], tune_*_us). */
 int povar_set_e0_kernel(povar_ctx* ctx, int32_t kernel);
+/* The m-term loop of solve_pOSE (sc/linearization_power_varproj.hpp:191-237) as per-term kernels inside a hipGraph
+ * (mode 0) or as ONE resident launch that keeps the term-invariant operands on the chip (mode 1; contexts of up to about
+ * a million observations in the LDS-accumulating E0 mode, without a communicator or with the peer-to-peer exchange);
+ * -1 (default): the library times both once per context on the caller's prepared system and keeps the faster one
+ * (povar_layout_info.res_auto, tune_terms_us, tune_res_us).  Environment: POVAR_RES=0|1. */
+int povar_set_series_kernel(povar_ctx* ctx, int32_t mode);
 /* Diagnostic builds only (-DPOVAR_CK_STAMPS, tools/ck_stamps.py): in-kernel s_memtime stamps of e0_ck's phases,
  * [workgroups][2 wavefronts][40]; the first call arms the collection.  The shipped library returns an error. */
 int povar_debug_ck_stamps(povar_ctx* ctx, uint64_t* out, int64_t n);

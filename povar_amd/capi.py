@@ -52,7 +52,13 @@ class LayoutInfo(C.Structure):
                 ("ck_chunks", C.c_int64), ("ck_cold_chunks", C.c_int64), ("ck_build_ms", C.c_double), ("e0_auto", C.c_int32),
                 ("tune_lpl_us", C.c_float), ("tune_ck_us", C.c_float), ("e0_kernel_h", C.c_int32), ("ckh_ready", C.c_int32),
                 ("ckh_batches", C.c_int32), ("ckh_slots", C.c_int32), ("ckh_chunks", C.c_int64), ("ckh_cold_chunks", C.c_int64),
-                ("e0_auto_h", C.c_int32), ("tune_lpl_h_us", C.c_float), ("tune_ck_h_us", C.c_float)]
+                ("e0_auto_h", C.c_int32), ("tune_lpl_h_us", C.c_float), ("tune_ck_h_us", C.c_float),
+                ("res_ready", C.c_int32), ("res_active", C.c_int32), ("res_auto", C.c_int32), ("res_wgs", C.c_int32),
+                ("res_waves", C.c_int32), ("res_rows", C.c_int32), ("res_rounds", C.c_int32), ("res_records", C.c_int32),
+                ("res_max_cams", C.c_int32), ("res_max_lms", C.c_int32), ("res_max_chunks", C.c_int32),
+                ("res_max_acc", C.c_int32), ("res_order", C.c_int32),
+                ("res_lds_bytes", C.c_int32), ("res_build_ms", C.c_double), ("tune_terms_us", C.c_float),
+                ("tune_res_us", C.c_float), ("res_failed", C.c_int32)]
 
 
 class TimingsInfo(C.Structure):
@@ -71,7 +77,8 @@ def build(force: bool = False) -> str:
     src_dir = os.path.join(_PKG, "csrc")
     srcs = [os.path.join(src_dir, f) for f in ("povar_hip.hip", "povar_kernels.hpp", "povar_kernels_joint.hpp",
                                                "povar_kernels_sc.hpp", "povar_kernels_chol.hpp", "lpl_layout.hpp",
-                                               "ck_layout.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_joint.hpp")] + [HEADER]
+                                               "ck_layout.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_joint.hpp",
+                                               "res_layout.hpp", "povar_kernels_res.hpp")] + [HEADER]
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)
@@ -363,6 +370,10 @@ class Context:
     def set_e0_kernel(self, kernel):
         """Per-term E0 kernel of step 1: 0 = e0_lpl, 1..5 = e0_ck instantiations (include/povar_hip.h)."""
         self._chk(self.L.povar_set_e0_kernel(self.h, C.c_int32(int(kernel))))
+
+    def set_series_kernel(self, mode):
+        """-1: timed choice, 0: per-term kernels in a hipGraph, 1: the resident power series (include/povar_hip.h)."""
+        self._chk(self.L.povar_set_series_kernel(self.h, C.c_int32(int(mode))))
 
     def comm_ranks(self):
         n = self.L.povar_comm_ranks(self.h)

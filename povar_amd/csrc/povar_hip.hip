@@ -27,6 +27,8 @@
 #include "ck_layout.hpp"
 #include "povar_kernels_ck.hpp"
 #include "povar_kernels_ck_joint.hpp"
+#include "res_layout.hpp"
+#include "povar_kernels_res.hpp"
 
 using namespace povar;
 
@@ -167,6 +169,32 @@ struct povar_ctx {
   } ck, pl_ck,       // step 1 (e0_ck): the layout in use / the one the placement thread built for the placed rows
     ckh, pl_ckh;     // step 2 (e0_ck_h): a second instance (64 bytes of LDS per landmark slot: more batches, other chunks)
   DevBuf<unsigned long long> ck_stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): CkP::stamps
+  // resident power series (series_res, povar_kernels_res.hpp): the layout of res_layout.hpp on the device
+  struct ResDev {
+    DevBuf<int> lane_cam, lane_tgt, lane_seg, lslot, oslot, wave_h, lm_off, lm_id, acc_off, acc_rec, own_off, own_cam;
+    DevBuf<double2> uv;
+    DevBuf<int2> own_rec;
+    DevBuf<double> part, zbuf, nrm;
+    DevBuf<unsigned> flags;      // [2][RES_MAX_WG]: f1, f2 (zeroed before every launch)
+    int W = 0, NW = 0, H = 0, R = 1, LS = 1, n_rec = 0, max_lm = 0, max_cam = 0, max_acc = 0, max_own = 0, max_chunks = 0, order = 0;
+    size_t lds_bytes = 0;
+    double build_ms = 0;
+    bool ready = false;
+    void release() {
+      lane_cam.release(); lane_tgt.release(); lane_seg.release(); lslot.release(); oslot.release(); wave_h.release();
+      lm_off.release(); lm_id.release(); acc_off.release(); acc_rec.release(); own_off.release(); own_cam.release();
+      uv.release(); own_rec.release(); part.release(); zbuf.release(); nrm.release(); flags.release();
+      ready = false;
+    }
+  } res;
+  int res_mode = -1;             // -1: the library times the resident series against the per-term kernels once per context
+                                 // (res_autotune); 0: per-term kernels; 1: resident series whenever the context allows
+  bool res_tuned = false, res_choice = false, res_failed = false;
+  float res_tune_us[2] = {0, 0}; // per term: per-term kernels (hipGraph), resident series
+  bool res_check = false;        // a resident series is in flight whose give-up bit (flags[0] & 4) has not been looked at
+  int res_last_m = 0;
+  double res_last_tol[2] = {0, 0};
+  unsigned res_spin_limit = 1u << 18;
   DevBuf<int2> ck_zero_range;    // [n_cams] empty runs: e0_ck leaves no per-observation cold view to the per-camera kernels
   int ck_variant = 0;            // 0: e0_lpl; 1..CK_VARIANTS: e0_ck instantiation (POVAR_CK_VARIANTS)
   int ckh_variant = 0;           // step 2: 0: e0_lpl_h; 1: e0_ck_h
@@ -600,6 +628,106 @@ void launch_e0_ck_h(povar_ctx* c, const Dp& da) {
     hipLaunchKernelGGL((e0_ck_h<16, 2, false>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ckh.part.p);
 }
 int ckh_autotune(povar_ctx* c);
+
+// ------------------------------------------------------------------------------------------
+// resident power series (series_res): upload, kernel parameters, launch
+// ------------------------------------------------------------------------------------------
+int res_upload(povar_ctx* c, const ResLayout& R) {
+  povar_ctx::ResDev& D = c->res;
+  int rc = 0;
+  if ((rc = upload(D.lane_cam, R.lane_cam, c)) || (rc = upload(D.lane_tgt, R.lane_tgt, c)) || (rc = upload(D.lane_seg, R.lane_seg, c)) ||
+      (rc = upload(D.uv, R.uv, c)) || (rc = upload(D.lslot, R.lslot, c)) || (rc = upload(D.oslot, R.oslot, c)) ||
+      (rc = upload(D.wave_h, R.wave_h, c)) || (rc = upload(D.lm_off, R.lm_off, c)) || (rc = upload(D.lm_id, R.lm_id, c)) ||
+      (rc = upload(D.acc_off, R.acc_off, c)) || (rc = upload(D.acc_rec, R.acc_rec, c)) || (rc = upload(D.own_off, R.own_off, c)) ||
+      (rc = upload(D.own_cam, R.own_cam, c)) || (rc = upload(D.own_rec, R.own_rec, c)))
+    return rc;
+  HIP_TRY(D.part.alloc((size_t)std::max(R.n_rec, 1) * 12, &c->bytes));
+  HIP_TRY(D.zbuf.alloc((size_t)c->n_cams * 12, &c->bytes));
+  HIP_TRY(D.nrm.alloc((size_t)RES_MAX_WG * 2, &c->bytes));
+  HIP_TRY(D.flags.alloc((size_t)RES_MAX_WG * 2, &c->bytes));
+  D.W = R.W; D.NW = R.NW; D.H = R.H; D.R = R.R; D.LS = R.LS; D.n_rec = R.n_rec; D.max_lm = R.max_lm; D.max_cam = R.max_cam;
+  D.max_acc = R.max_acc; D.max_own = R.max_own; D.max_chunks = R.max_chunks; D.order = R.order; D.lds_bytes = R.lds_bytes;
+  D.ready = true;
+  return 0;
+}
+// instantiations: wavefronts per workgroup, rows per chunk, chunks per lane, landmark slots per lane.  A 1024-thread
+// workgroup has 128 VGPRs per lane (two rows, G in LDS), a 512-thread one 256 (two chunks of four rows, G in registers)
+#define POVAR_RES_VARIANTS(X) X(16, 1, 1, 1) X(16, 2, 1, 1) X(8, 4, 2, 1) X(8, 4, 2, 2)
+template <int NW, int H, int RR, int LS>
+void launch_res_t(povar_ctx* c, const ResP& k) {
+  if (c->opt.robust_norm)
+    hipLaunchKernelGGL((series_res<NW, H, RR, LS, true>), dim3(c->res.W), dim3(NW * 64), c->res.lds_bytes, c->stream, c->d, k);
+  else
+    hipLaunchKernelGGL((series_res<NW, H, RR, LS, false>), dim3(c->res.W), dim3(NW * 64), c->res.lds_bytes, c->stream, c->d, k);
+}
+bool res_variant_exists(int nw, int h, int rr, int ls) {
+#define X(NW_, H_, R_, LS_) if (nw == NW_ && h == H_ && rr == R_ && ls == LS_) return true;
+  POVAR_RES_VARIANTS(X)
+#undef X
+  return false;
+}
+void launch_res(povar_ctx* c, const ResP& k) {
+#define X(NW_, H_, R_, LS_)                                                              \
+  if (c->res.NW == NW_ && c->res.H == H_ && c->res.R == R_ && c->res.LS == LS_) {        \
+    launch_res_t<NW_, H_, R_, LS_>(c, k);                                                \
+    return;                                                                              \
+  }
+  POVAR_RES_VARIANTS(X)
+#undef X
+}
+template <int NW, int H, int RR, int LS>
+hipError_t res_set_lds_t() {
+  hipError_t e = hipFuncSetAttribute((const void*)series_res<NW, H, RR, LS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_BYTES);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)series_res<NW, H, RR, LS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_BYTES);
+}
+hipError_t res_set_lds_all() {
+  hipError_t e = hipSuccess;
+#define X(NW_, H_, R_, LS_) if (e == hipSuccess) e = res_set_lds_t<NW_, H_, R_, LS_>();
+  POVAR_RES_VARIANTS(X)
+#undef X
+  return e;
+}
+// the layout for a context: the lightest instantiation that holds it (fewest rows in registers first)
+void res_build_for(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx, const double* obs,
+                   const std::vector<int>& rank1, const std::vector<int>& slot_of_obs, int wgs, ResLayout& R) {
+  build_res(n_cams, n_lms, lm_off, cam_idx, obs, rank1, slot_of_obs, wgs, 16, 1, 1, 2, 1, R);
+  if (R.fits) return;
+  build_res(n_cams, n_lms, lm_off, cam_idx, obs, rank1, slot_of_obs, wgs, 8, 2, 4, 4, 2, R);
+}
+bool sharded(const povar_ctx* c);
+// the context can run the resident series now (whether it SHOULD is res_mode / the timing of res_autotune)
+bool res_possible(const povar_ctx* c) {
+  return c->res.ready && !c->res_failed && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && !c->profile &&
+         !sharded(c);
+}
+bool res_active(const povar_ctx* c) {
+  return res_possible(c) && (c->res_mode == 1 || (c->res_mode < 0 && c->res_tuned && c->res_choice));
+}
+ResP res_params(const povar_ctx* c, int m, double q_tol, double r_tol) {
+  const povar_ctx::ResDev& D = c->res;
+  ResP k{};
+  k.lane_cam = D.lane_cam.p; k.lane_tgt = D.lane_tgt.p; k.lane_seg = D.lane_seg.p;
+  k.uv = D.uv.p; k.lslot = D.lslot.p; k.oslot = D.oslot.p; k.wave_h = D.wave_h.p;
+  k.lm_off = D.lm_off.p; k.lm_id = D.lm_id.p; k.acc_off = D.acc_off.p; k.acc_rec = D.acc_rec.p;
+  k.own_off = D.own_off.p; k.own_cam = D.own_cam.p; k.own_rec = D.own_rec.p;
+  k.part = D.part.p; k.zbuf = D.zbuf.p; k.f1 = D.flags.p; k.f2 = D.flags.p + RES_MAX_WG; k.nrm = D.nrm.p;
+  k.W = D.W; k.m = m;
+  k.want_norms = (q_tol > 0 || r_tol > 0) ? 1 : 0;
+  k.want_norm0 = r_tol > 0 ? 1 : 0;
+  // the robust weights of the linearisation in force: per slot (sqrt, lane-per-observation linearisation) or in row order
+  k.w_mode = c->aux_lin_id == c->lin_id ? 2 : 1;
+  k.q_tol = q_tol; k.r_tol = r_tol;
+  k.spin_limit = c->res_spin_limit;
+  return k;
+}
+// the whole series as one launch (+ the two memset nodes that re-arm the flag words)
+int enqueue_series_res(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
+  HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
+  HIP_TRY(hipMemsetAsync(c->res.flags.p, 0, sizeof(unsigned) * 2 * RES_MAX_WG, c->stream));
+  launch_res(c, res_params(c, m, q_tol, r_tol));
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------
 // launch helpers
@@ -1519,6 +1647,33 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
                  c->v2_wg_slot_rec.p, nt, V.hubs};
   }
   lap("uploads (lane/landmark)");
+  {
+    // resident power series (res_layout.hpp): for contexts whose observations fit the lanes' registers.  POVAR_RES=0|1
+    // forces the choice (default: timed against the per-term kernels at the first series), POVAR_RES_WGS the workgroups,
+    // POVAR_RES_OBS_PER_WG the observations a workgroup gets on small problems before all CUs are used.
+    if (const char* e = std::getenv("POVAR_RES")) c->res_mode = e[0] == '1' ? 1 : 0;
+    if (const char* e = std::getenv("POVAR_RES_SPIN")) c->res_spin_limit = (unsigned)std::max(1, std::atoi(e));
+    int64_t max_obs = 1 << 20;
+    if (const char* e = std::getenv("POVAR_RES_MAX_OBS")) max_obs = std::atoll(e);
+    if (c->res_mode != 0 && n_obs <= max_obs) {
+      const auto tr = std::chrono::steady_clock::now();
+      hipDeviceProp_t prop;
+      HIP_TRY_C(hipGetDeviceProperties(&prop, options->device));
+      const int cus = std::min(std::max(c->cu_limit > 0 ? c->cu_limit : prop.multiProcessorCount, 1), RES_MAX_WG);
+      int per_wg = 1024;
+      if (const char* e = std::getenv("POVAR_RES_OBS_PER_WG")) per_wg = std::max(64, std::atoi(e));
+      int wgs = (int)std::min<int64_t>(cus, std::max<int64_t>(8, (n_obs + per_wg - 1) / per_wg));
+      if (const char* e = std::getenv("POVAR_RES_WGS")) wgs = std::max(1, std::min(std::atoi(e), cus));
+      HIP_TRY_C(res_set_lds_all());
+      ResLayout R;
+      res_build_for(n_cams, n_lms, lm_offsets, cam_idx, obs, L.cam_hot, L.slot_of_obs, wgs, R);
+      if (R.fits && res_variant_exists(R.NW, R.H, R.R, R.LS)) {
+        if (int rc = res_upload(c, R)) { povar_destroy(c); return rc; }
+        c->res.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr).count();
+      }
+      lap("resident-series layout");
+    }
+  }
   part_b.join();
   if (part_b_failed.load()) { povar_destroy(c); return fail(-4, "out of host memory while building the lane-per-observation layout"); }
   lap("wait for the lane/obs arrays");
@@ -1642,6 +1797,7 @@ void povar_destroy(povar_ctx* c) {
   c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
   c->pl_c3_src.release(); c->c3_src.release();
   c->ck.release(); c->pl_ck.release(); c->ckh.release(); c->pl_ckh.release(); c->ck_zero_range.release(); c->ck_stamps.release();
+  c->res.release();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
   if (c->pin) (void)hipHostFree(c->pin);
@@ -1678,8 +1834,10 @@ void povar_destroy(povar_ctx* c) {
 
 int64_t povar_device_bytes(povar_ctx* c) { return c ? (int64_t)c->bytes : 0; }
 
+static int res_verify(povar_ctx* c);
 int povar_synchronize(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1789,6 +1947,7 @@ int povar_error_pose(povar_ctx* c, double alpha, povar_residual_info* out) {
 
 int povar_linearize_pose(povar_ctx* c, double alpha) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;
   c->linearized_h = false;
   set_alpha(c, alpha);
   c->alpha_lin = alpha;
@@ -1846,6 +2005,7 @@ int povar_linearize_pose(povar_ctx* c, double alpha) {
 
 int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;
   if (!c->linearized) return fail(-1, "povar_prepare_pose before povar_linearize_pose");
   set_alpha(c, c->alpha_lin);
   c->joint = false;
@@ -1923,23 +2083,18 @@ static int enqueue_series(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
   return 0;
 }
 
-int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol, int32_t* num_iterations,
-                            int32_t* termination) {
-  if (int rc = check_ctx(c)) return rc;
-  if (m < 0) return fail(-1, "power_sc_iterations < 0");
-  TimeScope ts(c, 2);
-  if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // not inside the graph capture
-  if (int rc = ck_autotune(c)) return rc;
-  if (int rc = ckh_autotune(c)) return rc;
-  if (ck_active(c) || ckh_active(c)) ensure_ck_w(c);
+// One series on the context's stream: the per-term kernels (use_res = false) or the resident kernel, through the cached
+// hipGraph where the context allows a capture.
+static int run_series(povar_ctx* c, int32_t m, double q_tol, double r_tol, bool use_res) {
   const bool norms = q_tol > 0 || r_tol > 0;
   // with a communicator the loop is launched kernel by kernel (the per-term all-reduce dominates and
   // RCCL-in-capture is not something a 1-GPU box can validate); POVAR_GRAPH_COMM=1 opts in
   const bool p2p_terms = c->p2p && !c->joint && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
-  if (c->use_graph && !c->profile && m > 0 && (p2p_terms || (!c->host_fn && (!c->comm || c->graph_with_comm)))) {
+  if (c->use_graph && !c->profile && m > 0 && (use_res || p2p_terms || (!c->host_fn && (!c->comm || c->graph_with_comm)))) {
     // the whole loop (memset, B^-1, m x {E0 kernels, [all-reduce], B^-1 + AXPY, [check]}) is one graph
     // launch; it is re-captured only when a kernel argument changes
-    const int key[6] = {m, c->joint ? 1 : 0, c->opt.e0_mode + 16 * (c->joint ? (ckh_active(c) ? 1 : 0) : ck_active(c) ? c->ck_variant : 0), (sharded(c) ? 1 : 0) | (p2p_terms ? 2 : 0), norms ? 1 : 0, r_tol > 0 ? 1 : 0};
+    const int key[6] = {m, (c->joint ? 1 : 0) | (use_res ? 2 : 0) | (use_res ? (res_params(c, m, q_tol, r_tol).w_mode << 2) : 0),
+                        c->opt.e0_mode + 16 * (c->joint ? (ckh_active(c) ? 1 : 0) : ck_active(c) ? c->ck_variant : 0), (sharded(c) ? 1 : 0) | (p2p_terms ? 2 : 0), norms ? 1 : 0, r_tol > 0 ? 1 : 0};
     // (the landmark damping is an argument of the prepare / back-substitution kernels only: no kernel of the loop reads
     // it, and step 2 changes it with every LM iteration -- a capture + instantiation of 0.25 ms each time)
     Dp key_d = c->d;
@@ -1953,7 +2108,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
       hipGraph_t g = nullptr;
       std::lock_guard<std::mutex> lk(g_capture_mu);  // no HIP call of the row-placement thread inside the capture
       HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      const int rc = enqueue_series(c, m, q_tol, r_tol);
+      const int rc = use_res ? enqueue_series_res(c, m, q_tol, r_tol) : enqueue_series(c, m, q_tol, r_tol);
       hipError_t e = hipStreamEndCapture(c->stream, &g);
       if (rc) return rc;
       HIP_TRY(e);
@@ -1965,10 +2120,83 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
       c->series_graph_tol[1] = r_tol;
     }
     HIP_TRY(hipGraphLaunch(c->series_graph, c->stream));
+  } else if (use_res) {
+    if (int rc = enqueue_series_res(c, m, q_tol, r_tol)) return rc;
   } else {
     if (int rc = enqueue_series(c, m, q_tol, r_tol)) return rc;
   }
+  if (use_res) {
+    c->res_check = true;  // the give-up bit is looked at with the caller's next read-back (res_verify)
+    c->res_last_m = m;
+    c->res_last_tol[0] = q_tol;
+    c->res_last_tol[1] = r_tol;
+    c->flag0_clean = false;
+  }
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// A resident series gives up (bit 2 of flags[0]) when its workgroups were not all on the device together -- another
+// context's kernels held CUs for longer than the bounded spins.  The result is then incomplete: the series is repeated
+// with the per-term kernels and the context stays on them.  Called before anything reads what the series left.
+static int res_verify(povar_ctx* c) {
+  if (!c->res_check) return 0;
+  c->res_check = false;
+  int f[4];
+  if (int rc = read_flags(c, f)) return rc;
+  if (!(f[0] & 4)) return 0;
+  c->res_failed = true;
+  HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+  if (c->series_graph) { (void)hipGraphExecDestroy(c->series_graph); c->series_graph = nullptr; }
+  return run_series(c, c->res_last_m, c->res_last_tol[0], c->res_last_tol[1], false);
+}
+
+// Which of the two forms of the series is faster is a property of the context (observations per workgroup, cameras per
+// workgroup): unless one is forced (POVAR_RES, povar_set_series_kernel) both are run once on the caller's prepared system
+// -- a warm-up and REPS timed solves each, the same m and tolerances -- and the faster one is kept.
+static int res_autotune(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
+  if (c->res_mode >= 0 || c->res_tuned || !res_possible(c) || m < 4) return 0;
+  c->res_tuned = true;
+  struct Events {
+    hipEvent_t e[2] = {nullptr, nullptr};
+    ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
+  } ev;
+  for (auto& x : ev.e) HIP_TRY(hipEventCreate(&x));
+  constexpr int REPS = 3;
+  float ms[2] = {0, 0};
+  for (int which = 0; which < 2; ++which) {
+    if (int rc = run_series(c, m, q_tol, r_tol, which == 1)) return rc;
+    HIP_TRY(hipEventRecord(ev.e[0], c->stream));
+    for (int i = 0; i < REPS; ++i)
+      if (int rc = run_series(c, m, q_tol, r_tol, which == 1)) return rc;
+    HIP_TRY(hipEventRecord(ev.e[1], c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventElapsedTime(&ms[which], ev.e[0], ev.e[1]));
+    if (which == 1) {
+      if (int rc = res_verify(c)) return rc;
+      if (c->res_failed) { c->res_choice = false; return 0; }
+    }
+  }
+  c->res_tune_us[0] = 1e3f * ms[0] / (REPS * m);
+  c->res_tune_us[1] = 1e3f * ms[1] / (REPS * m);
+  c->res_choice = ms[1] < 0.98f * ms[0];
+  return 0;
+}
+
+int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol, int32_t* num_iterations,
+                            int32_t* termination) {
+  if (int rc = check_ctx(c)) return rc;
+  if (m < 0) return fail(-1, "power_sc_iterations < 0");
+  TimeScope ts(c, 2);
+  if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // not inside the graph capture
+  if (int rc = ck_autotune(c)) return rc;
+  if (int rc = ckh_autotune(c)) return rc;
+  if (ck_active(c) || ckh_active(c)) ensure_ck_w(c);
+  if (int rc = res_autotune(c, m, q_tol, r_tol)) return rc;
+  const bool norms = q_tol > 0 || r_tol > 0;
+  const bool p2p_terms = c->p2p && !c->joint && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
+  const bool use_res = m > 0 && res_active(c);
+  if (int rc = run_series(c, m, q_tol, r_tol, use_res)) return rc;
   int iters = m, status = POVAR_LINEAR_SOLVER_NO_CONVERGENCE;
   if (p2p_terms) c->flag0_clean = false;  // the waits of the exchange kernels raise bit 1 of flags[0] on a time-out
   if (p2p_terms) {
@@ -1980,6 +2208,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
     }
   }
   if (norms) {
+    if (int rc = res_verify(c)) return rc;  // (the read-back below must see the flags of a complete series)
     int f[4];
     if (int rc = read_flags(c, f)) return rc;
     if (f[1]) {
@@ -1994,11 +2223,13 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
 
 int povar_get_increment(povar_ctx* c, double* inc) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;
   return read_cam_vector(c, inc, c->accum.p, (size_t)(c->joint ? 11 : 12) * c->n_cams);
 }
 
 int povar_get_term(povar_ctx* c, double* term) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;
   return read_cam_vector(c, term, c->tmp.p, (size_t)(c->joint ? 11 : 12) * c->n_cams);
 }
 
@@ -2035,6 +2266,7 @@ int povar_right_mul_e0_pose(povar_ctx* c, const double* x, double* y) {
 
 int povar_apply_pose(povar_ctx* c, int32_t solver_type, double alpha, const double* inc, double* l_diff) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;
   if (!c->linearized) return fail(-1, "povar_apply_pose before povar_linearize_pose");
   const size_t n = 12 * (size_t)c->n_cams;
   set_alpha(c, alpha);
@@ -2546,6 +2778,24 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->e0_auto_h = c->ck_auto ? (c->ckh_tuned ? 2 : 1) : 0;
   out->tune_lpl_h_us = c->ckh_tune_us[0];
   out->tune_ck_h_us = c->ckh_tune_us[1];
+  out->res_ready = c->res.ready ? 1 : 0;
+  out->res_active = res_active(c) ? 1 : 0;
+  out->res_auto = c->res_mode < 0 ? (c->res_tuned ? 2 : 1) : 0;
+  out->res_wgs = c->res.W;
+  out->res_waves = c->res.NW;
+  out->res_rows = c->res.H;
+  out->res_rounds = c->res.R;
+  out->res_max_acc = c->res.max_acc;
+  out->res_records = c->res.n_rec;
+  out->res_max_cams = c->res.max_cam;
+  out->res_max_lms = c->res.max_lm;
+  out->res_max_chunks = c->res.max_chunks;
+  out->res_order = c->res.order;
+  out->res_lds_bytes = (int32_t)c->res.lds_bytes;
+  out->res_build_ms = c->res.build_ms;
+  out->tune_terms_us = c->res_tune_us[0];
+  out->tune_res_us = c->res_tune_us[1];
+  out->res_failed = c->res_failed ? 1 : 0;
   return 0;
 }
 
@@ -2576,6 +2826,16 @@ int povar_set_e0_kernel(povar_ctx* c, int32_t kernel) {
   c->ck_auto = false;
   c->ck_variant = kernel;
   c->ckh_variant = kernel > 0 ? 1 : 0;  // (step 2 has one camera-chunk instantiation)
+  return 0;
+}
+
+int povar_set_series_kernel(povar_ctx* c, int32_t mode) {
+  if (int rc = check_ctx(c)) return rc;
+  if (mode < -1 || mode > 1) return fail(-1, "unknown series kernel");
+  if (mode == 1 && !c->res.ready) return fail(-1, "the resident-series layout was not built for this context");
+  if (int rc = res_verify(c)) return rc;
+  c->res_mode = mode;
+  if (mode < 0) c->res_tuned = false;
   return 0;
 }
 

@@ -1,0 +1,425 @@
+// povar_kernels_res.hpp -- gfx950 device code of the RESIDENT power series: the whole loop of solve_pOSE
+// (linearization_power_varproj.hpp:191-237: x_0 = B^-1 (-b); x_i = B^-1 E0 x_{i-1}; sum, early exit) in ONE launch, for
+// contexts whose term-invariant operands fit on the chip (res_layout.hpp).
+//
+// The per-term kernels re-read per term what does not change between the terms of a solve: rows, landmark records, tile
+// metadata, B^-1 -- and pay a launch ramp, a flush and two kernel boundaries each time (29 us per term on a venice-1778
+// shard of one rank in eight, where the rows cost 7; profiles/r04_shard_term_times.txt).  Here
+//   * a LANE keeps its chunk of <= H observations of one camera (uv, landmark slot, robust weight) and that camera's
+//     P3 = P_c[:, :3] in REGISTERS for the whole solve;
+//   * the workgroup's LANDMARKS live in LDS (h~ 24 bytes, u / g 24 bytes; G = diag(s) Hll^-1 diag(s) in the registers of
+//     the lane that owns the slot), next to one accumulator per camera of the workgroup;
+//   * every camera has an OWNER workgroup that holds B_c^-1, sigma_c, the running sum and the last term in LDS.
+// Per term only z = sigma x moves (right_mul_e0_pOSE :364-406 + right_mul_b_inv_pOSE :322-340):
+//   gather z_c of the lane's camera -> forward u_l += P3^T (w C (Z h~)) (LDS atomics) -> g = G u -> backward
+//   y_c += h~ (x) (w C (P3 g)) (registers, one segmented wavefront sum, one LDS add per run) -> the workgroup's partial
+//   records (one per camera it touches) -> [hand-over 1] -> the owner sums a camera's records in a fixed order, applies
+//   B_c^-1, adds to the sum, publishes z_c -> [hand-over 2] -> next term.
+// The reference's mutex-guarded `res += Jp^T s` (:388-398) is the LDS accumulation + the owner's fixed-order sum.
+//
+// Hand-overs (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", valid forms, first row
+// of the table): every handed-over byte is stored and loaded agent-scope (sc1: write-through, L1-bypassing) -- relaxed
+// agent atomics of 8 bytes --, every storing wavefront drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a
+// barrier, ONE lane stores the workgroup's flag word (the term number, monotone inside the launch); ONE wavefront of the
+// consumer polls the flag words of all workgroups (relaxed agent loads, s_sleep), the others wait at a workgroup barrier.
+// No fence, no dependence on dispatch order or placement; every spin is bounded (ResP::spin_limit): a launch whose
+// workgroups are not all resident (another context's kernels on the device) gives up, raises bit 2 of flags[0] and the
+// library repeats the solve with the per-term kernels.  The flag words are zeroed by a memset node before every launch.
+#pragma once
+
+#include "povar_kernels_ck.hpp"
+#include "res_layout.hpp"
+
+namespace povar {
+
+struct ResP {
+  const int* lane_cam;    // [W][R][T]
+  const int* lane_tgt;
+  const int* lane_seg;
+  const double2* uv;      // [W][R][H][T]
+  const int* lslot;
+  const int* oslot;
+  const int* wave_h;      // [W][R][NW]
+  const int* lm_off;      // [W + 1]
+  const int* lm_id;
+  const int* acc_off;     // [W + 1]
+  const int* acc_rec;
+  const int* own_off;     // [W + 1]
+  const int* own_cam;
+  const int2* own_rec;
+  double* part;           // [n_rec][12] partial records, camera-major
+  double* zbuf;           // [n_cams][12] z = sigma x of the current term
+  unsigned* f1;           // [RES_MAX_WG] term whose partial records workgroup w has published
+  unsigned* f2;           // [RES_MAX_WG] 1 + term whose z workgroup w has published for its cameras
+  double* nrm;            // [RES_MAX_WG][2] squared norms of (term, sum) over the cameras a workgroup owns
+  int W, m, want_norms, want_norm0;
+  int w_mode;             // robust weight of an observation: 1: V2::w through V2::of_slot, 2: Dp::sw squared
+  double q_tol, r_tol;
+  unsigned spin_limit;
+};
+
+typedef __attribute__((address_space(1))) double res_gd;
+typedef __attribute__((address_space(1))) unsigned res_gu;
+typedef __attribute__((address_space(1))) unsigned long long res_gull;
+// agent-scope (sc1) accesses of the handed-over bytes: global_load/store_dwordx2 ... sc1
+__device__ inline double res_ld(const double* p) {
+  return __hip_atomic_load((const res_gd*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void res_st(double* p, double v) {
+  __hip_atomic_store((res_gd*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void res_flag(unsigned* p, unsigned v) {
+  __hip_atomic_store((res_gu*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void res_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ONE wavefront: until every workgroup's flag word has reached `epoch` (monotone).  Lane l looks at words 4 l .. 4 l + 3.
+__device__ inline bool res_wait_all(const unsigned* flags, int W, unsigned epoch, int lane, unsigned limit) {
+  const res_gull* f = (const res_gull*)(uintptr_t)flags + 2 * lane;
+  const bool a0 = 4 * lane < W, a1 = 4 * lane + 1 < W, a2 = 4 * lane + 2 < W, a3 = 4 * lane + 3 < W;
+  for (unsigned spins = 0;; ++spins) {
+    bool ok = true;
+    if (a0) {
+      const unsigned long long lo = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = (unsigned)lo >= epoch && (!a1 || (unsigned)(lo >> 32) >= epoch);
+      if (a2) {
+        const unsigned long long hi = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (unsigned)hi >= epoch && (!a3 || (unsigned)(hi >> 32) >= epoch);
+      }
+    }
+    if (__all(ok)) return true;
+    if (spins >= limit) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// the per-lane state of one chunk
+template <int H>
+struct ResChunk {
+  double2 uv[H];
+  int ls[H];
+  double rw[H];
+  double P3[9];
+  int cam, tgt, seg, hrows, dup, steps;
+};
+
+// NW wavefronts per workgroup, chunks of H rows, RR chunks per lane, LS landmark slots per lane
+template <int NW, int H, int RR, int LS, bool ROBUST>
+__global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
+  constexpr int T = NW * 64;
+  extern __shared__ double res_lds[];
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int L0 = k.lm_off[g], nL = k.lm_off[g + 1] - L0;
+  const int A0 = k.acc_off[g], nA = k.acc_off[g + 1] - A0;
+  const int O0 = k.own_off[g], nO = k.own_off[g + 1] - O0;
+  int* ctl = reinterpret_cast<int*>(res_lds);  // [0] a wait gave up, [1] series converged, [2] iterations, [4..5] |x_0|
+  double* lh = res_lds + 8;             // [nL][3] landmark coordinates
+  double* lu = lh + 3 * nL;             // [nL][3] u = Jl^T Jp x, then g = G u
+  // 1024-thread workgroups have 128 VGPRs per lane: G lives in LDS there (res_g_in_lds)
+  constexpr bool GL = NW >= 16;
+  double* lG = lu + 3 * nL;             // [nL][6] G (GL only)
+  double* acc = lG + (GL ? 6 * nL : 0); // [nA][13] accumulators of the cameras several lane runs share
+  double* obinv = acc + nA * RES_ACC_STRIDE;  // [nO][144] B^-1 of the owned cameras
+  double* osig = obinv + 144 * nO;      // [nO][12] sigma
+  double* oacc = osig + 12 * nO;        // [nO][12] running sum
+  double* otmp = oacc + 12 * nO;        // [nO][12] last term
+  double* onrm = otmp + 12 * nO;        // [nO][2] squared norms of the last term / the sum
+  int* arec = reinterpret_cast<int*>(onrm + 2 * nO);  // [nA] partial record of each accumulator slot
+
+  // ---------------- prologue: everything that does not change between the terms
+  // owned cameras first (their registers are free again before the lane's own state is loaded): B^-1, sigma;
+  // x_0 = B^-1 (-b) (the series start, :196); z_0 published
+  for (int i = t; i < nA * RES_ACC_STRIDE; i += T) acc[i] = 0;
+  for (int i = t; i < nA; i += T) arec[i] = k.acc_rec[A0 + i];
+  if (t < 4) ctl[t] = 0;
+  for (int o = wave; o < nO; o += NW) {
+    const int c = k.own_cam[O0 + o];
+    for (int e = lane; e < 144; e += 64) obinv[144 * o + e] = d.binv[144 * (size_t)c + e];
+    if (lane < 12) osig[12 * o + lane] = d.sigma[12 * (size_t)c + lane];
+    if (lane >= 32 && lane < 44) otmp[12 * o + lane - 32] = -d.b[12 * (size_t)c + lane - 32];
+  }
+  __syncthreads();
+  for (int o = wave; o < nO; o += NW) {
+    const int c = k.own_cam[O0 + o];
+    double s = 0;
+    if (lane < 12) {
+      const double* Bi = obinv + 144 * o + 12 * lane;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) s += Bi[j] * otmp[12 * o + j];
+      oacc[12 * o + lane] = s;
+      res_st(k.zbuf + 12 * (size_t)c + lane, s * osig[12 * o + lane]);
+    }
+    if (k.want_norm0) {
+      double n2[1] = {s * s};
+      wave_sum<1>(n2);
+      if (lane == 0) { onrm[2 * o] = n2[0]; onrm[2 * o + 1] = n2[0]; }
+    }
+    // (otmp = x_0 once every lane of the wavefront has read -b from it)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 12) otmp[12 * o + lane] = s;
+  }
+  res_drain();
+  __syncthreads();
+  if (t == 0) {
+    if (k.want_norm0) {
+      double a = 0;
+      for (int o = 0; o < nO; ++o) a += onrm[2 * o];
+      res_st(k.nrm + 2 * g, a);
+      res_st(k.nrm + 2 * g + 1, a);
+      res_drain();
+    }
+    res_flag(k.f2 + g, 1u);
+  }
+  // the lane's chunks: rows, camera, P3
+  ResChunk<H> ch[RR];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) {
+    const size_t li = ((size_t)g * RR + r) * T + t;
+    ch[r].cam = k.lane_cam[li];
+    ch[r].tgt = k.lane_tgt[li];
+    ch[r].seg = k.lane_seg[li];
+    const int wh = __builtin_amdgcn_readfirstlane(k.wave_h[((size_t)g * RR + r) * NW + wave]);
+    ch[r].hrows = wh & 255;
+    ch[r].dup = (wh >> 8) & 1;
+    ch[r].steps = (wh >> 12) & 15;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const size_t row = (((size_t)g * RR + r) * H + j) * T + t;
+      ch[r].uv[j] = k.uv[row];
+      ch[r].ls[j] = k.lslot[row];
+      ch[r].rw[j] = 1.0;
+      if (ROBUST) {
+        const int os = k.oslot[row];
+        if (os >= 0) {
+          if (k.w_mode == 1) ch[r].rw[j] = d.v2.w[d.v2.of_slot[os]];
+          else { const double s = d.sw[os]; ch[r].rw[j] = s * s; }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) ch[r].P3[e] = 0;
+    if (ch[r].cam >= 0) {
+      const Cam P = load_cam(d.cams_lin4, ch[r].cam);
+      ch[r].P3[0] = P.r0.x; ch[r].P3[1] = P.r0.y; ch[r].P3[2] = P.r0.z;
+      ch[r].P3[3] = P.r1.x; ch[r].P3[4] = P.r1.y; ch[r].P3[5] = P.r1.z;
+      ch[r].P3[6] = P.r2.x; ch[r].P3[7] = P.r2.y; ch[r].P3[8] = P.r2.z;
+    }
+  }
+  // the landmark slots of the lane: h~ into LDS, G = diag(s) Hll^-1 diag(s) in registers
+  double G[GL ? 1 : LS][6];
+#pragma unroll
+  for (int q = 0; q < LS; ++q) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) G[GL ? 0 : q][e] = 0;
+    const int s = t + q * T;
+    if (s < nL) {
+      const int lm = k.lm_id[L0 + s];
+      const int pos = d.v2.lm_pos[lm] & ((1 << 26) - 1);
+      const double* rp = d.v2.lmrec + ((size_t)(pos >> 6) * 9) * WAVE + (pos & 63);
+      lh[3 * s] = rp[0];
+      lh[3 * s + 1] = rp[WAVE];
+      lh[3 * s + 2] = rp[2 * WAVE];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        if (GL) lG[6 * s + e] = rp[(3 + e) * WAVE];
+        else G[q][e] = rp[(3 + e) * WAVE];
+      }
+    }
+  }
+  int iters = k.m;
+
+  // ---------------- the terms
+  for (int i = 1; i <= k.m + 1; ++i) {
+    // u = 0 for the slots of this lane (nothing reads lu between the backward pass of the last term and here)
+#pragma unroll
+    for (int q = 0; q < LS; ++q) {
+      const int s = t + q * T;
+      if (s < nL) { lu[3 * s] = 0; lu[3 * s + 1] = 0; lu[3 * s + 2] = 0; }
+    }
+    if (i == k.m + 1 && !k.want_norms) break;  // (with the tests on: the last term's norms are looked at too)
+    // ---- hand-over 2: z of term i - 1 is there (and its norms)
+    if (wave == 0) {
+      const bool ok = res_wait_all(k.f2, k.W, (unsigned)i, lane, k.spin_limit);
+      if (!ok && lane == 0) ctl[0] = 1;
+      if (ok && k.want_norms && (i > 1 || k.want_norm0)) {
+        double v[2] = {0, 0};
+        for (int w = lane; w < k.W; w += 64) {
+          v[0] += res_ld(k.nrm + 2 * w);
+          v[1] += res_ld(k.nrm + 2 * w + 1);
+        }
+        wave_sum<2>(v);
+        const double iter_norm = sqrt(v[0]), acc_norm = sqrt(v[1]);
+        if (i == 1) {
+          if (lane == 0) reinterpret_cast<double*>(ctl)[2] = acc_norm;
+          if (g == 0 && lane == 0) d.norms[0] = acc_norm;
+        } else {
+          const double n0 = reinterpret_cast<double*>(ctl)[2];
+          bool conv = false;
+          if (k.q_tol > 0 && (i - 1) * iter_norm / acc_norm < k.q_tol) conv = true;    // :206-214
+          if (!conv && k.r_tol > 0 && iter_norm / n0 < k.r_tol) conv = true;             // :216-229
+          if (conv && lane == 0) { ctl[1] = 1; ctl[2] = i - 1; }
+          if (g == 0 && lane == 0) { d.norms[1] = iter_norm; d.norms[2] = acc_norm; }
+        }
+      }
+    }
+    __syncthreads();
+    if (ctl[0] | ctl[1]) break;
+    if (i == k.m + 1) break;
+    // ---- forward: u_l += P3^T (w C (Z h~_l)), z of each chunk's camera gathered first
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      if (ch[r].hrows == 0) continue;  // (wave-uniform)
+      double zz[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (ch[r].cam >= 0) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) zz[e] = res_ld(k.zbuf + 12 * (size_t)ch[r].cam + e);
+      }
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        if (j < ch[r].hrows && ch[r].ls[j] >= 0) {
+          const int s = ch[r].ls[j];
+          ck_obs_forward(d, ch[r].uv[j], ch[r].rw[j], zz, ch[r].P3, lh[s], lh[s + 1], lh[s + 2], lu, 0, (uint32_t)s);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- g = G u per landmark slot
+#pragma unroll
+    for (int q = 0; q < LS; ++q) {
+      const int s = t + q * T;
+      if (s < nL) {
+        const double u0 = lu[3 * s], u1 = lu[3 * s + 1], u2 = lu[3 * s + 2];
+        double Gs[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) Gs[e] = GL ? lG[6 * s + e] : G[GL ? 0 : q][e];
+        lu[3 * s] = Gs[0] * u0 + Gs[1] * u1 + Gs[2] * u2;
+        lu[3 * s + 1] = Gs[1] * u0 + Gs[3] * u1 + Gs[4] * u2;
+        lu[3 * s + 2] = Gs[2] * u0 + Gs[4] * u1 + Gs[5] * u2;
+      }
+    }
+    __syncthreads();
+    // ---- backward: y_c += h~_l (x) (w C (P3 g_l)); lanes of one camera are summed; the run's first lane writes the
+    // camera's partial record (its only run in the workgroup) or adds to the camera's accumulator in LDS
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      if (ch[r].hrows == 0) continue;
+      double y[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        if (j < ch[r].hrows && ch[r].ls[j] >= 0) {
+          const int s = ch[r].ls[j];
+          const double gg[3] = {lu[s], lu[s + 1], lu[s + 2]};
+          ck_obs_backward(d, ch[r].uv[j], ch[r].rw[j], ch[r].P3, lh[s], lh[s + 1], lh[s + 2], gg, y);
+        }
+      }
+      if (ch[r].dup) seg_reduce_steps<12>(y, lane, ch[r].seg & 255, (ch[r].seg >> 8) & 255, ch[r].steps);
+      if (ch[r].cam >= 0 && lane == (ch[r].seg & 255)) {
+        if (ch[r].tgt >= 0) {
+#pragma unroll
+          for (int e = 0; e < 12; ++e)
+            __hip_atomic_fetch_add(acc + ch[r].tgt * RES_ACC_STRIDE + e, y[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          double* o = k.part + (size_t)(~ch[r].tgt) * 12;
+#pragma unroll
+          for (int e = 0; e < 12; ++e) res_st(o + e, y[e]);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- the shared cameras' partial records (and their accumulators back to zero)
+    for (int e = t; e < nA * 12; e += T) {
+      const int r = e / 12, m = e % 12;
+      const double v = acc[r * RES_ACC_STRIDE + m];
+      acc[r * RES_ACC_STRIDE + m] = 0;
+      res_st(k.part + (size_t)arec[r] * 12 + m, v);
+    }
+    res_drain();
+    __syncthreads();
+    if (t == 0) res_flag(k.f1 + g, (unsigned)i);
+    // ---- hand-over 1: every workgroup's records of term i are there
+    if (wave == 0) {
+      const bool ok = res_wait_all(k.f1, k.W, (unsigned)i, lane, k.spin_limit);
+      if (!ok && lane == 0) ctl[0] = 1;
+    }
+    __syncthreads();
+    if (ctl[0]) break;
+    // ---- owners: x_i = B^-1 (sigma * sum of the records), sum += x_i, z published (:200-204, :322-340)
+    for (int o = wave; o < nO; o += NW) {
+      const int c = k.own_cam[O0 + o];
+      const int2 rr = k.own_rec[O0 + o];
+      // lanes 0-31 sum entries 0-5 of the records, lanes 32-63 entries 6-11 (six loads and six sums per lane instead of
+      // twelve: the registers of the lane's own rows stay live through this loop); fixed order: record r goes to lane
+      // (r - first) % 32, then the tree of the DPP network
+      const int half = lane >> 5;
+      double yh[6] = {0, 0, 0, 0, 0, 0};
+      for (int r = rr.x + (lane & 31); r < rr.y; r += 32) {
+        const double* ip = k.part + (size_t)r * 12 + 6 * half;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) yh[e] += res_ld(ip + e);
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x111>(yh[e]);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x112>(yh[e]);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x114>(yh[e]);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x118>(yh[e]);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x142>(yh[e]);  // row_bcast 15: lanes 31 / 63 hold the halves' totals
+      double y[12];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        y[e] = bcast_lane(yh[e], 31);
+        y[6 + e] = bcast_lane(yh[e], 63);
+      }
+      double s = 0, a = 0;
+      if (lane < 12) {
+        const double* Bi = obinv + 144 * o + 12 * lane;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) s += Bi[j] * (y[j] * osig[12 * o + j]);
+        a = oacc[12 * o + lane] + s;
+        otmp[12 * o + lane] = s;
+        oacc[12 * o + lane] = a;
+        res_st(k.zbuf + 12 * (size_t)c + lane, s * osig[12 * o + lane]);
+      }
+      if (k.want_norms) {
+        double n2[2] = {s * s, a * a};
+        wave_sum<2>(n2);
+        if (lane == 0) { onrm[2 * o] = n2[0]; onrm[2 * o + 1] = n2[1]; }
+      }
+    }
+    res_drain();
+    __syncthreads();
+    if (t == 0) {
+      if (k.want_norms) {
+        double a = 0, b = 0;
+        for (int o = 0; o < nO; ++o) { a += onrm[2 * o]; b += onrm[2 * o + 1]; }
+        res_st(k.nrm + 2 * g, a);
+        res_st(k.nrm + 2 * g + 1, b);
+        res_drain();
+      }
+      res_flag(k.f2 + g, (unsigned)(i + 1));
+    }
+  }
+  // ---------------- epilogue: sum and last term of the owned cameras, status
+  __syncthreads();
+  if (ctl[1]) iters = ctl[2];
+  for (int e = t; e < nO * 12; e += T) {
+    const int c = k.own_cam[O0 + e / 12];
+    d.accum[12 * (size_t)c + e % 12] = oacc[e];
+    d.tmp[12 * (size_t)c + e % 12] = otmp[e];
+  }
+  if (t == 0) {
+    if (ctl[0]) atomicOr(&d.flags[0], 4);
+    if (g == 0 && ctl[1]) {
+      d.flags[1] = 1;
+      d.flags[2] = iters;
+      d.flags[3] = 1;
+    }
+  }
+}
+
+}  // namespace povar
