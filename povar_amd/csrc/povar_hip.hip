@@ -171,11 +171,11 @@ struct povar_ctx {
   DevBuf<unsigned long long> ck_stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): CkP::stamps
   // resident power series (series_res, povar_kernels_res.hpp): the layout of res_layout.hpp on the device
   struct ResDev {
-    DevBuf<int> lane_cam, lane_tgt, lane_seg, lslot, oslot, wave_h, lm_off, lm_id, acc_off, acc_rec, own_off, own_cam;
+    DevBuf<int> lane_cam, lane_tgt, lane_seg, lslot, oslot, wave_h, lm_off, lm_id, acc_off, acc_rec, own_off, own_cam, oq_off, oq_rec, oq_seg, oq_ws;
     DevBuf<double2> uv;
-    DevBuf<int2> own_rec;
-    DevBuf<double> part, zbuf, nrm;
-    DevBuf<unsigned> flags;      // [2][RES_MAX_WG]: f1, f2 (zeroed before every launch)
+    DevBuf<int2> own_ws;
+    DevBuf<uint4> part, zbuf, nrm;   // granule pairs (povar_kernels_res.hpp)
+    DevBuf<unsigned> launch;         // launch counter: the high bits of the granule tags
     int W = 0, NW = 0, H = 0, R = 1, LS = 1, n_rec = 0, max_lm = 0, max_cam = 0, max_acc = 0, max_own = 0, max_chunks = 0, order = 0;
     size_t lds_bytes = 0;
     double build_ms = 0;
@@ -183,7 +183,8 @@ struct povar_ctx {
     void release() {
       lane_cam.release(); lane_tgt.release(); lane_seg.release(); lslot.release(); oslot.release(); wave_h.release();
       lm_off.release(); lm_id.release(); acc_off.release(); acc_rec.release(); own_off.release(); own_cam.release();
-      uv.release(); own_rec.release(); part.release(); zbuf.release(); nrm.release(); flags.release();
+      oq_off.release(); oq_rec.release(); oq_seg.release(); oq_ws.release();
+      uv.release(); own_ws.release(); part.release(); zbuf.release(); nrm.release(); launch.release();
       ready = false;
     }
   } res;
@@ -639,20 +640,29 @@ int res_upload(povar_ctx* c, const ResLayout& R) {
       (rc = upload(D.uv, R.uv, c)) || (rc = upload(D.lslot, R.lslot, c)) || (rc = upload(D.oslot, R.oslot, c)) ||
       (rc = upload(D.wave_h, R.wave_h, c)) || (rc = upload(D.lm_off, R.lm_off, c)) || (rc = upload(D.lm_id, R.lm_id, c)) ||
       (rc = upload(D.acc_off, R.acc_off, c)) || (rc = upload(D.acc_rec, R.acc_rec, c)) || (rc = upload(D.own_off, R.own_off, c)) ||
-      (rc = upload(D.own_cam, R.own_cam, c)) || (rc = upload(D.own_rec, R.own_rec, c)))
+      (rc = upload(D.own_cam, R.own_cam, c)) || (rc = upload(D.own_ws, R.own_ws, c)) || (rc = upload(D.oq_off, R.oq_off, c)) ||
+      (rc = upload(D.oq_rec, R.oq_rec, c)) || (rc = upload(D.oq_seg, R.oq_seg, c)) || (rc = upload(D.oq_ws, R.oq_ws, c)))
     return rc;
-  HIP_TRY(D.part.alloc((size_t)std::max(R.n_rec, 1) * 12, &c->bytes));
-  HIP_TRY(D.zbuf.alloc((size_t)c->n_cams * 12, &c->bytes));
-  HIP_TRY(D.nrm.alloc((size_t)RES_MAX_WG * 2, &c->bytes));
-  HIP_TRY(D.flags.alloc((size_t)RES_MAX_WG * 2, &c->bytes));
+  // granule buffers: tag 0 everywhere (no launch has the number 0), the launch counter starts at 1
+  const size_t n_part = (size_t)std::max(R.n_rec, 1) * 12, n_z = (size_t)c->n_cams * 12, n_nrm = (size_t)RES_MAX_WG * 2;
+  if (n_part * sizeof(uint4) >= (1ull << 32)) return fail(-1, "resident series: partial records exceed a buffer descriptor");
+  HIP_TRY(D.part.alloc(n_part, &c->bytes));
+  HIP_TRY(D.zbuf.alloc(n_z, &c->bytes));
+  HIP_TRY(D.nrm.alloc(n_nrm, &c->bytes));
+  HIP_TRY(D.launch.alloc(4, &c->bytes));
+  HIP_TRY(hipMemset(D.part.p, 0, n_part * sizeof(uint4)));
+  HIP_TRY(hipMemset(D.zbuf.p, 0, n_z * sizeof(uint4)));
+  HIP_TRY(hipMemset(D.nrm.p, 0, n_nrm * sizeof(uint4)));
+  const unsigned one[4] = {1u, 0u, 0u, 0u};
+  HIP_TRY(hipMemcpy(D.launch.p, one, sizeof(one), hipMemcpyHostToDevice));
   D.W = R.W; D.NW = R.NW; D.H = R.H; D.R = R.R; D.LS = R.LS; D.n_rec = R.n_rec; D.max_lm = R.max_lm; D.max_cam = R.max_cam;
   D.max_acc = R.max_acc; D.max_own = R.max_own; D.max_chunks = R.max_chunks; D.order = R.order; D.lds_bytes = R.lds_bytes;
   D.ready = true;
   return 0;
 }
-// instantiations: wavefronts per workgroup, rows per chunk, chunks per lane, landmark slots per lane.  A 1024-thread
-// workgroup has 128 VGPRs per lane (two rows, G in LDS), a 512-thread one 256 (two chunks of four rows, G in registers)
-#define POVAR_RES_VARIANTS(X) X(16, 1, 1, 1) X(16, 2, 1, 1) X(8, 4, 2, 1) X(8, 4, 2, 2)
+// instantiations: wavefronts per workgroup, rows per chunk, chunks per lane, landmark slots per lane.  512-thread
+// workgroups: 256 VGPRs per lane hold two chunks of up to four rows next to the 72 registers of a granule poll
+#define POVAR_RES_VARIANTS(X) X(8, 1, 2, 1) X(8, 1, 2, 2) X(8, 2, 2, 1) X(8, 2, 2, 2) X(8, 4, 2, 1) X(8, 4, 2, 2)
 template <int NW, int H, int RR, int LS>
 void launch_res_t(povar_ctx* c, const ResP& k) {
   if (c->opt.robust_norm)
@@ -691,9 +701,7 @@ hipError_t res_set_lds_all() {
 // the layout for a context: the lightest instantiation that holds it (fewest rows in registers first)
 void res_build_for(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx, const double* obs,
                    const std::vector<int>& rank1, const std::vector<int>& slot_of_obs, int wgs, ResLayout& R) {
-  build_res(n_cams, n_lms, lm_off, cam_idx, obs, rank1, slot_of_obs, wgs, 16, 1, 1, 2, 1, R);
-  if (R.fits) return;
-  build_res(n_cams, n_lms, lm_off, cam_idx, obs, rank1, slot_of_obs, wgs, 8, 2, 4, 4, 2, R);
+  build_res(n_cams, n_lms, lm_off, cam_idx, obs, rank1, slot_of_obs, wgs, 8, 2, 1, 4, 2, R);
 }
 bool sharded(const povar_ctx* c);
 // the context can run the resident series now (whether it SHOULD is res_mode / the timing of res_autotune)
@@ -702,7 +710,7 @@ bool res_possible(const povar_ctx* c) {
          !sharded(c);
 }
 bool res_active(const povar_ctx* c) {
-  return res_possible(c) && (c->res_mode == 1 || (c->res_mode < 0 && c->res_tuned && c->res_choice));
+  return res_possible(c) && (c->res_mode == 1 || (c->res_mode < 0 && c->res_tuned && c->res_choice));  // (and m <= 250: run_series' caller)
 }
 ResP res_params(const povar_ctx* c, int m, double q_tol, double r_tol) {
   const povar_ctx::ResDev& D = c->res;
@@ -710,8 +718,10 @@ ResP res_params(const povar_ctx* c, int m, double q_tol, double r_tol) {
   k.lane_cam = D.lane_cam.p; k.lane_tgt = D.lane_tgt.p; k.lane_seg = D.lane_seg.p;
   k.uv = D.uv.p; k.lslot = D.lslot.p; k.oslot = D.oslot.p; k.wave_h = D.wave_h.p;
   k.lm_off = D.lm_off.p; k.lm_id = D.lm_id.p; k.acc_off = D.acc_off.p; k.acc_rec = D.acc_rec.p;
-  k.own_off = D.own_off.p; k.own_cam = D.own_cam.p; k.own_rec = D.own_rec.p;
-  k.part = D.part.p; k.zbuf = D.zbuf.p; k.f1 = D.flags.p; k.f2 = D.flags.p + RES_MAX_WG; k.nrm = D.nrm.p;
+  k.own_off = D.own_off.p; k.own_cam = D.own_cam.p; k.own_ws = D.own_ws.p;
+  k.oq_off = D.oq_off.p; k.oq_rec = D.oq_rec.p; k.oq_seg = D.oq_seg.p; k.oq_ws = D.oq_ws.p;
+  k.part = D.part.p; k.zbuf = D.zbuf.p; k.nrm = D.nrm.p; k.launch = D.launch.p;
+  k.part_bytes = (unsigned)(D.part.n * sizeof(uint4)); k.z_bytes = (unsigned)(D.zbuf.n * sizeof(uint4)); k.nrm_bytes = (unsigned)(D.nrm.n * sizeof(uint4));
   k.W = D.W; k.m = m;
   k.want_norms = (q_tol > 0 || r_tol > 0) ? 1 : 0;
   k.want_norm0 = r_tol > 0 ? 1 : 0;
@@ -721,11 +731,11 @@ ResP res_params(const povar_ctx* c, int m, double q_tol, double r_tol) {
   k.spin_limit = c->res_spin_limit;
   return k;
 }
-// the whole series as one launch (+ the two memset nodes that re-arm the flag words)
+// the whole series as one launch (+ the node that numbers the next one)
 int enqueue_series_res(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
   HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
-  HIP_TRY(hipMemsetAsync(c->res.flags.p, 0, sizeof(unsigned) * 2 * RES_MAX_WG, c->stream));
   launch_res(c, res_params(c, m, q_tol, r_tol));
+  hipLaunchKernelGGL(res_bump_launch, dim3(1), dim3(1), 0, c->stream, c->res.launch.p);
   return 0;
 }
 
@@ -2155,7 +2165,7 @@ static int res_verify(povar_ctx* c) {
 // workgroup): unless one is forced (POVAR_RES, povar_set_series_kernel) both are run once on the caller's prepared system
 // -- a warm-up and REPS timed solves each, the same m and tolerances -- and the faster one is kept.
 static int res_autotune(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
-  if (c->res_mode >= 0 || c->res_tuned || !res_possible(c) || m < 4) return 0;
+  if (c->res_mode >= 0 || c->res_tuned || !res_possible(c) || m < 4 || m > 250) return 0;
   c->res_tuned = true;
   struct Events {
     hipEvent_t e[2] = {nullptr, nullptr};
@@ -2195,7 +2205,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (int rc = res_autotune(c, m, q_tol, r_tol)) return rc;
   const bool norms = q_tol > 0 || r_tol > 0;
   const bool p2p_terms = c->p2p && !c->joint && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
-  const bool use_res = m > 0 && res_active(c);
+  const bool use_res = m > 0 && m <= 250 && res_active(c);  // (a granule tag carries the term in 8 bits)
   if (int rc = run_series(c, m, q_tol, r_tol, use_res)) return rc;
   int iters = m, status = POVAR_LINEAR_SOLVER_NO_CONVERGENCE;
   if (p2p_terms) c->flag0_clean = false;  // the waits of the exchange kernels raise bit 1 of flags[0] on a time-out

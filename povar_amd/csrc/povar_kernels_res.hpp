@@ -17,14 +17,20 @@
 //   B_c^-1, adds to the sum, publishes z_c -> [hand-over 2] -> next term.
 // The reference's mutex-guarded `res += Jp^T s` (:388-398) is the LDS accumulation + the owner's fixed-order sum.
 //
-// Hand-overs (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", valid forms, first row
-// of the table): every handed-over byte is stored and loaded agent-scope (sc1: write-through, L1-bypassing) -- relaxed
-// agent atomics of 8 bytes --, every storing wavefront drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a
-// barrier, ONE lane stores the workgroup's flag word (the term number, monotone inside the launch); ONE wavefront of the
-// consumer polls the flag words of all workgroups (relaxed agent loads, s_sleep), the others wait at a workgroup barrier.
-// No fence, no dependence on dispatch order or placement; every spin is bounded (ResP::spin_limit): a launch whose
-// workgroups are not all resident (another context's kernels on the device) gives up, raises bit 2 of flags[0] and the
-// library repeats the solve with the per-term kernels.  The flag words are zeroed by a memset node before every launch.
+// Hand-overs (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", R2: "the data IS the
+// flag"): every handed-over double travels as TWO 8-byte granules {32 bits of the value, tag} written by one 16-byte
+// agent-scope (sc1: write-through, L1-bypassing) store; tag = launch number << 8 | term, so a granule of an earlier term or
+// an earlier launch never matches.  The reader re-reads its granules (16-byte sc1 loads) until every tag is the one it
+// waits for: no flag word, no fence, no drain of the producer's stores, no dependence on dispatch order or placement; a
+// granule is written by ONE store and is never torn.  (The first version of this kernel published plain sc1 doubles
+// behind a per-workgroup flag word -- drain, barrier, flag, poll, then load: six dependent memory round trips per term,
+// 12 us per term on ladybug-49; profiles/r05_res_experiments.txt.)  What may be overwritten when:
+//   * z_c of term i replaces z_c of term i - 1 after the owner has seen ALL records of c of term i, i.e. after every
+//     workgroup that reads z_c has used it;
+//   * workgroup w's record of camera c of term i + 1 replaces that of term i after w has seen z_c of term i, which the
+//     owner publishes after it has read the record.
+// Every spin is bounded (ResP::spin_limit): a launch whose workgroups are not all resident (another context's kernels on
+// the device) gives up, raises bit 2 of flags[0] and the library repeats the solve with the per-term kernels.
 #pragma once
 
 #include "povar_kernels_ck.hpp"
@@ -46,50 +52,59 @@ struct ResP {
   const int* acc_rec;
   const int* own_off;     // [W + 1]
   const int* own_cam;
-  const int2* own_rec;
-  double* part;           // [n_rec][12] partial records, camera-major
-  double* zbuf;           // [n_cams][12] z = sigma x of the current term
-  unsigned* f1;           // [RES_MAX_WG] term whose partial records workgroup w has published
-  unsigned* f2;           // [RES_MAX_WG] 1 + term whose z workgroup w has published for its cameras
-  double* nrm;            // [RES_MAX_WG][2] squared norms of (term, sum) over the cameras a workgroup owns
+  const int2* own_ws;
+  const int* oq_off;      // [W + 1]
+  const int* oq_rec;
+  const int* oq_seg;
+  const int* oq_ws;
+  uint4* part;            // [n_rec][12] partial records, camera-major, one 16-byte granule pair per entry
+  uint4* zbuf;            // [n_cams][12] z = sigma x of the current term
+  uint4* nrm;             // [RES_MAX_WG][2] squared norms of (term, sum) over the cameras a workgroup owns
+  unsigned* launch;       // launch counter (the high bits of the tags), bumped by the kernel
+  unsigned part_bytes, z_bytes, nrm_bytes;
   int W, m, want_norms, want_norm0;
   int w_mode;             // robust weight of an observation: 1: V2::w through V2::of_slot, 2: Dp::sw squared
   double q_tol, r_tol;
   unsigned spin_limit;
 };
 
-typedef __attribute__((address_space(1))) double res_gd;
-typedef __attribute__((address_space(1))) unsigned res_gu;
-typedef __attribute__((address_space(1))) unsigned long long res_gull;
-// agent-scope (sc1) accesses of the handed-over bytes: global_load/store_dwordx2 ... sc1
-__device__ inline double res_ld(const double* p) {
-  return __hip_atomic_load((const res_gd*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+typedef unsigned __attribute__((ext_vector_type(4))) res_u4;
+struct ResBufs {
+  __amdgpu_buffer_rsrc_t part, z, nrm;
+};
+__device__ inline ResBufs res_bufs(const ResP& k) {
+  ResBufs B;
+  B.part = __builtin_amdgcn_make_buffer_rsrc(k.part, 0, k.part_bytes, 0x00020000);
+  B.z = __builtin_amdgcn_make_buffer_rsrc(k.zbuf, 0, k.z_bytes, 0x00020000);
+  B.nrm = __builtin_amdgcn_make_buffer_rsrc(k.nrm, 0, k.nrm_bytes, 0x00020000);
+  return B;
 }
-__device__ inline void res_st(double* p, double v) {
-  __hip_atomic_store((res_gd*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+constexpr int RES_SC1 = 16;  // aux bits of the buffer instructions: sc1 (agent scope)
+// one double as a granule pair {lo, tag, hi, tag}
+__device__ inline void res_put(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double v, unsigned tag) {
+  res_u4 g;
+  g.x = (unsigned)__double2loint(v); g.y = tag; g.z = (unsigned)__double2hiint(v); g.w = tag;
+  __builtin_amdgcn_raw_buffer_store_b128(g, r, byte_off, 0, RES_SC1);
 }
-__device__ inline void res_flag(unsigned* p, unsigned v) {
-  __hip_atomic_store((res_gu*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline void res_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// ONE wavefront: until every workgroup's flag word has reached `epoch` (monotone).  Lane l looks at words 4 l .. 4 l + 3.
-__device__ inline bool res_wait_all(const unsigned* flags, int W, unsigned epoch, int lane, unsigned limit) {
-  const res_gull* f = (const res_gull*)(uintptr_t)flags + 2 * lane;
-  const bool a0 = 4 * lane < W, a1 = 4 * lane + 1 < W, a2 = 4 * lane + 2 < W, a3 = 4 * lane + 3 < W;
+// N consecutive granule pairs from byte_off on, re-read until every tag matches (for every active lane of the wavefront);
+// false: the spin budget ran out
+template <int N>
+__device__ inline bool res_get(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned tag, bool active, double (&v)[N], unsigned limit) {
   for (unsigned spins = 0;; ++spins) {
+    res_u4 g[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) g[e] = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16u * e, 0, RES_SC1);
     bool ok = true;
-    if (a0) {
-      const unsigned long long lo = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ok = (unsigned)lo >= epoch && (!a1 || (unsigned)(lo >> 32) >= epoch);
-      if (a2) {
-        const unsigned long long hi = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = ok && (unsigned)hi >= epoch && (!a3 || (unsigned)(hi >> 32) >= epoch);
-      }
+#pragma unroll
+    for (int e = 0; e < N; ++e) ok = ok && g[e].y == tag && g[e].w == tag;
+    if (__all(ok || !active)) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) v[e] = active ? __hiloint2double((int)g[e].z, (int)g[e].x) : 0.0;
+      return true;
     }
-    if (__all(ok)) return true;
     if (spins >= limit) return false;
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");  // (the loads above are re-issued: the compiler must not keep their values)
   }
 }
 
@@ -110,22 +125,27 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
   extern __shared__ double res_lds[];
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const ResBufs B = res_bufs(k);
+  const unsigned tag0 = (*k.launch) << 8;  // (the counter is bumped at the end of the launch: stream order)
   const int L0 = k.lm_off[g], nL = k.lm_off[g + 1] - L0;
   const int A0 = k.acc_off[g], nA = k.acc_off[g + 1] - A0;
   const int O0 = k.own_off[g], nO = k.own_off[g + 1] - O0;
+  const int Q0 = k.oq_off[g], nQ = k.oq_off[g + 1] - Q0;
+  const int nWS = nO > 0 ? k.own_ws[O0 + nO - 1].y : 0;
   int* ctl = reinterpret_cast<int*>(res_lds);  // [0] a wait gave up, [1] series converged, [2] iterations, [4..5] |x_0|
   double* lh = res_lds + 8;             // [nL][3] landmark coordinates
   double* lu = lh + 3 * nL;             // [nL][3] u = Jl^T Jp x, then g = G u
-  // 1024-thread workgroups have 128 VGPRs per lane: G lives in LDS there (res_g_in_lds)
-  constexpr bool GL = NW >= 16;
+  constexpr bool GL = true;             // G lives in LDS (res_g_in_lds): in registers it costs 12 LS VGPRs through every poll loop
   double* lG = lu + 3 * nL;             // [nL][6] G (GL only)
   double* acc = lG + (GL ? 6 * nL : 0); // [nA][13] accumulators of the cameras several lane runs share
   double* obinv = acc + nA * RES_ACC_STRIDE;  // [nO][144] B^-1 of the owned cameras
   double* osig = obinv + 144 * nO;      // [nO][12] sigma
   double* oacc = osig + 12 * nO;        // [nO][12] running sum
   double* otmp = oacc + 12 * nO;        // [nO][12] last term
-  double* onrm = otmp + 12 * nO;        // [nO][2] squared norms of the last term / the sum
-  int* arec = reinterpret_cast<int*>(onrm + 2 * nO);  // [nA] partial record of each accumulator slot
+  double* oy = otmp + 12 * nO;          // [nO][12] E0 row of the term: sum of the camera's records
+  double* onrm = oy + 12 * nO;          // [nO][2] squared norms of the last term / the sum
+  double* ows = onrm + 2 * nO;          // [nWS][12] sums of the runs of record readers
+  int* arec = reinterpret_cast<int*>(ows + 12 * nWS);  // [nA] partial record of each accumulator slot
 
   // ---------------- prologue: everything that does not change between the terms
   // owned cameras first (their registers are free again before the lane's own state is loaded): B^-1, sigma;
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
 #pragma unroll
       for (int j = 0; j < 12; ++j) s += Bi[j] * otmp[12 * o + j];
       oacc[12 * o + lane] = s;
-      res_st(k.zbuf + 12 * (size_t)c + lane, s * osig[12 * o + lane]);
+      res_put(B.z, (unsigned)(12 * c + lane) * 16u, s * osig[12 * o + lane], tag0 | 1u);
     }
     if (k.want_norm0) {
       double n2[1] = {s * s};
@@ -160,17 +180,14 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
     __builtin_amdgcn_wave_barrier();
     if (lane < 12) otmp[12 * o + lane] = s;
   }
-  res_drain();
-  __syncthreads();
-  if (t == 0) {
-    if (k.want_norm0) {
+  if (k.want_norm0) {
+    __syncthreads();
+    if (t == 0) {
       double a = 0;
       for (int o = 0; o < nO; ++o) a += onrm[2 * o];
-      res_st(k.nrm + 2 * g, a);
-      res_st(k.nrm + 2 * g + 1, a);
-      res_drain();
+      res_put(B.nrm, (unsigned)(2 * g) * 16u, a, tag0 | 1u);
+      res_put(B.nrm, (unsigned)(2 * g + 1) * 16u, a, tag0 | 1u);
     }
-    res_flag(k.f2 + g, 1u);
   }
   // the lane's chunks: rows, camera, P3
   ResChunk<H> ch[RR];
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
       ch[r].P3[6] = P.r2.x; ch[r].P3[7] = P.r2.y; ch[r].P3[8] = P.r2.z;
     }
   }
-  // the landmark slots of the lane: h~ into LDS, G = diag(s) Hll^-1 diag(s) in registers
+  // the landmark slots of the lane: h~ into LDS, G = diag(s) Hll^-1 diag(s) in registers (or LDS)
   double G[GL ? 1 : LS][6];
 #pragma unroll
   for (int q = 0; q < LS; ++q) {
@@ -224,14 +241,22 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
 #pragma unroll
       for (int e = 0; e < 6; ++e) {
         if (GL) lG[6 * s + e] = rp[(3 + e) * WAVE];
-        else G[q][e] = rp[(3 + e) * WAVE];
+        else G[GL ? 0 : q][e] = rp[(3 + e) * WAVE];
       }
     }
+  }
+  // the record this lane reads as an owner (first pass; further passes take theirs from the tables)
+  int oq_rec0 = -1, oq_seg0 = 0, oq_ws0 = 0;
+  if (t < nQ) {
+    oq_rec0 = k.oq_rec[Q0 + t];
+    oq_seg0 = k.oq_seg[Q0 + t];
+    oq_ws0 = k.oq_ws[Q0 + t];
   }
   int iters = k.m;
 
   // ---------------- the terms
   for (int i = 1; i <= k.m + 1; ++i) {
+    const unsigned tag = tag0 | (unsigned)i;
     // u = 0 for the slots of this lane (nothing reads lu between the backward pass of the last term and here)
 #pragma unroll
     for (int q = 0; q < LS; ++q) {
@@ -239,16 +264,18 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
       if (s < nL) { lu[3 * s] = 0; lu[3 * s + 1] = 0; lu[3 * s + 2] = 0; }
     }
     if (i == k.m + 1 && !k.want_norms) break;  // (with the tests on: the last term's norms are looked at too)
-    // ---- hand-over 2: z of term i - 1 is there (and its norms)
-    if (wave == 0) {
-      const bool ok = res_wait_all(k.f2, k.W, (unsigned)i, lane, k.spin_limit);
-      if (!ok && lane == 0) ctl[0] = 1;
-      if (ok && k.want_norms && (i > 1 || k.want_norm0)) {
+    // ---- the norms of term i - 1 (every owner's: the one step of a term that waits for ALL workgroups)
+    if (k.want_norms && (i > 1 || k.want_norm0)) {
+      if (wave == 0) {
         double v[2] = {0, 0};
-        for (int w = lane; w < k.W; w += 64) {
-          v[0] += res_ld(k.nrm + 2 * w);
-          v[1] += res_ld(k.nrm + 2 * w + 1);
+        bool ok = true;
+        for (int w0 = 0; w0 < k.W; w0 += 64) {
+          double e2[2];
+          ok = ok && res_get<2>(B.nrm, (unsigned)(2 * (w0 + lane)) * 16u, tag, w0 + lane < k.W, e2, k.spin_limit);
+          v[0] += e2[0];
+          v[1] += e2[1];
         }
+        if (!ok && lane == 0) ctl[0] = 1;
         wave_sum<2>(v);
         const double iter_norm = sqrt(v[0]), acc_norm = sqrt(v[1]);
         if (i == 1) {
@@ -259,23 +286,21 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
           bool conv = false;
           if (k.q_tol > 0 && (i - 1) * iter_norm / acc_norm < k.q_tol) conv = true;    // :206-214
           if (!conv && k.r_tol > 0 && iter_norm / n0 < k.r_tol) conv = true;             // :216-229
-          if (conv && lane == 0) { ctl[1] = 1; ctl[2] = i - 1; }
+          if (ok && conv && lane == 0) { ctl[1] = 1; ctl[2] = i - 1; }
           if (g == 0 && lane == 0) { d.norms[1] = iter_norm; d.norms[2] = acc_norm; }
         }
       }
+      __syncthreads();
+      if (ctl[0] | ctl[1]) break;
     }
-    __syncthreads();
-    if (ctl[0] | ctl[1]) break;
     if (i == k.m + 1) break;
-    // ---- forward: u_l += P3^T (w C (Z h~_l)), z of each chunk's camera gathered first
+    // ---- forward: u_l += P3^T (w C (Z h~_l)); z of each chunk's camera is polled for first (hand-over 2)
+    bool gave_up = false;
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
       if (ch[r].hrows == 0) continue;  // (wave-uniform)
-      double zz[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (ch[r].cam >= 0) {
-#pragma unroll
-        for (int e = 0; e < 12; ++e) zz[e] = res_ld(k.zbuf + 12 * (size_t)ch[r].cam + e);
-      }
+      double zz[12];
+      if (!res_get<12>(B.z, (unsigned)(12 * (ch[r].cam < 0 ? 0 : ch[r].cam)) * 16u, tag, ch[r].cam >= 0, zz, k.spin_limit)) gave_up = true;
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         if (j < ch[r].hrows && ch[r].ls[j] >= 0) {
@@ -284,7 +309,9 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
         }
       }
     }
+    if (gave_up && lane == 0) ctl[0] = 1;
     __syncthreads();
+    if (ctl[0]) break;
     // ---- g = G u per landmark slot
 #pragma unroll
     for (int q = 0; q < LS; ++q) {
@@ -321,69 +348,64 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
           for (int e = 0; e < 12; ++e)
             __hip_atomic_fetch_add(acc + ch[r].tgt * RES_ACC_STRIDE + e, y[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-          double* o = k.part + (size_t)(~ch[r].tgt) * 12;
+          const unsigned o = (unsigned)(~ch[r].tgt) * 192u;
 #pragma unroll
-          for (int e = 0; e < 12; ++e) res_st(o + e, y[e]);
+          for (int e = 0; e < 12; ++e) res_put(B.part, o + 16u * e, y[e], tag);
         }
       }
     }
-    __syncthreads();
-    // ---- the shared cameras' partial records (and their accumulators back to zero)
-    for (int e = t; e < nA * 12; e += T) {
-      const int r = e / 12, m = e % 12;
-      const double v = acc[r * RES_ACC_STRIDE + m];
-      acc[r * RES_ACC_STRIDE + m] = 0;
-      res_st(k.part + (size_t)arec[r] * 12 + m, v);
+    if (nA > 0) {
+      __syncthreads();
+      // ---- the shared cameras' partial records (and their accumulators back to zero)
+      for (int e = t; e < nA * 12; e += T) {
+        const int r = e / 12, m = e % 12;
+        const double v = acc[r * RES_ACC_STRIDE + m];
+        acc[r * RES_ACC_STRIDE + m] = 0;
+        res_put(B.part, (unsigned)arec[r] * 192u + 16u * m, v, tag);
+      }
     }
-    res_drain();
-    __syncthreads();
-    if (t == 0) res_flag(k.f1 + g, (unsigned)i);
-    // ---- hand-over 1: every workgroup's records of term i are there
-    if (wave == 0) {
-      const bool ok = res_wait_all(k.f1, k.W, (unsigned)i, lane, k.spin_limit);
-      if (!ok && lane == 0) ctl[0] = 1;
+    // ---- owners (hand-over 1): every lane polls for ONE record of a camera the workgroup owns; runs of lanes with one
+    // camera are summed and leave their sum in LDS; then x_i = B^-1 (sigma * sum), sum += x_i, z published
+    // (:200-204, :322-340)
+    for (int q0 = 0; q0 < nQ; q0 += T) {
+      const int q = q0 + t;
+      int rec = oq_rec0, sg = oq_seg0, ws = oq_ws0;
+      if (q0 > 0) {
+        rec = q < nQ ? k.oq_rec[Q0 + q] : -1;
+        sg = q < nQ ? k.oq_seg[Q0 + q] : 0;
+        ws = q < nQ ? k.oq_ws[Q0 + q] : 0;
+      }
+      if (q0 + wave * 64 >= nQ) continue;  // (wave-uniform: no reader in this wavefront)
+      double y[12];
+      if (!res_get<12>(B.part, (unsigned)(rec < 0 ? 0 : rec) * 192u, tag, rec >= 0, y, k.spin_limit)) gave_up = true;
+      seg_reduce_steps<12>(y, lane, sg & 255, (sg >> 8) & 255, (sg >> 16) & 15);
+      if (rec >= 0 && lane == (sg & 255)) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) ows[12 * ws + e] = y[e];
+      }
     }
+    if (gave_up && lane == 0) ctl[0] = 1;
     __syncthreads();
     if (ctl[0]) break;
-    // ---- owners: x_i = B^-1 (sigma * sum of the records), sum += x_i, z published (:200-204, :322-340)
     for (int o = wave; o < nO; o += NW) {
       const int c = k.own_cam[O0 + o];
-      const int2 rr = k.own_rec[O0 + o];
-      // lanes 0-31 sum entries 0-5 of the records, lanes 32-63 entries 6-11 (six loads and six sums per lane instead of
-      // twelve: the registers of the lane's own rows stay live through this loop); fixed order: record r goes to lane
-      // (r - first) % 32, then the tree of the DPP network
-      const int half = lane >> 5;
-      double yh[6] = {0, 0, 0, 0, 0, 0};
-      for (int r = rr.x + (lane & 31); r < rr.y; r += 32) {
-        const double* ip = k.part + (size_t)r * 12 + 6 * half;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) yh[e] += res_ld(ip + e);
-      }
-#pragma unroll
-      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x111>(yh[e]);
-#pragma unroll
-      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x112>(yh[e]);
-#pragma unroll
-      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x114>(yh[e]);
-#pragma unroll
-      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x118>(yh[e]);
-#pragma unroll
-      for (int e = 0; e < 6; ++e) yh[e] += dpp_d<0x142>(yh[e]);  // row_bcast 15: lanes 31 / 63 hold the halves' totals
-      double y[12];
-#pragma unroll
-      for (int e = 0; e < 6; ++e) {
-        y[e] = bcast_lane(yh[e], 31);
-        y[6 + e] = bcast_lane(yh[e], 63);
-      }
+      const int2 wr = k.own_ws[O0 + o];
       double s = 0, a = 0;
+      if (lane < 12) {
+        double yl = 0;
+        for (int w = wr.x; w < wr.y; ++w) yl += ows[12 * w + lane];  // fixed order
+        oy[12 * o + lane] = yl * osig[12 * o + lane];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
       if (lane < 12) {
         const double* Bi = obinv + 144 * o + 12 * lane;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) s += Bi[j] * (y[j] * osig[12 * o + j]);
+        for (int j = 0; j < 12; ++j) s += Bi[j] * oy[12 * o + j];
         a = oacc[12 * o + lane] + s;
         otmp[12 * o + lane] = s;
         oacc[12 * o + lane] = a;
-        res_st(k.zbuf + 12 * (size_t)c + lane, s * osig[12 * o + lane]);
+        res_put(B.z, (unsigned)(12 * c + lane) * 16u, s * osig[12 * o + lane], tag + 1u);
       }
       if (k.want_norms) {
         double n2[2] = {s * s, a * a};
@@ -391,17 +413,14 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
         if (lane == 0) { onrm[2 * o] = n2[0]; onrm[2 * o + 1] = n2[1]; }
       }
     }
-    res_drain();
-    __syncthreads();
-    if (t == 0) {
-      if (k.want_norms) {
+    if (k.want_norms) {
+      __syncthreads();
+      if (t == 0) {
         double a = 0, b = 0;
         for (int o = 0; o < nO; ++o) { a += onrm[2 * o]; b += onrm[2 * o + 1]; }
-        res_st(k.nrm + 2 * g, a);
-        res_st(k.nrm + 2 * g + 1, b);
-        res_drain();
+        res_put(B.nrm, (unsigned)(2 * g) * 16u, a, tag + 1u);
+        res_put(B.nrm, (unsigned)(2 * g + 1) * 16u, b, tag + 1u);
       }
-      res_flag(k.f2 + g, (unsigned)(i + 1));
     }
   }
   // ---------------- epilogue: sum and last term of the owned cameras, status
@@ -414,12 +433,22 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
   }
   if (t == 0) {
     if (ctl[0]) atomicOr(&d.flags[0], 4);
-    if (g == 0 && ctl[1]) {
-      d.flags[1] = 1;
-      d.flags[2] = iters;
-      d.flags[3] = 1;
+    if (g == 0) {
+      if (ctl[1]) {
+        d.flags[1] = 1;
+        d.flags[2] = iters;
+        d.flags[3] = 1;
+      }
     }
   }
+}
+
+// the launch counter (the high bits of the granule tags of the NEXT launch): a one-thread kernel behind series_res in the
+// stream -- inside the launch itself a workgroup that is late could still be reading the old value
+__global__ void res_bump_launch(unsigned* launch) {
+  unsigned v = *launch + 1u;
+  if (v >= (1u << 24)) v = 1u;  // (a tag is launch << 8 | term: 24 bits; a wrap meets granules 16 M launches old)
+  *launch = v;
 }
 
 }  // namespace povar

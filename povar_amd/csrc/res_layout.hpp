@@ -37,7 +37,7 @@ constexpr int RES_HMAX = 8;          // rows of a chunk at most
 constexpr int RES_MAX_WG = 256;      // workgroups (flag words swept by one wavefront: 4 per lane)
 constexpr int RES_LDS_BYTES = 160 * 1024;
 constexpr int RES_ACC_STRIDE = 13;   // doubles per accumulator slot in LDS (12 used; odd: 32 bank classes)
-constexpr int RES_OWN_DOUBLES = 144 + 12 + 12 + 12 + 2;  // per owned camera in LDS: B^-1, sigma, sum, term, norms
+constexpr int RES_OWN_DOUBLES = 144 + 12 + 12 + 12 + 12 + 2;  // per owned camera in LDS: B^-1, sigma, sum, term, E0 row, norms
 
 struct ResLayout {
   int W = 0, NW = 0, H = 0, R = 1;   // workgroups, wavefronts per workgroup, rows per chunk, chunks (rounds) per lane
@@ -60,6 +60,15 @@ struct ResLayout {
   // owners
   std::vector<int> own_off, own_cam; // [W + 1], cameras owned by each workgroup
   std::vector<int2> own_rec;         // [first, end) partial records of each owned camera
+  // The records a workgroup owns, flattened (camera after camera): position q is read by thread q % T in pass q / T.
+  // Lanes of a wavefront that read records of ONE camera are a run (one segmented wavefront sum); every run leaves its
+  // sum in a slot of the workgroup's LDS, and the camera's slots (in position order) are summed by its finishing lanes.
+  std::vector<int> oq_off;           // [W + 1]
+  std::vector<int> oq_rec;           // record read at each position
+  std::vector<int> oq_seg;           // first | last << 8 lane of the position's run | scan steps << 16
+  std::vector<int> oq_ws;            // LDS slot of the position's run
+  std::vector<int2> own_ws;          // [first, end) LDS slots of each owned camera
+  int max_ws = 0, max_oq = 0;
   int n_rec = 0;
   int max_lm = 0, max_cam = 0, max_acc = 0, max_own = 0, max_chunks = 0;
   int order = 0;                     // 0: natural landmark order, 1: by rarest camera
@@ -68,10 +77,11 @@ struct ResLayout {
   const char* why = "";              // when it does not fit
 };
 
-// 1024-thread workgroups (128 VGPRs per lane) keep G in LDS next to h~ and u, the others in registers
-inline bool res_g_in_lds(int n_waves) { return n_waves >= 16; }
-inline size_t res_lds_bytes(int n_lm, int n_acc, int n_own, bool g_in_lds) {
-  return 64 + (size_t)n_lm * (g_in_lds ? 96 : 48) + (size_t)n_acc * (RES_ACC_STRIDE * 8 + 4) + 8 + (size_t)n_own * RES_OWN_DOUBLES * 8;
+// G = diag(s) Hll^-1 diag(s) lives in LDS next to h~ and u
+inline bool res_g_in_lds(int) { return true; }
+inline size_t res_lds_bytes(int n_lm, int n_acc, int n_own, int n_ws, bool g_in_lds) {
+  return 64 + (size_t)n_lm * (g_in_lds ? 96 : 48) + (size_t)n_acc * (RES_ACC_STRIDE * 8 + 4) + 8 + (size_t)n_own * RES_OWN_DOUBLES * 8 +
+         (size_t)n_ws * 96;
 }
 
 // W workgroups of NW wavefronts whose lanes hold R chunks of at most H rows each; the smallest H <= hmax (a power of
@@ -128,7 +138,7 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         else if (cnt[c] % H == 0) ++add_chunks;
       }
       const bool over = lms > 0 && (chunks + add_chunks > cap || lms + 1 > ls_max * T ||
-                                    res_lds_bytes(lms + 1, cams + add_cams, own_guess, gl) > (size_t)RES_LDS_BYTES);
+                                    res_lds_bytes(lms + 1, cams + add_cams, own_guess, own_guess + 4 * NW, gl) > (size_t)RES_LDS_BYTES);
       if (over) {
         pairs += cams;
         ++groups;
@@ -267,6 +277,43 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       }
     }
   }
+  // ---- the owners' view of the records
+  R.oq_off.assign(W + 1, 0);
+  for (int g = 0; g < W; ++g) {
+    int n = 0;
+    for (int o = R.own_off[g]; o < R.own_off[g + 1]; ++o) n += R.own_rec[o].y - R.own_rec[o].x;
+    R.oq_off[g + 1] = R.oq_off[g] + n;
+    R.max_oq = std::max(R.max_oq, n);
+  }
+  R.oq_rec.resize(R.n_rec);
+  R.oq_seg.resize(R.n_rec);
+  R.oq_ws.resize(R.n_rec);
+  R.own_ws.resize(R.own_cam.size());
+  for (int g = 0; g < W; ++g) {
+    int q = 0, ws = 0;
+    for (int o = R.own_off[g]; o < R.own_off[g + 1]; ++o) {
+      const int n = R.own_rec[o].y - R.own_rec[o].x;
+      const int ws0 = ws;
+      for (int j = 0; j < n;) {
+        // the run: positions of this camera inside one wavefront of one pass
+        const int lane0 = (q + j) % WAVE;
+        const int len = std::min(n - j, WAVE - lane0);
+        int steps = 0;
+        while ((1 << steps) < std::min(len, 16)) ++steps;
+        for (int e = 0; e < len; ++e) {
+          const size_t at = (size_t)R.oq_off[g] + q + j + e;
+          R.oq_rec[at] = R.own_rec[o].x + j + e;
+          R.oq_seg[at] = lane0 | ((lane0 + len - 1) << 8) | (std::max(steps, 1) << 16);
+          R.oq_ws[at] = ws;
+        }
+        ++ws;
+        j += len;
+      }
+      R.own_ws[o] = make_int2(ws0, ws);
+      q += n;
+    }
+    R.max_ws = std::max(R.max_ws, ws);
+  }
   // ---- lanes and rows
   const size_t n_pos = (size_t)W * R.R * T;
   R.lane_cam.assign(n_pos, -1);
@@ -349,8 +396,11 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     R.acc_rec.insert(R.acc_rec.end(), wg_acc_rec[g].begin(), wg_acc_rec[g].end());
   }
   R.lds_bytes = 0;
-  for (int g = 0; g < W; ++g)
-    R.lds_bytes = std::max(R.lds_bytes, res_lds_bytes(R.lm_off[g + 1] - R.lm_off[g], R.acc_off[g + 1] - R.acc_off[g], R.own_off[g + 1] - R.own_off[g], gl));
+  for (int g = 0; g < W; ++g) {
+    const int n_ws = R.own_off[g + 1] > R.own_off[g] ? R.own_ws[R.own_off[g + 1] - 1].y : 0;
+    R.lds_bytes = std::max(R.lds_bytes, res_lds_bytes(R.lm_off[g + 1] - R.lm_off[g], R.acc_off[g + 1] - R.acc_off[g],
+                                                      R.own_off[g + 1] - R.own_off[g], n_ws, gl));
+  }
   if (R.lds_bytes > (size_t)RES_LDS_BYTES) { R.why = "landmarks + accumulators + owned cameras exceed the LDS"; return; }
   R.fits = true;
 }

@@ -167,6 +167,32 @@ int main(int argc, char** argv) {
     }
     max_own_rec = std::max(max_own_rec, load);
   }
+  // the owners' flattened view: every record at exactly one position of its owner, runs inside one wavefront, one LDS
+  // slot per run, a camera's slots consecutive and in position order
+  CHECK((int)R.oq_off.size() == R.W + 1 && R.oq_off[R.W] == R.n_rec && (int)R.oq_rec.size() == R.n_rec);
+  CHECK(R.own_ws.size() == R.own_cam.size());
+  std::vector<int> rec_seen(R.n_rec, 0);
+  for (int g = 0; g < R.W; ++g) {
+    int q = 0, next_ws = 0;
+    for (int o = R.own_off[g]; o < R.own_off[g + 1]; ++o) {
+      CHECK(R.own_ws[o].x == next_ws && R.own_ws[o].y >= R.own_ws[o].x);
+      const int n = R.own_rec[o].y - R.own_rec[o].x;
+      CHECK((n == 0) == (R.own_ws[o].y == R.own_ws[o].x));
+      for (int j = 0; j < n; ++j, ++q) {
+        const size_t at = (size_t)R.oq_off[g] + q;
+        CHECK(R.oq_rec[at] == R.own_rec[o].x + j && rec_seen[R.oq_rec[at]]++ == 0);
+        const int l = q % WAVE, s0 = R.oq_seg[at] & 255, s1 = (R.oq_seg[at] >> 8) & 255, steps = (R.oq_seg[at] >> 16) & 15;
+        CHECK(s0 <= l && l <= s1 && s1 < WAVE && steps >= 1 && (1 << steps) >= std::min(s1 - s0 + 1, 16));
+        CHECK(R.oq_ws[at] >= R.own_ws[o].x && R.oq_ws[at] < R.own_ws[o].y);
+        if (l > s0) CHECK(R.oq_ws[at] == R.oq_ws[at - 1] && R.oq_seg[at] == R.oq_seg[at - 1]);
+        else CHECK(j == 0 || R.oq_ws[at] == R.oq_ws[at - 1] + 1);
+        if (j == 0) CHECK(R.oq_ws[at] == R.own_ws[o].x && l == s0);
+        if (j == n - 1) CHECK(R.oq_ws[at] == R.own_ws[o].y - 1 && l == s1);
+      }
+      next_ws = R.own_ws[o].y;
+    }
+    CHECK(q == R.oq_off[g + 1] - R.oq_off[g] && next_ws <= R.max_ws);
+  }
   int64_t rec_sum = 0;
   for (int c = 0; c < n_cams; ++c) CHECK(owned[c] == 1);
   for (size_t o = 0; o < R.own_rec.size(); ++o) rec_sum += R.own_rec[o].y - R.own_rec[o].x;

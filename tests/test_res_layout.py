@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "build", "res_layout_check")
 
 
-def _run(tmp_path, n_cams, lm_off, cam_idx, obs, wgs, n_waves=16, rounds=1, hmin=1, hmax=2, ls_max=1, order=-1):
+def _run(tmp_path, n_cams, lm_off, cam_idx, obs, wgs, n_waves=8, rounds=2, hmin=1, hmax=4, ls_max=2, order=-1):
     src = [os.path.join(ROOT, "tests", "cpp", "res_layout_check.cpp"), os.path.join(ROOT, "povar_amd", "csrc", "res_layout.hpp"),
            os.path.join(ROOT, "povar_amd", "csrc", "lpl_layout.hpp")]
     if not os.path.exists(BIN) or any(os.path.getmtime(BIN) < os.path.getmtime(s) for s in src):
@@ -29,10 +29,11 @@ def _run(tmp_path, n_cams, lm_off, cam_idx, obs, wgs, n_waves=16, rounds=1, hmin
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-BIG = dict(n_waves=8, rounds=2, hmin=4, hmax=4, ls_max=2)  # the 512-thread instantiation: two chunks of four rows per lane
+BIG = dict(hmin=4)  # four rows per chunk whatever the problem needs
+WIDE = dict(n_waves=16, rounds=1, hmax=2, ls_max=1)  # a 1024-thread shape (not instantiated: 128 VGPRs per lane)
 
 
-@pytest.mark.parametrize("wgs,kw,must_fit", [(256, {}, True), (32, {}, False), (32, BIG, True), (7, BIG, False), (1, BIG, False),
+@pytest.mark.parametrize("wgs,kw,must_fit", [(256, {}, True), (256, WIDE, True), (32, WIDE, False), (32, BIG, True), (7, BIG, False), (1, BIG, False),
                                              (90, dict(hmax=1), False), (16, dict(n_waves=8, rounds=1, hmin=8, hmax=8, ls_max=2), False)])
 def test_res_layout_invariants_medium(tmp_path, wgs, kw, must_fit):
     from povar_amd import synth
@@ -56,7 +57,7 @@ def test_res_layout_long_tracks_and_single_observation_landmarks(tmp_path):
     w = 1.0 / np.arange(1, n_c + 1)
     cam_idx = np.concatenate([np.sort(rng.choice(n_c, k, replace=False, p=w / w.sum())) for k in ks]).astype(np.int32)
     obs = rng.normal(size=(cam_idx.shape[0], 2))
-    for wgs, kw in ((16, BIG), (64, {})):
+    for wgs, kw in ((16, BIG), (64, {}), (64, WIDE)):
         s = _run(tmp_path, n_c, lm_off, cam_idx, obs, wgs, **kw)
         assert s["ok"] == 1 and s["fits"] == 1
 
@@ -67,6 +68,7 @@ def test_res_layout_baseline_shapes(tmp_path, name, wgs):
     p = synth.make_bal_problem(name)
     s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, wgs)
     assert s["ok"] == 1 and s["fits"] == 1 and s["H"] <= 2, s
+    print(s)
 
 
 def test_res_layout_venice_shard_of_eight(tmp_path):
