@@ -286,8 +286,8 @@ typedef struct {
   int32_t res_auto;     /* 0 forced (POVAR_RES, povar_set_series_kernel), 1 to be timed at the next series, 2 timed */
   int32_t res_wgs, res_waves, res_rows, res_rounds;  /* workgroups, wavefronts per workgroup, rows per chunk, chunks per lane */
   int32_t res_records;  /* partial records = (workgroup, camera) pairs */
-  int32_t res_max_cams, res_max_lms, res_max_chunks, res_max_acc;  /* of the fullest workgroup: cameras, landmarks, chunks,
-                           cameras whose chunks are several lane runs (accumulator in LDS) */
+  int32_t res_max_cams, res_max_lms, res_max_chunks, res_max_oq;  /* of the fullest workgroup: cameras, landmarks, chunks,
+                           partial records it reads as the owner of cameras */
   int32_t res_order;    /* landmark order the workgroup ranges were cut from: 0 natural (file) order, 1 by rarest camera */
   int32_t res_lds_bytes;
   double res_build_ms;

@@ -56,7 +56,7 @@ class LayoutInfo(C.Structure):
                 ("res_ready", C.c_int32), ("res_active", C.c_int32), ("res_auto", C.c_int32), ("res_wgs", C.c_int32),
                 ("res_waves", C.c_int32), ("res_rows", C.c_int32), ("res_rounds", C.c_int32), ("res_records", C.c_int32),
                 ("res_max_cams", C.c_int32), ("res_max_lms", C.c_int32), ("res_max_chunks", C.c_int32),
-                ("res_max_acc", C.c_int32), ("res_order", C.c_int32),
+                ("res_max_oq", C.c_int32), ("res_order", C.c_int32),
                 ("res_lds_bytes", C.c_int32), ("res_build_ms", C.c_double), ("tune_terms_us", C.c_float),
                 ("tune_res_us", C.c_float), ("res_failed", C.c_int32)]
 

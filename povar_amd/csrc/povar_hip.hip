@@ -171,20 +171,20 @@ struct povar_ctx {
   DevBuf<unsigned long long> ck_stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): CkP::stamps
   // resident power series (series_res, povar_kernels_res.hpp): the layout of res_layout.hpp on the device
   struct ResDev {
-    DevBuf<int> lane_cam, lane_tgt, lane_seg, lslot, oslot, wave_h, lm_off, lm_id, acc_off, acc_rec, own_off, own_cam, oq_off, oq_rec, oq_seg, oq_ws;
+    DevBuf<int> lane_cam, lane_seg, lslot, oslot, wave_h, lm_off, lm_id, cam_off, cam_id, cam_zi, own_off, own_cam, own_zi, oq_off, oq_rec;
     DevBuf<double2> uv;
-    DevBuf<int2> own_ws;
+    DevBuf<int2> own_q;
     DevBuf<uint4> part, zbuf, nrm;   // granule pairs (povar_kernels_res.hpp)
     DevBuf<unsigned> launch;         // launch counter: the high bits of the granule tags
-    int W = 0, NW = 0, H = 0, R = 1, LS = 1, n_rec = 0, max_lm = 0, max_cam = 0, max_acc = 0, max_own = 0, max_chunks = 0, order = 0;
+    int W = 0, NW = 0, H = 0, R = 1, LS = 1, n_rec = 0, max_lm = 0, max_cam = 0, max_oq = 0, max_own = 0, max_chunks = 0, order = 0;
     size_t lds_bytes = 0;
     double build_ms = 0;
     bool ready = false;
     void release() {
-      lane_cam.release(); lane_tgt.release(); lane_seg.release(); lslot.release(); oslot.release(); wave_h.release();
-      lm_off.release(); lm_id.release(); acc_off.release(); acc_rec.release(); own_off.release(); own_cam.release();
-      oq_off.release(); oq_rec.release(); oq_seg.release(); oq_ws.release();
-      uv.release(); own_ws.release(); part.release(); zbuf.release(); nrm.release(); launch.release();
+      lane_cam.release(); lane_seg.release(); lslot.release(); oslot.release(); wave_h.release();
+      lm_off.release(); lm_id.release(); cam_off.release(); cam_id.release(); cam_zi.release(); own_off.release(); own_cam.release();
+      own_zi.release(); oq_off.release(); oq_rec.release();
+      uv.release(); own_q.release(); part.release(); zbuf.release(); nrm.release(); launch.release();
       ready = false;
     }
   } res;
@@ -636,12 +636,12 @@ int ckh_autotune(povar_ctx* c);
 int res_upload(povar_ctx* c, const ResLayout& R) {
   povar_ctx::ResDev& D = c->res;
   int rc = 0;
-  if ((rc = upload(D.lane_cam, R.lane_cam, c)) || (rc = upload(D.lane_tgt, R.lane_tgt, c)) || (rc = upload(D.lane_seg, R.lane_seg, c)) ||
+  if ((rc = upload(D.lane_cam, R.lane_cam, c)) || (rc = upload(D.lane_seg, R.lane_seg, c)) ||
       (rc = upload(D.uv, R.uv, c)) || (rc = upload(D.lslot, R.lslot, c)) || (rc = upload(D.oslot, R.oslot, c)) ||
       (rc = upload(D.wave_h, R.wave_h, c)) || (rc = upload(D.lm_off, R.lm_off, c)) || (rc = upload(D.lm_id, R.lm_id, c)) ||
-      (rc = upload(D.acc_off, R.acc_off, c)) || (rc = upload(D.acc_rec, R.acc_rec, c)) || (rc = upload(D.own_off, R.own_off, c)) ||
-      (rc = upload(D.own_cam, R.own_cam, c)) || (rc = upload(D.own_ws, R.own_ws, c)) || (rc = upload(D.oq_off, R.oq_off, c)) ||
-      (rc = upload(D.oq_rec, R.oq_rec, c)) || (rc = upload(D.oq_seg, R.oq_seg, c)) || (rc = upload(D.oq_ws, R.oq_ws, c)))
+      (rc = upload(D.cam_off, R.cam_off, c)) || (rc = upload(D.cam_id, R.cam_id, c)) || (rc = upload(D.cam_zi, R.cam_zi, c)) ||
+      (rc = upload(D.own_off, R.own_off, c)) || (rc = upload(D.own_cam, R.own_cam, c)) || (rc = upload(D.own_zi, R.own_zi, c)) ||
+      (rc = upload(D.own_q, R.own_q, c)) || (rc = upload(D.oq_off, R.oq_off, c)) || (rc = upload(D.oq_rec, R.oq_rec, c)))
     return rc;
   // granule buffers: tag 0 everywhere (no launch has the number 0), the launch counter starts at 1
   const size_t n_part = (size_t)std::max(R.n_rec, 1) * 12, n_z = (size_t)c->n_cams * 12, n_nrm = (size_t)RES_MAX_WG * 2;
@@ -656,13 +656,13 @@ int res_upload(povar_ctx* c, const ResLayout& R) {
   const unsigned one[4] = {1u, 0u, 0u, 0u};
   HIP_TRY(hipMemcpy(D.launch.p, one, sizeof(one), hipMemcpyHostToDevice));
   D.W = R.W; D.NW = R.NW; D.H = R.H; D.R = R.R; D.LS = R.LS; D.n_rec = R.n_rec; D.max_lm = R.max_lm; D.max_cam = R.max_cam;
-  D.max_acc = R.max_acc; D.max_own = R.max_own; D.max_chunks = R.max_chunks; D.order = R.order; D.lds_bytes = R.lds_bytes;
+  D.max_oq = R.max_oq; D.max_own = R.max_own; D.max_chunks = R.max_chunks; D.order = R.order; D.lds_bytes = R.lds_bytes;
   D.ready = true;
   return 0;
 }
-// instantiations: wavefronts per workgroup, rows per chunk, chunks per lane, landmark slots per lane.  512-thread
-// workgroups: 256 VGPRs per lane hold two chunks of up to four rows next to the 72 registers of a granule poll
-#define POVAR_RES_VARIANTS(X) X(8, 1, 2, 1) X(8, 1, 2, 2) X(8, 2, 2, 1) X(8, 2, 2, 2) X(8, 4, 2, 1) X(8, 4, 2, 2)
+// instantiations: wavefronts per workgroup, rows per chunk, chunks per lane, landmark slots per lane.  1024-thread
+// workgroups (128 VGPRs per lane): one chunk of at most two rows; 512-thread ones (256): two chunks of up to four rows
+#define POVAR_RES_VARIANTS(X) X(16, 1, 1, 1) X(16, 2, 1, 1) X(8, 1, 2, 1) X(8, 1, 2, 2) X(8, 2, 2, 1) X(8, 2, 2, 2) X(8, 4, 2, 1) X(8, 4, 2, 2)
 template <int NW, int H, int RR, int LS>
 void launch_res_t(povar_ctx* c, const ResP& k) {
   if (c->opt.robust_norm)
@@ -701,6 +701,8 @@ hipError_t res_set_lds_all() {
 // the layout for a context: the lightest instantiation that holds it (fewest rows in registers first)
 void res_build_for(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* cam_idx, const double* obs,
                    const std::vector<int>& rank1, const std::vector<int>& slot_of_obs, int wgs, ResLayout& R) {
+  build_res(n_cams, n_lms, lm_off, cam_idx, obs, rank1, slot_of_obs, wgs, 16, 1, 1, 2, 1, R);
+  if (R.fits) return;
   build_res(n_cams, n_lms, lm_off, cam_idx, obs, rank1, slot_of_obs, wgs, 8, 2, 1, 4, 2, R);
 }
 bool sharded(const povar_ctx* c);
@@ -715,11 +717,11 @@ bool res_active(const povar_ctx* c) {
 ResP res_params(const povar_ctx* c, int m, double q_tol, double r_tol) {
   const povar_ctx::ResDev& D = c->res;
   ResP k{};
-  k.lane_cam = D.lane_cam.p; k.lane_tgt = D.lane_tgt.p; k.lane_seg = D.lane_seg.p;
+  k.lane_cam = D.lane_cam.p; k.lane_seg = D.lane_seg.p;
   k.uv = D.uv.p; k.lslot = D.lslot.p; k.oslot = D.oslot.p; k.wave_h = D.wave_h.p;
-  k.lm_off = D.lm_off.p; k.lm_id = D.lm_id.p; k.acc_off = D.acc_off.p; k.acc_rec = D.acc_rec.p;
-  k.own_off = D.own_off.p; k.own_cam = D.own_cam.p; k.own_ws = D.own_ws.p;
-  k.oq_off = D.oq_off.p; k.oq_rec = D.oq_rec.p; k.oq_seg = D.oq_seg.p; k.oq_ws = D.oq_ws.p;
+  k.lm_off = D.lm_off.p; k.lm_id = D.lm_id.p; k.cam_off = D.cam_off.p; k.cam_id = D.cam_id.p; k.cam_zi = D.cam_zi.p;
+  k.own_off = D.own_off.p; k.own_cam = D.own_cam.p; k.own_zi = D.own_zi.p; k.own_q = D.own_q.p;
+  k.oq_off = D.oq_off.p; k.oq_rec = D.oq_rec.p;
   k.part = D.part.p; k.zbuf = D.zbuf.p; k.nrm = D.nrm.p; k.launch = D.launch.p;
   k.part_bytes = (unsigned)(D.part.n * sizeof(uint4)); k.z_bytes = (unsigned)(D.zbuf.n * sizeof(uint4)); k.nrm_bytes = (unsigned)(D.nrm.n * sizeof(uint4));
   k.W = D.W; k.m = m;
@@ -2795,7 +2797,7 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->res_waves = c->res.NW;
   out->res_rows = c->res.H;
   out->res_rounds = c->res.R;
-  out->res_max_acc = c->res.max_acc;
+  out->res_max_oq = c->res.max_oq;
   out->res_records = c->res.n_rec;
   out->res_max_cams = c->res.max_cam;
   out->res_max_lms = c->res.max_lm;

@@ -5,26 +5,30 @@
 // The per-term kernels re-read per term what does not change between the terms of a solve: rows, landmark records, tile
 // metadata, B^-1 -- and pay a launch ramp, a flush and two kernel boundaries each time (29 us per term on a venice-1778
 // shard of one rank in eight, where the rows cost 7; profiles/r04_shard_term_times.txt).  Here
-//   * a LANE keeps its chunk of <= H observations of one camera (uv, landmark slot, robust weight) and that camera's
+//   * a LANE keeps its chunks of <= H observations of one camera each (uv, landmark slot, robust weight) and that camera's
 //     P3 = P_c[:, :3] in REGISTERS for the whole solve;
 //   * the workgroup's LANDMARKS live in LDS (h~ 24 bytes, u / g 24 bytes; G = diag(s) Hll^-1 diag(s) in the registers of
-//     the lane that owns the slot), next to one accumulator per camera of the workgroup;
+//     the lane that owns the slot);
 //   * every camera has an OWNER workgroup that holds B_c^-1, sigma_c, the running sum and the last term in LDS.
-// Per term only z = sigma x moves (right_mul_e0_pOSE :364-406 + right_mul_b_inv_pOSE :322-340):
-//   gather z_c of the lane's camera -> forward u_l += P3^T (w C (Z h~)) (LDS atomics) -> g = G u -> backward
-//   y_c += h~ (x) (w C (P3 g)) (registers, one segmented wavefront sum, one LDS add per run) -> the workgroup's partial
-//   records (one per camera it touches) -> [hand-over 1] -> the owner sums a camera's records in a fixed order, applies
-//   B_c^-1, adds to the sum, publishes z_c -> [hand-over 2] -> next term.
+// Per term only z = sigma x and the per-camera partial sums move (right_mul_e0_pOSE :364-406 + right_mul_b_inv_pOSE
+// :322-340), through ONE region of LDS that is in turn
+//   1. the z of the workgroup's cameras (gathered from the z table by all threads, one 16-byte granule pair each),
+//   2. their accumulators: forward u_l += P3^T (w C (Z h~)) (LDS atomics on the landmark), g = G u, backward
+//      y_c += h~ (x) (w C (P3 g)) (registers, one segmented wavefront sum, one LDS add per run of lanes),
+//   3. after the accumulators have gone out as the workgroup's partial records (contiguous: a coalesced copy): the
+//      records the workgroup reads as an OWNER -- all threads again, a granule pair each --, which it sums camera by
+//      camera in a fixed order, applies B_c^-1 to, adds to the sum and publishes as the next z_c.
 // The reference's mutex-guarded `res += Jp^T s` (:388-398) is the LDS accumulation + the owner's fixed-order sum.
+// (A first version gave every lane its camera's z and its partial record to itself: twelve 16-byte accesses per chunk
+// and hand-over, each wavefront instruction touching 64 lines -- the address pipes of the CUs, not a latency, set the
+// term at 12 us on ladybug-49 and 44 us on a venice shard; profiles/r05_res_experiments.txt.)
 //
 // Hand-overs (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", R2: "the data IS the
 // flag"): every handed-over double travels as TWO 8-byte granules {32 bits of the value, tag} written by one 16-byte
 // agent-scope (sc1: write-through, L1-bypassing) store; tag = launch number << 8 | term, so a granule of an earlier term or
 // an earlier launch never matches.  The reader re-reads its granules (16-byte sc1 loads) until every tag is the one it
 // waits for: no flag word, no fence, no drain of the producer's stores, no dependence on dispatch order or placement; a
-// granule is written by ONE store and is never torn.  (The first version of this kernel published plain sc1 doubles
-// behind a per-workgroup flag word -- drain, barrier, flag, poll, then load: six dependent memory round trips per term,
-// 12 us per term on ladybug-49; profiles/r05_res_experiments.txt.)  What may be overwritten when:
+// granule is written by ONE store and is never torn.  What may be overwritten when:
 //   * z_c of term i replaces z_c of term i - 1 after the owner has seen ALL records of c of term i, i.e. after every
 //     workgroup that reads z_c has used it;
 //   * workgroup w's record of camera c of term i + 1 replaces that of term i after w has seen z_c of term i, which the
@@ -39,8 +43,7 @@
 namespace povar {
 
 struct ResP {
-  const int* lane_cam;    // [W][R][T]
-  const int* lane_tgt;
+  const int* lane_cam;    // [W][R][T] camera slot of the chunk
   const int* lane_seg;
   const double2* uv;      // [W][R][H][T]
   const int* lslot;
@@ -48,19 +51,19 @@ struct ResP {
   const int* wave_h;      // [W][R][NW]
   const int* lm_off;      // [W + 1]
   const int* lm_id;
-  const int* acc_off;     // [W + 1]
-  const int* acc_rec;
+  const int* cam_off;     // [W + 1] camera slots = partial records of the workgroup
+  const int* cam_id;
+  const int* cam_zi;
   const int* own_off;     // [W + 1]
   const int* own_cam;
-  const int2* own_ws;
+  const int* own_zi;
+  const int2* own_q;
   const int* oq_off;      // [W + 1]
   const int* oq_rec;
-  const int* oq_seg;
-  const int* oq_ws;
-  uint4* part;            // [n_rec][12] partial records, camera-major, one 16-byte granule pair per entry
-  uint4* zbuf;            // [n_cams][12] z = sigma x of the current term
+  uint4* part;            // [n_rec][12] partial records, workgroup-major, one 16-byte granule pair per entry
+  uint4* zbuf;            // [n_cams][12] z = sigma x of the current term, rows in popularity order
   uint4* nrm;             // [RES_MAX_WG][2] squared norms of (term, sum) over the cameras a workgroup owns
-  unsigned* launch;       // launch counter (the high bits of the tags), bumped by the kernel
+  unsigned* launch;       // launch counter (the high bits of the tags)
   unsigned part_bytes, z_bytes, nrm_bytes;
   int W, m, want_norms, want_norm0;
   int w_mode;             // robust weight of an observation: 1: V2::w through V2::of_slot, 2: Dp::sw squared
@@ -86,26 +89,54 @@ __device__ inline void res_put(__amdgpu_buffer_rsrc_t r, unsigned byte_off, doub
   g.x = (unsigned)__double2loint(v); g.y = tag; g.z = (unsigned)__double2hiint(v); g.w = tag;
   __builtin_amdgcn_raw_buffer_store_b128(g, r, byte_off, 0, RES_SC1);
 }
-// N consecutive granule pairs from byte_off on, re-read until every tag matches (for every active lane of the wavefront);
-// false: the spin budget ran out
+// N granule pairs (one per byte offset; inactive entries are not loaded), re-read until every tag matches for every lane
+// of the wavefront; false: the spin budget ran out
 template <int N>
-__device__ inline bool res_get(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned tag, bool active, double (&v)[N], unsigned limit) {
+__device__ inline bool res_get(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], const bool (&active)[N], unsigned tag, double (&v)[N],
+                               unsigned limit) {
   for (unsigned spins = 0;; ++spins) {
     res_u4 g[N];
 #pragma unroll
-    for (int e = 0; e < N; ++e) g[e] = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16u * e, 0, RES_SC1);
+    for (int e = 0; e < N; ++e) g[e] = __builtin_amdgcn_raw_buffer_load_b128(r, active[e] ? off[e] : 0u, 0, RES_SC1);
     bool ok = true;
 #pragma unroll
-    for (int e = 0; e < N; ++e) ok = ok && g[e].y == tag && g[e].w == tag;
-    if (__all(ok || !active)) {
+    for (int e = 0; e < N; ++e) ok = ok && (!active[e] || (g[e].y == tag && g[e].w == tag));
+    if (__all(ok)) {
 #pragma unroll
-      for (int e = 0; e < N; ++e) v[e] = active ? __hiloint2double((int)g[e].z, (int)g[e].x) : 0.0;
+      for (int e = 0; e < N; ++e) v[e] = __hiloint2double((int)g[e].z, (int)g[e].x);
       return true;
     }
     if (spins >= limit) return false;
     __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");  // (the loads above are re-issued: the compiler must not keep their values)
   }
+}
+
+// All threads of the workgroup: granule pair i of a list of n (pair i is entry i % 12 of row row_of(i / 12) of the
+// buffer) -> dst[(i / 12) * stride + i % 12], RES_GB pairs per thread in flight
+constexpr int RES_GB = 4;
+template <int T, class RowOf>
+__device__ inline bool res_gather(__amdgpu_buffer_rsrc_t r, int n, RowOf row_of, unsigned tag, double* dst, int stride, int t, unsigned limit) {
+  bool fine = true;
+  for (int i0 = 0; i0 < n; i0 += RES_GB * T) {
+    if (i0 + (t & ~63) >= n) break;  // (wave-uniform: nothing left for this wavefront)
+    unsigned off[RES_GB];
+    bool act[RES_GB];
+    double v[RES_GB];
+#pragma unroll
+    for (int b = 0; b < RES_GB; ++b) {
+      const int i = i0 + b * T + t;
+      act[b] = i < n;
+      off[b] = act[b] ? ((unsigned)row_of(i / 12) * 12u + (unsigned)(i % 12)) * 16u : 0u;
+    }
+    fine = res_get<RES_GB>(r, off, act, tag, v, limit) && fine;
+#pragma unroll
+    for (int b = 0; b < RES_GB; ++b) {
+      const int i = i0 + b * T + t;
+      if (act[b]) dst[(i / 12) * stride + i % 12] = v[b];
+    }
+  }
+  return fine;
 }
 
 // the per-lane state of one chunk
@@ -115,7 +146,7 @@ struct ResChunk {
   int ls[H];
   double rw[H];
   double P3[9];
-  int cam, tgt, seg, hrows, dup, steps;
+  int ci, seg, hrows, dup, steps;
 };
 
 // NW wavefronts per workgroup, chunks of H rows, RR chunks per lane, LS landmark slots per lane
@@ -126,32 +157,26 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const ResBufs B = res_bufs(k);
-  const unsigned tag0 = (*k.launch) << 8;  // (the counter is bumped at the end of the launch: stream order)
+  const unsigned tag0 = (*k.launch) << 8;  // (the counter is bumped by a kernel behind this one: stream order)
   const int L0 = k.lm_off[g], nL = k.lm_off[g + 1] - L0;
-  const int A0 = k.acc_off[g], nA = k.acc_off[g + 1] - A0;
+  const int C0 = k.cam_off[g], nC = k.cam_off[g + 1] - C0;
   const int O0 = k.own_off[g], nO = k.own_off[g + 1] - O0;
   const int Q0 = k.oq_off[g], nQ = k.oq_off[g + 1] - Q0;
-  const int nWS = nO > 0 ? k.own_ws[O0 + nO - 1].y : 0;
   int* ctl = reinterpret_cast<int*>(res_lds);  // [0] a wait gave up, [1] series converged, [2] iterations, [4..5] |x_0|
   double* lh = res_lds + 8;             // [nL][3] landmark coordinates
   double* lu = lh + 3 * nL;             // [nL][3] u = Jl^T Jp x, then g = G u
-  constexpr bool GL = true;             // G lives in LDS (res_g_in_lds): in registers it costs 12 LS VGPRs through every poll loop
-  double* lG = lu + 3 * nL;             // [nL][6] G (GL only)
-  double* acc = lG + (GL ? 6 * nL : 0); // [nA][13] accumulators of the cameras several lane runs share
-  double* obinv = acc + nA * RES_ACC_STRIDE;  // [nO][144] B^-1 of the owned cameras
+  double* reg = lu + 3 * nL;            // the region: z of the cameras [nC][13] -> accumulators [nC][13] -> owner's records [nQ][12]
+  double* obinv = reg + res_region_doubles(nC, nQ);  // [nO][144] B^-1 of the owned cameras
   double* osig = obinv + 144 * nO;      // [nO][12] sigma
   double* oacc = osig + 12 * nO;        // [nO][12] running sum
   double* otmp = oacc + 12 * nO;        // [nO][12] last term
-  double* oy = otmp + 12 * nO;          // [nO][12] E0 row of the term: sum of the camera's records
+  double* oy = otmp + 12 * nO;          // [nO][12] E0 row of the term: sigma * sum of the camera's records
   double* onrm = oy + 12 * nO;          // [nO][2] squared norms of the last term / the sum
-  double* ows = onrm + 2 * nO;          // [nWS][12] sums of the runs of record readers
-  int* arec = reinterpret_cast<int*>(ows + 12 * nWS);  // [nA] partial record of each accumulator slot
+  double* ops = onrm + 2 * nO;          // [nO][5][12] partial sums of the camera's records (five groups of twelve lanes)
 
   // ---------------- prologue: everything that does not change between the terms
   // owned cameras first (their registers are free again before the lane's own state is loaded): B^-1, sigma;
   // x_0 = B^-1 (-b) (the series start, :196); z_0 published
-  for (int i = t; i < nA * RES_ACC_STRIDE; i += T) acc[i] = 0;
-  for (int i = t; i < nA; i += T) arec[i] = k.acc_rec[A0 + i];
   if (t < 4) ctl[t] = 0;
   for (int o = wave; o < nO; o += NW) {
     const int c = k.own_cam[O0 + o];
@@ -161,14 +186,14 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
   }
   __syncthreads();
   for (int o = wave; o < nO; o += NW) {
-    const int c = k.own_cam[O0 + o];
+    const int zi = k.own_zi[O0 + o];
     double s = 0;
     if (lane < 12) {
       const double* Bi = obinv + 144 * o + 12 * lane;
 #pragma unroll
       for (int j = 0; j < 12; ++j) s += Bi[j] * otmp[12 * o + j];
       oacc[12 * o + lane] = s;
-      res_put(B.z, (unsigned)(12 * c + lane) * 16u, s * osig[12 * o + lane], tag0 | 1u);
+      res_put(B.z, (unsigned)(12 * zi + lane) * 16u, s * osig[12 * o + lane], tag0 | 1u);
     }
     if (k.want_norm0) {
       double n2[1] = {s * s};
@@ -189,13 +214,12 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
       res_put(B.nrm, (unsigned)(2 * g + 1) * 16u, a, tag0 | 1u);
     }
   }
-  // the lane's chunks: rows, camera, P3
+  // the lane's chunks: rows, camera slot, P3
   ResChunk<H> ch[RR];
 #pragma unroll
   for (int r = 0; r < RR; ++r) {
     const size_t li = ((size_t)g * RR + r) * T + t;
-    ch[r].cam = k.lane_cam[li];
-    ch[r].tgt = k.lane_tgt[li];
+    ch[r].ci = k.lane_cam[li];
     ch[r].seg = k.lane_seg[li];
     const int wh = __builtin_amdgcn_readfirstlane(k.wave_h[((size_t)g * RR + r) * NW + wave]);
     ch[r].hrows = wh & 255;
@@ -217,19 +241,19 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
     }
 #pragma unroll
     for (int e = 0; e < 9; ++e) ch[r].P3[e] = 0;
-    if (ch[r].cam >= 0) {
-      const Cam P = load_cam(d.cams_lin4, ch[r].cam);
+    if (ch[r].ci >= 0) {
+      const Cam P = load_cam(d.cams_lin4, k.cam_id[C0 + ch[r].ci]);
       ch[r].P3[0] = P.r0.x; ch[r].P3[1] = P.r0.y; ch[r].P3[2] = P.r0.z;
       ch[r].P3[3] = P.r1.x; ch[r].P3[4] = P.r1.y; ch[r].P3[5] = P.r1.z;
       ch[r].P3[6] = P.r2.x; ch[r].P3[7] = P.r2.y; ch[r].P3[8] = P.r2.z;
     }
   }
-  // the landmark slots of the lane: h~ into LDS, G = diag(s) Hll^-1 diag(s) in registers (or LDS)
-  double G[GL ? 1 : LS][6];
+  // the landmark slots of the lane: h~ into LDS, u = 0, G = diag(s) Hll^-1 diag(s) in registers
+  double G[LS][6];
 #pragma unroll
   for (int q = 0; q < LS; ++q) {
 #pragma unroll
-    for (int e = 0; e < 6; ++e) G[GL ? 0 : q][e] = 0;
+    for (int e = 0; e < 6; ++e) G[q][e] = 0;
     const int s = t + q * T;
     if (s < nL) {
       const int lm = k.lm_id[L0 + s];
@@ -238,31 +262,18 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
       lh[3 * s] = rp[0];
       lh[3 * s + 1] = rp[WAVE];
       lh[3 * s + 2] = rp[2 * WAVE];
+      lu[3 * s] = 0; lu[3 * s + 1] = 0; lu[3 * s + 2] = 0;
 #pragma unroll
-      for (int e = 0; e < 6; ++e) {
-        if (GL) lG[6 * s + e] = rp[(3 + e) * WAVE];
-        else G[GL ? 0 : q][e] = rp[(3 + e) * WAVE];
-      }
+      for (int e = 0; e < 6; ++e) G[q][e] = rp[(3 + e) * WAVE];
     }
   }
-  // the record this lane reads as an owner (first pass; further passes take theirs from the tables)
-  int oq_rec0 = -1, oq_seg0 = 0, oq_ws0 = 0;
-  if (t < nQ) {
-    oq_rec0 = k.oq_rec[Q0 + t];
-    oq_seg0 = k.oq_seg[Q0 + t];
-    oq_ws0 = k.oq_ws[Q0 + t];
-  }
   int iters = k.m;
+  auto z_row = [&](int s) { return k.cam_zi[C0 + s]; };
+  auto q_row = [&](int q) { return k.oq_rec[Q0 + q]; };
 
   // ---------------- the terms
   for (int i = 1; i <= k.m + 1; ++i) {
     const unsigned tag = tag0 | (unsigned)i;
-    // u = 0 for the slots of this lane (nothing reads lu between the backward pass of the last term and here)
-#pragma unroll
-    for (int q = 0; q < LS; ++q) {
-      const int s = t + q * T;
-      if (s < nL) { lu[3 * s] = 0; lu[3 * s + 1] = 0; lu[3 * s + 2] = 0; }
-    }
     if (i == k.m + 1 && !k.want_norms) break;  // (with the tests on: the last term's norms are looked at too)
     // ---- the norms of term i - 1 (every owner's: the one step of a term that waits for ALL workgroups)
     if (k.want_norms && (i > 1 || k.want_norm0)) {
@@ -270,10 +281,11 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
         double v[2] = {0, 0};
         bool ok = true;
         for (int w0 = 0; w0 < k.W; w0 += 64) {
+          const unsigned off[2] = {(unsigned)(2 * (w0 + lane)) * 16u, (unsigned)(2 * (w0 + lane) + 1) * 16u};
+          const bool act[2] = {w0 + lane < k.W, w0 + lane < k.W};
           double e2[2];
-          ok = ok && res_get<2>(B.nrm, (unsigned)(2 * (w0 + lane)) * 16u, tag, w0 + lane < k.W, e2, k.spin_limit);
-          v[0] += e2[0];
-          v[1] += e2[1];
+          ok = res_get<2>(B.nrm, off, act, tag, e2, k.spin_limit) && ok;
+          if (act[0]) { v[0] += e2[0]; v[1] += e2[1]; }
         }
         if (!ok && lane == 0) ctl[0] = 1;
         wave_sum<2>(v);
@@ -294,13 +306,20 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
       if (ctl[0] | ctl[1]) break;
     }
     if (i == k.m + 1) break;
-    // ---- forward: u_l += P3^T (w C (Z h~_l)); z of each chunk's camera is polled for first (hand-over 2)
-    bool gave_up = false;
+    // ---- hand-over 2: z of the workgroup's cameras into the region
+    // (the region's last readers were the owner sums of term i - 1: the barrier in front of them is B6 below, the one
+    // behind them the barrier at the end of the term)
+    if (!res_gather<T>(B.z, nC * 12, z_row, tag, reg, RES_ACC_STRIDE, t, k.spin_limit) && lane == 0) ctl[0] = 1;
+    __syncthreads();  // B1
+    if (ctl[0]) break;
+    // ---- forward: u_l += P3^T (w C (Z h~_l))
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
       if (ch[r].hrows == 0) continue;  // (wave-uniform)
       double zz[12];
-      if (!res_get<12>(B.z, (unsigned)(12 * (ch[r].cam < 0 ? 0 : ch[r].cam)) * 16u, tag, ch[r].cam >= 0, zz, k.spin_limit)) gave_up = true;
+      const double* zp = reg + (ch[r].ci < 0 ? 0 : ch[r].ci) * RES_ACC_STRIDE;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) zz[e] = zp[e];
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         if (j < ch[r].hrows && ch[r].ls[j] >= 0) {
@@ -309,26 +328,22 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
         }
       }
     }
-    if (gave_up && lane == 0) ctl[0] = 1;
-    __syncthreads();
-    if (ctl[0]) break;
-    // ---- g = G u per landmark slot
+    __syncthreads();  // B2
+    // ---- g = G u per landmark slot; the region becomes the accumulators
 #pragma unroll
     for (int q = 0; q < LS; ++q) {
       const int s = t + q * T;
       if (s < nL) {
         const double u0 = lu[3 * s], u1 = lu[3 * s + 1], u2 = lu[3 * s + 2];
-        double Gs[6];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) Gs[e] = GL ? lG[6 * s + e] : G[GL ? 0 : q][e];
-        lu[3 * s] = Gs[0] * u0 + Gs[1] * u1 + Gs[2] * u2;
-        lu[3 * s + 1] = Gs[1] * u0 + Gs[3] * u1 + Gs[4] * u2;
-        lu[3 * s + 2] = Gs[2] * u0 + Gs[4] * u1 + Gs[5] * u2;
+        lu[3 * s] = G[q][0] * u0 + G[q][1] * u1 + G[q][2] * u2;
+        lu[3 * s + 1] = G[q][1] * u0 + G[q][3] * u1 + G[q][4] * u2;
+        lu[3 * s + 2] = G[q][2] * u0 + G[q][4] * u1 + G[q][5] * u2;
       }
     }
-    __syncthreads();
-    // ---- backward: y_c += h~_l (x) (w C (P3 g_l)); lanes of one camera are summed; the run's first lane writes the
-    // camera's partial record (its only run in the workgroup) or adds to the camera's accumulator in LDS
+    for (int e = t; e < nC * RES_ACC_STRIDE; e += T) reg[e] = 0;
+    __syncthreads();  // B3
+    // ---- backward: y_c += h~_l (x) (w C (P3 g_l)); lanes of one camera are summed, the run's first lane adds to the
+    // camera's accumulator
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
       if (ch[r].hrows == 0) continue;
@@ -342,62 +357,47 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
         }
       }
       if (ch[r].dup) seg_reduce_steps<12>(y, lane, ch[r].seg & 255, (ch[r].seg >> 8) & 255, ch[r].steps);
-      if (ch[r].cam >= 0 && lane == (ch[r].seg & 255)) {
-        if (ch[r].tgt >= 0) {
+      if (ch[r].ci >= 0 && lane == (ch[r].seg & 255)) {
 #pragma unroll
-          for (int e = 0; e < 12; ++e)
-            __hip_atomic_fetch_add(acc + ch[r].tgt * RES_ACC_STRIDE + e, y[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-          const unsigned o = (unsigned)(~ch[r].tgt) * 192u;
-#pragma unroll
-          for (int e = 0; e < 12; ++e) res_put(B.part, o + 16u * e, y[e], tag);
-        }
+        for (int e = 0; e < 12; ++e)
+          __hip_atomic_fetch_add(reg + ch[r].ci * RES_ACC_STRIDE + e, y[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-    if (nA > 0) {
-      __syncthreads();
-      // ---- the shared cameras' partial records (and their accumulators back to zero)
-      for (int e = t; e < nA * 12; e += T) {
-        const int r = e / 12, m = e % 12;
-        const double v = acc[r * RES_ACC_STRIDE + m];
-        acc[r * RES_ACC_STRIDE + m] = 0;
-        res_put(B.part, (unsigned)arec[r] * 192u + 16u * m, v, tag);
-      }
-    }
-    // ---- owners (hand-over 1): every lane polls for ONE record of a camera the workgroup owns; runs of lanes with one
-    // camera are summed and leave their sum in LDS; then x_i = B^-1 (sigma * sum), sum += x_i, z published
-    // (:200-204, :322-340)
-    for (int q0 = 0; q0 < nQ; q0 += T) {
-      const int q = q0 + t;
-      int rec = oq_rec0, sg = oq_seg0, ws = oq_ws0;
-      if (q0 > 0) {
-        rec = q < nQ ? k.oq_rec[Q0 + q] : -1;
-        sg = q < nQ ? k.oq_seg[Q0 + q] : 0;
-        ws = q < nQ ? k.oq_ws[Q0 + q] : 0;
-      }
-      if (q0 + wave * 64 >= nQ) continue;  // (wave-uniform: no reader in this wavefront)
-      double y[12];
-      if (!res_get<12>(B.part, (unsigned)(rec < 0 ? 0 : rec) * 192u, tag, rec >= 0, y, k.spin_limit)) gave_up = true;
-      seg_reduce_steps<12>(y, lane, sg & 255, (sg >> 8) & 255, (sg >> 16) & 15);
-      if (rec >= 0 && lane == (sg & 255)) {
+    __syncthreads();  // B4
+    // ---- the workgroup's partial records: one contiguous run of granule pairs (hand-over 1, the producer's side);
+    // u back to zero for the next term (its last readers were the backward pass)
+    for (int e = t; e < nC * 12; e += T)
+      res_put(B.part, (unsigned)(C0 * 12 + e) * 16u, reg[(e / 12) * RES_ACC_STRIDE + e % 12], tag);
 #pragma unroll
-        for (int e = 0; e < 12; ++e) ows[12 * ws + e] = y[e];
-      }
+    for (int q = 0; q < LS; ++q) {
+      const int s = t + q * T;
+      if (s < nL) { lu[3 * s] = 0; lu[3 * s + 1] = 0; lu[3 * s + 2] = 0; }
     }
-    if (gave_up && lane == 0) ctl[0] = 1;
-    __syncthreads();
+    __syncthreads();  // B5 (the accumulators have been read: the region becomes the owner's records)
+    // ---- owners (hand-over 1): the records of the cameras the workgroup owns into the region
+    if (!res_gather<T>(B.part, nQ * 12, q_row, tag, reg, 12, t, k.spin_limit) && lane == 0) ctl[0] = 1;
+    __syncthreads();  // B6
     if (ctl[0]) break;
+    // ---- x_i = B^-1 (sigma * sum of the records), sum += x_i, z published (:200-204, :322-340).  A camera's records are
+    // summed by five groups of twelve lanes (record q of the camera by group q % 5), then the five partial sums in order
     for (int o = wave; o < nO; o += NW) {
-      const int c = k.own_cam[O0 + o];
-      const int2 wr = k.own_ws[O0 + o];
-      double s = 0, a = 0;
+      const int zi = k.own_zi[O0 + o];
+      const int2 qr = k.own_q[O0 + o];
+      if (lane < 60) {
+        const int e = lane % 12, grp = lane / 12;
+        double a = 0;
+        for (int q = qr.x + grp; q < qr.y; q += 5) a += reg[12 * q + e];
+        ops[60 * o + lane] = a;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
       if (lane < 12) {
-        double yl = 0;
-        for (int w = wr.x; w < wr.y; ++w) yl += ows[12 * w + lane];  // fixed order
+        const double yl = (((ops[60 * o + lane] + ops[60 * o + 12 + lane]) + ops[60 * o + 24 + lane]) + ops[60 * o + 36 + lane]) + ops[60 * o + 48 + lane];
         oy[12 * o + lane] = yl * osig[12 * o + lane];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      double s = 0, a = 0;
       if (lane < 12) {
         const double* Bi = obinv + 144 * o + 12 * lane;
 #pragma unroll
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
         a = oacc[12 * o + lane] + s;
         otmp[12 * o + lane] = s;
         oacc[12 * o + lane] = a;
-        res_put(B.z, (unsigned)(12 * c + lane) * 16u, s * osig[12 * o + lane], tag + 1u);
+        res_put(B.z, (unsigned)(12 * zi + lane) * 16u, s * osig[12 * o + lane], tag + 1u);
       }
       if (k.want_norms) {
         double n2[2] = {s * s, a * a};
@@ -413,14 +413,12 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
         if (lane == 0) { onrm[2 * o] = n2[0]; onrm[2 * o + 1] = n2[1]; }
       }
     }
-    if (k.want_norms) {
-      __syncthreads();
-      if (t == 0) {
-        double a = 0, b = 0;
-        for (int o = 0; o < nO; ++o) { a += onrm[2 * o]; b += onrm[2 * o + 1]; }
-        res_put(B.nrm, (unsigned)(2 * g) * 16u, a, tag + 1u);
-        res_put(B.nrm, (unsigned)(2 * g + 1) * 16u, b, tag + 1u);
-      }
+    __syncthreads();  // B7 (the owner sums have read the region: the next term's z may land in it)
+    if (k.want_norms && t == 0) {
+      double a = 0, b = 0;
+      for (int o = 0; o < nO; ++o) { a += onrm[2 * o]; b += onrm[2 * o + 1]; }
+      res_put(B.nrm, (unsigned)(2 * g) * 16u, a, tag + 1u);
+      res_put(B.nrm, (unsigned)(2 * g + 1) * 16u, b, tag + 1u);
     }
   }
   // ---------------- epilogue: sum and last term of the owned cameras, status
@@ -433,12 +431,10 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
   }
   if (t == 0) {
     if (ctl[0]) atomicOr(&d.flags[0], 4);
-    if (g == 0) {
-      if (ctl[1]) {
-        d.flags[1] = 1;
-        d.flags[2] = iters;
-        d.flags[3] = 1;
-      }
+    if (g == 0 && ctl[1]) {
+      d.flags[1] = 1;
+      d.flags[2] = iters;
+      d.flags[3] = 1;
     }
   }
 }

@@ -37,14 +37,12 @@ constexpr int RES_HMAX = 8;          // rows of a chunk at most
 constexpr int RES_MAX_WG = 256;      // workgroups (flag words swept by one wavefront: 4 per lane)
 constexpr int RES_LDS_BYTES = 160 * 1024;
 constexpr int RES_ACC_STRIDE = 13;   // doubles per accumulator slot in LDS (12 used; odd: 32 bank classes)
-constexpr int RES_OWN_DOUBLES = 144 + 12 + 12 + 12 + 12 + 2;  // per owned camera in LDS: B^-1, sigma, sum, term, E0 row, norms
 
 struct ResLayout {
   int W = 0, NW = 0, H = 0, R = 1;   // workgroups, wavefronts per workgroup, rows per chunk, chunks (rounds) per lane
   int LS = 1;                        // landmark slots per lane (slot s of a workgroup belongs to thread s % T)
   // per chunk position [W][R][T]
-  std::vector<int> lane_cam;         // camera of the chunk (-1: none)
-  std::vector<int> lane_tgt;         // >= 0: accumulator slot of the workgroup (LDS); < 0: ~(partial record), written directly
+  std::vector<int> lane_cam;         // camera SLOT of the chunk in its workgroup (-1: none)
   std::vector<int> lane_seg;         // first | last << 8 lane (of the wavefront) of the run of lanes that share the camera
   // per row [W][R][H][T]
   std::vector<double2> uv;
@@ -53,35 +51,35 @@ struct ResLayout {
   std::vector<int> wave_h;           // [W][R][NW] rows of the wavefront's chunks | needs a segmented sum << 8 | scan steps << 12
   // landmark slots of the workgroups
   std::vector<int> lm_off, lm_id;    // [W + 1], landmark of each slot
-  // shared-camera accumulator slots of the workgroups
-  std::vector<int> acc_off, acc_rec; // [W + 1], partial record of each slot
-  // every (workgroup, camera) pair (statistics, checks): record of each
-  std::vector<int> cam_off, cam_id, cam_rec;
+  // camera slots of the workgroups, most observed camera first.  Slot s of workgroup g IS partial record cam_off[g] + s:
+  // the records are workgroup-major, a workgroup writes its own as one contiguous run
+  std::vector<int> cam_off, cam_id;  // [W + 1], camera of each slot
+  std::vector<int> cam_zi;           // row of the camera in the z table (popularity rank: the hub cameras share lines)
   // owners
   std::vector<int> own_off, own_cam; // [W + 1], cameras owned by each workgroup
-  std::vector<int2> own_rec;         // [first, end) partial records of each owned camera
-  // The records a workgroup owns, flattened (camera after camera): position q is read by thread q % T in pass q / T.
-  // Lanes of a wavefront that read records of ONE camera are a run (one segmented wavefront sum); every run leaves its
-  // sum in a slot of the workgroup's LDS, and the camera's slots (in position order) are summed by its finishing lanes.
-  std::vector<int> oq_off;           // [W + 1]
-  std::vector<int> oq_rec;           // record read at each position
-  std::vector<int> oq_seg;           // first | last << 8 lane of the position's run | scan steps << 16
-  std::vector<int> oq_ws;            // LDS slot of the position's run
-  std::vector<int2> own_ws;          // [first, end) LDS slots of each owned camera
-  int max_ws = 0, max_oq = 0;
+  std::vector<int> own_zi;           // z-table row of each owned camera
+  std::vector<int2> own_q;           // [first, end) positions of the camera's records in the workgroup's read list
+  std::vector<int> oq_off, oq_rec;   // [W + 1]; the records a workgroup reads as an owner, camera after camera, each
+                                     // camera's in workgroup order (the fixed order of its sum)
   int n_rec = 0;
-  int max_lm = 0, max_cam = 0, max_acc = 0, max_own = 0, max_chunks = 0;
+  int max_lm = 0, max_cam = 0, max_own = 0, max_chunks = 0, max_oq = 0;
   int order = 0;                     // 0: natural landmark order, 1: by rarest camera
   size_t lds_bytes = 0;
   bool fits = false;
   const char* why = "";              // when it does not fit
 };
 
-// G = diag(s) Hll^-1 diag(s) lives in LDS next to h~ and u
-inline bool res_g_in_lds(int) { return true; }
-inline size_t res_lds_bytes(int n_lm, int n_acc, int n_own, int n_ws, bool g_in_lds) {
-  return 64 + (size_t)n_lm * (g_in_lds ? 96 : 48) + (size_t)n_acc * (RES_ACC_STRIDE * 8 + 4) + 8 + (size_t)n_own * RES_OWN_DOUBLES * 8 +
-         (size_t)n_ws * 96;
+// LDS of a workgroup: control words, h~ and u per landmark (G stays in the registers of the slot's lane), ONE region that
+// is in turn the z of the workgroup's cameras, their accumulators, and the records it reads as an owner, and per owned
+// camera B^-1, sigma, sum, term, E0 row, norms and five partial sums
+constexpr int RES_LM_BYTES = 48;
+constexpr int RES_OWN_DOUBLES = 144 + 12 + 12 + 12 + 12 + 2 + 5 * 12;
+__host__ __device__ inline size_t res_region_doubles(int n_cam, int n_oq) {
+  const size_t a = (size_t)n_cam * RES_ACC_STRIDE, b = (size_t)n_oq * 12;
+  return a > b ? a : b;
+}
+inline size_t res_lds_bytes(int n_lm, int n_cam, int n_own, int n_oq) {
+  return 64 + (size_t)n_lm * RES_LM_BYTES + res_region_doubles(n_cam, n_oq) * 8 + (size_t)n_own * RES_OWN_DOUBLES * 8;
 }
 
 // W workgroups of NW wavefronts whose lanes hold R chunks of at most H rows each; the smallest H <= hmax (a power of
@@ -94,7 +92,6 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   R.NW = NW;
   R.R = std::max(1, R_);
   const int cap_lanes = R.R * T;
-  const bool gl = res_g_in_lds(NW);
   ls_max = std::max(1, std::min(ls_max, 2));
   W = std::max(1, std::min(W, RES_MAX_WG));
   hmax = std::max(1, std::min(hmax, RES_HMAX));
@@ -123,6 +120,7 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   // Greedy cut of an order into ranges of at most `cap` chunks (chunk cap H), ls_max T landmarks and what the LDS holds next to
   // the owned cameras; returns the number of ranges (first[]: their starts) and the (range, camera) pairs
   const int own_guess = (n_cams + W - 1) / W + 2;
+  const int oq_guess = (int)std::min<int64_t>((int64_t)n_cams * 2, lm_off[n_lms] / std::max(W, 1) / 5 + 64);  // (checked exactly at the end)
   auto cut = [&](const std::vector<int>& order, int H, int cap, std::vector<int>* first, int64_t* pairs_out) {
     std::vector<int> cnt(n_cams, 0), stamp(n_cams, -1);
     int groups = 0, chunks = 0, lms = 0, cams = 0;
@@ -138,7 +136,7 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         else if (cnt[c] % H == 0) ++add_chunks;
       }
       const bool over = lms > 0 && (chunks + add_chunks > cap || lms + 1 > ls_max * T ||
-                                    res_lds_bytes(lms + 1, cams + add_cams, own_guess, own_guess + 4 * NW, gl) > (size_t)RES_LDS_BYTES);
+                                    res_lds_bytes(lms + 1, cams + add_cams, own_guess, oq_guess) > (size_t)RES_LDS_BYTES);
       if (over) {
         pairs += cams;
         ++groups;
@@ -232,23 +230,18 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
   }
   R.LS = std::max(1, (R.max_lm + T - 1) / T);
   if (R.LS > ls_max || R.max_chunks > cap_lanes) { R.why = "internal: the cut does not respect its caps"; return; }
-  // ---- partial records (camera-major) and owners
-  std::vector<int> rec_cnt(n_cams, 0), rec_first(n_cams + 1, 0);
+  // ---- partial records (workgroup-major: record = the workgroup's camera slot) and owners
+  std::vector<int> rec_cnt(n_cams, 0);
   for (int g = 0; g < W; ++g)
     for (int c : wg_cams[g]) rec_cnt[c]++;
-  for (int c = 0; c < n_cams; ++c) rec_first[c + 1] = rec_first[c] + rec_cnt[c];
-  R.n_rec = rec_first[n_cams];
-  R.cam_id.resize(R.cam_off[W]);
-  R.cam_rec.resize(R.cam_off[W]);
-  {
-    std::vector<int> next(rec_first.begin(), rec_first.end() - 1);
-    for (int g = 0; g < W; ++g)
-      for (size_t s = 0; s < wg_cams[g].size(); ++s) {
-        const int c = wg_cams[g][s];
-        R.cam_id[R.cam_off[g] + s] = c;
-        R.cam_rec[R.cam_off[g] + s] = next[c]++;
-      }
-  }
+  R.n_rec = R.cam_off[W];
+  R.cam_id.resize(R.n_rec);
+  R.cam_zi.resize(R.n_rec);
+  for (int g = 0; g < W; ++g)
+    for (size_t s = 0; s < wg_cams[g].size(); ++s) {
+      R.cam_id[R.cam_off[g] + s] = wg_cams[g][s];
+      R.cam_zi[R.cam_off[g] + s] = rank1[wg_cams[g][s]] - 1;
+    }
   {
     // every camera (also one without observations in this shard: its x is still B^-1 times the exchanged sum) gets the
     // least loaded workgroup, most records first; load = records + a fixed cost per camera (B^-1, publication)
@@ -260,70 +253,47 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
     for (int g = 0; g < W; ++g) heap.push_back({0, g});
     auto cmp = [](const std::pair<int64_t, int>& a, const std::pair<int64_t, int>& b) { return a > b; };
     std::make_heap(heap.begin(), heap.end(), cmp);
+    std::vector<int> owner_of(n_cams, 0), own_idx(n_cams, 0);
     for (int c : by) {
       std::pop_heap(heap.begin(), heap.end(), cmp);
       auto& top = heap.back();
+      owner_of[c] = top.second;
       own[top.second].push_back(c);
       top.first += rec_cnt[c] + 16;
       std::push_heap(heap.begin(), heap.end(), cmp);
     }
     R.own_off.assign(W + 1, 0);
+    R.oq_off.assign(W + 1, 0);
     for (int g = 0; g < W; ++g) {
       R.own_off[g + 1] = R.own_off[g] + (int)own[g].size();
       R.max_own = std::max(R.max_own, (int)own[g].size());
+      int q = 0;
       for (int c : own[g]) {
+        own_idx[c] = (int)R.own_cam.size();
         R.own_cam.push_back(c);
-        R.own_rec.push_back(make_int2(rec_first[c], rec_first[c + 1]));
+        R.own_zi.push_back(rank1[c] - 1);
+        R.own_q.push_back(make_int2(q, q + rec_cnt[c]));
+        q += rec_cnt[c];
       }
+      R.oq_off[g + 1] = R.oq_off[g] + q;
+      R.max_oq = std::max(R.max_oq, q);
     }
-  }
-  // ---- the owners' view of the records
-  R.oq_off.assign(W + 1, 0);
-  for (int g = 0; g < W; ++g) {
-    int n = 0;
-    for (int o = R.own_off[g]; o < R.own_off[g + 1]; ++o) n += R.own_rec[o].y - R.own_rec[o].x;
-    R.oq_off[g + 1] = R.oq_off[g] + n;
-    R.max_oq = std::max(R.max_oq, n);
-  }
-  R.oq_rec.resize(R.n_rec);
-  R.oq_seg.resize(R.n_rec);
-  R.oq_ws.resize(R.n_rec);
-  R.own_ws.resize(R.own_cam.size());
-  for (int g = 0; g < W; ++g) {
-    int q = 0, ws = 0;
-    for (int o = R.own_off[g]; o < R.own_off[g + 1]; ++o) {
-      const int n = R.own_rec[o].y - R.own_rec[o].x;
-      const int ws0 = ws;
-      for (int j = 0; j < n;) {
-        // the run: positions of this camera inside one wavefront of one pass
-        const int lane0 = (q + j) % WAVE;
-        const int len = std::min(n - j, WAVE - lane0);
-        int steps = 0;
-        while ((1 << steps) < std::min(len, 16)) ++steps;
-        for (int e = 0; e < len; ++e) {
-          const size_t at = (size_t)R.oq_off[g] + q + j + e;
-          R.oq_rec[at] = R.own_rec[o].x + j + e;
-          R.oq_seg[at] = lane0 | ((lane0 + len - 1) << 8) | (std::max(steps, 1) << 16);
-          R.oq_ws[at] = ws;
-        }
-        ++ws;
-        j += len;
+    R.oq_rec.assign(R.n_rec, -1);
+    std::vector<int> fill(n_cams, 0);
+    for (int g = 0; g < W; ++g)  // (workgroup order: the order of a camera's sum)
+      for (size_t s = 0; s < wg_cams[g].size(); ++s) {
+        const int c = wg_cams[g][s], o = own_idx[c];
+        R.oq_rec[(size_t)R.oq_off[owner_of[c]] + R.own_q[o].x + fill[c]++] = R.cam_off[g] + (int)s;
       }
-      R.own_ws[o] = make_int2(ws0, ws);
-      q += n;
-    }
-    R.max_ws = std::max(R.max_ws, ws);
   }
   // ---- lanes and rows
   const size_t n_pos = (size_t)W * R.R * T;
   R.lane_cam.assign(n_pos, -1);
-  R.lane_tgt.assign(n_pos, 0);
   R.lane_seg.assign(n_pos, 0);
   R.uv.assign(n_pos * H, make_double2(0, 0));
   R.lslot.assign(n_pos * H, -1);
   R.oslot.assign(n_pos * H, -1);
   R.wave_h.assign((size_t)W * R.R * NW, 0);
-  std::vector<std::vector<int>> wg_acc_rec(W);
   lpl_parallel(W, n_threads, [&](int g) {
     const std::vector<Ob>& ob = wg_obs[g];
     const std::vector<Chunk>& ch = wg_chunks[g];
@@ -340,7 +310,7 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
       cam_of_pos[pos] = ch[q].cam;
       ci_of_pos[pos] = ch[q].ci;
       const size_t lane = ((size_t)g * R.R + rt.first) * T + rt.second;
-      R.lane_cam[lane] = ch[q].cam;
+      R.lane_cam[lane] = ch[q].ci;
       for (int j = 0; j < ch[q].len; ++j) {
         const Ob& o = ob[ch[q].at + j];
         const size_t row = (((size_t)g * R.R + rt.first) * H + j) * T + rt.second;
@@ -349,8 +319,7 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         R.oslot[row] = slot_of_obs[o.i];
       }
     }
-    // runs of adjacent lanes with one camera inside a wavefront and round; a camera with ONE run writes its record
-    // from registers, the others get an accumulator slot
+    // runs of adjacent lanes with one camera inside a wavefront and round (one segmented wavefront sum, one LDS add)
     std::vector<int> runs(wg_cams[g].size(), 0), len_of_pos((size_t)R.R * T, 0);
     for (size_t q = 0; q < ch.size(); ++q) {
       const auto rt = pos_of(q);
@@ -377,30 +346,11 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         while ((1 << steps) < std::min(longest, 16)) ++steps;
         R.wave_h[((size_t)g * R.R + r) * NW + wv] = h | (dup << 8) | (std::max(steps, 1) << 12);
       }
-    std::vector<int> acc_of_ci(wg_cams[g].size(), -1);
-    for (size_t ci = 0; ci < wg_cams[g].size(); ++ci)
-      if (runs[ci] > 1) {
-        acc_of_ci[ci] = (int)wg_acc_rec[g].size();
-        wg_acc_rec[g].push_back(R.cam_rec[R.cam_off[g] + ci]);
-      }
-    for (size_t pos = 0; pos < (size_t)R.R * T; ++pos) {
-      const int ci = ci_of_pos[pos];
-      if (ci < 0) continue;
-      R.lane_tgt[(size_t)g * R.R * T + pos] = acc_of_ci[ci] >= 0 ? acc_of_ci[ci] : ~R.cam_rec[R.cam_off[g] + ci];
-    }
   });
-  R.acc_off.assign(W + 1, 0);
-  for (int g = 0; g < W; ++g) {
-    R.acc_off[g + 1] = R.acc_off[g] + (int)wg_acc_rec[g].size();
-    R.max_acc = std::max(R.max_acc, (int)wg_acc_rec[g].size());
-    R.acc_rec.insert(R.acc_rec.end(), wg_acc_rec[g].begin(), wg_acc_rec[g].end());
-  }
   R.lds_bytes = 0;
-  for (int g = 0; g < W; ++g) {
-    const int n_ws = R.own_off[g + 1] > R.own_off[g] ? R.own_ws[R.own_off[g + 1] - 1].y : 0;
-    R.lds_bytes = std::max(R.lds_bytes, res_lds_bytes(R.lm_off[g + 1] - R.lm_off[g], R.acc_off[g + 1] - R.acc_off[g],
-                                                      R.own_off[g + 1] - R.own_off[g], n_ws, gl));
-  }
+  for (int g = 0; g < W; ++g)
+    R.lds_bytes = std::max(R.lds_bytes, res_lds_bytes(R.lm_off[g + 1] - R.lm_off[g], R.cam_off[g + 1] - R.cam_off[g],
+                                                      R.own_off[g + 1] - R.own_off[g], R.oq_off[g + 1] - R.oq_off[g]));
   if (R.lds_bytes > (size_t)RES_LDS_BYTES) { R.why = "landmarks + accumulators + owned cameras exceed the LDS"; return; }
   R.fits = true;
 }

@@ -63,10 +63,9 @@ int main(int argc, char** argv) {
   const int T = NW * WAVE, H = R.H;
   CHECK(R.W >= 1 && R.W <= RES_MAX_WG && R.W <= W && R.NW == NW && R.R == RR && H >= hmin && H <= hmax && (H & (H - 1)) == 0);
   CHECK((int)R.lm_off.size() == R.W + 1 && R.lm_off[R.W] == n_lms && (int)R.lm_id.size() == n_lms);
-  CHECK((int)R.cam_off.size() == R.W + 1 && (int)R.cam_id.size() == R.cam_off[R.W] && R.cam_rec.size() == R.cam_id.size());
-  CHECK((int)R.acc_off.size() == R.W + 1 && (int)R.acc_rec.size() == R.acc_off[R.W]);
+  CHECK((int)R.cam_off.size() == R.W + 1 && (int)R.cam_id.size() == R.cam_off[R.W] && R.cam_zi.size() == R.cam_id.size() && R.n_rec == R.cam_off[R.W]);
   const size_t n_pos = (size_t)R.W * RR * T;
-  CHECK(R.lane_cam.size() == n_pos && R.lane_tgt.size() == n_pos && R.lane_seg.size() == n_pos);
+  CHECK(R.lane_cam.size() == n_pos && R.lane_seg.size() == n_pos);
   CHECK(R.uv.size() == n_pos * H && R.lslot.size() == R.uv.size() && R.oslot.size() == R.uv.size());
   CHECK(R.wave_h.size() == (size_t)R.W * RR * NW);
   CHECK(R.lds_bytes <= (size_t)RES_LDS_BYTES && R.LS >= 1 && R.LS <= ls_max && R.max_lm <= R.LS * T);
@@ -84,17 +83,16 @@ int main(int argc, char** argv) {
   for (int l = 0; l < n_lms; ++l)
     for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) where[{l, cam_idx[i]}] = i;
   std::vector<char> seen(n_obs, 0);
-  std::vector<int> rec_used(R.n_rec, 0);
-  int64_t lanes_used = 0, rows_issued = 0, direct = 0;
+  int64_t lanes_used = 0, rows_issued = 0, single_run = 0;
   for (int g = 0; g < R.W; ++g) {
-    const int nC = R.cam_off[g + 1] - R.cam_off[g], nA = R.acc_off[g + 1] - R.acc_off[g];
-    std::map<int, int> rec_of_cam;
+    const int nC = R.cam_off[g + 1] - R.cam_off[g];
+    std::set<int> cams_of_wg;
     for (int s = 0; s < nC; ++s) {
-      const int c = R.cam_id[R.cam_off[g] + s], rec = R.cam_rec[R.cam_off[g] + s];
-      CHECK(c >= 0 && c < n_cams && rec_of_cam.emplace(c, rec).second);
-      CHECK(rec >= 0 && rec < R.n_rec && rec_used[rec]++ == 0);
+      const int c = R.cam_id[R.cam_off[g] + s];
+      CHECK(c >= 0 && c < n_cams && cams_of_wg.insert(c).second && R.cam_zi[R.cam_off[g] + s] == rank1[c] - 1);
+      if (s > 0) CHECK(rank1[c] > rank1[R.cam_id[R.cam_off[g] + s - 1]]);  // most observed first
     }
-    std::map<int, int> runs_of_cam, tgt_of_cam;
+    std::map<int, int> runs_of_slot;
     for (int r = 0; r < RR; ++r)
       for (int wv = 0; wv < NW; ++wv) {
         const int wh = R.wave_h[((size_t)g * RR + r) * NW + wv], hrows = wh & 255, dup = (wh >> 8) & 1, steps = (wh >> 12) & 15;
@@ -103,25 +101,21 @@ int main(int argc, char** argv) {
         bool any_dup = false;
         for (int l = 0; l < WAVE; ++l) {
           const size_t t = (size_t)wv * WAVE + l, lane = ((size_t)g * RR + r) * T + t;
-          const int cam = R.lane_cam[lane];
-          if (cam < 0) {
+          const int ci = R.lane_cam[lane];
+          if (ci < 0) {
             for (int j = 0; j < H; ++j) CHECK(R.lslot[(((size_t)g * RR + r) * H + j) * T + t] < 0);
             continue;
           }
           ++lanes_used;
-          CHECK(rec_of_cam.count(cam) == 1);
-          const int tg = R.lane_tgt[lane];
-          if (tg >= 0) CHECK(tg < nA && R.acc_rec[R.acc_off[g] + tg] == rec_of_cam[cam]);
-          else CHECK(~tg == rec_of_cam[cam]);
-          if (tgt_of_cam.count(cam)) CHECK(tgt_of_cam[cam] == tg);
-          tgt_of_cam[cam] = tg;
+          CHECK(ci < nC);
+          const int cam = R.cam_id[R.cam_off[g] + ci];
           const int s0 = R.lane_seg[lane] & 255, s1 = (R.lane_seg[lane] >> 8) & 255;
           CHECK(s0 <= l && l <= s1 && s1 < WAVE);
           const size_t base = ((size_t)g * RR + r) * T + (size_t)wv * WAVE;
-          for (int q = s0; q <= s1; ++q) CHECK(R.lane_cam[base + q] == cam && R.lane_seg[base + q] == R.lane_seg[lane]);
-          if (s0 > 0) CHECK(R.lane_cam[base + s0 - 1] != cam);
-          if (s1 + 1 < WAVE) CHECK(R.lane_cam[base + s1 + 1] != cam);
-          if (l == s0) runs_of_cam[cam]++;
+          for (int q = s0; q <= s1; ++q) CHECK(R.lane_cam[base + q] == ci && R.lane_seg[base + q] == R.lane_seg[lane]);
+          if (s0 > 0) CHECK(R.lane_cam[base + s0 - 1] != ci);
+          if (s1 + 1 < WAVE) CHECK(R.lane_cam[base + s1 + 1] != ci);
+          if (l == s0) runs_of_slot[ci]++;
           if (s1 > s0) { any_dup = true; CHECK((1 << steps) >= std::min(s1 - s0 + 1, 16)); }
           bool ended = false;
           for (int j = 0; j < H; ++j) {
@@ -141,66 +135,38 @@ int main(int argc, char** argv) {
         }
         CHECK(any_dup == (dup != 0));
       }
-    CHECK(runs_of_cam.size() == rec_of_cam.size());
-    // a record is written from registers exactly when its camera is ONE run of lanes
-    for (auto& kv : runs_of_cam) {
-      CHECK((tgt_of_cam[kv.first] < 0) == (kv.second == 1));
-      if (kv.second == 1) ++direct;
-    }
+    CHECK((int)runs_of_slot.size() == nC);  // every camera slot of the workgroup has a chunk
+    for (auto& kv : runs_of_slot) single_run += kv.second == 1;
   }
   for (int64_t i = 0; i < n_obs; ++i) CHECK(seen[i]);
-  for (int r = 0; r < R.n_rec; ++r) CHECK(rec_used[r] == 1);
-  // owners: every camera once, its records = the slots that name it, contiguous
+  // owners: every camera once; its records = the slots that name it, each once, in workgroup order
   CHECK((int)R.own_off.size() == R.W + 1 && R.own_off[R.W] == n_cams && (int)R.own_cam.size() == n_cams);
-  std::vector<int> owned(n_cams, 0), rec_cam(R.n_rec, -1);
-  for (int g = 0; g < R.W; ++g)
-    for (int s = R.cam_off[g]; s < R.cam_off[g + 1]; ++s) rec_cam[R.cam_rec[s]] = R.cam_id[s];
+  CHECK((int)R.oq_off.size() == R.W + 1 && R.oq_off[R.W] == R.n_rec && (int)R.oq_rec.size() == R.n_rec);
+  CHECK(R.own_q.size() == R.own_cam.size() && R.own_zi.size() == R.own_cam.size());
+  std::vector<int> owned(n_cams, 0), rec_seen(R.n_rec, 0);
   int64_t max_own_rec = 0;
   for (int g = 0; g < R.W; ++g) {
-    int64_t load = 0;
+    int q = 0;
     for (int o = R.own_off[g]; o < R.own_off[g + 1]; ++o) {
       const int c = R.own_cam[o];
-      CHECK(c >= 0 && c < n_cams && owned[c]++ == 0);
-      CHECK(R.own_rec[o].x <= R.own_rec[o].y && R.own_rec[o].y <= R.n_rec);
-      for (int r = R.own_rec[o].x; r < R.own_rec[o].y; ++r) CHECK(rec_cam[r] == c);
-      load += R.own_rec[o].y - R.own_rec[o].x;
-    }
-    max_own_rec = std::max(max_own_rec, load);
-  }
-  // the owners' flattened view: every record at exactly one position of its owner, runs inside one wavefront, one LDS
-  // slot per run, a camera's slots consecutive and in position order
-  CHECK((int)R.oq_off.size() == R.W + 1 && R.oq_off[R.W] == R.n_rec && (int)R.oq_rec.size() == R.n_rec);
-  CHECK(R.own_ws.size() == R.own_cam.size());
-  std::vector<int> rec_seen(R.n_rec, 0);
-  for (int g = 0; g < R.W; ++g) {
-    int q = 0, next_ws = 0;
-    for (int o = R.own_off[g]; o < R.own_off[g + 1]; ++o) {
-      CHECK(R.own_ws[o].x == next_ws && R.own_ws[o].y >= R.own_ws[o].x);
-      const int n = R.own_rec[o].y - R.own_rec[o].x;
-      CHECK((n == 0) == (R.own_ws[o].y == R.own_ws[o].x));
-      for (int j = 0; j < n; ++j, ++q) {
-        const size_t at = (size_t)R.oq_off[g] + q;
-        CHECK(R.oq_rec[at] == R.own_rec[o].x + j && rec_seen[R.oq_rec[at]]++ == 0);
-        const int l = q % WAVE, s0 = R.oq_seg[at] & 255, s1 = (R.oq_seg[at] >> 8) & 255, steps = (R.oq_seg[at] >> 16) & 15;
-        CHECK(s0 <= l && l <= s1 && s1 < WAVE && steps >= 1 && (1 << steps) >= std::min(s1 - s0 + 1, 16));
-        CHECK(R.oq_ws[at] >= R.own_ws[o].x && R.oq_ws[at] < R.own_ws[o].y);
-        if (l > s0) CHECK(R.oq_ws[at] == R.oq_ws[at - 1] && R.oq_seg[at] == R.oq_seg[at - 1]);
-        else CHECK(j == 0 || R.oq_ws[at] == R.oq_ws[at - 1] + 1);
-        if (j == 0) CHECK(R.oq_ws[at] == R.own_ws[o].x && l == s0);
-        if (j == n - 1) CHECK(R.oq_ws[at] == R.own_ws[o].y - 1 && l == s1);
+      CHECK(c >= 0 && c < n_cams && owned[c]++ == 0 && R.own_zi[o] == rank1[c] - 1);
+      CHECK(R.own_q[o].x == q && R.own_q[o].y >= q);
+      int prev = -1;
+      for (q = R.own_q[o].x; q < R.own_q[o].y; ++q) {
+        const int rec = R.oq_rec[(size_t)R.oq_off[g] + q];
+        CHECK(rec >= 0 && rec < R.n_rec && rec_seen[rec]++ == 0 && R.cam_id[rec] == c && rec > prev);
+        prev = rec;
       }
-      next_ws = R.own_ws[o].y;
     }
-    CHECK(q == R.oq_off[g + 1] - R.oq_off[g] && next_ws <= R.max_ws);
+    CHECK(q == R.oq_off[g + 1] - R.oq_off[g]);
+    max_own_rec = std::max<int64_t>(max_own_rec, q);
   }
-  int64_t rec_sum = 0;
   for (int c = 0; c < n_cams; ++c) CHECK(owned[c] == 1);
-  for (size_t o = 0; o < R.own_rec.size(); ++o) rec_sum += R.own_rec[o].y - R.own_rec[o].x;
-  CHECK(rec_sum == R.n_rec);
-  std::printf("{\"ok\": 1, \"fits\": 1, \"W\": %d, \"H\": %d, \"LS\": %d, \"order\": %d, \"n_rec\": %d, \"direct_rec\": %lld, \"max_lm\": %d, "
-              "\"max_cam\": %d, \"max_acc\": %d, \"max_own\": %d, \"max_chunks\": %d, \"max_own_rec\": %lld, \"lanes_used\": %lld, "
+  for (int r = 0; r < R.n_rec; ++r) CHECK(rec_seen[r] == 1);
+  std::printf("{\"ok\": 1, \"fits\": 1, \"W\": %d, \"H\": %d, \"LS\": %d, \"order\": %d, \"n_rec\": %d, \"single_run\": %lld, \"max_lm\": %d, "
+              "\"max_cam\": %d, \"max_oq\": %d, \"max_own\": %d, \"max_chunks\": %d, \"max_own_rec\": %lld, \"lanes_used\": %lld, "
               "\"lane_fill\": %.3f, \"row_fill\": %.3f, \"lds_bytes\": %zu, \"build_ms\": %.1f}\n",
-              R.W, H, R.LS, R.order, R.n_rec, (long long)direct, R.max_lm, R.max_cam, R.max_acc, R.max_own, R.max_chunks,
+              R.W, H, R.LS, R.order, R.n_rec, (long long)single_run, R.max_lm, R.max_cam, R.max_oq, R.max_own, R.max_chunks,
               (long long)max_own_rec, (long long)lanes_used, (double)lanes_used / ((double)R.W * RR * T),
               (double)n_obs / std::max<double>(1.0, (double)rows_issued * WAVE), R.lds_bytes, ms);
   return 0;

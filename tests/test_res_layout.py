@@ -57,7 +57,7 @@ def test_res_layout_long_tracks_and_single_observation_landmarks(tmp_path):
     w = 1.0 / np.arange(1, n_c + 1)
     cam_idx = np.concatenate([np.sort(rng.choice(n_c, k, replace=False, p=w / w.sum())) for k in ks]).astype(np.int32)
     obs = rng.normal(size=(cam_idx.shape[0], 2))
-    for wgs, kw in ((16, BIG), (64, {}), (64, WIDE)):
+    for wgs, kw in ((40, BIG), (64, {}), (64, WIDE)):
         s = _run(tmp_path, n_c, lm_off, cam_idx, obs, wgs, **kw)
         assert s["ok"] == 1 and s["fits"] == 1
 

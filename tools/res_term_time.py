@@ -46,7 +46,7 @@ def main():
     d = np.linalg.norm(out[("inc", 1)] - out[("inc", 0)]) / np.linalg.norm(out[("inc", 0)]) if 1 in out else float("nan")
     print(f"{shape} world={world} {robust}: {oe - ob} obs, {le - lb} lms; per-term kernels {out[0]:.2f} us/term"
           + (f", resident {out[1]:.2f} us/term (|d inc| {d:.1e}; {li.res_wgs} wgs x {li.res_waves} waves, {li.res_rounds} x {li.res_rows} rows, "
-             f"{li.res_records} records, max {li.res_max_chunks} chunks / {li.res_max_cams} cams / {li.res_max_lms} lms / {li.res_max_acc} acc, "
+             f"{li.res_records} records, max {li.res_max_chunks} chunks / {li.res_max_cams} cams / {li.res_max_lms} lms / {li.res_max_oq} owned records, "
              f"order {li.res_order}, lds {li.res_lds_bytes}, build {li.res_build_ms:.0f} ms, failed {li.res_failed})" if 1 in out else ", no resident layout"))
     ctx.close()
 
