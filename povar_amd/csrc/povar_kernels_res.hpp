@@ -113,9 +113,9 @@ __device__ inline bool res_get(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[N
 }
 
 // All threads of the workgroup: granule pair i of a list of n (pair i is entry i % 12 of row row_of(i / 12) of the
-// buffer) -> dst[(i / 12) * stride + i % 12], RES_GB pairs per thread in flight
-constexpr int RES_GB = 4;
-template <int T, class RowOf>
+// buffer) -> dst[(i / 12) * stride + i % 12], RES_GB pairs per thread in flight (all of a workgroup's in one round trip
+// where the registers allow: 1024-thread workgroups have few cameras each)
+template <int T, int RES_GB, class RowOf>
 __device__ inline bool res_gather(__amdgpu_buffer_rsrc_t r, int n, RowOf row_of, unsigned tag, double* dst, int stride, int t, unsigned limit) {
   bool fine = true;
   for (int i0 = 0; i0 < n; i0 += RES_GB * T) {
@@ -153,6 +153,7 @@ struct ResChunk {
 template <int NW, int H, int RR, int LS, bool ROBUST>
 __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
   constexpr int T = NW * 64;
+  constexpr int GB = NW >= 16 ? 4 : 8;
   extern __shared__ double res_lds[];
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -173,11 +174,20 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
   double* oy = otmp + 12 * nO;          // [nO][12] E0 row of the term: sigma * sum of the camera's records
   double* onrm = oy + 12 * nO;          // [nO][2] squared norms of the last term / the sum
   double* ops = onrm + 2 * nO;          // [nO][5][12] partial sums of the camera's records (five groups of twelve lanes)
+  int* lzi = reinterpret_cast<int*>(ops + 60 * nO);  // [nC] z-table row of each camera slot
+  int* loq = lzi + nC;                  // [nQ] the records read as an owner
+  int* lown = loq + nQ;                 // [nO][4] z-table row, first / end position of the records
 
   // ---------------- prologue: everything that does not change between the terms
   // owned cameras first (their registers are free again before the lane's own state is loaded): B^-1, sigma;
   // x_0 = B^-1 (-b) (the series start, :196); z_0 published
   if (t < 4) ctl[t] = 0;
+  for (int e = t; e < nC; e += T) lzi[e] = k.cam_zi[C0 + e];
+  for (int e = t; e < nQ; e += T) loq[e] = k.oq_rec[Q0 + e];
+  for (int e = t; e < nO; e += T) {
+    const int2 qr = k.own_q[O0 + e];
+    lown[4 * e] = k.own_zi[O0 + e]; lown[4 * e + 1] = qr.x; lown[4 * e + 2] = qr.y;
+  }
   for (int o = wave; o < nO; o += NW) {
     const int c = k.own_cam[O0 + o];
     for (int e = lane; e < 144; e += 64) obinv[144 * o + e] = d.binv[144 * (size_t)c + e];
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
   }
   __syncthreads();
   for (int o = wave; o < nO; o += NW) {
-    const int zi = k.own_zi[O0 + o];
+    const int zi = lown[4 * o];
     double s = 0;
     if (lane < 12) {
       const double* Bi = obinv + 144 * o + 12 * lane;
@@ -268,8 +278,8 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
     }
   }
   int iters = k.m;
-  auto z_row = [&](int s) { return k.cam_zi[C0 + s]; };
-  auto q_row = [&](int q) { return k.oq_rec[Q0 + q]; };
+  auto z_row = [&](int s) { return lzi[s]; };
+  auto q_row = [&](int q) { return loq[q]; };
 
   // ---------------- the terms
   for (int i = 1; i <= k.m + 1; ++i) {
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
     // ---- hand-over 2: z of the workgroup's cameras into the region
     // (the region's last readers were the owner sums of term i - 1: the barrier in front of them is B6 below, the one
     // behind them the barrier at the end of the term)
-    if (!res_gather<T>(B.z, nC * 12, z_row, tag, reg, RES_ACC_STRIDE, t, k.spin_limit) && lane == 0) ctl[0] = 1;
+    if (!res_gather<T, GB>(B.z, nC * 12, z_row, tag, reg, RES_ACC_STRIDE, t, k.spin_limit) && lane == 0) ctl[0] = 1;
     __syncthreads();  // B1
     if (ctl[0]) break;
     // ---- forward: u_l += P3^T (w C (Z h~_l))
@@ -358,9 +368,14 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
       }
       if (ch[r].dup) seg_reduce_steps<12>(y, lane, ch[r].seg & 255, (ch[r].seg >> 8) & 255, ch[r].steps);
       if (ch[r].ci >= 0 && lane == (ch[r].seg & 255)) {
+        double* a = reg + ch[r].ci * RES_ACC_STRIDE;
+        if (ch[r].seg & (1 << 16)) {  // the camera's only run in the workgroup: a plain store
 #pragma unroll
-        for (int e = 0; e < 12; ++e)
-          __hip_atomic_fetch_add(reg + ch[r].ci * RES_ACC_STRIDE + e, y[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int e = 0; e < 12; ++e) a[e] = y[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 12; ++e) __hip_atomic_fetch_add(a + e, y[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
     __syncthreads();  // B4
@@ -375,14 +390,14 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
     }
     __syncthreads();  // B5 (the accumulators have been read: the region becomes the owner's records)
     // ---- owners (hand-over 1): the records of the cameras the workgroup owns into the region
-    if (!res_gather<T>(B.part, nQ * 12, q_row, tag, reg, 12, t, k.spin_limit) && lane == 0) ctl[0] = 1;
+    if (!res_gather<T, GB>(B.part, nQ * 12, q_row, tag, reg, 12, t, k.spin_limit) && lane == 0) ctl[0] = 1;
     __syncthreads();  // B6
     if (ctl[0]) break;
     // ---- x_i = B^-1 (sigma * sum of the records), sum += x_i, z published (:200-204, :322-340).  A camera's records are
     // summed by five groups of twelve lanes (record q of the camera by group q % 5), then the five partial sums in order
     for (int o = wave; o < nO; o += NW) {
-      const int zi = k.own_zi[O0 + o];
-      const int2 qr = k.own_q[O0 + o];
+      const int zi = lown[4 * o];
+      const int2 qr = make_int2(lown[4 * o + 1], lown[4 * o + 2]);
       if (lane < 60) {
         const int e = lane % 12, grp = lane / 12;
         double a = 0;

@@ -44,6 +44,7 @@ struct ResLayout {
   // per chunk position [W][R][T]
   std::vector<int> lane_cam;         // camera SLOT of the chunk in its workgroup (-1: none)
   std::vector<int> lane_seg;         // first | last << 8 lane (of the wavefront) of the run of lanes that share the camera
+                                     // | 1 << 16: the camera's only run in the workgroup (plain store instead of an LDS add)
   // per row [W][R][H][T]
   std::vector<double2> uv;
   std::vector<int> lslot;            // 3 x landmark slot of the workgroup (-1: no observation)
@@ -79,7 +80,8 @@ __host__ __device__ inline size_t res_region_doubles(int n_cam, int n_oq) {
   return a > b ? a : b;
 }
 inline size_t res_lds_bytes(int n_lm, int n_cam, int n_own, int n_oq) {
-  return 64 + (size_t)n_lm * RES_LM_BYTES + res_region_doubles(n_cam, n_oq) * 8 + (size_t)n_own * RES_OWN_DOUBLES * 8;
+  return 64 + (size_t)n_lm * RES_LM_BYTES + res_region_doubles(n_cam, n_oq) * 8 + (size_t)n_own * (RES_OWN_DOUBLES * 8 + 16) +
+         (size_t)(n_cam + n_oq) * 4 + 8;
 }
 
 // W workgroups of NW wavefronts whose lanes hold R chunks of at most H rows each; the smallest H <= hmax (a power of
@@ -346,6 +348,8 @@ inline void build_res(int n_cams, int n_lms, const int32_t* lm_off, const int32_
         while ((1 << steps) < std::min(longest, 16)) ++steps;
         R.wave_h[((size_t)g * R.R + r) * NW + wv] = h | (dup << 8) | (std::max(steps, 1) << 12);
       }
+    for (size_t pos = 0; pos < (size_t)R.R * T; ++pos)
+      if (ci_of_pos[pos] >= 0 && runs[ci_of_pos[pos]] == 1) R.lane_seg[(size_t)g * R.R * T + pos] |= 1 << 16;
   });
   R.lds_bytes = 0;
   for (int g = 0; g < W; ++g)

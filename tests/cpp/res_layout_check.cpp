@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
       CHECK(c >= 0 && c < n_cams && cams_of_wg.insert(c).second && R.cam_zi[R.cam_off[g] + s] == rank1[c] - 1);
       if (s > 0) CHECK(rank1[c] > rank1[R.cam_id[R.cam_off[g] + s - 1]]);  // most observed first
     }
-    std::map<int, int> runs_of_slot;
+    std::map<int, int> runs_of_slot, single_flag;
     for (int r = 0; r < RR; ++r)
       for (int wv = 0; wv < NW; ++wv) {
         const int wh = R.wave_h[((size_t)g * RR + r) * NW + wv], hrows = wh & 255, dup = (wh >> 8) & 1, steps = (wh >> 12) & 15;
@@ -113,6 +113,7 @@ int main(int argc, char** argv) {
           CHECK(s0 <= l && l <= s1 && s1 < WAVE);
           const size_t base = ((size_t)g * RR + r) * T + (size_t)wv * WAVE;
           for (int q = s0; q <= s1; ++q) CHECK(R.lane_cam[base + q] == ci && R.lane_seg[base + q] == R.lane_seg[lane]);
+          single_flag[ci] = (R.lane_seg[lane] >> 16) & 1;
           if (s0 > 0) CHECK(R.lane_cam[base + s0 - 1] != ci);
           if (s1 + 1 < WAVE) CHECK(R.lane_cam[base + s1 + 1] != ci);
           if (l == s0) runs_of_slot[ci]++;
@@ -136,7 +137,10 @@ int main(int argc, char** argv) {
         CHECK(any_dup == (dup != 0));
       }
     CHECK((int)runs_of_slot.size() == nC);  // every camera slot of the workgroup has a chunk
-    for (auto& kv : runs_of_slot) single_run += kv.second == 1;
+    for (auto& kv : runs_of_slot) {
+      single_run += kv.second == 1;
+      CHECK(single_flag[kv.first] == (kv.second == 1 ? 1 : 0));
+    }
   }
   for (int64_t i = 0; i < n_obs; ++i) CHECK(seen[i]);
   // owners: every camera once; its records = the slots that name it, each once, in workgroup order
