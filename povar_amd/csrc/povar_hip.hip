@@ -708,8 +708,10 @@ void res_build_for(int n_cams, int n_lms, const int32_t* lm_off, const int32_t* 
 bool sharded(const povar_ctx* c);
 // the context can run the resident series now (whether it SHOULD is res_mode / the timing of res_autotune)
 bool res_possible(const povar_ctx* c) {
+  // (a communicator of ONE rank exchanges nothing: such a context -- the one-GPU proxy of a shard, tools/shard_sweep.sh --
+  // is as good as unsharded; with peers the resident kernel would need their sums inside the launch: not built)
   return c->res.ready && !c->res_failed && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && !c->profile &&
-         !sharded(c);
+         (!sharded(c) || (c->world == 1 && !c->p2p));
 }
 bool res_active(const povar_ctx* c) {
   return res_possible(c) && (c->res_mode == 1 || (c->res_mode < 0 && c->res_tuned && c->res_choice));  // (and m <= 250: run_series' caller)
@@ -1672,7 +1674,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       hipDeviceProp_t prop;
       HIP_TRY_C(hipGetDeviceProperties(&prop, options->device));
       const int cus = std::min(std::max(c->cu_limit > 0 ? c->cu_limit : prop.multiProcessorCount, 1), RES_MAX_WG);
-      int per_wg = 1024;
+      int per_wg = 256;  // (ladybug-49: 32 workgroups 8.7, 63: 7.5, 125: 7.3 us per term -- the phases of a term are the workgroup's size)
       if (const char* e = std::getenv("POVAR_RES_OBS_PER_WG")) per_wg = std::max(64, std::atoi(e));
       int wgs = (int)std::min<int64_t>(cus, std::max<int64_t>(8, (n_obs + per_wg - 1) / per_wg));
       if (const char* e = std::getenv("POVAR_RES_WGS")) wgs = std::max(1, std::min(std::atoi(e), cus));

@@ -22,6 +22,9 @@ _BOTH_KERNEL_FAMILIES = {"test_gpu_step1", "test_gpu_step2", "test_gpu_fuzz", "t
 # lane-per-landmark layout: every small-problem case of these modules (term by term, early exit, long landmarks, fuzz,
 # shards, PCG / RIPCG)
 _WITH_CAMERA_CHUNKS = {"test_gpu_step1", "test_gpu_step2", "test_gpu_fuzz", "test_gpu_sharded", "test_gpu_sc_solvers"}
+# ... and a fourth time with the RESIDENT power series (series_res, one launch per solve_pOSE; round 5) forced for every
+# step-1 solve in the LDS-accumulating E0 mode of these modules (early exit, robust norms, long landmarks, fuzz)
+_WITH_RESIDENT_SERIES = {"test_gpu_step1", "test_gpu_fuzz"}
 
 
 def pytest_generate_tests(metafunc):
@@ -32,7 +35,10 @@ def pytest_generate_tests(metafunc):
         which = ["auto", "lane-per-landmark"]
         if metafunc.module.__name__.split(".")[-1] in _WITH_CAMERA_CHUNKS:
             which.append("camera-chunk")
+        if metafunc.module.__name__.split(".")[-1] in _WITH_RESIDENT_SERIES:
+            which.append("resident-series")
         metafunc.parametrize("_term_kernels", which, indirect=True)
+
 
 
 @pytest.fixture(autouse=True)
@@ -43,6 +49,8 @@ def _term_kernels(request, monkeypatch):
     if which == "camera-chunk":
         monkeypatch.setenv("POVAR_E0_CK", "1")
         monkeypatch.setenv("POVAR_LPL_PLACE", "sync")  # the chunk layout belongs to the row order: have it from the start
+    if which == "resident-series":
+        monkeypatch.setenv("POVAR_RES", "1")
     return which
 
 

@@ -11,12 +11,16 @@ from test_known_answer import COMMON, KNOWN_ANSWER, check_floor, run_bal, write_
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("family", ["auto", "lane-per-landmark"])
+@pytest.mark.parametrize("family", ["auto", "lane-per-landmark", "resident-series"])
 @pytest.mark.parametrize("shape,seed,flags", KNOWN_ANSWER)
 def test_bal_hip_reaches_noise_floor(tmp_path, monkeypatch, shape, seed, flags, family):
-    if family == "lane-per-landmark":
+    if family in ("lane-per-landmark", "resident-series"):
         if "CHOLESKY" in flags and "RIPCG" in flags:
             pytest.skip("no power-series kernel on this route")
+    if family == "resident-series":  # step 1's power series as ONE launch (series_res) in every LM iteration of the run
+        monkeypatch.setenv("POVAR_RES", "1")
+        monkeypatch.delenv("POVAR_E0_V1", raising=False)
+    elif family == "lane-per-landmark":
         monkeypatch.setenv("POVAR_E0_V1", "0")
     else:
         monkeypatch.delenv("POVAR_E0_V1", raising=False)
