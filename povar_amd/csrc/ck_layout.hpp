@@ -26,7 +26,10 @@
 
 namespace povar {
 
-constexpr int CK_HMAX = 16;        // rows per chunk tile at most (observations per chunk)
+#ifndef POVAR_CK_HMAX_BUILD
+#define POVAR_CK_HMAX_BUILD 16
+#endif
+constexpr int CK_HMAX = POVAR_CK_HMAX_BUILD;  // rows per chunk tile at most (observations per chunk)
 constexpr int CK_LDS_BYTES = 160 * 1024;
 constexpr int CK_FLAG_DUP = 1;     // lanes of the tile share accumulators: segmented wavefront sum before the flush
 constexpr int CK_FLAG_COLD = 2;    // some chunk of the tile writes its own partial record

@@ -449,6 +449,7 @@ class LinearizorPowerVarprojHipMulti : public Linearizor, public StateMirror {
     use_rccl_ = distinct && !(force_host && force_host[0] == '1');
     uint8_t uid[128] = {0};
     if (use_rccl_) check(povar_comm_unique_id(uid), "povar_comm_unique_id");
+    std::fprintf(stderr, "[bal] shard team of %d on %d device(s): exchange: %s\n", world, n_dev, use_rccl_ ? "RCCL" : "host all-reduce");
     shards_.resize(world);
     team_.hook_args.resize(world);
     for (int r = 0; r < world; ++r) team_.hook_args[r] = {&team_, r};
@@ -651,7 +652,11 @@ LinearizorFactory g_factory = nullptr;
 
 std::unique_ptr<Linearizor> make(BalProblem& p, const SolverOptions& o, SolverSummary* s, bool hom) {
   if (g_factory) return g_factory(p, o, s, hom);
-  if (o.gpus > 1) return std::make_unique<LinearizorPowerVarprojHipMulti>(p, o, s, hom);
+  // POVAR_FORCE_MULTI=1: also `--gpus 1` goes through the N-shard class (a team of one: an RCCL communicator of one rank
+  // created on the worker thread, the all-reduces of the one shard inside its captured term loop with POVAR_GRAPH_COMM=1)
+  // -- the branch a one-GPU box can otherwise never execute (tests/test_gpu_bal_cli.py)
+  const char* force_multi = std::getenv("POVAR_FORCE_MULTI");
+  if (o.gpus > 1 || (force_multi && force_multi[0] == '1')) return std::make_unique<LinearizorPowerVarprojHipMulti>(p, o, s, hom);
   return std::make_unique<LinearizorPowerVarprojHip>(p, o, s, hom);
 }
 

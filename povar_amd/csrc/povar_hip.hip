@@ -492,8 +492,19 @@ inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block
 // camera-chunk layout of e0_ck: upload, kernel parameters, launch
 // ------------------------------------------------------------------------------------------
 // locked: called by the row-placement thread -- its HIP calls go in short pieces under g_capture_mu (povar_ctx::placer_cancel)
+// POVAR_CK_MAX_CAMS lowers the camera limit of the camera-chunk kernels (tests: the fall-back to e0_lpl without a 65536-camera problem)
+int ck_max_cams() {
+  if (const char* e = std::getenv("POVAR_CK_MAX_CAMS")) return std::max(0, std::atoi(e));
+  return 65535;
+}
+// Returns false only on a HIP failure (allocation, copy).  A layout this kernel family cannot run -- more than 65535 cameras
+// (the lane metadata keeps a popularity rank in 16 bits), a row array of 4 GiB or more (32-bit buffer offsets) -- is not
+// an error: D.ready stays false, what was uploaded is released and the term loop stays on e0_lpl / e0_lpl_h.
 bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked, size_t* bytes, bool need_uv = true) {
   bool ok = true;
+  const bool usable = K.uv.size() * sizeof(double2) < (1ull << 32) && c->n_cams <= ck_max_cams();
+  D.ready = false;
+  if (!usable) return true;
   auto guarded = [&](auto&& fn) {
     if (locked) {
       std::lock_guard<std::mutex> lk(g_capture_mu);
@@ -524,13 +535,10 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
     guarded([&] { ok = D.w.alloc(std::max<size_t>(K.uv.size(), 1), bytes) == hipSuccess; });  // (padded like uv)
   D.nb = K.nb; D.slots = K.slots; D.n_part_rec = K.n_part_rec; D.max_acc = K.max_acc; D.max_tiles_bt = K.max_tiles_bt;
   D.rows = K.rows; D.li_rows = K.li_rows; D.n_chunks = K.n_chunks; D.n_cold_chunks = K.n_cold_chunks;
-  // (the kernel reads the rows through 32-bit buffer descriptors: a row array of 4 GiB or more is left to e0_lpl)
-  ok = ok && K.uv.size() * sizeof(double2) < (1ull << 32);
-  // the lane metadata keeps a camera's popularity rank in 16 bits
-  ok = ok && c->n_cams <= 65535;
   D.w_lin_id = -1;
   D.ready = ok && !(locked && c->placer_cancel.load());
-  return D.ready;
+  if (!ok) D.release();
+  return ok;
 }
 CkP ck_params(const povar_ctx* c, const povar_ctx::CkDev& D) {
   return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p,
@@ -1168,6 +1176,21 @@ void launch_binv(povar_ctx* c, int mode, int want_norms) {
   }
 }
 
+// hipEvents that are destroyed on every return path (the HIP_TRY early returns of the timing functions included)
+template <int N>
+struct EventSet {
+  hipEvent_t e[N] = {};
+  hipError_t create() {
+    for (auto& x : e) {
+      hipError_t r = hipEventCreate(&x);
+      if (r != hipSuccess) return r;
+    }
+    return hipSuccess;
+  }
+  hipEvent_t& operator[](int i) { return e[i]; }
+  ~EventSet() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
+};
+
 int ck_autotune(povar_ctx* c) {
   if (!c->ck_auto || c->ck_tuned || !c->ck.ready || !c->use_lpl || c->joint || c->opt.e0_mode != POVAR_E0_IMPLICIT_LDSACC ||
       !ck_variant_fits(c, 1))
@@ -1175,14 +1198,18 @@ int ck_autotune(povar_ctx* c) {
   c->ck_tuned = true;
   ensure_ck_w(c);
   HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));  // (a series that ended early leaves "done" set)
-  hipEvent_t ev[4];
-  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  EventSet<4> ev;
+  HIP_TRY(ev.create());
   Dp da = ldsacc_dp(c, true);
   da.p2p_peer = nullptr;
   da.p2p_epoch = nullptr;
   Dp dk = da;
   ck_dp(c, dk);
   const int keep = c->ck_variant;
+  struct Restore {  // a failure below leaves the choice as it was and the timing to be repeated
+    povar_ctx* c; int keep; bool done = false;
+    ~Restore() { if (!done) { c->ck_variant = keep; c->ck_tuned = false; } }
+  } restore{c, keep};
   c->ck_variant = 1;
   auto run_lpl = [&]() {
     if (c->opt.robust_norm)
@@ -1205,7 +1232,7 @@ int ck_autotune(povar_ctx* c) {
   float ms_lpl = 0, ms_ck = 0;
   HIP_TRY(hipEventElapsedTime(&ms_lpl, ev[0], ev[1]));
   HIP_TRY(hipEventElapsedTime(&ms_ck, ev[2], ev[3]));
-  for (auto& e : ev) (void)hipEventDestroy(e);
+  restore.done = true;
   c->ck_tune_us[0] = 1e3f * ms_lpl / REPS;
   c->ck_tune_us[1] = 1e3f * ms_ck / REPS;
   c->ck_variant = ms_ck < 0.98f * ms_lpl ? 1 : 0;
@@ -1223,8 +1250,12 @@ int ckh_autotune(povar_ctx* c) {
   }
   ensure_ck_w(c);
   HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
-  hipEvent_t ev[4];
-  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  EventSet<4> ev;
+  HIP_TRY(ev.create());
+  struct Restore {
+    povar_ctx* c; bool done = false;
+    ~Restore() { if (!done) { c->ckh_variant = 0; c->ckh_tuned = false; } }
+  } restore{c};
   Dp da = ldsacc_dp(c, true);
   Dp dk = da;
   ck_dp(c, dk);
@@ -1248,7 +1279,7 @@ int ckh_autotune(povar_ctx* c) {
   float ms_lpl = 0, ms_ck = 0;
   HIP_TRY(hipEventElapsedTime(&ms_lpl, ev[0], ev[1]));
   HIP_TRY(hipEventElapsedTime(&ms_ck, ev[2], ev[3]));
-  for (auto& e : ev) (void)hipEventDestroy(e);
+  restore.done = true;
   c->ckh_tune_us[0] = 1e3f * ms_lpl / REPS;
   c->ckh_tune_us[1] = 1e3f * ms_ck / REPS;
   c->ckh_variant = ms_ck < 0.98f * ms_lpl ? 1 : 0;
@@ -2171,11 +2202,8 @@ static int res_verify(povar_ctx* c) {
 static int res_autotune(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
   if (c->res_mode >= 0 || c->res_tuned || !res_possible(c) || m < 4 || m > 250) return 0;
   c->res_tuned = true;
-  struct Events {
-    hipEvent_t e[2] = {nullptr, nullptr};
-    ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
-  } ev;
-  for (auto& x : ev.e) HIP_TRY(hipEventCreate(&x));
+  EventSet<2> ev;
+  HIP_TRY(ev.create());
   constexpr int REPS = 3;
   float ms[2] = {0, 0};
   for (int which = 0; which < 2; ++which) {

@@ -86,3 +86,52 @@ def test_bal_gpus_n_matches_one_device(tmp_path, gpus):
     assert np.abs(ca / cb - 1).max() <= 1e-6, np.abs(ca / cb - 1).max()
     assert np.allclose(one["trust_region_radius"], many["trust_region_radius"], rtol=1e-4)
     assert one["_static"]["solver"]["termination_type"] == many["_static"]["solver"]["termination_type"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph_comm", ["0", "1"])
+def test_bal_rccl_branch_of_the_shard_team_with_one_rank(tmp_path, graph_comm):
+    """The RCCL branch of LinearizorPowerVarprojHipMulti on the one GPU there is: POVAR_FORCE_MULTI=1
+    routes `bal --gpus 1` through the shard team -- ncclCommInitRank on the worker thread, every exchange step of the run
+    an ncclAllReduce of one rank on the context's stream, with POVAR_GRAPH_COMM=1 inside the captured term loop -- against
+    plain `bal`: identical accept / reject sequences and iteration counts, every cost to 1e-9."""
+    from povar_amd import synth
+    p = synth.make_bal_problem("trafalgar-257", init="gt", init_noise=0.02)
+    f = str(tmp_path / "problem-257-65132-gt.txt")
+    synth.write_data_custom(f, p)
+    extra = ["--max-num-iterations-step-1", "12", "--max-num-iterations-step-2", "8", "--power-sc-iterations", "20"]
+    one, _ = _run("bin/bal", f, str(tmp_path / "one.json"), extra)
+    env = dict(os.environ, POVAR_FORCE_MULTI="1", POVAR_GRAPH_COMM=graph_comm, POVAR_HOST_COMM="0")
+    cmd = [os.path.join(ROOT, "bin/bal"), "--input", f, "--log-log-path", str(tmp_path / "team.json"), "--quiet"] + extra + ["--gpus", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "exchange: RCCL" in r.stdout + r.stderr, (r.stdout + r.stderr)[-1500:]
+    team = json.load(open(str(tmp_path / "team.json")))
+    assert one["iteration"] == team["iteration"] and len(one["iteration"]) > 6
+    assert one["step_is_successful"] == team["step_is_successful"]
+    assert one["linear_solver_iterations"] == team["linear_solver_iterations"]
+    ca, cb = np.array(one["cost"]), np.array(team["cost"])
+    assert np.abs(ca / cb - 1).max() <= 1e-9, np.abs(ca / cb - 1).max()
+
+
+@pytest.mark.gpu
+def test_bal_gpus_2_from_the_random_start(tmp_path):
+    """`bal --gpus 2` against one context from the reference's RANDOM initial cameras (bal_problem.cpp:398-407), where no
+    route gets near the noise floor.  Step 1 agrees to 1e-8 in every cost and in the accept / reject
+    sequence.  The first step-2 cost is a sum dominated by a dozen observations whose depth (P X)_z is within 1e-3 of zero
+    after step 1 (r = (P X)_xy / (P X)_z: a relative change of 1e-9 in such a depth moves the cost by per cent): it has a
+    STATED tolerance of 10 % here (measured: 1.5 %, profiles/r04_bal_end_to_end.txt), not 1e-6 -- the converged comparison
+    is test_bal_gpus_n_matches_one_device."""
+    from povar_amd import synth
+    p = synth.make_bal_problem("trafalgar-257")
+    f = str(tmp_path / "problem-257-65132.txt")
+    synth.write_data_custom(f, p)
+    extra = ["--max-num-iterations-step-1", "30", "--max-num-iterations-step-2", "2", "--power-sc-iterations", "20"]
+    one, _ = _run("bin/bal", f, str(tmp_path / "one.json"), extra)
+    two, _ = _run("bin/bal", f, str(tmp_path / "two.json"), extra + ["--gpus", "2"])
+    n1 = [i for i, it in enumerate(one["iteration"]) if it == 0][1]
+    assert one["iteration"][:n1] == two["iteration"][:n1] and n1 > 5
+    assert one["step_is_successful"][:n1] == two["step_is_successful"][:n1]
+    ca, cb = np.array(one["cost"]), np.array(two["cost"])
+    assert np.abs(ca[:n1] / cb[:n1] - 1).max() <= 1e-8
+    assert abs(ca[n1] / cb[n1] - 1) <= 0.10, (ca[n1], cb[n1])

@@ -145,7 +145,7 @@ def test_step2_at_size(name, e0_kernel):
     cams /= np.linalg.norm(cams, axis=1, keepdims=True)
     lms_h = np.concatenate([rng.normal(size=(p.n_lms, 3)), np.ones((p.n_lms, 1))], 1)
     obs = p.obs / 500.0
-    m = 10
+    m = M  # (power_sc_iterations = 20, as the BASELINE configs say)
     orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, obs)
     ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
     if e0_kernel == "camera-chunk":
@@ -367,4 +367,15 @@ def test_final_13682_huber():
     ref, it, status, _ = o.solve_pose(st, hll, binv0, b0, M, n_threads=NT)
     inc, it2, st2, rc = sub.solve_pose(LAM, capi.POWER_VARPROJ, M)
     assert rc == 0 and (it2, st2) == (it, status) and rel(inc, ref) < 1e-10
+    # a rank of config 5 picks its step-1 term kernel by timing: BOTH candidates against the oracle at this shape
+    sub.layout_finalize(True)
+    sub.set_cameras(p.cams)
+    sub.set_landmarks(lms[:le])
+    assert sub.linearize_pose(ALPHA)
+    assert sub.layout_info().ck_ready == 1
+    for kernel in (0, 1):
+        sub.set_e0_kernel(kernel)
+        assert sub.layout_info().e0_kernel == kernel
+        inc, it2, st2, rc = sub.solve_pose(LAM, capi.POWER_VARPROJ, M)
+        assert rc == 0 and (it2, st2) == (it, status) and rel(inc, ref) < 1e-10, kernel
     sub.close()

@@ -36,11 +36,16 @@ def _prepared(p, robust="NONE", **kw):
     return ctx
 
 
-@pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778", "local-900"])
-def test_e0_ck_oracle_parity_at_size(name):
-    """E0 x and the 20-term increment of the camera-chunk kernel against the oracle (same linearisation point)."""
+@pytest.mark.parametrize("name", ["ladybug-49", "trafalgar-257", "venice-1778", "local-900"])
+def test_e0_ck_oracle_parity_at_size(name, monkeypatch):
+    """E0 x and the 20-term increment of the camera-chunk kernel against the oracle (same linearisation point).
+    (ladybug-49 is below the size from which the library uses the lane-per-landmark layout the chunk layout derives
+    from: forced, so that BASELINE config 2's shape sees e0_ck too.)"""
     from povar_amd import capi
     from oracle import povar_oracle as O
+    if name == "ladybug-49":
+        monkeypatch.setenv("POVAR_E0_V1", "0")
+        monkeypatch.setenv("POVAR_LPL_PLACE", "sync")
     p = _problem(name)
     orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs)
     ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
@@ -165,3 +170,35 @@ def test_e0_kernel_is_chosen_by_timing_both():
     assert rel(ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0], inc_auto) < 1e-10
     assert ctx.layout_info().e0_auto == 2
     ctx.close()
+
+
+@pytest.mark.parametrize("place", ["sync", "async"])
+def test_a_layout_the_chunk_kernels_cannot_run_is_not_an_error(monkeypatch, place):
+    """More cameras than the camera-chunk kernels' 16-bit ranks hold (here: the limit lowered to ten, POVAR_CK_MAX_CAMS):
+    povar_create succeeds on either placement path, no chunk layout is kept, the term loop runs e0_lpl whatever kernel is
+    asked for (the synchronous path used to fail the whole context)."""
+    from povar_amd import capi, synth
+    monkeypatch.setenv("POVAR_E0_V1", "0")
+    monkeypatch.setenv("POVAR_CK_MAX_CAMS", "10")
+    monkeypatch.setenv("POVAR_LPL_PLACE", place)
+    monkeypatch.setenv("POVAR_E0_CK", "1")
+    p = synth.make_problem(49, 2000, 8200, seed=7)
+    ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    ctx.layout_finalize(True)
+    li = ctx.layout_info()
+    assert li.ck_ready == 0 and li.e0_kernel == 0 and li.ckh_ready == 0
+    ctx.set_cameras(p.cams)
+    ctx.init_landmarks_pose(ALPHA)
+    assert ctx.linearize_pose(ALPHA)
+    inc, it, st, rc = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)
+    assert rc == 0 and it == M and np.all(np.isfinite(inc))
+    monkeypatch.delenv("POVAR_CK_MAX_CAMS")
+    ref = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+    ref.layout_finalize(True)
+    assert ref.layout_info().ck_ready == 1
+    ref.set_cameras(p.cams)
+    ref.init_landmarks_pose(ALPHA)
+    assert ref.linearize_pose(ALPHA)
+    assert rel(ref.solve_pose(LAM, capi.POWER_VARPROJ, M)[0], inc) < 1e-10
+    ctx.close()
+    ref.close()
