@@ -168,7 +168,6 @@ struct povar_ctx {
     }
   } ck, pl_ck,       // step 1 (e0_ck): the layout in use / the one the placement thread built for the placed rows
     ckh, pl_ckh;     // step 2 (e0_ck_h): a second instance (64 bytes of LDS per landmark slot: more batches, other chunks)
-  DevBuf<unsigned long long> ck_stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): CkP::stamps
   // resident power series (series_res, povar_kernels_res.hpp): the layout of res_layout.hpp on the device
   struct ResDev {
     DevBuf<int> lane_cam, lane_seg, lslot, oslot, wave_h, lm_off, lm_id, cam_off, cam_id, cam_zi, own_off, own_cam, own_zi, oq_off, oq_rec;
@@ -542,7 +541,7 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
 }
 CkP ck_params(const povar_ctx* c, const povar_ctx::CkDev& D) {
   return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p,
-             D.nb, D.slots, (unsigned)(D.src.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t)), c->ck_stamps.p};
+             D.nb, D.slots, (unsigned)(D.src.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t))};
 }
 CkP ck_params(const povar_ctx* c) { return ck_params(c, c->ck); }
 // e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight, double-buffered
@@ -1841,7 +1840,7 @@ void povar_destroy(povar_ctx* c) {
   (void)hipSetDevice(c->opt.device);
   c->pl_uv.release(); c->pl_cw.release(); c->pl_cpos.release(); c->pl_lm_pos.release(); c->pl_lm_of.release(); c->pl_of_slot.release();
   c->pl_c3_src.release(); c->c3_src.release();
-  c->ck.release(); c->pl_ck.release(); c->ckh.release(); c->pl_ckh.release(); c->ck_zero_range.release(); c->ck_stamps.release();
+  c->ck.release(); c->pl_ck.release(); c->ckh.release(); c->pl_ckh.release(); c->ck_zero_range.release();
   c->res.release();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->series_graph) (void)hipGraphExecDestroy(c->series_graph);
@@ -2882,22 +2881,9 @@ int povar_set_series_kernel(povar_ctx* c, int32_t mode) {
 }
 
 int povar_debug_ck_stamps(povar_ctx* c, uint64_t* out, int64_t n) {
-  if (int rc = check_ctx(c)) return rc;
-#ifdef POVAR_CK_STAMPS
-  const size_t want = (size_t)c->e0c_grid * 16 * CK_N_STAMPS;
-  if (!c->ck_stamps.p) {  // first call: allocate; the stamps of the launches from now on are returned by the next call
-    HIP_TRY(c->ck_stamps.alloc(want, &c->bytes));
-    HIP_TRY(hipMemset(c->ck_stamps.p, 0, want * sizeof(unsigned long long)));
-    if (c->series_graph) { (void)hipGraphExecDestroy(c->series_graph); c->series_graph = nullptr; }
-    return 0;
-  }
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemcpy(out, c->ck_stamps.p, std::min<size_t>((size_t)n, want) * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  return (int)std::min<size_t>((size_t)n, want);
-#else
-  (void)out; (void)n;
-  return fail(-1, "library built without POVAR_CK_STAMPS");
-#endif
+  // (the diagnostic build -- tools/variants/ck_stamps.patch -- replaces this body; the shipped kernels execute no stamp)
+  (void)c; (void)out; (void)n;
+  return fail(-1, "diagnostic builds only (tools/variants/build_variant.sh ck_stamps)");
 }
 
 int povar_comm_ranks(povar_ctx* c) {

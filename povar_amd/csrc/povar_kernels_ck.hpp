@@ -36,19 +36,7 @@ struct CkP {
   const int* slot_rec;   // partial record of each workgroup slot
   int nb, slots;
   unsigned uv_bytes, li_bytes;  // sizes of uv (= w's in doubles x 2) and li: the rows are read through buffer descriptors
-  unsigned long long* stamps;  // diagnostic builds (-DPOVAR_CK_STAMPS): [grid][16][CK_N_STAMPS] s_memtime stamps, else nullptr
 };
-constexpr int CK_N_STAMPS = 40;
-#ifdef POVAR_CK_STAMPS
-#define CK_STAMP(i)                                                                                   \
-  do {                                                                                                \
-    if (k.stamps && lane0 == 0 && (i) < CK_N_STAMPS)                                                  \
-      k.stamps[((size_t)blockIdx.x * 16 + wave_all) * CK_N_STAMPS + (i)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define CK_STAMP(i)
-#endif
-
 constexpr int CK_ACC_STRIDE = 13;  // doubles per accumulator slot in LDS (12 used)
 __host__ __device__ inline size_t ck_lds_bytes_dev(int slots, int n_acc, int ng) { return 16 + (size_t)ng * slots * 48 + (size_t)n_acc * CK_ACC_STRIDE * 8 + 64; }
 
@@ -97,13 +85,9 @@ __device__ inline void ck_obs_forward(const Dp& d, double2 uv, double w, const d
   o.set(d, uv, w);
   double red[3];
   ck_forward_math(o, zz, P3, hx, hy, hz, red);
-#ifdef POVAR_CK_EXP_NOATOMIC  // timing-only experiment: plain stores instead of the three LDS atomics
-  lu[s] = red[0]; lu[s + 1] = red[1]; lu[s + 2] = red[2];
-#else
   __hip_atomic_fetch_add(lu + s, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (s = 3 x slot)
   __hip_atomic_fetch_add(lu + s + 1, red[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __hip_atomic_fetch_add(lu + s + 2, red[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
 }
 __device__ inline void ck_obs_backward(const Dp& d, double2 uv, double w, const double* P3, double hx, double hy, double hz,
                                        const double* g, double* y) {
@@ -178,11 +162,6 @@ struct CkStream {
     for (int i = 0; i < D; ++i) load(R, row0, li0, DIR > 0 ? i : h - 1 - i, h, lane, i);
   }
 };
-#ifdef POVAR_CK_EXP_NOBWDROWS  // timing-only experiment: the way back re-reads ONE row of the tile (what rows kept on chip would cost)
-#define CK_BWD_ROW(j) 0
-#else
-#define CK_BWD_ROW(j) (j)
-#endif
 // the rows of one tile (h >= 1); st has been started on the tile (steps 0 .. D-1 are in flight)
 template <int D, bool ROBUST>
 __device__ inline void ck_forward_step(const Dp& d, const CkRows& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
@@ -215,15 +194,10 @@ __device__ inline void ck_backward_step(const Dp& d, const CkRows& k, CkStream<D
   const double2 uv = st.uv[i];
   const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
   const double rw = ROBUST ? st.rw[i] : 1.0;
-  st.load(k, row0, li0, CK_BWD_ROW(j - D), h, lane, i);
+  st.load(k, row0, li0, j - D, h, lane, i);
   if (s != 0xffffu) {
-#ifdef POVAR_CK_EXP_NOBWDLDS  // timing-only experiment: the way back without its six LDS reads per observation
-    const double hx = uv.x, hy = uv.y, hz = rw;
-    const double g[3] = {uv.y, uv.x, rw};
-#else
     const double hx = lh[s], hy = lh[s + 1], hz = lh[s + 2];
     const double g[3] = {lg[s], lg[s + 1], lg[s + 2]};
-#endif
     ck_obs_backward(d, uv, rw, P3, hx, hy, hz, g, y);
   }
 }
@@ -288,7 +262,7 @@ __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int r
 
 // NW wavefronts per workgroup; SD: rows a tile keeps in flight ahead of the row being worked on.
 //
-// What bounds the kernel (in-kernel stamps, tools/ck_stamps.py; profiles/r04_*): the row loops issue 38 VALU instructions
+// What bounds the kernel (in-kernel stamps of a diagnostic build, tools/variants/ck_stamps.patch + tools/ck_stamps.py; profiles/r04_*): the row loops issue 38 VALU instructions
 // per row and pass (31 fp64) -- and are not what sets the time: 14 % fewer instructions changed nothing --; the rest is the
 // time line of ONE wavefront -- round trips that nothing of its own hides (one or two tiles per wavefront and pass):
 // tile metadata (which camera is in which lane), the record gather that depends on it (64 lanes, 64 different cache
@@ -373,7 +347,6 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     // VGPRs held across the way back; the row loop's camera record went to scratch: 8 reloads per row).
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    CK_STAMP(8 * (b / NG) + 0);
     const int tb0 = bt[blockIdx.x * k.nb + b], tb1 = bt[blockIdx.x * k.nb + b + 1];
     int q_t = 0;  // round of the tile walk
     int t = tile_of(tb0, 0);
@@ -406,7 +379,6 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       ck_load_p3(d, rk, P3);
       st.template start<1>(R, row0, li0, h, lane);
     }
-    CK_STAMP(8 * (b / NG) + 1);
     // ---- landmark coordinates of the batch into LDS (requested a phase ago), u = 0
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
@@ -444,13 +416,10 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       }
     };
     request_next_fwd();
-    CK_STAMP(8 * (b / NG) + 2);
     group_barrier();
-    CK_STAMP(8 * (b / NG) + 3);
     // ---- forward
     while (t < tb1) {
       ck_forward_rows<SD, ROBUST>(d, R, st, row0, li0, h, lane, zz, P3, lh, lu, S);
-      if (b < NG) CK_STAMP(20 + 2 * q_t);
       if (tn >= tb1) break;  // (t, q_t, rank, P3 stay on the last tile: the way back starts there)
       t = tn;
       ++q_t;
@@ -473,9 +442,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         ck_load_p3(d, rk, P3);
         st.template start<1>(R, row0, li0, h, lane);
       }
-      if (b < NG) CK_STAMP(19 + 2 * q_t);
     }
-    CK_STAMP(8 * (b / NG) + 4);
     // ---- the way back starts before the barriers in front of it: accumulator metadata and last rows of the tile the
     // wavefront has just left (its P3 is in registers), G of its landmark slots, and the next batch's first requests
     asm volatile("" : "+v"(lane));  // (the two passes share no per-lane address register)
@@ -510,7 +477,6 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       st.template start<-1>(R, row0, li0, h, lane);
     }
     group_barrier();
-    CK_STAMP(8 * (b / NG) + 5);
     // ---- g = G u per landmark slot (over u)
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
@@ -549,7 +515,6 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     };
     request_next_bwd();
     group_barrier();
-    CK_STAMP(8 * (b / NG) + 6);
     // ---- backward: the wavefront's tiles in reverse
     while (t < tb1) {
       double y[12];
@@ -581,18 +546,15 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         st.template start<-1>(R, row0, li0, h, lane);
       }
     }
-    CK_STAMP(8 * (b / NG) + 7);
     group_barrier();  // the next batch overwrites h~ and u; after the last one: the accumulators are complete
   }
   if (NG > 1) ck_barrier();  // every group is done: the accumulators are complete
-  CK_STAMP(8 * (k.nb / NG));
   // ---- accumulators -> this workgroup's partial records (camera-major in part_out)
   for (int i = threadIdx.x; i < n_acc * 6; i += NW * 64) {
     const int r = i / 6, m = 2 * (i % 6);
     const int rec = k.slot_rec[cam0 + r];
     reinterpret_cast<double2*>(part_out + (size_t)rec * 12)[i % 6] = make_double2(acc[r * CK_ACC_STRIDE + m], acc[r * CK_ACC_STRIDE + m + 1]);
   }
-  CK_STAMP(8 * (k.nb / NG) + 1);
   if (d.p2p_epoch && blockIdx.x == 0 && threadIdx.x == 0) *d.p2p_epoch += 1;  // one tick per term (as e0_lpl)
 }
 

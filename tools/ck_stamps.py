@@ -1,5 +1,5 @@
 """Where the time of e0_ck goes, phase by phase: in-kernel s_memtime stamps of a diagnostic build of the library
-(-DPOVAR_CK_STAMPS; the shipped library executes no stamp).
+(tools/variants/ck_stamps.patch applied to a copy of the sources; the shipped library carries no stamp code).
 
     make -C povar_amd/csrc stamps && POVAR_LIB=build/libpovar_hip_stamps.so python tools/ck_stamps.py venice-1778 --variant 1
 """

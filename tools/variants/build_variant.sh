@@ -1,0 +1,18 @@
+#!/bin/bash
+# Diagnostic / experiment builds of the library from PATCHED copies of the sources (the shipping sources carry no stamp
+# and no experiment branch).  usage: tools/variants/build_variant.sh <patch name without .patch> [out name] [-D flags...]
+#   ck_stamps             in-kernel s_memtime stamps of e0_ck's phases (tools/ck_stamps.py) + the timing-only experiment
+#                         branches of round 4 (-DPOVAR_CK_EXP_NOATOMIC, -DPOVAR_CK_EXP_NOBWDROWS, -DPOVAR_CK_EXP_NOBWDLDS)
+# (series_res has its own generator: tools/variants/res_stamps.py)
+set -e
+cd "$(dirname "$0")/../.."
+patch=$1; shift
+out=${1:-$patch}; [ $# -gt 0 ] && shift
+top=build/variants/$out
+rm -rf $top; mkdir -p $top/povar_amd
+cp -r povar_amd/csrc $top/povar_amd/csrc
+cp -r include $top/include
+(cd $top && patch -p1 -s < ../../../tools/variants/$patch.patch)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -shared -o build/libpovar_hip_$out.so \
+  $top/povar_amd/csrc/povar_hip.hip -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+echo build/libpovar_hip_$out.so
