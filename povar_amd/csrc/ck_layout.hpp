@@ -107,7 +107,11 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
   int n_threads = std::min(lpl_effective_cpus(), 128);
   if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
   hmax = std::min(CK_HMAX, std::max(1, hmax));
-  int tile_overhead = 3;
+  // rows a tile is charged on top of its height in the schedule.  What a wavefront's SECOND tile of a batch really costs is
+  // 6-11 thousand cycles of latency (metadata, record gather, first rows: profiles/r04_e0_ck_phase_stamps.txt), i.e. far
+  // more than its rows: with 3 the schedule cut venice into 20 tiles per (workgroup, batch) -- four wavefronts walk two --,
+  // from 8 on into at most 16 (15.96 k -> 16.5 k terms/s; 8 ... 32 within 0.5 %: profiles/r05_experiments.txt)
+  int tile_overhead = 12;
   if (const char* e = std::getenv("POVAR_CK_TILE_COST")) tile_overhead = std::max(0, std::atoi(e));
   // ---- batches: the smallest count whose landmark slots fit next to the accumulators
   int max_tiles_w = 1, max_acc = 1;

@@ -1539,6 +1539,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   const CkVariant ckv = ck_variant_info(c->ck_variant > 0 ? c->ck_variant : 1);
   int ck_nw = ckv.nw / ckv.ng, ck_hmax = CK_HMAX;  // (wavefronts of one group)
   const int ck_ng = ckv.ng;
+  const bool ck_place = std::getenv("POVAR_CK_NOPLACE") == nullptr;  // LDS bank placement of the chunk rows (ck_layout.hpp)
   if (const char* e = std::getenv("POVAR_CK_HMAX")) ck_hmax = std::min(CK_HMAX, std::max(1, std::atoi(e)));
 
   // The arrays of the lane-per-observation kernels (part B) are built on a second host thread while this one builds
@@ -1585,7 +1586,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       const int dev = options->device, grid = c->e0c_grid, n_acc = c->n_hot_acc;
       const size_t n_slots = (size_t)c->n_slots;
       c->placer_state.store(1);
-      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax, ck_ng]() {
+      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax, ck_ng, ck_place]() {
         const auto t0 = std::chrono::steady_clock::now();
         LplLayout P;
         bool built = true;
@@ -1619,12 +1620,12 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
           try {
             const auto tk = std::chrono::steady_clock::now();
             CkLayout K;
-            build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, true, ck_hmax, ck_ng);
+            build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, ck_place, ck_hmax, ck_ng);
             c->pl_ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
             if (!c->placer_cancel.load()) ck_upload(c, c->pl_ck, K, true, &c->pl_bytes);
             if (!c->placer_cancel.load()) {  // step 2's instance
               CkLayout KH;
-              build_ck(P, n_cams, grid, job->cam_of_rank, 16, KH, true, ck_hmax, 1, ck_shape_step2());
+              build_ck(P, n_cams, grid, job->cam_of_rank, 16, KH, ck_place, ck_hmax, 1, ck_shape_step2());
               if (!c->placer_cancel.load()) ck_upload(c, c->pl_ckh, KH, true, &c->pl_bytes, false);
             }
           } catch (...) {
@@ -1674,14 +1675,26 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     n_cold_lpl = V.cold_lm.size();
     if (want_ck && !V.tile.empty()) {
       if (int rc = upload(c->ck_zero_range, std::vector<int2>((size_t)n_cams, make_int2(0, 0)), c)) { povar_destroy(c); return rc; }
-      if (place_mode != 2) {  // (else: built from the placed rows by the host thread, swapped in with them)
+      if (place_mode == 2) {
+        // The rows are placed on a host thread, and the chunk layouts of the placed rows arrive with them -- half a second
+        // later on venice-1778, i.e. after the first two hundred LM iterations.  e0_ck does not care which order the
+        // lane-per-landmark rows are in (its own bank placement is what counts: 16.0 k terms/s on the natural rows, 15.9 k
+        // without its placement on either; profiles/r05_experiments.txt), so step 1's layout is built here from the natural
+        // rows: 0.09 s of povar_create for e0_ck from the first solve on (`bal` on venice: 96 -> 70 us per term).
         const auto tk = std::chrono::steady_clock::now();
         CkLayout K;
-        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, true, ck_hmax, ck_ng);
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, ck_place, ck_hmax, ck_ng);
+        c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
+        if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
+        lap("camera-chunk layout (step 1, natural rows)");
+      } else {  // (step 2's, and both of the placed rows, come from the host thread with place_mode 2)
+        const auto tk = std::chrono::steady_clock::now();
+        CkLayout K;
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, ck_place, ck_hmax, ck_ng);
         c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
         if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
         CkLayout KH;  // step 2's instance: 64 bytes of LDS per landmark slot, no image coordinates
-        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, KH, true, ck_hmax, 1, ck_shape_step2());
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, KH, ck_place, ck_hmax, 1, ck_shape_step2());
         if (!ck_upload(c, c->ckh, KH, false, &c->bytes, false)) { povar_destroy(c); return fail(-1, "camera-chunk layout (step 2): upload failed"); }
         lap("camera-chunk layouts");
       }

@@ -116,10 +116,11 @@ def test_e0_ck_several_batches_and_cold_chunks(monkeypatch):
     ctx.close()
 
 
-def test_e0_ck_arrives_with_the_placed_rows(monkeypatch):
-    """Rows placed on a host thread (POVAR_LPL_PLACE=async): until they are swapped in the context has no chunk layout and
-    the term loop runs e0_lpl whatever kernel is asked for; afterwards e0_ck runs on the layout derived from the placed
-    rows.  Same increment before and after (to the summation order)."""
+def test_e0_ck_on_the_natural_rows_then_on_the_placed_rows(monkeypatch):
+    """Rows placed on a host thread (POVAR_LPL_PLACE=async): povar_create builds step 1's chunk layout from the NATURAL rows
+    (e0_ck from the first solve on: it does not depend on the order of the lane-per-landmark rows), the chunk layouts of the
+    placed rows -- step 2's with them -- replace it when the rows are swapped in.  Same increment before and after (to the
+    summation order)."""
     from povar_amd import capi, synth
     monkeypatch.setenv("POVAR_E0_V1", "0")
     monkeypatch.setenv("POVAR_LPL_PLACE", "async")
@@ -129,13 +130,14 @@ def test_e0_ck_arrives_with_the_placed_rows(monkeypatch):
     ctx.set_cameras(p.cams)
     ctx.init_landmarks_pose(ALPHA)
     before = ctx.layout_info()
-    if before.placement == 2:  # not swapped in yet (the thread may already have finished: then the swap is pending too)
-        assert before.ck_ready == 0 and before.e0_kernel == 0
+    assert before.ck_ready == 1 and before.e0_kernel == 1
+    if before.placement == 2:  # not swapped in yet: step 2's layout is still on its way
+        assert before.ckh_ready == 0 and before.e0_kernel_h == 0
     assert ctx.linearize_pose(ALPHA)
     inc_a = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0]
     assert ctx.layout_finalize(True)
     after = ctx.layout_info()
-    assert after.placement == 3 and after.ck_ready == 1 and after.e0_kernel == 1
+    assert after.placement == 3 and after.ck_ready == 1 and after.e0_kernel == 1 and after.ckh_ready == 1
     assert ctx.linearize_pose(ALPHA)
     inc_b = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0]
     assert rel(inc_b, inc_a) < 1e-10
