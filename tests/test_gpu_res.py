@@ -20,9 +20,9 @@ NT = min(os.cpu_count() or 1, 16)
 
 def _problem(name):
     from povar_amd import capi, synth
-    if name == "venice-1778/8":  # rank 0's landmark shard at world = 8 (BASELINE config 4)
+    if name.startswith("venice-1778/"):  # rank 0's landmark shard at world = 8 (BASELINE config 4) / 16
         p = synth.make_bal_problem("venice-1778")
-        lb, le = capi.shard_range(p.lm_off, 8, 0)
+        lb, le = capi.shard_range(p.lm_off, int(name.split("/")[1]), 0)
         ob, oe = int(p.lm_off[lb]), int(p.lm_off[le])
         return synth.Problem(p.n_cams, le - lb, (p.lm_off[lb:le + 1] - p.lm_off[lb]).astype(np.int32), p.cam_idx[ob:oe], p.obs[ob:oe],
                              p.cams, p.lms[lb:le])
@@ -36,12 +36,14 @@ def _ctx(p, robust="NONE", **kw):
     return ctx
 
 
-@pytest.mark.parametrize("name", ["ladybug-49", "trafalgar-257", "venice-1778/8"])
-def test_resident_series_oracle_parity_at_size(name):
+@pytest.mark.parametrize("name", ["ladybug-49", "trafalgar-257", "venice-1778/16", "venice-1778/8"])
+def test_resident_series_oracle_parity_at_size(name, monkeypatch):
     """The 20-term increment and the last term of the resident series against the oracle (same linearisation point), and
-    against the per-term kernels of the same context."""
+    against the per-term kernels of the same context.  (The shard of one rank in eight is beyond the size up to which the
+    library builds the layout by default -- it is slower than the per-term kernels there --: the limit is lifted.)"""
     from povar_amd import capi
     from oracle import povar_oracle as O
+    monkeypatch.setenv("POVAR_RES_MAX_OBS", "1000000")
     p = _problem(name)
     orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs)
     ctx = _ctx(p)
