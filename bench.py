@@ -58,7 +58,7 @@ def kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
     for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_joint.hpp", "povar_hip.hip",
-              "lpl_layout.hpp", "ck_layout.hpp"):
+              "lpl_layout.hpp", "ck_layout.hpp", "povar_kernels_res.hpp", "res_layout.hpp"):
         with open(os.path.join(ROOT, "povar_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -506,6 +506,12 @@ def main():
     e0_ms = prof.e0_ms / max(prof.e0_launches, 1)
     binv_ms = prof.binv_ms / max(prof.binv_launches, 1)
     comm_ms = prof.comm_ms / max(prof.comm_launches, 1)
+    # the RESIDENT power series (series_res: one launch per solve) has no per-term kernels to put events around -- the event
+    # mode above ran the per-term kernels --: a term of the timed loop is then the whole-launch time / m
+    series_resident = bool(ctx.layout_info().res_active) and args.step == 1
+    per_term_kernels_e0_ms = e0_ms
+    if series_resident:
+        e0_ms, binv_ms = dt / terms * 1e3, 0.0
 
     # ONE E0 application on THIS rank (its landmark shard): the bytes its two kernels stream by design, and the
     # SURVEY 8(d) stored-tile figure the implicit kernels are only "effectively" delivering
@@ -574,7 +580,8 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": {capi.E0_IMPLICIT: "E0 x (e0_lm_cached<false> + cm_scatter)",
-                       capi.E0_IMPLICIT_LDSACC: (("E0 x (e0_ck_h + cam_cold_sum[_binv]_h)" if args.step == 2 and ctx.layout_info().e0_kernel_h > 0
+                       capi.E0_IMPLICIT_LDSACC: (("one term of series_res (resident power series: E0 x, B^-1, AXPY in ONE launch per solve)" if series_resident
+                                                  else "E0 x (e0_ck_h + cam_cold_sum[_binv]_h)" if args.step == 2 and ctx.layout_info().e0_kernel_h > 0
                                                   else "E0 x (e0_lpl_h + cam_cold_sum[_binv]_h)" if args.step == 2
                                                   else "E0 x (e0_ck + cam_cold_sum[_binv])" if ctx.layout_info().e0_kernel > 0
                                                   else "E0 x (e0_lpl + cam_cold_sum[_binv])")
@@ -632,6 +639,15 @@ def main():
                                   "e0_kernel_choice": {0: "forced", 1: "automatic (not timed yet)",
                                                        2: "automatic: both kernels timed on this problem"}[li.e0_auto],
                                   "e0_tune_us": {"e0_lpl": round(li.tune_lpl_us, 2), "e0_ck": round(li.tune_ck_us, 2)},
+                                  # the m-term loop: per-term kernels replayed from a hipGraph, or the resident kernel (one
+                                  # launch per solve; contexts of up to 400 k observations) -- chosen by timing both
+                                  "series_kernel": "resident (series_res)" if series_resident else "per-term kernels (hipGraph)",
+                                  "series_kernel_choice": {0: "forced", 1: "automatic (not timed yet)",
+                                                           2: "automatic: both forms timed on this problem"}[li.res_auto],
+                                  "series_tune_us_per_term": {"per_term_kernels": round(li.tune_terms_us, 2), "resident": round(li.tune_res_us, 2)},
+                                  "resident_series": {"workgroups": li.res_wgs, "wavefronts": li.res_waves, "rows_per_chunk": li.res_rows,
+                                                      "chunks_per_lane": li.res_rounds, "partial_records": li.res_records,
+                                                      "per_term_kernels_e0_ms": per_term_kernels_e0_ms} if li.res_ready else None,
                                   # step 2: 0: e0_lpl_h, 1: e0_ck_h (its own layout instance: more batches, shorter chunks)
                                   "e0_kernel_step2": li.e0_kernel_h,
                                   "e0_tune_us_step2": {"e0_lpl_h": round(li.tune_lpl_h_us, 2), "e0_ck_h": round(li.tune_ck_h_us, 2)},
@@ -707,6 +723,24 @@ def main():
         out["cpu_baseline"] = None
 
     ctx.close()
+    if rank == 0 and world == 1 and not args.no_secondary and args.step == 1 and not bal_path and args.popularity == "zipf1" \
+            and args.problem == "venice-1778":
+        # The SURVEY 8(d) generator draws cameras with Zipf(1) popularity: ONE hub camera sits in 45 % of the landmarks, which
+        # no real BAL problem looks like, and the graph decides which term kernel wins.  A second family with bounded camera
+        # degree and locality (cameras on a ring, a landmark seen from neighbouring positions; synth.POPULARITY "local") is
+        # therefore reported beside it -- its own process, its own line, never part of `value`.
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--popularity", "local", "--steps", str(max(args.steps // 2, 10)),
+                            "--warmup", "2", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True)
+        try:
+            f = json.loads(r.stdout.strip().splitlines()[-1])
+            out.setdefault("secondary", {})["family_local"] = {
+                "workload": f["config"]["workload"], "value": f["value"], "unit": f["unit"], "kernel_ms": f["kernel_ms"],
+                "roofline": {k: f["roofline"][k] for k in ("kernel", "achieved", "frac", "traffic", "once_frac", "basis")},
+                "e0_kernel": f["config"]["e0_layout"]["e0_kernel"], "e0_tune_us": f["config"]["e0_layout"]["e0_tune_us"],
+                "lds_resident_obs_frac": f["config"]["e0_layout"]["lds_resident_obs_frac"]}
+        except Exception as e:  # the headline is unaffected
+            out.setdefault("secondary", {})["family_local"] = {"error": f"{type(e).__name__}: {e}", "stderr_tail": r.stderr[-500:]}
     if rank == 0 and world == 1 and args.with_final:
         # the one workload of BASELINE.json that is HBM-resident for real (2-3.7 GB per term): its own process, its own line
         import subprocess

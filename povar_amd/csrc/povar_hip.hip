@@ -195,6 +195,7 @@ struct povar_ctx {
   int res_last_m = 0;
   double res_last_tol[2] = {0, 0};
   unsigned res_spin_limit = 1u << 18;
+  bool deterministic = false;    // POVAR_DETERMINISTIC=1: the E0 mode and the kernel choices are pinned
   DevBuf<int2> ck_zero_range;    // [n_cams] empty runs: e0_ck leaves no per-observation cold view to the per-camera kernels
   int ck_variant = 0;            // 0: e0_lpl; 1..CK_VARIANTS: e0_ck instantiation (POVAR_CK_VARIANTS)
   int ckh_variant = 0;           // step 2: 0: e0_lpl_h; 1: e0_ck_h
@@ -1450,6 +1451,20 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   } else {
     HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   }
+  // POVAR_DETERMINISTIC=1: run-to-run BIT-reproducible results for a given device count (SURVEY 8(e) "fixed reduction order
+  // inside a GPU"): the E0 operator in its gather form (POVAR_E0_IMPLICIT: per-landmark wavefront scans, per-camera sums
+  // through the camera-major index -- no atomics anywhere) whatever the caller asked for, and no run-time timing decides a
+  // kernel.  Costs a factor of about two on the term rate at venice-1778 (profiles/r05_experiments.txt); the default mode
+  // accumulates in LDS in arrival order and is reproducible to rounding (1e-15), like the reference's mutex order.
+  if (const char* g = std::getenv("POVAR_DETERMINISTIC")) {
+    if (g[0] == '1') {
+      c->opt.e0_mode = POVAR_E0_IMPLICIT;
+      c->ck_auto = false;
+      c->ck_variant = c->ckh_variant = 0;
+      c->res_mode = 0;
+      c->deterministic = true;
+    }
+  }
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_NO_ERR_MEMO")) c->no_err_memo = g[0] == '1';
   if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
@@ -1529,7 +1544,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     HIP_TRY_C(hipFuncSetAttribute((const void*)e0_ck_h<16, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
   }
   // per-term E0 kernel of step 1: e0_lpl (0) or an e0_ck instantiation (POVAR_E0_CK=<variant>, povar_set_e0_kernel)
-  if (const char* g = std::getenv("POVAR_E0_CK")) {
+  if (const char* g = std::getenv("POVAR_E0_CK"); g && !c->deterministic) {
     c->ck_variant = std::max(0, std::min(CK_VARIANTS, std::atoi(g)));
     c->ckh_variant = c->ck_variant > 0 ? 1 : 0;  // (step 2 has one camera-chunk instantiation)
     c->ck_auto = false;
@@ -1708,7 +1723,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     // resident power series (res_layout.hpp): for contexts whose observations fit the lanes' registers.  POVAR_RES=0|1
     // forces the choice (default: timed against the per-term kernels at the first series), POVAR_RES_WGS the workgroups,
     // POVAR_RES_OBS_PER_WG the observations a workgroup gets on small problems before all CUs are used.
-    if (const char* e = std::getenv("POVAR_RES")) c->res_mode = e[0] == '1' ? 1 : 0;
+    if (const char* e = std::getenv("POVAR_RES"); e && !c->deterministic) c->res_mode = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("POVAR_RES_SPIN")) c->res_spin_limit = (unsigned)std::max(1, std::atoi(e));
     // (measured, profiles/r05_res_term_times.txt: ahead of the per-term kernels up to a shard of 313 k observations, behind them
     // on one of 625 k, where the partial records -- 21.7 MB written and read per term -- are the term)

@@ -335,3 +335,38 @@ def test_graph_capture_while_the_placement_thread_uploads(monkeypatch):
         ref = inc if ref is None else ref
         assert rel(inc, ref) < 1e-10
         ctx.close()
+
+
+@pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778"])
+def test_povar_deterministic_is_bit_reproducible(monkeypatch, name):
+    """POVAR_DETERMINISTIC=1 (fixed reduction order inside a GPU): whatever E0 mode the caller asks for, the
+    context runs the gather form of the operator and no run-time timing picks a kernel -- two contexts on the same problem
+    and repeated solves give BIT-identical increments, model decreases and costs; the default mode agrees with them to
+    rounding."""
+    from povar_amd import capi, synth
+    p = synth.make_bal_problem(name)
+
+    def run(det):
+        if det:
+            monkeypatch.setenv("POVAR_DETERMINISTIC", "1")
+        else:
+            monkeypatch.delenv("POVAR_DETERMINISTIC", raising=False)
+        ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+        ctx.layout_finalize(True)
+        ctx.set_cameras(p.cams)
+        ctx.init_landmarks_pose(0.01)
+        assert ctx.linearize_pose(0.01)
+        incs = [ctx.solve_pose(1e-4, capi.POWER_VARPROJ, 20)[0] for _ in range(2)]
+        ld = ctx.apply_pose(capi.POWER_VARPROJ, 0.01, incs[0])
+        cost = ctx.error_pose(0.01).all_error
+        li = ctx.layout_info()
+        ctx.close()
+        return incs, ld, cost, li
+
+    (a0, a1), lda, ca, lia = run(True)
+    (b0, b1), ldb, cb, lib = run(True)
+    assert lia.e0_auto == 0 and lia.e0_kernel == 0 and lia.res_active == 0 and lia.res_auto == 0
+    assert np.array_equal(a0, a1) and np.array_equal(a0, b0) and np.array_equal(b0, b1)
+    assert lda == ldb and ca == cb
+    (c0, _), ldc, cc, _ = run(False)
+    assert np.linalg.norm(c0 - a0) <= 1e-10 * np.linalg.norm(a0) and abs(cc / ca - 1) < 1e-9
