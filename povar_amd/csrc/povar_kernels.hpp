@@ -333,8 +333,20 @@ __device__ inline double dpp_dm(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+// (body shared with seg_scan_steps: BCAST = false leaves the inclusive scan -- the segment's total is in its LAST lane --
+// and saves the 2 N ds_bpermute of the broadcast: what the callers that only write the total from one lane want)
+template <int N, bool BCAST>
+__device__ inline void seg_scan_impl(double (&v)[N], int lane, int seg_first, int seg_last, int steps);
 template <int N>
 __device__ inline void seg_reduce_steps(double (&v)[N], int lane, int seg_first, int seg_last, int steps) {
+  seg_scan_impl<N, true>(v, lane, seg_first, seg_last, steps);
+}
+template <int N>
+__device__ inline void seg_scan_steps(double (&v)[N], int lane, int seg_first, int steps) {
+  seg_scan_impl<N, false>(v, lane, seg_first, 0, steps);
+}
+template <int N, bool BCAST>
+__device__ inline void seg_scan_impl(double (&v)[N], int lane, int seg_first, int seg_last, int steps) {
   auto mask = [](bool c) { return __hiloint2double(c ? 0x3FF00000 : 0, 0); };
   const double m1 = mask(lane - 1 >= seg_first), m2 = mask(lane - 2 >= seg_first), m4 = mask(lane - 4 >= seg_first),
                m8 = mask(lane - 8 >= seg_first), mc = mask(seg_first < (lane & ~15));
@@ -358,8 +370,10 @@ __device__ inline void seg_reduce_steps(double (&v)[N], int lane, int seg_first,
   for (int k = 0; k < N; ++k) v[k] = fma(mc, dpp_dm<0x142, 0x4>(v[k]), v[k]);
 #pragma unroll
   for (int k = 0; k < N; ++k) v[k] = fma(mc, dpp_dm<0x142, 0x8>(v[k]), v[k]);
+  if (BCAST) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = shfl_d(v[k], seg_last);
+    for (int k = 0; k < N; ++k) v[k] = shfl_d(v[k], seg_last);
+  }
 }
 
 // value of lane (src lane per the DPP control), 0 where the source lane does not exist (bound_ctrl)

@@ -244,10 +244,10 @@ __device__ inline void ck_load_p3(const Dp& d, int rank, double* P3) {
 // first) or, for a camera without a slot in this workgroup, to the chunk's own partial record
 __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int rank, int acc_slot, int seg, double* acc, int n_acc,
                                      double* part_out) {
-  if (flags & 1) seg_reduce_steps<12>(y, lane, seg & 255, (seg >> 8) & 255, 4);
+  if (flags & 1) seg_scan_steps<12>(y, lane, seg & 255, 4);  // (inclusive scan: the run's total is in its LAST lane)
   if (rank >= 0) {
     if (acc_slot >= 0) {
-      if (lane == (seg & 255)) {
+      if (lane == ((seg >> 8) & 255)) {
 #pragma unroll
         for (int m = 0; m < 12; ++m)  // acc[slot][13]: one address register, twelve immediate offsets; odd stride: 32 bank classes
           __hip_atomic_fetch_add(acc + acc_slot * CK_ACC_STRIDE + m, y[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
     }
     for (int e = t; e < nC * RES_ACC_STRIDE; e += T) reg[e] = 0;
     __syncthreads();  // B3
-    // ---- backward: y_c += h~_l (x) (w C (P3 g_l)); lanes of one camera are summed, the run's first lane adds to the
+    // ---- backward: y_c += h~_l (x) (w C (P3 g_l)); lanes of one camera are summed, the run's last lane adds to the
     // camera's accumulator
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
@@ -366,8 +366,9 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
           ck_obs_backward(d, ch[r].uv[j], ch[r].rw[j], ch[r].P3, lh[s], lh[s + 1], lh[s + 2], gg, y);
         }
       }
-      if (ch[r].dup) seg_reduce_steps<12>(y, lane, ch[r].seg & 255, (ch[r].seg >> 8) & 255, ch[r].steps);
-      if (ch[r].ci >= 0 && lane == (ch[r].seg & 255)) {
+      // (the run's LAST lane holds its sum after the scan: no broadcast)
+      if (ch[r].dup) seg_scan_steps<12>(y, lane, ch[r].seg & 255, ch[r].steps);
+      if (ch[r].ci >= 0 && lane == ((ch[r].seg >> 8) & 255)) {
         double* a = reg + ch[r].ci * RES_ACC_STRIDE;
         if (ch[r].seg & (1 << 16)) {  // the camera's only run in the workgroup: a plain store
 #pragma unroll
