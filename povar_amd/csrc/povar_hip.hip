@@ -1695,13 +1695,19 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
         // later on venice-1778, i.e. after the first two hundred LM iterations.  e0_ck does not care which order the
         // lane-per-landmark rows are in (its own bank placement is what counts: 16.0 k terms/s on the natural rows, 15.9 k
         // without its placement on either; profiles/r05_experiments.txt), so step 1's layout is built here from the natural
-        // rows: 0.09 s of povar_create for e0_ck from the first solve on (`bal` on venice: 96 -> 70 us per term).
+        // rows (and step 2's after it): 0.09 s of povar_create each for e0_ck / e0_ck_h from the first solve on.
         const auto tk = std::chrono::steady_clock::now();
         CkLayout K;
         build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, ck_place, ck_hmax, ck_ng);
         c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
         if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
         lap("camera-chunk layout (step 1, natural rows)");
+        if (std::getenv("POVAR_CKH_LATE") == nullptr) {  // step 2's instance likewise (POVAR_CKH_LATE=1: only with the placed rows)
+          CkLayout KH;
+          build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, KH, ck_place, ck_hmax, 1, ck_shape_step2());
+          if (!ck_upload(c, c->ckh, KH, false, &c->bytes, false)) { povar_destroy(c); return fail(-1, "camera-chunk layout (step 2): upload failed"); }
+          lap("camera-chunk layout (step 2, natural rows)");
+        }
       } else {  // (step 2's, and both of the placed rows, come from the host thread with place_mode 2)
         const auto tk = std::chrono::steady_clock::now();
         CkLayout K;

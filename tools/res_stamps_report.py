@@ -18,9 +18,10 @@ def main():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "res_term_time.py")] + sys.argv[1:], env=env, capture_output=True, text=True)
     print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:])
     import numpy as np
-    a = np.loadtxt(out, dtype=np.uint64).reshape(-1, 2, 16).astype(np.float64)
+    raw = np.loadtxt(out, dtype=np.uint64).reshape(2, -1, 2, 16).astype(np.float64)
+    a, rt = raw[0], raw[1]  # shader-clock stamps (per XCD: only differences inside a workgroup mean anything), 100 MHz real time
     used = a[:, 0, 2] > 0
-    a = a[used]
+    a, rt = a[used], rt[used]
     print(f"{a.shape[0]} workgroups; cycles (s_memtime, 100 MHz reference clock ticks x ...: raw counter units)")
     t0 = a[:, :, 1].min()
     order = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
@@ -38,6 +39,17 @@ def main():
                 line += f"   since {prev:2d}: median {np.median(dlt):8.0f} max {dlt.max():8.0f}"
             print(line)
             prev = n
+    # the same phases on the chip-wide 100 MHz clock: when the FIRST and the LAST workgroup reach each stamp, from the moment the
+    # first workgroup starts the term (10 ns resolution) -- who waits for whom across workgroups
+    r0 = rt[:, :, 1].min()
+    print("-- chip-wide (s_memrealtime), microseconds after the first workgroup's top of the term: first / median / last workgroup")
+    for n in order:
+        v = rt[:, :, n]
+        if not (v > 0).all():
+            continue
+        x = (v.min(axis=1) - r0) / 100.0
+        y = (v.max(axis=1) - r0) / 100.0
+        print(f"  {n:2d} {NAMES[n]:45s} first wave {x.min():6.2f} {np.median(x):6.2f} {x.max():6.2f}   last wave {y.min():6.2f} {np.median(y):6.2f} {y.max():6.2f}")
     if (a[:, 0, 12] > 0).all():
         print(f"term length (stamp 1 of this term -> 1 of the next is not stamped; kernel entry -> exit): {np.median(a[:, 0, 12] - a[:, 0, 0]):.0f} ticks for the launch")
 

@@ -37,7 +37,7 @@ def main():
     s = open(p).read()
     s = s.replace("  unsigned spin_limit;\n};", "  unsigned spin_limit;\n  unsigned long long* stamps;  // [W][2][16]\n  int stamp_term;\n};", 1)
     macro = ('#define RES_STAMP(n) do { if (k.stamps && lane == 0 && (wave == 0 || wave == NW - 1) && i == k.stamp_term) '
-             'k.stamps[((size_t)g * 2 + (wave != 0)) * 16 + (n)] = __builtin_amdgcn_s_memtime(); } while (0)\n')
+             '{ k.stamps[((size_t)g * 2 + (wave != 0)) * 16 + (n)] = __builtin_amdgcn_s_memtime(); k.stamps[(size_t)RES_MAX_WG * 32 + ((size_t)g * 2 + (wave != 0)) * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } } while (0)\n')
     s = s.replace("// All threads of the workgroup: granule pair i", macro + "// All threads of the workgroup: granule pair i", 1)
     for mark, n in MARKS:
         assert s.count(mark) == 1, (mark, s.count(mark))
@@ -51,7 +51,7 @@ def main():
     s = s.replace("  k.spin_limit = c->res_spin_limit;\n", '''  k.spin_limit = c->res_spin_limit;
   {
     static unsigned long long* g_stamps = nullptr;
-    if (!g_stamps) { (void)hipMalloc((void**)&g_stamps, sizeof(unsigned long long) * RES_MAX_WG * 2 * 16); (void)hipMemset(g_stamps, 0, sizeof(unsigned long long) * RES_MAX_WG * 2 * 16); }
+    if (!g_stamps) { (void)hipMalloc((void**)&g_stamps, sizeof(unsigned long long) * RES_MAX_WG * 2 * 16 * 2); (void)hipMemset(g_stamps, 0, sizeof(unsigned long long) * RES_MAX_WG * 2 * 16 * 2); }
     k.stamps = g_stamps;
     k.stamp_term = std::getenv("POVAR_RES_STAMP_TERM") ? std::atoi(std::getenv("POVAR_RES_STAMP_TERM")) : 5;
     if (const char* f = std::getenv("POVAR_RES_STAMPS_OUT")) {
@@ -59,11 +59,11 @@ def main():
       static povar_ctx* cc; cc = const_cast<povar_ctx*>(c);
       static bool reg = false;
       if (!reg) { reg = true; std::atexit([]() {
-        std::vector<unsigned long long> hbuf((size_t)RES_MAX_WG * 2 * 16);
+        std::vector<unsigned long long> hbuf((size_t)RES_MAX_WG * 2 * 16 * 2);
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(hbuf.data(), g_stamps, hbuf.size() * 8, hipMemcpyDeviceToHost);
         if (FILE* o = std::fopen(path.c_str(), "w")) {
-          for (int g = 0; g < RES_MAX_WG; ++g) for (int w = 0; w < 2; ++w) { for (int n = 0; n < 16; ++n) std::fprintf(o, "%llu ", hbuf[((size_t)g * 2 + w) * 16 + n]); std::fprintf(o, "\\n"); }
+          for (int g = 0; g < 2 * RES_MAX_WG; ++g) for (int w = 0; w < 2; ++w) { for (int n = 0; n < 16; ++n) std::fprintf(o, "%llu ", hbuf[((size_t)g * 2 + w) * 16 + n]); std::fprintf(o, "\\n"); }
           std::fclose(o);
         } }); }
     }
