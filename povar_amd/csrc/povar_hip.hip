@@ -1582,6 +1582,24 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
               c->n_hot_acc, V, place_mode == 1);
     lap("build_lpl (lane/landmark)");
     c->placement = place_mode;
+    // The rows are placed on a host thread, and the chunk layouts of the placed rows arrive with them -- half a second later
+    // on venice-1778, i.e. after the first two hundred LM iterations.  e0_ck does not care which order the
+    // lane-per-landmark rows are in (its own bank placement is what counts: 16.0 k terms/s on the natural rows, 15.9 k
+    // without its placement on either; profiles/r05_experiments.txt), so step 1's layout is built HERE from the natural
+    // rows -- before the host thread starts: the two would share the CPUs -- for e0_ck from the first solve on (0.09 s of
+    // povar_create; `bal` on venice: 96 -> 62 us per term).  POVAR_CKH_EARLY=1: step 2's instance likewise.
+    std::unique_ptr<CkLayout> ck_nat, ckh_nat;
+    if (place_mode == 2 && want_ck && !V.tile.empty()) {
+      const auto tk = std::chrono::steady_clock::now();
+      ck_nat.reset(new CkLayout());
+      build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, *ck_nat, ck_place, ck_hmax, ck_ng);
+      c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
+      if (std::getenv("POVAR_CKH_EARLY") != nullptr) {
+        ckh_nat.reset(new CkLayout());
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, *ckh_nat, ck_place, ck_hmax, 1, ck_shape_step2());
+      }
+      lap("camera-chunk layout(s) from the natural rows");
+    }
     if (place_mode == 2 && !V.tile.empty()) {
       // the same builder again, with the placement, on copies of the caller's arrays (they need not outlive this call)
       struct Job {
@@ -1691,23 +1709,9 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (want_ck && !V.tile.empty()) {
       if (int rc = upload(c->ck_zero_range, std::vector<int2>((size_t)n_cams, make_int2(0, 0)), c)) { povar_destroy(c); return rc; }
       if (place_mode == 2) {
-        // The rows are placed on a host thread, and the chunk layouts of the placed rows arrive with them -- half a second
-        // later on venice-1778, i.e. after the first two hundred LM iterations.  e0_ck does not care which order the
-        // lane-per-landmark rows are in (its own bank placement is what counts: 16.0 k terms/s on the natural rows, 15.9 k
-        // without its placement on either; profiles/r05_experiments.txt), so step 1's layout is built here from the natural
-        // rows (and step 2's after it): 0.09 s of povar_create each for e0_ck / e0_ck_h from the first solve on.
-        const auto tk = std::chrono::steady_clock::now();
-        CkLayout K;
-        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, ck_place, ck_hmax, ck_ng);
-        c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
-        if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
-        lap("camera-chunk layout (step 1, natural rows)");
-        if (std::getenv("POVAR_CKH_LATE") == nullptr) {  // step 2's instance likewise (POVAR_CKH_LATE=1: only with the placed rows)
-          CkLayout KH;
-          build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, KH, ck_place, ck_hmax, 1, ck_shape_step2());
-          if (!ck_upload(c, c->ckh, KH, false, &c->bytes, false)) { povar_destroy(c); return fail(-1, "camera-chunk layout (step 2): upload failed"); }
-          lap("camera-chunk layout (step 2, natural rows)");
-        }
+        if (!ck_upload(c, c->ck, *ck_nat, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
+        if (ckh_nat && !ck_upload(c, c->ckh, *ckh_nat, false, &c->bytes, false)) { povar_destroy(c); return fail(-1, "camera-chunk layout (step 2): upload failed"); }
+        lap("camera-chunk layouts (natural rows): uploads");
       } else {  // (step 2's, and both of the placed rows, come from the host thread with place_mode 2)
         const auto tk = std::chrono::steady_clock::now();
         CkLayout K;
