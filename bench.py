@@ -524,6 +524,12 @@ def main():
     li0 = ctx.layout_info()
     once_bytes = model_bytes - (li0.ck_rows * 64 * (18 + (8 if args.robust_norm != "NONE" else 0))
                                 if args.step == 1 and li0.e0_kernel > 0 else 0)  # (step 2's rows are 2-4 bytes: no correction)
+    if series_resident:
+        # what ONE term of the resident kernel moves: every (workgroup, camera) pair reads the camera's z (192 B of granule
+        # pairs), writes its partial record (192 B) and the owner reads it (192 B); every camera's z is published once
+        model_lm, model_cm = li0.res_records * 192 * 2, li0.res_records * 192 + n_c * 192
+        model_bytes = once_bytes = model_lm + model_cm
+        achieved = model_bytes / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
     traffic, traffic_note = None, "no PMC figure for this workload/mode"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -537,7 +543,7 @@ def main():
                 (f":{args.popularity}" if args.popularity != "zipf1" else "") + \
                 (f":ltf{args.long_track_frac:g}" if args.long_track_frac > 0 else "") + (":file" if bal_path else "") + \
                 (f":ck{ctx.layout_info().e0_kernel}" if args.step == 1 and ctx.layout_info().e0_kernel > 0 else "") + \
-                (":ckh1" if args.step == 2 and ctx.layout_info().e0_kernel_h > 0 else "")
+                (":ckh1" if args.step == 2 and ctx.layout_info().e0_kernel_h > 0 else "") + (":resident" if series_resident else "")
             if key in tj:
                 if tj.get("_source_sha", {}).get(key) == kernel_source_sha():
                     traffic, traffic_note = tj[key], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/"
