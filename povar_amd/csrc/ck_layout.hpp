@@ -45,8 +45,6 @@ struct CkLayout {
   std::vector<int> lane_seg;     // [tiles][64] first | last << 8 lane of the run that shares this lane's accumulator
   std::vector<int> bt_off;       // [grid * nb + 1] tiles of (workgroup, batch)
   std::vector<int> slot_rec;     // [lpl wg_cams.size()] partial record each workgroup slot is flushed to
-  std::vector<int> slot_map;     // [lpl tiles][64] LDS slot (inside its batch) of the landmark lane: a permutation of the lane order
-                                 // that spreads the observations of every half tile evenly over the 32 bank-pair classes
   std::vector<int2> part_range;  // [n_cams] partial records of camera c (by camera index): [first, end)
   int nb = 1;                    // batches per workgroup
   int li_mul = 3;                // the slot words hold li_mul x slot (CkShape)
@@ -114,10 +112,6 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
   // more than its rows: with 3 the schedule cut venice into 20 tiles per (workgroup, batch) -- four wavefronts walk two --,
   // from 8 on into at most 16 (15.96 k -> 16.5 k terms/s; 8 ... 32 within 0.5 %: profiles/r05_experiments.txt)
   int tile_overhead = 12;
-  int refine_passes = 2;
-  bool renumber = true;
-  if (const char* e = std::getenv("POVAR_CK_SLOTS")) renumber = !(e[0] == 'l');
-  if (const char* e = std::getenv("POVAR_CK_REFINE")) refine_passes = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("POVAR_CK_TILE_COST")) tile_overhead = std::max(0, std::atoi(e));
   // ---- batches: the smallest count whose landmark slots fit next to the accumulators
   int max_tiles_w = 1, max_acc = 1;
@@ -141,7 +135,6 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     std::vector<int> src, lane_cam, lane_acc, lane_seg, bt_tiles;  // bt_tiles[b]: tiles of batch b
     std::vector<int4> tile;  // x, w: local row / li-row numbers
     std::vector<int> cold_rank;  // rank of every cold chunk, in the order their lanes say ~(index)
-    std::vector<int> slot_map;   // [tiles of the workgroup][64]
     int64_t chunks = 0, obs = 0;
     double extra = 0;
   };
@@ -150,9 +143,6 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     WgOut& o = out[w];
     o.bt_tiles.assign(nb, 0);
     const int t0 = L.wg_tile_off[w], t1 = L.wg_tile_off[w + 1];
-    o.slot_map.assign((size_t)(t1 - t0) * WAVE, 0);
-    for (int t = t0; t < t1; ++t)
-      for (int lane = 0; lane < WAVE; ++lane) o.slot_map[(size_t)(t - t0) * WAVE + lane] = ((t - t0) / nb) * WAVE + lane;  // identity
     struct Ob { int key, li, src; };  // key: accumulator slot, or n_acc_w + rank for a camera without one
     const int n_acc_w = L.wg_cam_off[w + 1] - L.wg_cam_off[w];
     std::vector<Ob> obs;
@@ -213,47 +203,6 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
         const int ra = rank_of(a.key), rc = rank_of(c.key);
         return ra != rc ? ra < rc : a.key < c.key;
       });
-      // ---- slots: a permutation of the landmark lanes of the batch that balances the bank-pair classes.  A ds_add_f64 costs
-      // 8 LDS cycles per wavefront plus 8 per extra lane on a bank pair, and the order of a chunk's observations over the rows
-      // (below) can only avoid what the class HISTOGRAM of a half tile allows: a class hit more often than the tile has rows
-      // must repeat inside a row.  In lane order the classes of a half tile's ~ 32 T observations are a random draw (the
-      // fullest class of 32 is 1.5 x the mean); chosen greedily -- landmarks by observation count, each to the class that
-      // keeps the fullest (half tile, class) cell it touches lowest -- they are level.  POVAR_CK_SLOTS=lane: round 4's order.
-      if (renumber) {
-        const int n_bt = (t1 - t0 - b + nb - 1) / nb;             // lane-per-landmark tiles of this batch
-        const int n_slots_b = n_bt * WAVE, per_class = n_slots_b / 32;
-        const int n_ht = 2 * (((int)chunks.size() + WAVE - 1) / WAVE);
-        std::vector<std::vector<int>> hts(n_slots_b);             // half tiles of each landmark slot's observations
-        for (size_t q = 0; q < chunks.size(); ++q) {
-          const int ht = 2 * (int)(q / WAVE) + (int)((q % WAVE) >> 5);
-          for (int a = 0; a < chunks[q].len; ++a) hts[obs[chunks[q].first + a].li].push_back(ht);
-        }
-        std::vector<int> order(n_slots_b);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hts[x].size() > hts[y].size(); });
-        std::vector<uint16_t> hist((size_t)n_ht * 32, 0);
-        std::vector<int> used(32, 0), new_of(n_slots_b, -1);
-        for (int s_old : order) {
-          int best_c = -1;
-          long best_cost = LONG_MAX;
-          for (int c = 0; c < 32; ++c) {
-            if (used[c] >= per_class) continue;
-            long mx = 0, sum = 0;
-            for (int ht : hts[s_old]) {
-              const long v = hist[(size_t)ht * 32 + c] + 1;
-              mx = std::max(mx, v);
-              sum += v;
-            }
-            const long cst = mx * 100000 + sum * 64 + used[c];
-            if (cst < best_cost) { best_cost = cst; best_c = c; }
-          }
-          for (int ht : hts[s_old]) ++hist[(size_t)ht * 32 + best_c];
-          new_of[s_old] = best_c + 32 * used[best_c]++;
-        }
-        for (Ob& ob : obs) ob.li = new_of[ob.li];
-        for (int m = 0; m < n_bt; ++m)
-          for (int lane = 0; lane < WAVE; ++lane) o.slot_map[(size_t)(b + nb * m) * WAVE + lane] = new_of[m * WAVE + lane];
-      }
       o.chunks += (int64_t)chunks.size();
       const int n_tiles = ((int)chunks.size() + WAVE - 1) / WAVE;
       o.bt_tiles[b] = n_tiles;
@@ -320,91 +269,6 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
             mx[j][half] = std::max(mx[j][half], v);
           }
         }
-        // Refinement passes: every lane again, now against ALL the other lanes of its half (the first pass saw only the
-        // lanes before it): its rows are taken out of the occupancy, the assignment is solved again, and kept when the
-        // half-rows' worst multiplicities (what a ds_add_f64 costs: 8 LDS cycles per extra lane on a bank pair) do not get
-        // worse.  POVAR_CK_REFINE=<passes> (default 2; 0: the single greedy pass of round 4).
-        if (place && T > 1 && refine_passes > 0) {
-          auto row_of = [&](int lane, int a, const Chunk& ck) {  // the row observation a of the lane's chunk sits in
-            for (int j = 0; j < T; ++j) {
-              const size_t idx = r0 + (size_t)j * WAVE + lane;
-              if (o.src[idx] == obs[ck.first + a].src) return j;
-            }
-            return -1;
-          };
-          for (int pass = 0; pass < refine_passes; ++pass) {
-            bool any = false;
-            for (int q = c0; q < c1; ++q) {
-              const int lane = q - c0, half = lane >> 5;
-              const Chunk& ck = chunks[q];
-              const int h = ck.len;
-              // current rows of the lane, taken out of the occupancy
-              std::vector<int> cur(h);
-              for (int a = 0; a < h; ++a) {
-                cur[a] = row_of(lane, a, ck);
-                --occ[cur[a]][half][obs[ck.first + a].li & 31];
-              }
-              auto worst = [&](int j) {
-                uint16_t m = 1;
-                for (int c = 0; c < 32; ++c) m = std::max(m, occ[j][half][c]);
-                return m;
-              };
-              std::vector<uint16_t> base(T);
-              for (int j = 0; j < T; ++j) base[j] = worst(j);
-              cost.assign((size_t)T * T, 0);
-              for (int a = 0; a < h; ++a) {
-                const int cls = obs[ck.first + a].li & 31;
-                for (int j = 0; j < T; ++j) {
-                  const int v = occ[j][half][cls];
-                  cost[(size_t)a * T + j] = 1000L * std::max(0, v + 1 - (int)base[j]) + v;
-                }
-              }
-              std::vector<int> full;
-              lpl_assign(T, cost, full);
-              long c_new = 0, c_old = 0;
-              for (int a = 0; a < h; ++a) {
-                c_new += cost[(size_t)a * T + full[a]];
-                c_old += cost[(size_t)a * T + cur[a]];
-              }
-              const bool move = c_new < c_old;
-              if (move) {
-                any = true;
-                // rewrite the lane's column of the tile
-                std::vector<double2> uvs(h);
-                std::vector<int> srcs(h);
-                std::vector<uint32_t> lis(h);
-                for (int a = 0; a < h; ++a) {
-                  const size_t idx = r0 + (size_t)cur[a] * WAVE + lane;
-                  uvs[a] = o.uv[idx];
-                  srcs[a] = o.src[idx];
-                  lis[a] = (o.li[q0 + (size_t)(cur[a] >> 1) * WAVE + lane] >> (16 * (cur[a] & 1))) & 0xffffu;
-                }
-                for (int j = 0; j < T; ++j) {
-                  const size_t idx = r0 + (size_t)j * WAVE + lane;
-                  o.uv[idx] = make_double2(0, 0);
-                  o.src[idx] = -1;
-                }
-                for (int jj = 0; jj < (T + 1) / 2; ++jj) o.li[q0 + (size_t)jj * WAVE + lane] = CK_NONE | (CK_NONE << 16);
-                for (int a = 0; a < h; ++a) {
-                  const int j = full[a];
-                  const size_t idx = r0 + (size_t)j * WAVE + lane;
-                  o.uv[idx] = uvs[a];
-                  o.src[idx] = srcs[a];
-                  uint32_t& word = o.li[q0 + (size_t)(j >> 1) * WAVE + lane];
-                  word = (j & 1) ? ((word & 0xffffu) | (lis[a] << 16)) : ((word & 0xffff0000u) | lis[a]);
-                }
-              }
-              for (int a = 0; a < h; ++a) ++occ[move ? full[a] : cur[a]][half][obs[ck.first + a].li & 31];
-            }
-            if (!any) break;
-          }
-          for (int j = 0; j < T; ++j)
-            for (int half = 0; half < 2; ++half) {
-              uint16_t m = 1;
-              for (int c = 0; c < 32; ++c) m = std::max(m, occ[j][half][c]);
-              mx[j][half] = m;
-            }
-        }
         for (int j = 0; j < T; ++j) o.extra += (mx[j][0] - 1) + (mx[j][1] - 1);
         // runs of lanes with the same accumulator (resident chunks of one camera are adjacent: sorted by key)
         if (ti.z & CK_FLAG_DUP) {
@@ -452,8 +316,6 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     K.extra_lanes += o.extra;
   }
   K.bt_off[(size_t)grid * nb] = (int)K.tile.size();
-  K.slot_map.clear();
-  for (int w = 0; w < grid; ++w) K.slot_map.insert(K.slot_map.end(), out[w].slot_map.begin(), out[w].slot_map.end());
   K.n_cold_chunks = n_cold_chunks;
   // ---- partial records, camera-major: a camera's workgroup slots first, then its cold chunks
   std::vector<int> n_rec(n_cams, 0);  // by rank

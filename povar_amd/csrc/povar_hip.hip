@@ -151,7 +151,7 @@ struct povar_ctx {
   struct CkDev {
     DevBuf<double2> uv;
     DevBuf<uint32_t> li;
-    DevBuf<int> src, bt_off, slot_rec, slot_map;
+    DevBuf<int> src, bt_off, slot_rec;
     DevBuf<int2> lane_meta;
     DevBuf<int4> tile;
     DevBuf<int2> part_range;
@@ -163,7 +163,7 @@ struct povar_ctx {
     bool ready = false;
     void release() {
       uv.release(); li.release(); src.release(); lane_meta.release(); bt_off.release();
-      slot_rec.release(); slot_map.release(); tile.release(); part_range.release(); part.release(); w.release();
+      slot_rec.release(); tile.release(); part_range.release(); part.release(); w.release();
       ready = false;
     }
   } ck, pl_ck,       // step 1 (e0_ck): the layout in use / the one the placement thread built for the placed rows
@@ -529,7 +529,7 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
   }
   if (need_uv) up(D.uv, K.uv);  // (step 2's operator does not read the image coordinates)
   up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_meta, meta);
-  up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.slot_map, K.slot_map); up(D.part_range, K.part_range);
+  up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
   if (ok) guarded([&] { ok = D.part.alloc((size_t)std::max(K.n_part_rec, 1) * 12, bytes) == hipSuccess; });
   if (ok && c->opt.robust_norm)
     guarded([&] { ok = D.w.alloc(std::max<size_t>(K.uv.size(), 1), bytes) == hipSuccess; });  // (padded like uv)
@@ -541,7 +541,7 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
   return ok;
 }
 CkP ck_params(const povar_ctx* c, const povar_ctx::CkDev& D) {
-  return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p, D.slot_map.p,
+  return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p,
              D.nb, D.slots, (unsigned)(D.src.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t))};
 }
 CkP ck_params(const povar_ctx* c) { return ck_params(c, c->ck); }

@@ -34,8 +34,6 @@ struct CkP {
                          // (x < 0: empty lane); y: >= 0 accumulator slot, < 0: ~(partial record of a cold chunk)
   const int* bt_off;     // [grid * nb + 1]
   const int* slot_rec;   // partial record of each workgroup slot
-  const int* slot_map;   // [lane-per-landmark tiles][64] LDS slot of the landmark lane inside its batch (ck_layout.hpp: a permutation
-                         // of the lane order that levels the bank-pair classes of every half tile)
   int nb, slots;
   unsigned uv_bytes, li_bytes;  // sizes of uv (= w's in doubles x 2) and li: the rows are read through buffer descriptors
 };
@@ -320,17 +318,14 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
   auto tile_of = [&](int tb0, int q) { return tb0 + q * GW + ((q & 1) ? GW - 1 - wave : wave); };
   constexpr int HM = 32 / NW > 0 ? 32 / NW : 1;  // slot tiles per wavefront whose h~ / G are requested a phase ahead
   double hn[HM][3];
-  int sn[HM];  // the LDS slots of the lane's landmarks in the batch requested (CkP::slot_map)
   auto request_h = [&](int b, int lane) {
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
       hn[q][0] = hn[q][1] = hn[q][2] = 0;
-      sn[q] = 0;
       const int m = wave + q * GW;
       if (b < k.nb && t0 + b + k.nb * m < t1) {
         const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9) * WAVE + lane;
         hn[q][0] = rp[0]; hn[q][1] = rp[WAVE]; hn[q][2] = rp[2 * WAVE];
-        sn[q] = k.slot_map[(size_t)(t0 + b + k.nb * m) * WAVE + lane];
       }
     }
   };
@@ -385,13 +380,11 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       st.template start<1>(R, row0, li0, h, lane);
     }
     // ---- landmark coordinates of the batch into LDS (requested a phase ago), u = 0
-    int sb[HM];  // (this batch's slots: sn is overwritten by the next batch's request before g = G u)
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
       const int m = wave + q * GW;
-      sb[q] = sn[q];
       if (t0 + b + k.nb * m < t1) {
-        const int s = sb[q];
+        const int s = m * WAVE + lane;
         lh[3 * s] = hn[q][0];
         lh[3 * s + 1] = hn[q][1];
         lh[3 * s + 2] = hn[q][2];
@@ -402,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     }
     for (int m = wave + HM * GW; t0 + b + k.nb * m < t1; m += GW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9) * WAVE + lane;
-      const int s = k.slot_map[(size_t)(t0 + b + k.nb * m) * WAVE + lane];
+      const int s = m * WAVE + lane;
       lh[3 * s] = rp[0];
       lh[3 * s + 1] = rp[WAVE];
       lh[3 * s + 2] = rp[2 * WAVE];
@@ -489,7 +482,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     for (int q = 0; q < HM; ++q) {
       const int m = wave + q * GW;
       if (t0 + b + k.nb * m < t1) {
-        const int s = sb[q];
+        const int s = m * WAVE + lane;
         const double u0 = lu[3 * s], u1 = lu[3 * s + 1], u2 = lu[3 * s + 2];
         lu[3 * s] = G[q][0] * u0 + G[q][1] * u1 + G[q][2] * u2;
         lu[3 * s + 1] = G[q][1] * u0 + G[q][3] * u1 + G[q][4] * u2;
@@ -499,7 +492,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     for (int m = wave + HM * GW; t0 + b + k.nb * m < t1; m += GW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * 9 + 3) * WAVE + lane;
       const double g0 = rp[0], g1 = rp[WAVE], g2 = rp[2 * WAVE], g3 = rp[3 * WAVE], g4 = rp[4 * WAVE], g5 = rp[5 * WAVE];
-      const int s = k.slot_map[(size_t)(t0 + b + k.nb * m) * WAVE + lane];
+      const int s = m * WAVE + lane;
       const double u0 = lu[3 * s], u1 = lu[3 * s + 1], u2 = lu[3 * s + 2];
       lu[3 * s] = g0 * u0 + g1 * u1 + g2 * u2;
       lu[3 * s + 1] = g1 * u0 + g3 * u1 + g4 * u2;

@@ -210,18 +210,15 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
   auto tile_of = [&](int tb0, int q) { return tb0 + q * NW + ((q & 1) ? NW - 1 - wave : wave); };
   constexpr int HM = 32 / NW > 0 ? 32 / NW : 1;  // slot tiles per wavefront whose X is requested a phase ahead
   double xn[HM][4];
-  int sn[HM];  // the LDS slots of the lane's landmarks in the batch requested (CkP::slot_map)
   auto request_x = [&](int b, int lane) {
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
       xn[q][0] = xn[q][1] = xn[q][2] = 0;
       xn[q][3] = 1;
-      sn[q] = 0;
       const int m = wave + q * NW;
       if (b < k.nb && t0 + b + k.nb * m < t1) {
         const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * CKH_REC) * WAVE + lane;
         xn[q][0] = rp[0]; xn[q][1] = rp[WAVE]; xn[q][2] = rp[2 * WAVE]; xn[q][3] = rp[3 * WAVE];
-        sn[q] = k.slot_map[(size_t)(t0 + b + k.nb * m) * WAVE + lane];
       }
     }
   };
@@ -259,13 +256,11 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
       st.template start<1>(R, row0, li0, h, lane);
     }
     // ---- X of the batch into LDS (requested a phase ago), U4 = 0
-    int sb[HM];  // (this batch's slots: sn is overwritten by the next batch's request before the landmark step)
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
       const int m = wave + q * NW;
-      sb[q] = sn[q];
       if (t0 + b + k.nb * m < t1) {
-        const int s = sb[q];
+        const int s = m * WAVE + lane;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           lx[e * CKH_STRIDE + s] = xn[q][e];
@@ -275,7 +270,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
     }
     for (int m = wave + HM * NW; t0 + b + k.nb * m < t1; m += NW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * CKH_REC) * WAVE + lane;
-      const int s = k.slot_map[(size_t)(t0 + b + k.nb * m) * WAVE + lane];
+      const int s = m * WAVE + lane;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         lx[e * CKH_STRIDE + s] = rp[e * WAVE];
@@ -333,14 +328,14 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
       const int m = wave + q * NW;
-      if (t0 + b + k.nb * m < t1) ckh_landmark_step(lx, lu, sb[q], rec[q]);
+      if (t0 + b + k.nb * m < t1) ckh_landmark_step(lx, lu, m * WAVE + lane, rec[q]);
     }
     for (int m = wave + HM * NW; t0 + b + k.nb * m < t1; m += NW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * CKH_REC + 4) * WAVE + lane;
       double r2[10];
 #pragma unroll
       for (int e = 0; e < 10; ++e) r2[e] = rp[e * WAVE];
-      ckh_landmark_step(lx, lu, k.slot_map[(size_t)(t0 + b + k.nb * m) * WAVE + lane], r2);
+      ckh_landmark_step(lx, lu, m * WAVE + lane, r2);
     }
     ck_barrier();
     // ---- backward: the wavefront's tiles in reverse

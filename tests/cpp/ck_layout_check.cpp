@@ -66,19 +66,6 @@ int main(int argc, char** argv) {
   std::vector<int> obs_of_slot(L.uv.size(), -1);
   for (int64_t i = 0; i < n_obs; ++i) obs_of_slot[L.of_slot[i]] = (int)i;
   std::vector<char> seen(n_obs, 0), rec_used(K.n_part_rec, 0);
-  // K.slot_map: per (workgroup, batch) a bijection of the batch's landmark lanes onto [0, 64 x tiles of the batch)
-  CHECK(K.slot_map.size() == L.tile.size() * 64);
-  std::vector<int> inv((size_t)grid * K.nb * K.slots, -1);
-  for (int w = 0; w < grid; ++w)
-    for (int t = L.wg_tile_off[w]; t < L.wg_tile_off[w + 1]; ++t) {
-      const int b = (t - L.wg_tile_off[w]) % K.nb;
-      const int n_bt = (L.wg_tile_off[w + 1] - L.wg_tile_off[w] - b + K.nb - 1) / K.nb;
-      for (int lane = 0; lane < 64; ++lane) {
-        const int s = K.slot_map[(size_t)t * 64 + lane];
-        CHECK(s >= 0 && s < 64 * n_bt && s < K.slots && inv[(size_t)(w * K.nb + b) * K.slots + s] < 0);
-        inv[(size_t)(w * K.nb + b) * K.slots + s] = t * 64 + lane;
-      }
-    }
   int64_t n_placed = 0, hist[CK_HMAX + 1] = {};
   for (int w = 0; w < grid; ++w) {
     const int nw = L.wg_cam_off[w + 1] - L.wg_cam_off[w];
@@ -110,12 +97,10 @@ int main(int argc, char** argv) {
             ++n_placed;
             CHECK(K.uv[idx].x == obs[2 * (size_t)i] && K.uv[idx].y == obs[2 * (size_t)i + 1]);
             CHECK(rank1[cam_idx[i]] - 1 == rank);
-            // the landmark slot: a lane of a lane-per-landmark tile of this batch (K.slot_map, inverted below)
-            const int pos = inv[(size_t)(w * K.nb + b) * K.slots + li];
-            CHECK(pos >= 0);
-            const int lt = pos / 64, ll = pos % 64;
-            CHECK(lt >= t0w && lt < L.wg_tile_off[w + 1] && (lt - t0w) % K.nb == b && L.lm_of[(size_t)lt * 64 + ll] == lm_of_obs[i]);
-            CHECK((L.seg[(size_t)lt * 64 + ll] & 255) == ll);
+            // the landmark slot: tile (slot / 64) of this batch, a lane of the landmark
+            const int lt = t0w + b + K.nb * (int)(li / 64);
+            CHECK(lt < L.wg_tile_off[w + 1] && L.lm_of[(size_t)lt * 64 + (li & 63)] == lm_of_obs[i]);
+            CHECK((L.seg[(size_t)lt * 64 + (li & 63)] & 255) == (int)(li & 63));
           }
           if (rank < 0) { CHECK(n_lane == 0); continue; }
           CHECK(n_lane >= 1);
@@ -138,38 +123,6 @@ int main(int argc, char** argv) {
       rec_used[rec] = 1;
     }
   }
-  // structural lower bound of the bank collisions of the forward atomics: a bank-pair class that a half tile hits more
-  // often than the tile has rows must repeat inside a row whatever the order of a chunk's observations over the rows
-  int64_t lb_extra = 0, achieved_extra = 0, half_rows = 0;
-  for (size_t t = 0; t < K.tile.size(); ++t) {
-    const int4 ti = K.tile[t];
-    for (int half = 0; half < 2; ++half) {
-      int deg[32] = {0};
-      int rowmax_sum = 0;
-      for (int j = 0; j < ti.y; ++j) {
-        int occ[32] = {0}, mx = 1;
-        for (int lane = 32 * half; lane < 32 * half + 32; ++lane) {
-          const uint32_t word = K.li[((size_t)ti.w + (j >> 1)) * 64 + lane];
-          const uint32_t s3 = (word >> (16 * (j & 1))) & 0xffffu;
-          if (s3 == CK_NONE) continue;
-          const int cls = (int)((s3 / (uint32_t)K.li_mul) & 31);
-          deg[cls]++;
-          mx = std::max(mx, ++occ[cls]);
-        }
-        rowmax_sum += mx - 1;
-      }
-      int excess = 0;
-      for (int c = 0; c < 32; ++c) excess += std::max(0, deg[c] - ti.y);
-      // excess observations have to sit on top of others: at best each raises a different row's worst multiplicity by one,
-      // at least ceil(excess / rows) rows... the bound used: excess spread over the rows, one level at a time
-      lb_extra += excess > 0 ? std::min(excess, std::max(1, (excess + ti.y - 1) / ti.y) * ti.y) * 0 + ((excess + 0) > ti.y ? excess / 1 : excess) : 0;
-      achieved_extra += rowmax_sum;
-      half_rows += ti.y;
-    }
-  }
-  std::fprintf(stderr, "forward atomics: extra lanes per half row achieved %.4f, structural lower bound (class excess per half tile, "
-               "each excess observation one extra lane in some row) %.4f\n", (double)achieved_extra / std::max<int64_t>(half_rows, 1),
-               (double)lb_extra / std::max<int64_t>(half_rows, 1));
   CHECK(n_placed == n_obs);
   for (int r = 0; r < K.n_part_rec; ++r) CHECK(rec_used[r]);
   for (int h = 1; h <= CK_HMAX; ++h)
