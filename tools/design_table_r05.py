@@ -12,8 +12,9 @@ ROWS = [("bench", "venice-1778 (headline, default command)"), ("bench_driver_fla
         ("bench_final_huber", "final-13682, HUBER"), ("bench_trafalgar", "trafalgar-257"),
         ("bench_trafalgar_per_term_kernels", "trafalgar-257, per-term kernels forced (`POVAR_RES=0`)"), ("bench_ladybug", "ladybug-49"),
         ("bench_ladybug_per_term_kernels", "ladybug-49, per-term kernels forced"), ("bench_deterministic", "venice-1778, `POVAR_DETERMINISTIC=1`")]
-print("| workload | terms/s | term kernel(s) | pair time (events) | bytes per E0 (measured / every array once) | fraction (measured / once) |")
-print("|---|---|---|---|---|---|")
+lines = []
+lines.append("| workload | terms/s | term kernel(s) | pair time (events) | bytes per E0 (measured / every array once) | fraction (measured / once) |")
+lines.append("|---|---|---|---|---|---|")
 for f, name in ROWS:
     path = os.path.join(ROOT, "profiles", f"r05_{f}.json")
     if not os.path.exists(path):
@@ -33,5 +34,11 @@ for f, name in ROWS:
     once = r["once_bytes_per_launch"]
     ms = d["kernel_ms"]["e0"]
     frac_m = f"{tr / (ms * 1e-3) / 8e12:.2f}" if tr else "—"
-    print(f"| {name} | {d['value']:,.0f} | {kern} | {1e3 * ms:.1f} µs | {tr / 1e6:.0f} MB / {once / 1e6:.0f} MB | {frac_m} / {r['once_frac']:.2f} |" if tr else
-          f"| {name} | {d['value']:,.0f} | {kern} | {1e3 * ms:.1f} µs | — / {once / 1e6:.1f} MB | — / {r['once_frac']:.2f} |")
+    lines.append(f"| {name} | {d['value']:,.0f} | {kern} | {1e3 * ms:.1f} µs | {tr / 1e6:.0f} MB / {once / 1e6:.0f} MB | {frac_m} / {r['once_frac']:.2f} |" if tr else
+                 f"| {name} | {d['value']:,.0f} | {kern} | {1e3 * ms:.1f} µs | — / {once / 1e6:.1f} MB | — / {r['once_frac']:.2f} |")
+
+print("\n".join(lines))
+dpath = os.path.join(ROOT, "DESIGN.md")
+s = open(dpath).read()
+a, b = s.index("<!-- R05-TABLE-BEGIN -->"), s.index("<!-- R05-TABLE-END -->")
+open(dpath, "w").write(s[:a] + "<!-- R05-TABLE-BEGIN -->\n" + "\n".join(lines) + "\n" + s[b:])
