@@ -46,6 +46,13 @@ struct CkLayout {
   std::vector<int> bt_off;       // [grid * nb + 1] tiles of (workgroup, batch)
   std::vector<int> slot_rec;     // [lpl wg_cams.size()] partial record each workgroup slot is flushed to
   std::vector<int2> part_range;  // [n_cams] partial records of camera c (by camera index): [first, end)
+  // for the bit-reproducible form of the kernel (e0_ck_det): ceil(log2(number of observations)) that are added into a
+  // landmark slot ([lpl tiles][64], the lane order of V2::lmrec; 255: none -- a lane without a landmark, whose record is
+  // undefined), and the ticket of every run total at its accumulator slot ([tiles][64], at the run's last lane): the order
+  // is batches, then rounds of the tile walk over n_waves wavefronts, then the tiles of a round from the last (shortest)
+  // to the first, then the lanes of a tile -- consistent with every wavefront's program order
+  std::vector<uint8_t> lcnt_log2;
+  std::vector<uint16_t> tick;
   int nb = 1;                    // batches per workgroup
   int li_mul = 3;                // the slot words hold li_mul x slot (CkShape)
   int ng = 1;                    // of which ng are in LDS at the same time (groups of wavefronts)
@@ -139,6 +146,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     double extra = 0;
   };
   std::vector<WgOut> out(grid);
+  std::vector<int> lcnt(L.tile.size() * WAVE, 0);  // (every workgroup writes its own tiles)
   lpl_parallel(grid, n_threads, [&](int w) {
     WgOut& o = out[w];
     o.bt_tiles.assign(nb, 0);
@@ -166,6 +174,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
             ob.li = slot0 + (L.seg[(size_t)t * WAVE + lane] & 255);  // a landmark dealt over several lanes: its first lane's slot
             ob.src = (int)idx;
             obs.push_back(ob);
+            lcnt[(size_t)t * WAVE + (L.seg[(size_t)t * WAVE + lane] & 255)]++;
           }
       }
       o.obs += (int64_t)obs.size();
@@ -317,6 +326,10 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
   }
   K.bt_off[(size_t)grid * nb] = (int)K.tile.size();
   K.n_cold_chunks = n_cold_chunks;
+  auto clog2 = [](int n) { int e = 0; while ((1 << e) < n) ++e; return (uint8_t)(n == 0 ? 255 : e); };  // 255: nothing is added there
+  K.lcnt_log2.resize(lcnt.size());
+  for (size_t i = 0; i < lcnt.size(); ++i) K.lcnt_log2[i] = clog2(lcnt[i]);
+
   // ---- partial records, camera-major: a camera's workgroup slots first, then its cold chunks
   std::vector<int> n_rec(n_cams, 0);  // by rank
   for (size_t s = 0; s < L.wg_cams.size(); ++s) n_rec[L.wg_cams[s]]++;
@@ -357,6 +370,21 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
       }
     });
   }
+  // ---- tickets of the run totals (e0_ck_det)
+  K.tick.assign(K.tile.size() * WAVE, 0);
+  lpl_parallel(grid, n_threads, [&](int w) {
+    std::vector<int> next((size_t)std::max(1, L.wg_cam_off[w + 1] - L.wg_cam_off[w]), 0);
+    for (int b = 0; b < nb; ++b) {
+      const int tb0 = K.bt_off[(size_t)w * nb + b], tb1 = K.bt_off[(size_t)w * nb + b + 1];
+      for (int q0 = tb0; q0 < tb1; q0 += n_waves)
+        for (int t = std::min(q0 + n_waves, tb1) - 1; t >= q0; --t)
+          for (int lane = 0; lane < WAVE; ++lane) {
+            const size_t i = (size_t)t * WAVE + lane;
+            if (K.lane_cam[i] >= 0 && K.lane_acc[i] >= 0 && lane == ((K.lane_seg[i] >> 8) & 255))
+              K.tick[i] = (uint16_t)next[K.lane_acc[i]]++;
+          }
+    }
+  });
 }
 
 }  // namespace povar

@@ -26,6 +26,7 @@
 #include "lpl_layout.hpp"
 #include "ck_layout.hpp"
 #include "povar_kernels_ck.hpp"
+#include "povar_kernels_ck_det.hpp"
 #include "povar_kernels_ck_joint.hpp"
 #include "res_layout.hpp"
 #include "povar_kernels_res.hpp"
@@ -156,6 +157,8 @@ struct povar_ctx {
     DevBuf<int4> tile;
     DevBuf<int2> part_range;
     DevBuf<double> part, w;
+    DevBuf<uint8_t> lcnt;        // e0_ck_det: ceil(log2(observations)) per landmark lane
+    DevBuf<uint16_t> tick;       // e0_ck_det: ticket of every run total
     int nb = 0, slots = 0, n_part_rec = 0, max_acc = 0, max_tiles_bt = 0;
     int64_t rows = 0, li_rows = 0, n_chunks = 0, n_cold_chunks = 0;
     double build_ms = 0;
@@ -164,6 +167,7 @@ struct povar_ctx {
     void release() {
       uv.release(); li.release(); src.release(); lane_meta.release(); bt_off.release();
       slot_rec.release(); tile.release(); part_range.release(); part.release(); w.release();
+      lcnt.release(); tick.release();
       ready = false;
     }
   } ck, pl_ck,       // step 1 (e0_ck): the layout in use / the one the placement thread built for the placed rows
@@ -196,6 +200,7 @@ struct povar_ctx {
   double res_last_tol[2] = {0, 0};
   unsigned res_spin_limit = 1u << 18;
   bool deterministic = false;    // POVAR_DETERMINISTIC=1: the E0 mode and the kernel choices are pinned
+  bool det_ck = false;           // ... and step 1's terms run e0_ck_det where the chunk layout fits (else: the gather form)
   DevBuf<int2> ck_zero_range;    // [n_cams] empty runs: e0_ck leaves no per-observation cold view to the per-camera kernels
   int ck_variant = 0;            // 0: e0_lpl; 1..CK_VARIANTS: e0_ck instantiation (POVAR_CK_VARIANTS)
   int ckh_variant = 0;           // step 2: 0: e0_lpl_h; 1: e0_ck_h
@@ -530,6 +535,7 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
   if (need_uv) up(D.uv, K.uv);  // (step 2's operator does not read the image coordinates)
   up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_meta, meta);
   up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
+  if (c->det_ck && need_uv) { up(D.lcnt, K.lcnt_log2); up(D.tick, K.tick); }
   if (ok) guarded([&] { ok = D.part.alloc((size_t)std::max(K.n_part_rec, 1) * 12, bytes) == hipSuccess; });
   if (ok && c->opt.robust_norm)
     guarded([&] { ok = D.w.alloc(std::max<size_t>(K.uv.size(), 1), bytes) == hipSuccess; });  // (padded like uv)
@@ -542,7 +548,8 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
 }
 CkP ck_params(const povar_ctx* c, const povar_ctx::CkDev& D) {
   return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p,
-             D.nb, D.slots, (unsigned)(D.src.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t))};
+             D.nb, D.slots, (unsigned)(D.src.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t)),
+             D.lcnt.p, D.tick.p, D.max_acc};
 }
 CkP ck_params(const povar_ctx* c) { return ck_params(c, c->ck); }
 // e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight, double-buffered
@@ -560,7 +567,15 @@ CkVariant ck_variant_info(int variant) {
   }
 }
 bool ck_variant_fits(const povar_ctx* c, int variant);
+// (POVAR_DETERMINISTIC: the context is in the gather mode -- its linearisation and preparation kernels have no atomics --
+// and step 1's terms run the fixed-point form of e0_ck on the records those kernels leave in lane order)
+bool ck_det_possible(const povar_ctx* c) {
+  return c->det_ck && c->ck.ready && c->ck.lcnt.p && c->ck.tick.p && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT &&
+         c->ck.nb >= 1 && ck_lds_bytes_det(c->ck.slots, c->ck.max_acc) <= (size_t)CK_LDS_BYTES;
+}
+bool ck_det_active(const povar_ctx* c) { return ck_det_possible(c) && !c->joint; }
 bool ck_active(const povar_ctx* c) {
+  if (c->deterministic) return ck_det_active(c);
   return c->ck_variant > 0 && c->ck.ready && c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
          ck_variant_fits(c, c->ck_variant);
 }
@@ -593,6 +608,15 @@ bool ck_variant_fits(const povar_ctx* c, int variant) {
   return c->ck.ready && c->ck.nb % v.ng == 0 && ck_lds_bytes(c->ck.slots, c->ck.max_acc, v.ng) <= (size_t)CK_LDS_BYTES;
 }
 void launch_e0_ck(povar_ctx* c, const Dp& da) {
+  if (c->deterministic) {  // the bit-reproducible form (povar_kernels_ck_det.hpp)
+    const CkP k = ck_params(c);
+    const size_t lds = ck_lds_bytes_det(c->ck.slots, c->ck.max_acc);
+    if (c->opt.robust_norm)
+      hipLaunchKernelGGL((e0_ck_det<16, 2, true>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ck.part.p);
+    else
+      hipLaunchKernelGGL((e0_ck_det<16, 2, false>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ck.part.p);
+    return;
+  }
   switch (c->ck_variant) {
 #define X(id, nw, sd, db, ng) case id: launch_e0_ck_t<nw, sd, db, ng>(c, da); break;
     POVAR_CK_VARIANTS(X)
@@ -607,7 +631,8 @@ hipError_t ck_set_lds_t() {
   return hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, NG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
 }
 hipError_t ck_set_lds_all() {
-  hipError_t e = hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)e0_ck_det<16, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)e0_ck_det<16, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
 #define X(id, nw, sd, db, ng) if (e == hipSuccess) e = ck_set_lds_t<nw, sd, db, ng>();
   POVAR_CK_VARIANTS(X)
 #undef X
@@ -1094,13 +1119,17 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
       }
     }
   } else {
-    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC;
+    const bool ck_now = ck_active(c);
+    // (the fixed-point e0_ck of the deterministic mode leaves partial records like the LDS-accumulating kernels)
+    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || c->opt.e0_mode == POVAR_E0_TILES_LDSACC || ck_now;
     // ACC: cold observations write q to their camera-major position (q4c); the implicit form also walks the
     // long landmarks inside e0_lm_cached (its own cold view)
-    const bool lik = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->long_in_kernel;
+    const bool lik = (c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && c->long_in_kernel) || ck_now;
     Dp da = acc ? ldsacc_dp(c, lik) : c->d;
-    const bool ck_now = ck_active(c);
-    if (ck_now) ck_dp(c, da);
+    if (ck_now) {
+      ck_dp(c, da);
+      da.long_in_kernel = 1;  // (e0_ck walks every landmark)
+    }
     // peer-to-peer exchange: only inside the term loop (fuse_norms >= 0) of the lane-per-landmark kernels; every other
     // caller (right_mul_e0, PCG) wants the dense, all-reduced y
     const bool p2p_now = c->p2p && fuse_norms >= 0 && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
@@ -1452,10 +1481,16 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   }
   // POVAR_DETERMINISTIC=1: run-to-run BIT-reproducible results for a given device count (SURVEY 8(e) "fixed reduction order
-  // inside a GPU"): the E0 operator in its gather form (POVAR_E0_IMPLICIT: per-landmark wavefront scans, per-camera sums
-  // through the camera-major index -- no atomics anywhere) whatever the caller asked for, and no run-time timing decides a
-  // kernel.  Costs a factor of about two on the term rate at venice-1778 (profiles/r05_experiments.txt); the default mode
-  // accumulates in LDS in arrival order and is reproducible to rounding (1e-15), like the reference's mutex order.
+  // inside a GPU"), whatever E0 mode the caller asked for, and no run-time timing decides a kernel:
+  //   * linearisation, preparation, cost and step 2 run in the gather mode (POVAR_E0_IMPLICIT: per-landmark wavefront scans,
+  //     per-camera sums through the camera-major index -- no atomics anywhere);
+  //   * the terms of step 1's power series -- the hot path -- run e0_ck_det (povar_kernels_ck_det.hpp: the camera-chunk
+  //     kernel with the landmark sums in 64-bit fixed point -- integer adds are associative -- and the accumulator adds in
+  //     ticket order) + cam_cold_sum_binv (a fixed-order sum), on the landmark records and camera image the gather mode's
+  //     kernels leave in lane order anyway.  POVAR_DET_CK=0: the gather form there too (3.7 x slower
+  //     than the default mode on venice-1778, profiles/r05_experiments.txt; also what runs when the chunk layout does not fit).
+  // The default mode accumulates in LDS in arrival order and is reproducible to rounding (1e-15), like the reference's
+  // mutex order.
   if (const char* g = std::getenv("POVAR_DETERMINISTIC")) {
     if (g[0] == '1') {
       c->opt.e0_mode = POVAR_E0_IMPLICIT;
@@ -1463,6 +1498,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       c->ck_variant = c->ckh_variant = 0;
       c->res_mode = 0;
       c->deterministic = true;
+      const char* k = std::getenv("POVAR_DET_CK");
+      c->det_ck = !(k && k[0] == '0');
     }
   }
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
@@ -2606,6 +2643,7 @@ int povar_set_e0_mode(povar_ctx* c, int32_t mode) {
   if (int rc = check_ctx(c)) return rc;
   if (mode != POVAR_E0_IMPLICIT && mode != POVAR_E0_TILES && mode != POVAR_E0_IMPLICIT_LDSACC &&
       mode != POVAR_E0_TILES_LDSACC) return fail(-1, "bad e0 mode");
+  if (c->deterministic) return 0;  // pinned (POVAR_DETERMINISTIC)
   c->opt.e0_mode = mode;
   if (c->linearized) return ensure_tiles(c);
   return 0;
@@ -2841,6 +2879,7 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->placement = c->placement;
   out->placement_ms = c->placer_state.load(std::memory_order_acquire) >= 2 ? c->placement_ms : 0.0;
   out->e0_kernel = c->ck_variant > 0 && c->ck.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC && ck_variant_fits(c, c->ck_variant) ? c->ck_variant : 0;
+  if (c->deterministic) out->e0_kernel = ck_det_possible(c) ? CK_VARIANTS + 1 : 0;  // (the fixed-point form of e0_ck)
   out->ck_ready = c->ck.ready ? 1 : 0;
   out->ck_batches = c->ck.nb;
   out->ck_slots = c->ck.slots;
@@ -2902,6 +2941,7 @@ int povar_set_e0_kernel(povar_ctx* c, int32_t kernel) {
   if (int rc = check_ctx(c)) return rc;
   if (kernel < -1 || kernel > CK_VARIANTS) return fail(-1, "unknown E0 kernel");
   if (kernel > 0 && !c->ck_zero_range.p) return fail(-1, "the camera-chunk layout was not built for this context");
+  if (c->deterministic) return 0;  // pinned (POVAR_DETERMINISTIC)
   if (kernel < 0) {  // back to the library's own choice
     c->ck_auto = true;
     c->ck_tuned = c->ckh_tuned = false;
@@ -2919,6 +2959,7 @@ int povar_set_series_kernel(povar_ctx* c, int32_t mode) {
   if (mode < -1 || mode > 1) return fail(-1, "unknown series kernel");
   if (mode == 1 && !c->res.ready) return fail(-1, "the resident-series layout was not built for this context");
   if (int rc = res_verify(c)) return rc;
+  if (c->deterministic) return 0;  // pinned (POVAR_DETERMINISTIC)
   c->res_mode = mode;
   if (mode < 0) c->res_tuned = false;
   return 0;

@@ -36,6 +36,10 @@ struct CkP {
   const int* slot_rec;   // partial record of each workgroup slot
   int nb, slots;
   unsigned uv_bytes, li_bytes;  // sizes of uv (= w's in doubles x 2) and li: the rows are read through buffer descriptors
+  // the bit-reproducible form (e0_ck_det, povar_kernels_ck_det.hpp)
+  const uint8_t* lcnt;     // [lpl tiles][64] ceil(log2(observations added into the lane's landmark slot)); 255: none
+  const uint16_t* tick;    // [tiles][64] ticket of the lane's run total at its accumulator slot (last lane of a run with a slot)
+  int max_acc;             // accumulator slots the LDS is laid out for
 };
 constexpr int CK_ACC_STRIDE = 13;  // doubles per accumulator slot in LDS (12 used)
 __host__ __device__ inline size_t ck_lds_bytes_dev(int slots, int n_acc, int ng) { return 16 + (size_t)ng * slots * 48 + (size_t)n_acc * CK_ACC_STRIDE * 8 + 64; }

@@ -25,6 +25,9 @@ _WITH_CAMERA_CHUNKS = {"test_gpu_step1", "test_gpu_step2", "test_gpu_fuzz", "tes
 # ... and a fourth time with the RESIDENT power series (series_res, one launch per solve_pOSE; round 5) forced for every
 # step-1 solve in the LDS-accumulating E0 mode of these modules (early exit, robust norms, long landmarks, fuzz)
 _WITH_RESIDENT_SERIES = {"test_gpu_step1", "test_gpu_fuzz"}
+# ... and a fifth time in the bit-reproducible mode (POVAR_DETERMINISTIC=1: gather-mode linearisation, the terms of step 1
+# through the fixed-point form of e0_ck on the lane-per-landmark layout; round 5)
+_WITH_DETERMINISTIC = {"test_gpu_step1", "test_gpu_fuzz"}
 
 
 def pytest_generate_tests(metafunc):
@@ -37,6 +40,8 @@ def pytest_generate_tests(metafunc):
             which.append("camera-chunk")
         if metafunc.module.__name__.split(".")[-1] in _WITH_RESIDENT_SERIES:
             which.append("resident-series")
+        if metafunc.module.__name__.split(".")[-1] in _WITH_DETERMINISTIC:
+            which.append("deterministic")
         metafunc.parametrize("_term_kernels", which, indirect=True)
 
 
@@ -51,6 +56,10 @@ def _term_kernels(request, monkeypatch):
         monkeypatch.setenv("POVAR_LPL_PLACE", "sync")  # the chunk layout belongs to the row order: have it from the start
     if which == "resident-series":
         monkeypatch.setenv("POVAR_RES", "1")
+    if which == "deterministic":
+        monkeypatch.setenv("POVAR_E0_V1", "0")
+        monkeypatch.setenv("POVAR_LPL_PLACE", "sync")
+        monkeypatch.setenv("POVAR_DETERMINISTIC", "1")
     return which
 
 

@@ -29,6 +29,14 @@ def _problem(name):
     return synth.make_bal_problem(name)
 
 
+def _need_layout(li):
+    """The resident layout exists at the sizes of this module -- unless the environment has cut the workgroups it may use
+    (tools/forced_mode_suite.sh: POVAR_RES_WGS=7 runs the small problems of the other modules through a seven-workgroup layout)."""
+    if li.res_ready != 1 and os.environ.get("POVAR_RES_WGS") is not None:
+        pytest.skip("POVAR_RES_WGS leaves no layout at this size")
+    assert li.res_ready == 1 and li.res_wgs >= 1, "the resident layout must exist at this size"
+
+
 def _ctx(p, robust="NONE", **kw):
     from povar_amd import capi
     ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm=robust, e0_mode=capi.E0_IMPLICIT_LDSACC, **kw)
@@ -47,8 +55,7 @@ def test_resident_series_oracle_parity_at_size(name, monkeypatch):
     p = _problem(name)
     orc = O.Oracle(p.n_cams, p.lm_off, p.cam_idx, p.obs)
     ctx = _ctx(p)
-    li = ctx.layout_info()
-    assert li.res_ready == 1 and li.res_wgs >= 1, "the resident layout must exist at this size"
+    _need_layout(ctx.layout_info())
     lms = orc.init_landmarks_pose(ALPHA, p.cams)
     ctx.set_cameras(p.cams)
     ctx.set_landmarks(lms)
@@ -81,7 +88,7 @@ def test_resident_series_against_the_per_term_kernels(name, robust):
     from povar_amd import capi
     p = _problem(name)
     ctx = _ctx(p, robust)
-    assert ctx.layout_info().res_ready == 1
+    _need_layout(ctx.layout_info())
     ctx.set_cameras(p.cams)
     ctx.init_landmarks_pose(ALPHA)
     assert ctx.linearize_pose(ALPHA)

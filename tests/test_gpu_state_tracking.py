@@ -337,36 +337,48 @@ def test_graph_capture_while_the_placement_thread_uploads(monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("robust", ["NONE", "HUBER"])
+@pytest.mark.parametrize("form", ["fixed-point", "gather"])
 @pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778"])
-def test_povar_deterministic_is_bit_reproducible(monkeypatch, name):
+def test_povar_deterministic_is_bit_reproducible(monkeypatch, name, form, robust):
     """POVAR_DETERMINISTIC=1 (fixed reduction order inside a GPU): whatever E0 mode the caller asks for, the
-    context runs the gather form of the operator and no run-time timing picks a kernel -- two contexts on the same problem
-    and repeated solves give BIT-identical increments, model decreases and costs; the default mode agrees with them to
-    rounding."""
+    context linearises and prepares in the gather mode (no atomics), the terms of step 1's series run the fixed-point form
+    of e0_ck (integer LDS adds: associative) -- or, POVAR_DET_CK=0, the gather form of the operator --, and no run-time
+    timing picks a kernel: two contexts on the same problem and repeated solves give BIT-identical increments, terms, model
+    decreases and costs; the default mode agrees with them to rounding (1e-10 on the 20-term increment, as the parity tests
+    against the oracle ask of every mode)."""
     from povar_amd import capi, synth
+    if robust != "NONE" and form == "gather":
+        pytest.skip("one robust case per size is enough for the gather form")
     p = synth.make_bal_problem(name)
+    monkeypatch.setenv("POVAR_DET_CK", "1" if form == "fixed-point" else "0")
 
     def run(det):
         if det:
             monkeypatch.setenv("POVAR_DETERMINISTIC", "1")
         else:
             monkeypatch.delenv("POVAR_DETERMINISTIC", raising=False)
-        ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+        ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, robust_norm=robust, e0_mode=capi.E0_IMPLICIT_LDSACC)
         ctx.layout_finalize(True)
         ctx.set_cameras(p.cams)
         ctx.init_landmarks_pose(0.01)
         assert ctx.linearize_pose(0.01)
+        ctx.set_e0_kernel(0)          # (pinned in the deterministic mode: these calls change nothing there)
+        ctx.set_series_kernel(0)
         incs = [ctx.solve_pose(1e-4, capi.POWER_VARPROJ, 20)[0] for _ in range(2)]
+        term = ctx.get_term()
         ld = ctx.apply_pose(capi.POWER_VARPROJ, 0.01, incs[0])
         cost = ctx.error_pose(0.01).all_error
         li = ctx.layout_info()
         ctx.close()
-        return incs, ld, cost, li
+        return incs, term, ld, cost, li
 
-    (a0, a1), lda, ca, lia = run(True)
-    (b0, b1), ldb, cb, lib = run(True)
-    assert lia.e0_auto == 0 and lia.e0_kernel == 0 and lia.res_active == 0 and lia.res_auto == 0
-    assert np.array_equal(a0, a1) and np.array_equal(a0, b0) and np.array_equal(b0, b1)
+    (a0, a1), ta, lda, ca, lia = run(True)
+    (b0, b1), tb, ldb, cb, lib = run(True)
+    assert lia.e0_auto == 0 and lia.res_active == 0 and lia.res_auto == 0
+    assert lia.e0_kernel == (7 if form == "fixed-point" else 0), "7: the fixed-point form of e0_ck"
+    assert np.array_equal(a0, a1) and np.array_equal(a0, b0) and np.array_equal(b0, b1) and np.array_equal(ta, tb)
     assert lda == ldb and ca == cb
-    (c0, _), ldc, cc, _ = run(False)
+    (c0, _), tc, ldc, cc, _ = run(False)
     assert np.linalg.norm(c0 - a0) <= 1e-10 * np.linalg.norm(a0) and abs(cc / ca - 1) < 1e-9
+    assert np.linalg.norm(tc - ta) <= 1e-9 * np.linalg.norm(ta)
