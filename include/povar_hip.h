@@ -260,8 +260,9 @@ typedef struct {
                            2 being placed on a host thread (the kernels run on the natural order meanwhile),
                            3 placed rows swapped in */
   double placement_ms;  /* host wall time of the background placement (0 until it has finished) */
-  int32_t e0_kernel;    /* per-term E0 kernel of step 1: 0 e0_lpl (lane = landmark, cameras in LDS), > 0: the e0_ck
-                           instantiation in use (lane = camera chunk, landmarks in LDS; povar_set_e0_kernel) */
+  int32_t e0_kernel;    /* per-term E0 kernel of step 1: 0 e0_lpl (lane = landmark, cameras in LDS), 1..6: the e0_ck
+                           instantiation in use (lane = camera chunk, landmarks in LDS; povar_set_e0_kernel); with
+                           POVAR_DETERMINISTIC=1: 7 = e0_ck_det (the bit-reproducible camera-chunk kernel), 0 = the gather form */
   int32_t ck_ready;     /* 1: the camera-chunk layout of the rows in use exists (with the rows placed on a host thread
                            it arrives together with them) */
   int32_t ck_batches, ck_slots;  /* landmark batches per workgroup, landmark slots per batch */

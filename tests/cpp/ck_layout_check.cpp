@@ -125,6 +125,42 @@ int main(int argc, char** argv) {
   }
   CHECK(n_placed == n_obs);
   for (int r = 0; r < K.n_part_rec; ++r) CHECK(rec_used[r]);
+  // ---- what the bit-reproducible kernel (e0_ck_det) reads on top: observation counts per landmark lane, tickets per run total
+  CHECK(K.lcnt_log2.size() == L.tile.size() * 64 && K.tick.size() == K.tile.size() * 64);
+  {
+    std::vector<int> cnt(L.tile.size() * 64, 0);
+    for (int w = 0; w < grid; ++w)
+      for (int b = 0; b < K.nb; ++b)
+        for (int t = K.bt_off[(size_t)w * K.nb + b]; t < K.bt_off[(size_t)w * K.nb + b + 1]; ++t)
+          for (int j = 0; j < K.tile[t].y; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+              const uint32_t word = K.li[((size_t)K.tile[t].w + (j >> 1)) * 64 + lane];
+              const uint32_t li3 = (j & 1) ? word >> 16 : word & 0xffffu;
+              if (li3 == CK_NONE) continue;
+              const uint32_t li = li3 / (uint32_t)K.li_mul;
+              cnt[(size_t)(L.wg_tile_off[w] + b + K.nb * (int)(li / 64)) * 64 + (li & 63)]++;
+            }
+    for (size_t i = 0; i < cnt.size(); ++i) {
+      if (cnt[i] == 0) { CHECK(K.lcnt_log2[i] == 255); continue; }
+      CHECK((1 << K.lcnt_log2[i]) >= cnt[i] && (K.lcnt_log2[i] == 0 || (1 << (K.lcnt_log2[i] - 1)) < cnt[i]));
+    }
+    // tickets: per (workgroup, slot) 0, 1, 2, ... in the order batches -> rounds of n_waves tiles -> tiles of a round from the
+    // last to the first -> lanes; exactly the last lanes of the runs with a slot carry one
+    for (int w = 0; w < grid; ++w) {
+      std::vector<int> next(std::max(1, L.wg_cam_off[w + 1] - L.wg_cam_off[w]), 0);
+      for (int b = 0; b < K.nb; ++b) {
+        const int tb0 = K.bt_off[(size_t)w * K.nb + b], tb1 = K.bt_off[(size_t)w * K.nb + b + 1];
+        for (int q0 = tb0; q0 < tb1; q0 += n_waves)
+          for (int t = std::min(q0 + n_waves, tb1) - 1; t >= q0; --t)
+            for (int lane = 0; lane < 64; ++lane) {
+              const size_t i = (size_t)t * 64 + lane;
+              const bool last = K.lane_cam[i] >= 0 && K.lane_acc[i] >= 0 && lane == (K.lane_seg[i] >> 8);
+              if (last) CHECK(K.tick[i] == next[K.lane_acc[i]]++ && K.tick[i] < 65535);
+              else CHECK(K.tick[i] == 0);
+            }
+      }
+    }
+  }
   for (int h = 1; h <= CK_HMAX; ++h)
     if (hist[h]) std::fprintf(stderr, "tiles of %2d rows: %lld\n", h, (long long)hist[h]);
   std::printf("{\"ok\": 1, \"nb\": %d, \"slots\": %d, \"tiles\": %zu, \"rows\": %lld, \"chunks\": %lld, \"cold_chunks\": %lld, "

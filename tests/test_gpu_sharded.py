@@ -181,3 +181,56 @@ def test_sharded_explicit_sc_solvers_match_single(world):
             inc_r, it_r, st_r, rc_r = ref[key]
             assert rc == 0 and (it, st) == (it_r, st_r) and rel(inc, inc_r) < tol, key
         assert np.array_equal(o["pcg"][0], out[0]["pcg"][0])
+
+
+def test_sharded_deterministic_mode(monkeypatch):
+    """POVAR_DETERMINISTIC=1 with two landmark shards: the shards' terms run e0_ck_det, the
+    per-camera sums and the exchange have a fixed order -- two runs of the two-shard pipeline give BIT-identical increments,
+    model decreases and costs, and the two-shard increment is within 1e-13 of the one-context one (a different, equally fixed
+    summation tree)."""
+    from povar_amd import capi, synth
+    monkeypatch.setenv("POVAR_DETERMINISTIC", "1")
+    p = synth.make_bal_problem("trafalgar-257")
+    world = 2
+
+    def single():
+        ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC)
+        ctx.set_cameras(p.cams)
+        ctx.init_landmarks_pose(ALPHA)
+        assert ctx.linearize_pose(ALPHA)
+        inc = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0]
+        kern = ctx.layout_info().e0_kernel
+        ctx.close()
+        return inc, kern
+
+    def sharded():
+        ar = HostAllReduce(world)
+        out = [None] * world
+
+        def worker(rank):
+            lb, le = capi.shard_range(p.lm_off, world, rank)
+            ob, oe = int(p.lm_off[lb]), int(p.lm_off[le])
+            ctx = capi.Context(p.n_cams, p.lm_off[lb:le + 1] - p.lm_off[lb], p.cam_idx[ob:oe], p.obs[ob:oe], e0_mode=capi.E0_IMPLICIT_LDSACC)
+            ctx.comm_init_host(world, rank, ar.fn(rank))
+            ctx.set_cameras(p.cams)
+            ctx.init_landmarks_pose(ALPHA)
+            ok = ctx.linearize_pose(ALPHA)
+            inc, it, st, rc = ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)
+            ld = ctx.apply_pose(capi.POWER_VARPROJ, ALPHA, inc)
+            cost = ctx.error_pose(ALPHA).all_error
+            out[rank] = dict(ok=ok, rc=rc, inc=inc, ld=ld, cost=cost, kern=ctx.layout_info().e0_kernel)
+            ctx.close()
+
+        th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join(timeout=300) for t in th]
+        assert all(o is not None and o["ok"] and o["rc"] == 0 for o in out)
+        return out
+
+    inc1, kern1 = single()
+    a, b = sharded(), sharded()
+    assert kern1 == 7 and all(o["kern"] == 7 for o in a), "e0_ck_det on the one context and on both shards"
+    for r in range(world):
+        assert np.array_equal(a[r]["inc"], b[r]["inc"]) and a[r]["ld"] == b[r]["ld"] and a[r]["cost"] == b[r]["cost"]
+        assert np.array_equal(a[r]["inc"], a[0]["inc"])
+    assert rel(a[0]["inc"], inc1) < 1e-13
