@@ -537,8 +537,8 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
   up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
   if (c->det_ck && need_uv) { up(D.lcnt, K.lcnt_log2); up(D.tick, K.tick); }
   if (ok) guarded([&] { ok = D.part.alloc((size_t)std::max(K.n_part_rec, 1) * 12, bytes) == hipSuccess; });
-  if (ok && c->opt.robust_norm)
-    guarded([&] { ok = D.w.alloc(std::max<size_t>(K.uv.size(), 1), bytes) == hipSuccess; });  // (padded like uv)
+  if (ok && c->opt.robust_norm && !need_uv)  // (step 2's kernel reads the weights in chunk order; step 1's recomputes them)
+    guarded([&] { ok = D.w.alloc(std::max<size_t>(K.src.size(), 1), bytes) == hipSuccess; });  // (padded like the rows)
   D.nb = K.nb; D.slots = K.slots; D.n_part_rec = K.n_part_rec; D.max_acc = K.max_acc; D.max_tiles_bt = K.max_tiles_bt;
   D.rows = K.rows; D.li_rows = K.li_rows; D.n_chunks = K.n_chunks; D.n_cold_chunks = K.n_cold_chunks;
   D.w_lin_id = -1;
@@ -597,7 +597,7 @@ template <int NW, int SD, bool DB, int NG>
 void launch_e0_ck_t(povar_ctx* c, const Dp& da) {
   const CkP k = ck_params(c);
   const size_t lds = ck_lds_bytes(c->ck.slots, c->ck.max_acc, NG);
-  if (c->opt.robust_norm)
+  if (c->opt.robust_norm == POVAR_NORM_HUBER)  // (the kernel recomputes the weights; CAUCHY's are 1: compute_error_weight)
     hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, true>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
   else
     hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, false>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
@@ -611,7 +611,7 @@ void launch_e0_ck(povar_ctx* c, const Dp& da) {
   if (c->deterministic) {  // the bit-reproducible form (povar_kernels_ck_det.hpp)
     const CkP k = ck_params(c);
     const size_t lds = ck_lds_bytes_det(c->ck.slots, c->ck.max_acc);
-    if (c->opt.robust_norm)
+    if (c->opt.robust_norm == POVAR_NORM_HUBER)
       hipLaunchKernelGGL((e0_ck_det<16, 2, true>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ck.part.p);
     else
       hipLaunchKernelGGL((e0_ck_det<16, 2, false>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ck.part.p);
@@ -2794,7 +2794,7 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
         // the 72-byte landmark records once, 8 bytes of lane metadata per chunk lane and pass, the partial records out
         // (one per workgroup slot + one per chunk of a camera without a slot); the per-camera kernel reads those back
         const int64_t part = (int64_t)c->ck.n_part_rec * 96;
-        lm = 2 * c->ck.rows * WAVE * (18 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * 72 + cam_static +
+        lm = 2 * c->ck.rows * WAVE * 18 /* no weight array: recomputed (ck_huber_w) */ + (int64_t)c->d.v2.n_tiles * WAVE * 72 + cam_static +
              2 * (int64_t)(c->ck.lane_meta.n) * 8 + part;
         cm = part + tail;
         break;

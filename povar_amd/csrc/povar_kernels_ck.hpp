@@ -14,7 +14,9 @@
 // A batch = the lane-per-landmark tiles {b, b + NB, ...} of the workgroup (ck_layout.hpp), so V2::lmrec -- written by
 // prepare_lpl in lane order -- is read as it stands.  Phases per batch, separated by workgroup barriers:
 //   load h~ -> forward (all chunk tiles) -> g = G u per landmark slot -> backward (all chunk tiles).
-// Every row (18 bytes per observation) is read on both passes.  (Keeping the rows of a batch in registers between the
+// Every row (18 bytes per observation) is read on both passes.  With the HUBER norm the observation's weight is NOT a third
+// row array (8 bytes per observation and pass more: round 4): the lane recomputes it from what it holds anyway -- the camera
+// at the linearisation point (P3 and the translation column, registers), the landmark (LDS) and the image point (ck_huber_w).  (Keeping the rows of a batch in registers between the
 // passes was built and measured: at the four wavefronts per SIMD the kernel needs for latency there are 128 VGPRs per
 // lane, the forward pass alone needs ~120 of them, and with 8 or 12 wavefronts per workgroup it ran twice as long.)
 #pragma once
@@ -82,6 +84,27 @@ __device__ inline void ck_forward_math(const LplObs& o, const double* zz, const 
   red[2] = P3[2] * a0 + P3[5] * a1 + P3[8] * a2;
 }
 
+// The HUBER weight of an observation at the linearisation point (compute_error_weight, bal_bundle_adjustment_helper.cpp:52-74,
+// on the pOSE residual :250-261), from the camera P = [P3 | t] (P3[0..8] row-major, P3[9..11] = t), the landmark and the
+// image point: with p = P3 h + t the residual is (sb (p0 - u p2), sb (p1 - v p2), sa (p0 - u), sa (p1 - v)).
+// (The lane-per-landmark linearisation stores the same number in V2::w; the two differ by rounding only, and the weight
+// is continuous where the norm switches branches.)
+__device__ inline double ck_huber_w(const Dp& d, const double* P3, double hx, double hy, double hz, double2 uv) {
+  const double p0 = P3[0] * hx + P3[1] * hy + P3[2] * hz + P3[9];
+  const double p1 = P3[3] * hx + P3[4] * hy + P3[5] * hz + P3[10];
+  const double p2 = P3[6] * hx + P3[7] * hy + P3[8] * hz + P3[11];
+  const double a = p0 - uv.x * p2, b = p1 - uv.y * p2, c = p0 - uv.x, e = p1 - uv.y;
+  const double r2 = d.sb * d.sb * (a * a + b * b) + d.sa * d.sa * (c * c + e * e);
+  // w = min(1, t / sqrt(r2)) without the division and the square root (some sixty instructions whenever one lane of the
+  // wavefront has an outlier): the hardware's reciprocal square root (about 2^-26) and two Newton steps, every lane
+  const double t = d.huber;
+  double y = __builtin_amdgcn_rsq(r2);
+  const double hr = 0.5 * r2;
+  y = y * __builtin_fma(-hr * y, y, 1.5);
+  y = y * __builtin_fma(-hr * y, y, 1.5);
+  return r2 < t * t ? 1.0 : t * y;
+}
+
 // One observation forward: u_l += P3^T (w C (Z h~_l)); backward: y_c += h~_l (x) (w C (P3 g_l))
 __device__ inline void ck_obs_forward(const Dp& d, double2 uv, double w, const double* zz, const double* P3, double hx, double hy,
                                       double hz, double* lu, int S, uint32_t s) {
@@ -116,7 +139,7 @@ __device__ inline void ck_obs_backward(const Dp& d, double2 uv, double w, const 
 // landmark slots of an li word then sit at a static shift.
 // buffer descriptors of the row arrays (wave-uniform: built once per kernel from kernel arguments)
 struct CkRows {
-  __amdgpu_buffer_rsrc_t uv, li, w;
+  __amdgpu_buffer_rsrc_t uv, li, w;  // (w: step 2's e0_ck_h only)
 };
 __device__ inline CkRows ck_rows(const CkP& k) {
   CkRows R;
@@ -129,13 +152,11 @@ template <int D, bool ROBUST>
 struct CkStream {
   double2 uv[D];
   uint32_t w[D];
-  double rw[D];
   __device__ inline void clear() {
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       uv[i] = make_double2(0, 0);
       w[i] = 0xffffffffu;
-      rw[i] = 1.0;
     }
   }
   // buffer i <- row j of the tile (j clamped into the tile: a request past its end re-reads its last row -- a cache hit --
@@ -149,14 +170,9 @@ struct CkStream {
     const unsigned ul = (unsigned)lane;
     const unsigned ro = (unsigned)(row0 + j) * (unsigned)(WAVE * 16), lo = (unsigned)(li0 + (j >> 1)) * (unsigned)(WAVE * 4);
     typedef unsigned __attribute__((ext_vector_type(4))) u4;
-    typedef unsigned __attribute__((ext_vector_type(2))) u2;
     const u4 a = __builtin_amdgcn_raw_buffer_load_b128(R.uv, ul * 16u, ro, 0);
     uv[i] = make_double2(__longlong_as_double(((long long)a.y << 32) | a.x), __longlong_as_double(((long long)a.w << 32) | a.z));
     w[i] = __builtin_amdgcn_raw_buffer_load_b32(R.li, ul * 4u, lo, 0);
-    if (ROBUST) {
-      const u2 b = __builtin_amdgcn_raw_buffer_load_b64(R.w, ul * 8u, ro >> 1, 0);
-      rw[i] = __longlong_as_double(((long long)b.y << 32) | b.x);
-    }
   }
   // step n of the walk is row n (DIR = +1) or row h - 1 - n (DIR = -1: the way back starts with the rows the way forward
   // read last, the ones most likely still in the XCD's L2); buffer n % D holds it
@@ -172,10 +188,10 @@ __device__ inline void ck_forward_step(const Dp& d, const CkRows& k, CkStream<D,
                                        const double* zz, const double* P3, const double* lh, double* lu, int S, int j, int i) {
   const double2 uv = st.uv[i];
   const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
-  const double rw = ROBUST ? st.rw[i] : 1.0;
   st.load(k, row0, li0, j + D, h, lane, i);
   if (s != 0xffffu) {
     const double hx = lh[s], hy = lh[s + 1], hz = lh[s + 2];  // (s = 3 x slot: ck_layout.hpp)
+    const double rw = ROBUST ? ck_huber_w(d, P3, hx, hy, hz, uv) : 1.0;
     ck_obs_forward(d, uv, rw, zz, P3, hx, hy, hz, lu, S, s);
   }
 }
@@ -197,10 +213,10 @@ __device__ inline void ck_backward_step(const Dp& d, const CkRows& k, CkStream<D
                                         const double* P3, const double* lh, const double* lg, int S, double* y, int j, int i) {
   const double2 uv = st.uv[i];
   const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
-  const double rw = ROBUST ? st.rw[i] : 1.0;
   st.load(k, row0, li0, j - D, h, lane, i);
   if (s != 0xffffu) {
     const double hx = lh[s], hy = lh[s + 1], hz = lh[s + 2];
+    const double rw = ROBUST ? ck_huber_w(d, P3, hx, hy, hz, uv) : 1.0;
     const double g[3] = {lg[s], lg[s + 1], lg[s + 2]};
     ck_obs_backward(d, uv, rw, P3, hx, hy, hz, g, y);
   }
@@ -242,6 +258,18 @@ __device__ inline void ck_load_p3(const Dp& d, int rank, double* P3) {
     P3[2 * j + 1] = v.y;
   }
   P3[8] = d.hot_rec[(size_t)rank * HOT_REC_STRIDE + 20];
+}
+// ... and its translation column (entries 21..23 of the record: build_hot_rec), for ck_huber_w
+template <bool ROBUST>
+__device__ inline void ck_load_p(const Dp& d, int rank, double* P3) {
+  ck_load_p3(d, rank, P3);
+  if (ROBUST) {
+    const double* r = d.hot_rec + (size_t)rank * HOT_REC_STRIDE;
+    P3[9] = r[21];
+    const double2 v = reinterpret_cast<const double2*>(r)[11];
+    P3[10] = v.x;
+    P3[11] = v.y;
+  }
 }
 
 // end of a tile's backward pass: the chunk sums go to the camera's accumulator in LDS (lanes that share one are summed
@@ -355,7 +383,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     int q_t = 0;  // round of the tile walk
     int t = tile_of(tb0, 0);
     int rank = rank_next;
-    double zz[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, P3[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double zz[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, P3[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (P3[9..11]: t, HUBER only)
     CkStream<SD, ROBUST> st;
     st.clear();
     int row0 = 0, h = 0, fl = 0, li0 = 0;
@@ -370,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     // four wavefronts with a second tile the tail of every pass.
     int tn = tile_of(tb0, 1);
     int rank_n = 0, rank_nn = 0;
-    double zn[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, Pn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double zn[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, Pn[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     CkStream<SD, ROBUST> stn;
     stn.clear();
     int row0n = 0, hnx = 0, fln = 0, li0n = 0;
@@ -380,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
       const int rk = rank < 0 ? 0 : rank;
       ck_load_z(d, rk, zz);
-      ck_load_p3(d, rk, P3);
+      ck_load_p<ROBUST>(d, rk, P3);
       st.template start<1>(R, row0, li0, h, lane);
     }
     // ---- landmark coordinates of the batch into LDS (requested a phase ago), u = 0
@@ -415,7 +443,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         if (tnn < tb1) rank_nn = ck_rank(k.lane_meta[(size_t)tnn * WAVE + lane].x);
         const int rk = rank_n < 0 ? 0 : rank_n;
         ck_load_z(d, rk, zn);
-        ck_load_p3(d, rk, Pn);
+        ck_load_p<ROBUST>(d, rk, Pn);
         stn.template start<1>(R, row0n, li0n, hnx, lane);
       }
     };
@@ -433,7 +461,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
 #pragma unroll
         for (int e = 0; e < 12; ++e) zz[e] = zn[e];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) P3[e] = Pn[e];
+        for (int e = 0; e < (ROBUST ? 12 : 9); ++e) P3[e] = Pn[e];
         st = stn;
         row0 = row0n; h = hnx; li0 = li0n;
         rank_n = rank_nn;
@@ -443,7 +471,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
         const int rk = rank < 0 ? 0 : rank;
         ck_load_z(d, rk, zz);
-        ck_load_p3(d, rk, P3);
+        ck_load_p<ROBUST>(d, rk, P3);
         st.template start<1>(R, row0, li0, h, lane);
       }
     }
@@ -513,7 +541,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
           seg_pp = ck_seg(mp.x);
           acc_pp = mp.y;
         }
-        ck_load_p3(d, rank_p < 0 ? 0 : rank_p, Pn);
+        ck_load_p<ROBUST>(d, rank_p < 0 ? 0 : rank_p, Pn);
         stn.template start<-1>(R, row0n, li0n, hnx, lane);
       }
     };
@@ -533,7 +561,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       tp = q_t > 0 ? tile_of(tb0, q_t - 1) : tb1;
       if (DB) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) P3[e] = Pn[e];
+        for (int e = 0; e < (ROBUST ? 12 : 9); ++e) P3[e] = Pn[e];
         st = stn;
         row0 = row0n; h = hnx; fl = fln; li0 = li0n;
         rank_p = rank_pp; acc_p = acc_pp; seg_p = seg_pp;
@@ -546,7 +574,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
           seg_p = ck_seg(mp.x);
           acc_p = mp.y;
         }
-        ck_load_p3(d, rank < 0 ? 0 : rank, P3);
+        ck_load_p<ROBUST>(d, rank < 0 ? 0 : rank, P3);
         st.template start<-1>(R, row0, li0, h, lane);
       }
     }

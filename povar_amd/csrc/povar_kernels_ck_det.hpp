@@ -52,10 +52,10 @@ __device__ inline void ckd_forward_step(const Dp& d, const CkRows& k, CkStream<D
                                         const double* zz, const double* P3, const double* lh, double* lu, const short* lexp, int j, int i) {
   const double2 uv = st.uv[i];
   const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
-  const double rw = ROBUST ? st.rw[i] : 1.0;
   st.load(k, row0, li0, j + D, h, lane, i);
   if (s != 0xffffu) {
     const double hx = lh[s], hy = lh[s + 1], hz = lh[s + 2];  // (s = 3 x slot)
+    const double rw = ROBUST ? ck_huber_w(d, P3, hx, hy, hz, uv) : 1.0;
     LplObs o;
     o.set(d, uv, rw);
     double red[3];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_det(Dp d, CkP k, double* part_o
       lu[3 * s + 1] = 0;
       lu[3 * s + 2] = 0;
     }
-    double zz[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, P3[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double zz[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, P3[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     CkStream<SD, ROBUST> st;
     st.clear();
     // first tile of the first walk: in flight across the barrier
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_det(Dp d, CkP k, double* part_o
       if (t < tb1) {
         const int rank = ck_rank(k.lane_meta[(size_t)t * WAVE + lane].x), rk = rank < 0 ? 0 : rank;
         ck_load_z(d, rk, zz);
-        ck_load_p3(d, rk, P3);
+        ck_load_p<ROBUST>(d, rk, P3);
         st.template start<1>(R, tiles[4 * t], tiles[4 * t + 3], tiles[4 * t + 1], lane);
       }
     }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_det(Dp d, CkP k, double* part_o
         if (q > 0 || (pass > 0 && !one_tile)) {
           const int rank = ck_rank(k.lane_meta[(size_t)t * WAVE + lane].x), rk = rank < 0 ? 0 : rank;
           ck_load_z(d, rk, zz);
-          ck_load_p3(d, rk, P3);
+          ck_load_p<ROBUST>(d, rk, P3);
         }
         if (q > 0 || pass > 0) st.template start<1>(R, row0, li0, h, lane);
         if (pass == 0) ckd_forward_rows<SD, ROBUST, 0>(d, R, st, row0, li0, h, lane, zz, P3, lh, lu, lexp);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_det(Dp d, CkP k, double* part_o
       const int2 me = k.lane_meta[(size_t)t * WAVE + lane];
       const int rank = ck_rank(me.x), seg = ck_seg(me.x), acc_slot = me.y;
       const int my_ticket = k.tick[(size_t)t * WAVE + lane];
-      if (q > 0 || !one_tile) ck_load_p3(d, rank < 0 ? 0 : rank, P3);
+      if (q > 0 || !one_tile) ck_load_p<ROBUST>(d, rank < 0 ? 0 : rank, P3);
       st.template start<-1>(R, row0, li0, h, lane);
       double y[12];
 #pragma unroll
