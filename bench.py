@@ -57,7 +57,7 @@ def kernel_source_sha():
     """Stamp of the device code the PMC traffic figures in profiles/traffic.json were measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_joint.hpp", "povar_hip.hip",
+    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_det.hpp", "povar_kernels_ck_joint.hpp", "povar_hip.hip",
               "lpl_layout.hpp", "ck_layout.hpp", "povar_kernels_res.hpp", "res_layout.hpp"):
         with open(os.path.join(ROOT, "povar_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
@@ -522,7 +522,8 @@ def main():
     achieved = model_bytes / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
     effective = bytes_e0 / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
     li0 = ctx.layout_info()
-    once_bytes = model_bytes - (li0.ck_rows * 64 * (18 + (8 if args.robust_norm != "NONE" else 0))
+    # "every array once": the chunk kernels read their 18-byte rows on every walk (e0_ck: 2, e0_ck_det: 3)
+    once_bytes = model_bytes - (li0.ck_rows * 64 * 18 * (2 if li0.e0_kernel == 7 else 1)
                                 if args.step == 1 and li0.e0_kernel > 0 else 0)  # (step 2's rows are 2-4 bytes: no correction)
     if series_resident:
         # what ONE term of the resident kernel moves: every (workgroup, camera) pair reads the camera's z (192 B of granule
@@ -585,7 +586,9 @@ def main():
         "device_bytes": ctx.device_bytes(),
         "roofline": {
             "bound": "hbm",
-            "kernel": {capi.E0_IMPLICIT: "E0 x (e0_lm_cached<false> + cm_scatter)",
+            "kernel": "E0 x (e0_ck_det + cam_cold_sum_binv: POVAR_DETERMINISTIC=1)" if ctx.layout_info().e0_kernel == 7 else
+                      "E0 x (e0_lm_cached<false> + cm_scatter: POVAR_DETERMINISTIC=1, gather form)" if os.environ.get("POVAR_DETERMINISTIC") == "1" else
+                      {capi.E0_IMPLICIT: "E0 x (e0_lm_cached<false> + cm_scatter)",
                        capi.E0_IMPLICIT_LDSACC: (("one term of series_res (resident power series: E0 x, B^-1, AXPY in ONE launch per solve)" if series_resident
                                                   else "E0 x (e0_ck_h + cam_cold_sum[_binv]_h)" if args.step == 2 and ctx.layout_info().e0_kernel_h > 0
                                                   else "E0 x (e0_lpl_h + cam_cold_sum[_binv]_h)" if args.step == 2

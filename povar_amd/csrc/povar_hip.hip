@@ -2787,6 +2787,15 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
   const int64_t hot_flush = lpl ? (int64_t)c->v2_part.n * 8 : acc ? (int64_t)c->e0c_grid * c->n_hot_acc * 96 : 0;
   const int64_t tail = nc * (1152 + 96 /*sigma*/ + 3 * 96 /*accum rw, tmp*/ + 96 /*z*/);
   int64_t lm = 0, cm = 0;
+  if (c->deterministic && ck_active(c)) {
+    // e0_ck_det: as e0_ck below with the rows THREE times (two walks forward, one back), the landmark records twice (h~, G),
+    // and 1 + 2 bytes of counts / tickets per landmark lane / chunk lane
+    const int64_t part = (int64_t)c->ck.n_part_rec * 96;
+    *lm_kernel = 3 * c->ck.rows * WAVE * 18 + (int64_t)c->d.v2.n_tiles * WAVE * (72 + 1) + cam_static +
+                 4 * (int64_t)(c->ck.lane_meta.n) * 8 + (int64_t)c->ck.lane_meta.n * 2 + part;
+    *cam_kernel = part + tail;
+    return 0;
+  }
   switch (c->opt.e0_mode) {
     case POVAR_E0_IMPLICIT_LDSACC:
       if (ck_active(c)) {

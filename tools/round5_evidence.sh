@@ -6,6 +6,7 @@
 #   stamps.txt   in-kernel phase stamps of e0_ck (diagnostic build: tools/variants/build_variant.sh ck_stamps stamps)
 #   res_*        the resident power series: per-term times against the per-term kernels (tools/res_term_time.py), in-kernel
 #                phase stamps (tools/variants/res_stamps.py + tools/res_stamps_report.py), kernel trace of both forms
+#   det_*        POVAR_DETERMINISTIC=1: tools/det_probe.py (time per term, bit identity, distance from the default mode), kernel trace
 #   bench_*.json plain bench lines (the library's own kernel choice unless the name says otherwise)
 #   sweep.txt    e0_ck against e0_lpl over the graph families (tools/ck_sweep.sh)
 #   shards.txt   sharded term times on one GPU (tools/shard_sweep.sh)
@@ -46,6 +47,11 @@ POVAR_E0_CK=0 $B --step 2 > $out/bench_step2_forced_e0_lpl_h.json 2> /dev/null <
 $B --step 2 --robust-norm HUBER > $out/bench_step2_huber.json 2> /dev/null < /dev/null
 $B --problem final-13682 --robust-norm HUBER --huber 20 --steps 5 --warmup 1 > $out/bench_final_huber.json 2> /dev/null < /dev/null
 POVAR_DETERMINISTIC=1 $B --steps 40 > $out/bench_deterministic.json 2> /dev/null < /dev/null
+POVAR_DETERMINISTIC=1 POVAR_DET_CK=0 $B --steps 40 > $out/bench_deterministic_gather.json 2> /dev/null < /dev/null
+POVAR_DETERMINISTIC=1 $B --steps 40 --robust-norm HUBER > $out/bench_deterministic_huber.json 2> /dev/null < /dev/null
+(for a in "venice-1778 NONE" "venice-1778 HUBER" "trafalgar-257 NONE" "final-13682 HUBER 5"; do timeout 600 python3 tools/det_probe.py $a 2>&1; done) > $out/det_probe.txt < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/det_kt -- python3 tools/det_probe.py venice-1778 NONE 5 > $out/det_kt.out 2>&1 < /dev/null
+rm -rf $out/det_kt/*/*kernel_trace.csv
 bash tools/ck_sweep.sh $out/sweep_raw.txt 1 > $out/sweep.txt 2>&1 < /dev/null
 bash tools/shard_sweep.sh > $out/shards.txt 2>&1 < /dev/null
 (echo "# rank 0's shard of final-13682 HUBER at world = 8 (what one rank of BASELINE config 5 executes)"; POVAR_FORCE_COMM=1 python3 tools/shard_term_time.py 8 final-13682 2>&1 | grep "world=") >> $out/shards.txt 2>&1 < /dev/null
