@@ -1593,6 +1593,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   const int ck_ng = ckv.ng;
   const bool ck_place = std::getenv("POVAR_CK_NOPLACE") == nullptr;  // LDS bank placement of the chunk rows (ck_layout.hpp)
   if (const char* e = std::getenv("POVAR_CK_HMAX")) ck_hmax = std::min(CK_HMAX, std::max(1, std::atoi(e)));
+  const CkShape ck_shape1 = c->det_ck ? ck_shape_det() : CkShape();  // (step 1's layout: batches cut for the kernel that runs them)
 
   // The arrays of the lane-per-observation kernels (part B) are built on a second host thread while this one builds
   // and uploads the lane-per-landmark layout: the two only share the slot numbers and camera ranks of part A.
@@ -1629,7 +1630,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (place_mode == 2 && want_ck && !V.tile.empty()) {
       const auto tk = std::chrono::steady_clock::now();
       ck_nat.reset(new CkLayout());
-      build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, *ck_nat, ck_place, ck_hmax, ck_ng);
+      build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, *ck_nat, ck_place, ck_hmax, ck_ng, ck_shape1);
       c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
       if (std::getenv("POVAR_CKH_EARLY") != nullptr) {
         ckh_nat.reset(new CkLayout());
@@ -1656,7 +1657,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       const int dev = options->device, grid = c->e0c_grid, n_acc = c->n_hot_acc;
       const size_t n_slots = (size_t)c->n_slots;
       c->placer_state.store(1);
-      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax, ck_ng, ck_place]() {
+      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax, ck_ng, ck_place, ck_shape1]() {
         const auto t0 = std::chrono::steady_clock::now();
         LplLayout P;
         bool built = true;
@@ -1690,7 +1691,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
           try {
             const auto tk = std::chrono::steady_clock::now();
             CkLayout K;
-            build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, ck_place, ck_hmax, ck_ng);
+            build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, ck_place, ck_hmax, ck_ng, ck_shape1);
             c->pl_ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
             if (!c->placer_cancel.load()) ck_upload(c, c->pl_ck, K, true, &c->pl_bytes);
             if (!c->placer_cancel.load()) {  // step 2's instance
@@ -1752,7 +1753,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       } else {  // (step 2's, and both of the placed rows, come from the host thread with place_mode 2)
         const auto tk = std::chrono::steady_clock::now();
         CkLayout K;
-        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, ck_place, ck_hmax, ck_ng);
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, ck_place, ck_hmax, ck_ng, ck_shape1);
         c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
         if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
         CkLayout KH;  // step 2's instance: 64 bytes of LDS per landmark slot, no image coordinates
