@@ -50,5 +50,19 @@ for i, nm in ((8 * nb, "last barrier"), (8 * nb + 1, "flushed")):
 for i, nm in ((20, 'b0 fwd tile0 done'), (21, 'b0 tile1 issued'), (22, 'b0 fwd tile1 done')):
     v = np.median(s[:, :nw, i] - t0, axis=0)
     print(f"   {nm:14s}" + "".join(f"{x / 1000:7.1f}" for x in v))
-hs = np.zeros((nw, 3))
+# Who does a barrier wait for?  Per workgroup: the wavefront that reaches "fwd done" / "bwd done" LAST, how far behind the
+# workgroup's median wavefront it is, whether it walked a second tile (stamp 22 set), and what is left between its arrival
+# and the barrier opening (the drain of its LDS traffic + the barrier itself)
+for b in range(nb):
+    for i_done, i_bar, nm in ((8 * b + 4, 8 * b + 5, "forward"), (8 * b + 7, 8 * b + 8 if b + 1 < nb else 8 * nb, "backward")):
+        done = s[:, :nw, i_done] - t0
+        bar = np.median(s[:, :nw, i_bar] - t0, axis=1)
+        last = done.argmax(axis=1)
+        lag = done.max(axis=1) - np.median(done, axis=1)
+        two = (s[np.arange(li.grid), last, 22] > 0) if b == 0 and nm == "forward" else None
+        hist = np.bincount(last, minlength=nw)
+        print(f"b{b} {nm}: last wavefront by index " + " ".join(str(x) for x in hist) +
+              f"; it is {np.median(lag) / 1000:.1f} k cycles behind the workgroup's median wavefront (90 %: {np.percentile(lag, 90) / 1000:.1f});"
+              f" last 'done' -> barrier open {np.median(bar - done.max(axis=1)) / 1000:.1f} k" +
+              (f"; the last one walked a second tile in {int(two.sum())} of {li.grid} workgroups" if two is not None else ""))
 ctx.close()
