@@ -361,11 +361,22 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       }
     }
   };
+  // The tile ranges of the workgroup's batches: from LDS after the first batch (sixteen spare ints behind the accumulators),
+  // and the next batch's first requests are issued BEHIND the barrier that ends the way forward: every scalar load -- each
+  // workgroup's first touch of its bt_off entries is a miss all the way -- counts against the lgkmcnt(0) in front of a
+  // barrier (in-kernel stamps: that barrier opened 9.0 k cycles after the last wavefront's last row in the first batch,
+  // 4.1 k in the last one, which requests no next batch; now 4.0 k in both)
+  int* lbt = reinterpret_cast<int*>(acc + (size_t)k.max_acc * CK_ACC_STRIDE);
+  const bool bt_lds = k.nb + 1 <= 16;
+  if (bt_lds && (int)threadIdx.x <= k.nb) lbt[threadIdx.x] = k.bt_off[blockIdx.x * k.nb + threadIdx.x];
+  auto bt_of = [&](int i, bool first) {
+    return (bt_lds && !first) ? __builtin_amdgcn_readfirstlane(lbt[i]) : bt[blockIdx.x * k.nb + i];
+  };
   int rank_next = 0;  // camera ranks of the wavefront's first tile of the next batch (requested with hn)
   auto request_first_meta = [&](int b, int lane) {
     rank_next = 0;
     if (b < k.nb) {
-      const int tb0 = bt[blockIdx.x * k.nb + b], tb1 = bt[blockIdx.x * k.nb + b + 1];
+      const int tb0 = bt_of(b, b == grp), tb1 = bt_of(b + 1, b == grp);
       if (tb0 + wave < tb1) rank_next = ck_rank(k.lane_meta[(size_t)(tb0 + wave) * WAVE + lane].x);
     }
   };
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     // VGPRs held across the way back; the row loop's camera record went to scratch: 8 reloads per row).
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    const int tb0 = bt[blockIdx.x * k.nb + b], tb1 = bt[blockIdx.x * k.nb + b + 1];
+    const int tb0 = bt_of(b, b == grp), tb1 = bt_of(b + 1, b == grp);
     int q_t = 0;  // round of the tile walk
     int t = tile_of(tb0, 0);
     int rank = rank_next;
@@ -493,8 +504,6 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         for (int e = 0; e < 6; ++e) G[q][e] = rp[e * WAVE];
       }
     }
-    request_first_meta(b + NG, lane);  // the next batch is started from here: its coordinates and first metadata are in
-    request_h(b + NG, lane);           // flight during the way back
     if (t < tb1) {
       const int2 me = k.lane_meta[(size_t)t * WAVE + lane];
       seg = ck_seg(me.x);
@@ -509,6 +518,8 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       st.template start<-1>(R, row0, li0, h, lane);
     }
     group_barrier();
+    request_first_meta(b + NG, lane);  // the next batch is started from here: its coordinates and first metadata are in
+    request_h(b + NG, lane);           // flight during the way back (behind the barrier: see lbt)
     // ---- g = G u per landmark slot (over u)
 #pragma unroll
     for (int q = 0; q < HM; ++q) {

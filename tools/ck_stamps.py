@@ -65,4 +65,16 @@ for b in range(nb):
               f"; it is {np.median(lag) / 1000:.1f} k cycles behind the workgroup's median wavefront (90 %: {np.percentile(lag, 90) / 1000:.1f});"
               f" last 'done' -> barrier open {np.median(bar - done.max(axis=1)) / 1000:.1f} k" +
               (f"; the last one walked a second tile in {int(two.sum())} of {li.grid} workgroups" if two is not None else ""))
+# the kernel ends with its slowest workgroup: duration (first wavefront's start -> flushed) over the workgroups
+dur = s[:, :nw, 8 * nb + 1].max(axis=1) - s[:, :nw, 0].min(axis=1)
+order = np.argsort(dur)
+print("workgroup durations (k cycles): min %.1f  10 %% %.1f  median %.1f  90 %% %.1f  max %.1f;  slowest workgroups: %s" % (
+    dur.min() / 1000, np.percentile(dur, 10) / 1000, np.median(dur) / 1000, np.percentile(dur, 90) / 1000, dur.max() / 1000,
+    " ".join(f"{int(w)}:{dur[w] / 1000:.1f}" for w in order[-6:][::-1])))
+for xcd in range(8):
+    m = np.arange(li.grid) % 8 == xcd
+    st0 = s[m, :nw, 0].min(axis=1)
+    en = s[m, :nw, 8 * nb + 1].max(axis=1)
+    print(f"  XCD {xcd} (workgroups {xcd}, {xcd + 8}, ...): starts spread over {(st0.max() - st0.min()) / 1000:.1f} k cycles, first start -> last end {(en.max() - st0.min()) / 1000:.1f} k,"
+          f" median duration {np.median(en - st0) / 1000:.1f} k")
 ctx.close()
