@@ -201,6 +201,7 @@ struct povar_ctx {
   unsigned res_spin_limit = 1u << 18;
   bool deterministic = false;    // POVAR_DETERMINISTIC=1: the E0 mode and the kernel choices are pinned
   bool det_ck = false;           // ... and step 1's terms run e0_ck_det where the chunk layout fits (else: the gather form)
+  bool det_check = false;        // a series of e0_ck_det is in flight whose failure bit (flags[0] & 8) has not been looked at
   DevBuf<int2> ck_zero_range;    // [n_cams] empty runs: e0_ck leaves no per-observation cold view to the per-camera kernels
   int ck_variant = 0;            // 0: e0_lpl; 1..CK_VARIANTS: e0_ck instantiation (POVAR_CK_VARIANTS)
   int ckh_variant = 0;           // step 2: 0: e0_lpl_h; 1: e0_ck_h
@@ -2265,6 +2266,15 @@ static int run_series(povar_ctx* c, int32_t m, double q_tol, double r_tol, bool 
 // context's kernels held CUs for longer than the bounded spins.  The result is then incomplete: the series is repeated
 // with the per-term kernels and the context stays on them.  Called before anything reads what the series left.
 static int res_verify(povar_ctx* c) {
+  if (c->det_check) {
+    c->det_check = false;
+    int f[4];
+    if (int rc = read_flags(c, f)) return rc;
+    if (f[0] & 8) {
+      HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream));
+      return fail(-3, "e0_ck_det: the accumulator tickets of the chunk layout do not match the kernel's tile walk");
+    }
+  }
   if (!c->res_check) return 0;
   c->res_check = false;
   int f[4];
@@ -2321,6 +2331,10 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (int rc = run_series(c, m, q_tol, r_tol, use_res)) return rc;
   int iters = m, status = POVAR_LINEAR_SOLVER_NO_CONVERGENCE;
   if (p2p_terms) c->flag0_clean = false;  // the waits of the exchange kernels raise bit 1 of flags[0] on a time-out
+  if (c->deterministic && ck_active(c)) {  // e0_ck_det: a ticket that never came up raises bit 3 (its spins are bounded):
+    c->flag0_clean = false;                // looked at where the caller next waits for the series (res_verify)
+    c->det_check = true;
+  }
   if (p2p_terms) {
     int f[4];
     if (int rc = read_flags(c, f)) return rc;

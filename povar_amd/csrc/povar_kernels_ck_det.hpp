@@ -212,12 +212,17 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_det(Dp d, CkP k, double* part_o
         }
       }
       const int a_slot = pending ? acc_slot : 0;
+      int spins = 0;
       while (__builtin_amdgcn_ballot_w64(pending) != 0) {
-        if (pending && __hip_atomic_load(tick + a_slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == (short)my_ticket) {
+        // (every spin is bounded: a layout whose tickets do not match this walk -- which the host never builds -- must end
+        // in a reported failure, flags[0] bit 3, not in a hung device)
+        const bool give_up = ++spins > (1 << 20);
+        if (pending && (give_up || __hip_atomic_load(tick + a_slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == (short)my_ticket)) {
           double* a = acc + a_slot * CK_ACC_STRIDE;
 #pragma unroll
           for (int m = 0; m < 12; ++m) a[m] += y[m];
           __hip_atomic_store(tick + a_slot, (short)(my_ticket + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (give_up) atomicOr(&d.flags[0], 8);
           pending = false;
         } else if (pending) {
           __builtin_amdgcn_s_sleep(1);
