@@ -222,11 +222,19 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
       }
     }
   };
+  // (the batches' tile ranges from LDS after the first batch, the next batch's first requests behind the barrier that ends
+  // the way forward: as e0_ck -- the lgkmcnt(0) in front of a barrier waits for every scalar load in flight)
+  int* lbt = reinterpret_cast<int*>(acc + (size_t)k.max_acc * CK_ACC_STRIDE);
+  const bool bt_lds = k.nb + 1 <= 16;
+  if (bt_lds && (int)threadIdx.x <= k.nb) lbt[threadIdx.x] = k.bt_off[blockIdx.x * k.nb + threadIdx.x];
+  auto bt_of = [&](int i, bool first) {
+    return (bt_lds && !first) ? __builtin_amdgcn_readfirstlane(lbt[i]) : bt[blockIdx.x * k.nb + i];
+  };
   int rank_next = 0;
   auto request_first_meta = [&](int b, int lane) {
     rank_next = 0;
     if (b < k.nb) {
-      const int tb0 = bt[blockIdx.x * k.nb + b], tb1 = bt[blockIdx.x * k.nb + b + 1];
+      const int tb0 = bt_of(b, b == 0), tb1 = bt_of(b + 1, b == 0);
       if (tb0 + wave < tb1) rank_next = ck_rank(k.lane_meta[(size_t)(tb0 + wave) * WAVE + lane].x);
     }
   };
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
     // (opaque lane number per batch and pass, every array assigned on every path: see e0_ck)
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    const int tb0 = bt[blockIdx.x * k.nb + b], tb1 = bt[blockIdx.x * k.nb + b + 1];
+    const int tb0 = bt_of(b, b == 0), tb1 = bt_of(b + 1, b == 0);
     int q_t = 0;
     int t = tile_of(tb0, 0);
     int rank = rank_next;
@@ -308,8 +316,6 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
         for (int e = 0; e < 10; ++e) rec[q][e] = rp[e * WAVE];
       }
     }
-    request_first_meta(b + 1, lane);
-    request_x(b + 1, lane);
     if (t < tb1) {
       const int2 me = k.lane_meta[(size_t)t * WAVE + lane];
       seg = ck_seg(me.x);
@@ -324,6 +330,8 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
       st.template start<-1>(R, row0, li0, h, lane);
     }
     ck_barrier();
+    request_first_meta(b + 1, lane);
+    request_x(b + 1, lane);
     // ---- per landmark slot: U4 -> G4
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
