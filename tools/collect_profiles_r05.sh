@@ -1,12 +1,13 @@
 #!/bin/bash
 # Copies what tools/round5_evidence.sh <tag> and tools/round5_traffic.sh <ttag> left under gpurun_out/ into profiles/
 # (tracked) and stamps profiles/traffic.json (one key per measured term loop) with the hash of the kernel sources:
-#   tools/collect_profiles_r05.sh [tag] [ttag]
+#   tools/collect_profiles_r05.sh [tag] [ttag] [traffic]
 set -eu
 tag=${1:-r05}; ttag=${2:-r05T}
 cd "$(dirname "$0")/.."
 R=gpurun_out/$tag; T=gpurun_out/$ttag; P=profiles
 newest() { ls -t $@ | head -1; }
+if [ "${3:-all}" != "traffic" ]; then  # (third argument "traffic": only the PMC passes -> profiles/traffic.json)
 cp $(newest $R/e0/kt/*/*kernel_stats.csv) $P/r05_kernel_stats_e0_lpl_vs_e0_ck.csv
 cp $(newest $R/e0/sq/*/*counter_collection.csv) $P/r05_pmc_sq_e0_lpl_vs_e0_ck.csv
 cp $R/e0_summary.txt $P/r05_e0_lpl_vs_e0_ck_summary.txt
@@ -31,6 +32,7 @@ for n in driver_flags forced_e0_lpl huber local zipf05 uniform trafalgar trafalg
  cat $R/bal_venice_gt.json
  echo "# trafalgar-257 (BASELINE config 3) and ladybug-49 (config 2) from the perturbed ground truth, --eta 0: step 1's series runs as the resident kernel"
  cat $R/bal_trafalgar.json $R/bal_ladybug.json) > $P/r05_bal_end_to_end.txt
+fi
 if [ -d $T ]; then
 for n in ck1 det lpl huber huber_ck1 local_ck1 local zipf05_ck1 uniform_ck1 step2 step2_ckh final_huber final_local_huber; do
   cp $(newest $T/pmc_$n/fetch/*/*counter_collection.csv) $P/r05_pmc_fetch_size_$n.csv
