@@ -275,7 +275,7 @@ typedef struct {
   float tune_lpl_us, tune_ck_us;  /* what that timing saw, microseconds per launch */
   /* step 2 (solve_joint): the same pair of kernels for the homogeneous operator, on a layout instance of its own
    * (64 instead of 48 bytes of LDS per landmark slot: more batches, shorter chunks) */
-  int32_t e0_kernel_h;  /* 0: e0_lpl_h, 1: e0_ck_h */
+  int32_t e0_kernel_h;  /* 0: e0_lpl_h, 1: e0_ck_h; with POVAR_DETERMINISTIC=1: 2 = e0_ck_h_det, 0 = the gather form */
   int32_t ckh_ready, ckh_batches, ckh_slots;
   int64_t ckh_chunks, ckh_cold_chunks;
   int32_t e0_auto_h;    /* as e0_auto: 0 forced, 1 to be timed at the next step-2 power series, 2 timed */

@@ -108,9 +108,12 @@ struct CkShape {
 // e0_ck_det (povar_kernels_ck_det.hpp) keeps two more bytes per landmark slot (the sum's binary point) and per accumulator
 // slot (the ticket counter)
 inline CkShape ck_shape_det() { CkShape s; s.slot_bytes = 50; s.acc_bytes = 106; return s; }
+inline CkShape ck_shape_step2_det();
 inline CkShape ck_shape_step2() { return CkShape{64, 1, 1536, false}; }  // 1536 = CKH_STRIDE (povar_kernels_ck_joint.hpp)
+inline CkShape ck_shape_step2_det() { CkShape s = ck_shape_step2(); s.slot_bytes = 66; s.acc_bytes = 106; return s; }  // (e0_ck_h_det)
 inline size_t ck_lds_bytes_shape(const CkShape& sh, int slots, int n_acc, int ng) {
-  if (sh.max_slots != INT_MAX) return 16 + (size_t)sh.slot_bytes * sh.max_slots + (size_t)n_acc * sh.acc_bytes + 64;  // = ckh_lds_bytes
+  if (sh.max_slots != INT_MAX)  // = ckh_lds_bytes[_det]
+    return 16 + (size_t)sh.slot_bytes * sh.max_slots + (size_t)n_acc * sh.acc_bytes + 64 + (sh.acc_bytes != 104 ? 16 : 0);
   return 16 + (size_t)ng * slots * sh.slot_bytes + (size_t)n_acc * sh.acc_bytes + 64 + (sh.acc_bytes != 104 ? 16 : 0);
 }
 inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector<int>& cam_of_rank, int n_waves,

@@ -536,7 +536,7 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
   if (need_uv) up(D.uv, K.uv);  // (step 2's operator does not read the image coordinates)
   up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_meta, meta);
   up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
-  if (c->det_ck && need_uv) { up(D.lcnt, K.lcnt_log2); up(D.tick, K.tick); }
+  if (c->det_ck) { up(D.lcnt, K.lcnt_log2); up(D.tick, K.tick); }
   if (ok) guarded([&] { ok = D.part.alloc((size_t)std::max(K.n_part_rec, 1) * 12, bytes) == hipSuccess; });
   if (ok && c->opt.robust_norm && !need_uv)  // (step 2's kernel reads the weights in chunk order; step 1's recomputes them)
     guarded([&] { ok = D.w.alloc(std::max<size_t>(K.src.size(), 1), bytes) == hipSuccess; });  // (padded like the rows)
@@ -580,7 +580,12 @@ bool ck_active(const povar_ctx* c) {
   return c->ck_variant > 0 && c->ck.ready && c->use_lpl && !c->joint && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
          ck_variant_fits(c, c->ck_variant);
 }
+bool ckh_det_possible(const povar_ctx* c) {
+  return c->det_ck && c->ckh.ready && c->ckh.lcnt.p && c->ckh.tick.p && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT &&
+         c->ckh.slots <= CKH_STRIDE && ckh_lds_bytes_det(c->ckh.max_acc) <= (size_t)CK_LDS_BYTES;
+}
 bool ckh_active(const povar_ctx* c) {
+  if (c->deterministic) return c->joint && ckh_det_possible(c);
   return c->joint && c->ckh_variant > 0 && c->ckh.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
          c->ckh.slots <= CKH_STRIDE && ckh_lds_bytes(c->ckh.max_acc) <= (size_t)CK_LDS_BYTES;
 }
@@ -633,6 +638,8 @@ hipError_t ck_set_lds_t() {
 }
 hipError_t ck_set_lds_all() {
   hipError_t e = hipFuncSetAttribute((const void*)e0_ck_det<16, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)e0_ck_h_det<16, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)e0_ck_h_det<16, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)e0_ck_det<16, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
 #define X(id, nw, sd, db, ng) if (e == hipSuccess) e = ck_set_lds_t<nw, sd, db, ng>();
   POVAR_CK_VARIANTS(X)
@@ -656,6 +663,14 @@ void ensure_ck_w(povar_ctx* c) {
 }
 void launch_e0_ck_h(povar_ctx* c, const Dp& da) {
   const CkP k = ck_params(c, c->ckh);
+  if (c->deterministic) {  // the bit-reproducible form (povar_kernels_ck_det.hpp)
+    const size_t ldsd = ckh_lds_bytes_det(c->ckh.max_acc);
+    if (c->opt.robust_norm)
+      hipLaunchKernelGGL((e0_ck_h_det<16, 2, true>), dim3(c->e0c_grid), dim3(1024), ldsd, c->stream, da, k, c->ckh.part.p);
+    else
+      hipLaunchKernelGGL((e0_ck_h_det<16, 2, false>), dim3(c->e0c_grid), dim3(1024), ldsd, c->stream, da, k, c->ckh.part.p);
+    return;
+  }
   const size_t lds = ckh_lds_bytes(c->ckh.max_acc);
   if (c->opt.robust_norm)
     hipLaunchKernelGGL((e0_ck_h<16, 2, true>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ckh.part.p);
@@ -1081,8 +1096,8 @@ int launch_e0(povar_ctx* c, int* binv_mode, int fuse_norms = -1) {
   if (!(c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC)) ensure_legacy(c);  // cm_scatter / legacy cold views
   if (ck_active(c) || ckh_active(c)) ensure_ck_w(c);  // (a no-op inside the graph capture: the solve entry points have called it before)
   if (c->joint) {
-    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC;
     const bool ckh_now = ckh_active(c);
+    const bool acc = c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC || ckh_now;  // (e0_ck_h_det leaves partial records too)
     Dp dj = ldsacc_dp(c, true);  // what the per-camera kernels below see: e0_ck_h leaves partial records only
     if (ckh_now) ck_dp(c, dj);
     if (ckh_now) {
@@ -1595,6 +1610,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   const bool ck_place = std::getenv("POVAR_CK_NOPLACE") == nullptr;  // LDS bank placement of the chunk rows (ck_layout.hpp)
   if (const char* e = std::getenv("POVAR_CK_HMAX")) ck_hmax = std::min(CK_HMAX, std::max(1, std::atoi(e)));
   const CkShape ck_shape1 = c->det_ck ? ck_shape_det() : CkShape();  // (step 1's layout: batches cut for the kernel that runs them)
+  const CkShape ck_shape2 = c->det_ck ? ck_shape_step2_det() : ck_shape_step2();
 
   // The arrays of the lane-per-observation kernels (part B) are built on a second host thread while this one builds
   // and uploads the lane-per-landmark layout: the two only share the slot numbers and camera ranks of part A.
@@ -1617,6 +1633,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     int place_mode = n_obs >= (1 << 20) ? 2 : 1;  // 0 none, 1 in this call, 2 on a host thread
     if (std::getenv("POVAR_LPL_NOPLACE")) place_mode = 0;
     if (const char* e = std::getenv("POVAR_LPL_PLACE")) place_mode = e[0] == 'n' ? 0 : e[0] == 's' ? 1 : e[0] == 'a' ? 2 : place_mode;
+    // POVAR_DETERMINISTIC: never on a host thread -- WHEN the placed rows (and the chunk layout cut from them: another, equally
+    // fixed summation order) arrive would depend on the host's timing, and with it the bits of every later solve.  None at
+    // all unless asked for: the gather-mode kernels do not read these rows, e0_ck_det does not care about their order.
+    if (c->deterministic) place_mode = place_mode == 1 && std::getenv("POVAR_LPL_PLACE") ? 1 : 0;
     build_lpl(n_cams, n_lms, lm_offsets, cam_idx, obs, L.cam_hot, L.slot_of_obs, (size_t)c->n_slots, c->e0c_grid,
               c->n_hot_acc, V, place_mode == 1);
     lap("build_lpl (lane/landmark)");
@@ -1635,7 +1655,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
       if (std::getenv("POVAR_CKH_EARLY") != nullptr) {
         ckh_nat.reset(new CkLayout());
-        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, *ckh_nat, ck_place, ck_hmax, 1, ck_shape_step2());
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, *ckh_nat, ck_place, ck_hmax, 1, ck_shape2);
       }
       lap("camera-chunk layout(s) from the natural rows");
     }
@@ -1658,7 +1678,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       const int dev = options->device, grid = c->e0c_grid, n_acc = c->n_hot_acc;
       const size_t n_slots = (size_t)c->n_slots;
       c->placer_state.store(1);
-      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax, ck_ng, ck_place, ck_shape1]() {
+      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax, ck_ng, ck_place, ck_shape1, ck_shape2]() {
         const auto t0 = std::chrono::steady_clock::now();
         LplLayout P;
         bool built = true;
@@ -1697,7 +1717,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
             if (!c->placer_cancel.load()) ck_upload(c, c->pl_ck, K, true, &c->pl_bytes);
             if (!c->placer_cancel.load()) {  // step 2's instance
               CkLayout KH;
-              build_ck(P, n_cams, grid, job->cam_of_rank, 16, KH, ck_place, ck_hmax, 1, ck_shape_step2());
+              build_ck(P, n_cams, grid, job->cam_of_rank, 16, KH, ck_place, ck_hmax, 1, ck_shape2);
               if (!c->placer_cancel.load()) ck_upload(c, c->pl_ckh, KH, true, &c->pl_bytes, false);
             }
           } catch (...) {
@@ -1758,7 +1778,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
         c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
         if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
         CkLayout KH;  // step 2's instance: 64 bytes of LDS per landmark slot, no image coordinates
-        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, KH, ck_place, ck_hmax, 1, ck_shape_step2());
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, 16, KH, ck_place, ck_hmax, 1, ck_shape2);
         if (!ck_upload(c, c->ckh, KH, false, &c->bytes, false)) { povar_destroy(c); return fail(-1, "camera-chunk layout (step 2): upload failed"); }
         lap("camera-chunk layouts");
       }
@@ -2331,7 +2351,7 @@ int povar_power_series_pose(povar_ctx* c, int32_t m, double q_tol, double r_tol,
   if (int rc = run_series(c, m, q_tol, r_tol, use_res)) return rc;
   int iters = m, status = POVAR_LINEAR_SOLVER_NO_CONVERGENCE;
   if (p2p_terms) c->flag0_clean = false;  // the waits of the exchange kernels raise bit 1 of flags[0] on a time-out
-  if (c->deterministic && ck_active(c)) {  // e0_ck_det: a ticket that never came up raises bit 3 (its spins are bounded):
+  if (c->deterministic && (ck_active(c) || ckh_active(c))) {  // e0_ck[_h]_det: a ticket that never came up raises bit 3 (bounded spins):
     c->flag0_clean = false;                // looked at where the caller next waits for the series (res_verify)
     c->det_check = true;
   }
@@ -2811,6 +2831,13 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
     *cam_kernel = part + tail;
     return 0;
   }
+  if (c->deterministic && ckh_active(c)) {  // e0_ck_h_det: the 2-byte rows (+ 8 with a robust norm) three times, X / records twice
+    const int64_t part = (int64_t)c->ckh.n_part_rec * 96;
+    *lm_kernel = 3 * c->ckh.rows * WAVE * (2 + robust) + (int64_t)c->d.v2.n_tiles * WAVE * (112 + 1) + cam_static +
+                 4 * (int64_t)(c->ckh.lane_meta.n) * 8 + (int64_t)c->ckh.lane_meta.n * 2 + part;
+    *cam_kernel = part + tail;
+    return 0;
+  }
   switch (c->opt.e0_mode) {
     case POVAR_E0_IMPLICIT_LDSACC:
       if (ck_active(c)) {
@@ -2918,6 +2945,7 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->tune_ck_us = c->ck_tune_us[1];
   out->e0_kernel_h = c->ckh_variant > 0 && c->ckh.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
                      c->ckh.slots <= CKH_STRIDE ? 1 : 0;
+  if (c->deterministic) out->e0_kernel_h = ckh_det_possible(c) ? 2 : 0;  // (2: e0_ck_h_det)
   out->ckh_ready = c->ckh.ready ? 1 : 0;
   out->ckh_batches = c->ckh.nb;
   out->ckh_slots = c->ckh.slots;

@@ -22,6 +22,7 @@
 #pragma once
 
 #include "povar_kernels_ck.hpp"
+#include "povar_kernels_ck_joint.hpp"
 
 namespace povar {
 
@@ -236,6 +237,191 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_det(Dp d, CkP k, double* part_o
     const int r = i / 6, m = 2 * (i % 6);
     const int rec = k.slot_rec[cam0 + r];
     reinterpret_cast<double2*>(part_out + (size_t)rec * 12)[i % 6] = make_double2(acc[r * CK_ACC_STRIDE + m], acc[r * CK_ACC_STRIDE + m + 1]);
+  }
+}
+
+// ---- step 2: the bit-reproducible form of e0_ck_h (right_mul_e0_poBA, linearization_power_varproj.hpp:408-453), the same
+// two measures: the ambient sums U4_l in fixed point (two walks forward), the accumulator adds in ticket order.
+__host__ __device__ inline size_t ckh_lds_bytes_det(int n_acc) { return ckh_lds_bytes(n_acc) + 2 * ((size_t)CKH_STRIDE + n_acc) + 16; }
+
+template <int D, bool ROBUST, int PASS>
+__device__ inline void ckhd_forward_rows(const CkRows& R, CkStreamH<D, ROBUST>& st, int row0, int li0, int h, int lane,
+                                         const Cam& P, const double4 (&zz)[3], const double* lx, double* lu, const short* lexp) {
+  auto step = [&](int j, int i) {
+    const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
+    const double rw = ROBUST ? st.rw[i] : 1.0;
+    st.load(R, row0, li0, j + D, h, lane, i);
+    if (s != 0xffffu) {
+      const double4 X = make_double4(lx[s], lx[CKH_STRIDE + s], lx[2 * CKH_STRIDE + s], lx[3 * CKH_STRIDE + s]);
+      const double sw = ROBUST ? sqrt(rw) : 1.0;
+      const Hom hp = ckh_project(P, X);
+      double t[2];
+      hom_jp_x(hp, X, sw, zz, t);
+      const double e0 = sw * hp.D00 * t[0], e1 = sw * hp.D00 * t[1], e2 = sw * (hp.D02 * t[0] + hp.D12 * t[1]);
+      const double v[4] = {P.r0.x * e0 + P.r1.x * e1 + P.r2.x * e2, P.r0.y * e0 + P.r1.y * e1 + P.r2.y * e2,
+                           P.r0.z * e0 + P.r1.z * e1 + P.r2.z * e2, P.r0.w * e0 + P.r1.w * e1 + P.r2.w * e2};
+      if (PASS == 0) {
+        const int e = ck_xp(fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3]))));
+        __hip_atomic_fetch_max(reinterpret_cast<int*>(lu + s), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        const int e = lexp[s];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(lu + m * CKH_STRIDE + s), ck_fix(v[m], e), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  };
+  int n0 = 0;
+#pragma nounroll
+  for (; n0 + D <= h; n0 += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) step(n0 + i, i);
+  }
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)
+    if (n0 + i < h) step(n0 + i, i);
+}
+
+template <int NW, int SD, bool ROBUST>
+__global__ __launch_bounds__(NW * 64) void e0_ck_h_det(Dp d, CkP k, double* part_out) {
+  const int done = d.flags[1];
+  extern __shared__ double ck_lds[];
+  const CkRows R = ck_rows(k);
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double* lx = ck_lds + 2;                  // [4][CKH_STRIDE] X of the batch's landmarks
+  double* lu = lx + 4 * CKH_STRIDE;         // [4][CKH_STRIDE] U4 (exponent maximum, then fixed point), then G4
+  double* acc = lu + 4 * CKH_STRIDE;        // [n_acc][13]
+  short* lexp = reinterpret_cast<short*>(acc + (size_t)k.max_acc * CK_ACC_STRIDE);  // [CKH_STRIDE] binary point of U4 per slot
+  short* tick = lexp + CKH_STRIDE;                                                   // [n_acc] tickets served per accumulator
+  const V2& v = d.v2;
+  const int cam0 = v.wg_cam_off[blockIdx.x];
+  const int n_acc = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  const int t0 = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
+  const int t1 = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
+  for (int i = threadIdx.x; i < n_acc * CK_ACC_STRIDE; i += NW * 64) acc[i] = 0;
+  for (int i = threadIdx.x; i < n_acc; i += NW * 64) tick[i] = 0;
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  const cint_p tiles = (cint_p)(uintptr_t)k.tile;
+  const cint_p bt = (cint_p)(uintptr_t)k.bt_off;
+  if (done) return;
+  auto tile_of = [&](int tb0, int q) { return tb0 + q * NW + ((q & 1) ? NW - 1 - wave : wave); };
+  for (int b = 0; b < k.nb; ++b) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tb0 = bt[blockIdx.x * k.nb + b], tb1 = bt[blockIdx.x * k.nb + b + 1];
+    const bool one_tile = tile_of(tb0, 1) >= tb1;
+    for (int m = wave; t0 + b + k.nb * m < t1; m += NW) {
+      const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * CKH_REC) * WAVE + lane;
+      const int s = m * WAVE + lane;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lx[e * CKH_STRIDE + s] = rp[e * WAVE];
+        lu[e * CKH_STRIDE + s] = e == 0 ? __longlong_as_double((long long)(unsigned)INT_MIN) : 0.0;
+      }
+    }
+    double4 zz[3] = {make_double4(0, 0, 0, 0), make_double4(0, 0, 0, 0), make_double4(0, 0, 0, 0)};
+    Cam P;
+    P.r0 = P.r1 = P.r2 = make_double4(0, 0, 0, 0);
+    CkStreamH<SD, ROBUST> st;
+    st.clear();
+    {
+      const int t = tile_of(tb0, 0);
+      if (t < tb1) {
+        const int rank = ck_rank(k.lane_meta[(size_t)t * WAVE + lane].x);
+        ckh_load_rec(d, rank < 0 ? 0 : rank, zz, P);
+        st.template start<1>(R, tiles[4 * t], tiles[4 * t + 3], tiles[4 * t + 1], lane);
+      }
+    }
+    ck_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int q = 0;; ++q) {
+        const int t = tile_of(tb0, q);
+        if (t >= tb1) break;
+        const int row0 = tiles[4 * t], h = tiles[4 * t + 1], li0 = tiles[4 * t + 3];
+        if (q > 0 || (pass > 0 && !one_tile)) {
+          const int rank = ck_rank(k.lane_meta[(size_t)t * WAVE + lane].x);
+          ckh_load_rec(d, rank < 0 ? 0 : rank, zz, P);
+        }
+        if (q > 0 || pass > 0) st.template start<1>(R, row0, li0, h, lane);
+        if (pass == 0) ckhd_forward_rows<SD, ROBUST, 0>(R, st, row0, li0, h, lane, P, zz, lx, lu, lexp);
+        else ckhd_forward_rows<SD, ROBUST, 1>(R, st, row0, li0, h, lane, P, zz, lx, lu, lexp);
+      }
+      if (pass == 0) {
+        ck_barrier();
+        for (int m = wave; t0 + b + k.nb * m < t1; m += NW) {
+          const int s = m * WAVE + lane;
+          const int e = (int)(unsigned)__double_as_longlong(lu[s]);
+          const int lc = k.lcnt[(size_t)(t0 + b + k.nb * m) * WAVE + lane];
+          lexp[s] = (short)((e == INT_MIN || lc == 255) ? 0 : CK_FIX_BITS - (e + lc));
+          lu[s] = 0;
+        }
+      }
+      ck_barrier();
+    }
+    // ---- per landmark slot: U4 (back from fixed point) -> G4
+    for (int m = wave; t0 + b + k.nb * m < t1; m += NW) {
+      const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * CKH_REC + 4) * WAVE + lane;
+      double r2[10];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) r2[e] = rp[e * WAVE];
+      const int s = m * WAVE + lane;
+      const int ex = lexp[s];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lu[e * CKH_STRIDE + s] = ck_unfix(__double_as_longlong(lu[e * CKH_STRIDE + s]), ex);
+      ckh_landmark_step(lx, lu, s, r2);
+    }
+    asm volatile("" : "+v"(lane));
+    ck_barrier();
+    // ---- the way back: the wavefront's tiles in the order of the walk; run totals into the accumulators in ticket order
+    for (int q = 0;; ++q) {
+      const int t = tile_of(tb0, q);
+      if (t >= tb1) break;
+      const int row0 = tiles[4 * t], h = tiles[4 * t + 1], fl = tiles[4 * t + 2], li0 = tiles[4 * t + 3];
+      const int2 me = k.lane_meta[(size_t)t * WAVE + lane];
+      const int rank = ck_rank(me.x), seg = ck_seg(me.x), acc_slot = me.y;
+      const int my_ticket = k.tick[(size_t)t * WAVE + lane];
+      if (q > 0 || !one_tile) ckh_load_cam(d, rank < 0 ? 0 : rank, P);
+      st.template start<-1>(R, row0, li0, h, lane);
+      double y[12];
+#pragma unroll
+      for (int m = 0; m < 12; ++m) y[m] = 0;
+      ckh_backward_rows<SD, ROBUST>(R, st, row0, li0, h, lane, P, lx, lu, y);
+      if (fl & 1) seg_scan_steps<12>(y, lane, seg & 255, 4);
+      bool pending = false;
+      if (rank >= 0) {
+        if (acc_slot >= 0) {
+          pending = lane == ((seg >> 8) & 255);
+        } else {
+          double2* o = reinterpret_cast<double2*>(part_out + (size_t)(~acc_slot) * 12);
+#pragma unroll
+          for (int m = 0; m < 6; ++m) o[m] = make_double2(y[2 * m], y[2 * m + 1]);
+        }
+      }
+      const int a_slot = pending ? acc_slot : 0;
+      int spins = 0;
+      while (__builtin_amdgcn_ballot_w64(pending) != 0) {
+        const bool give_up = ++spins > (1 << 20);  // (bounded: see e0_ck_det)
+        if (pending && (give_up || __hip_atomic_load(tick + a_slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == (short)my_ticket)) {
+          double* a = acc + a_slot * CK_ACC_STRIDE;
+#pragma unroll
+          for (int m = 0; m < 12; ++m) a[m] += y[m];
+          __hip_atomic_store(tick + a_slot, (short)(my_ticket + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (give_up) atomicOr(&d.flags[0], 8);
+          pending = false;
+        } else if (pending) {
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+    }
+    ck_barrier();
+  }
+  for (int i = threadIdx.x; i < n_acc * 6; i += NW * 64) {
+    const int r = i / 6, m = 2 * (i % 6);
+    const int rc = k.slot_rec[cam0 + r];
+    reinterpret_cast<double2*>(part_out + (size_t)rc * 12)[i % 6] = make_double2(acc[r * CK_ACC_STRIDE + m], acc[r * CK_ACC_STRIDE + m + 1]);
   }
 }
 

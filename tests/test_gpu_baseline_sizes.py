@@ -129,14 +129,17 @@ def test_step1_apply_at_size(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("e0_kernel", ["auto", "camera-chunk"])
+@pytest.mark.parametrize("e0_kernel", ["auto", "camera-chunk", "deterministic"])
 @pytest.mark.parametrize("name", ["trafalgar-257", "venice-1778", "local-900"])
-def test_step2_at_size(name, e0_kernel):
+def test_step2_at_size(name, e0_kernel, monkeypatch):
     """solve_joint (RIPOBA inner solve: prepare_lpl_h, the step-2 term kernel term by term) and apply_joint against the
     oracle, bench-default mode; once with the library's own choice of the term kernel (e0_lpl_h until the solve has timed
-    both) and once with e0_ck_h, the camera-chunk form (povar_kernels_ck_joint.hpp), forced for every term."""
+    both), once with e0_ck_h, the camera-chunk form (povar_kernels_ck_joint.hpp), forced for every term, and once in the
+    bit-reproducible mode (POVAR_DETERMINISTIC=1: gather-mode linearisation and preparation, the terms through e0_ck_h_det)."""
     from povar_amd import capi, synth
     from oracle import povar_oracle as O
+    if e0_kernel == "deterministic":
+        monkeypatch.setenv("POVAR_DETERMINISTIC", "1")
     p = _problem(name)
     rng = np.random.default_rng(11)
     cams = rng.normal(size=(p.n_cams, 12))
@@ -153,6 +156,9 @@ def test_step2_at_size(name, e0_kernel):
         ctx.set_e0_kernel(1)
         li = ctx.layout_info()
         assert li.ckh_ready == 1 and li.e0_kernel_h == 1 and li.ckh_slots <= 1536
+    if e0_kernel == "deterministic":
+        li = ctx.layout_info()
+        assert li.ckh_ready == 1 and li.e0_kernel_h == 2 and li.e0_kernel == 7, "e0_ck_h_det / e0_ck_det"
     ctx.set_cameras(cams)
     ctx.set_landmarks_homogeneous(lms_h)
     ri, ro = ctx.error_homogeneous(), orc.error_homogeneous(cams, lms_h)
@@ -178,6 +184,8 @@ def test_step2_at_size(name, e0_kernel):
         assert rel(ctx.get_term(11), terms[i]) < 1e-10, i
     inc, it2, st2, rc = ctx.solve_joint(LAM, m)
     assert rc == 0 and it2 == m and rel(inc, ref) < 1e-10
+    if e0_kernel == "deterministic":  # the same bits from a second solve
+        assert np.array_equal(ctx.solve_joint(LAM, m)[0], inc)
     ld = ctx.apply_joint(ref)
     ld_o, lms_new = orc.back_substitute_joint(st_h, jls, LAM, cams, lms_h, ref)
     cams_new = orc.apply_cam_inc_joint(cams, ref, sigma)

@@ -23,7 +23,7 @@ cp $R/shards.txt $P/r05_shard_term_times.txt
 cp $R/det_probe.txt $P/r05_det_probe.txt
 cp $(newest $R/det_kt/*/*kernel_stats.csv) $P/r05_kernel_stats_deterministic.csv
 cp $R/bench_default.json $P/r05_bench.json
-for n in driver_flags forced_e0_lpl huber local zipf05 uniform trafalgar trafalgar_per_term_kernels ladybug ladybug_per_term_kernels step2 step2_forced_e0_lpl_h step2_huber final_huber deterministic deterministic_gather deterministic_huber; do cp $R/bench_$n.json $P/r05_bench_$n.json; done
+for n in driver_flags forced_e0_lpl huber local zipf05 uniform trafalgar trafalgar_per_term_kernels ladybug ladybug_per_term_kernels step2 step2_forced_e0_lpl_h step2_huber final_huber deterministic deterministic_gather deterministic_huber deterministic_step2 deterministic_step2_gather; do cp $R/bench_$n.json $P/r05_bench_$n.json; done
 (echo "# tools/run_bal_config.py venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0"
  cat $R/bal_venice.json
  echo "# venice-1778, step 1 only, 30 iterations x 20 terms (--eta 0)"
@@ -34,13 +34,14 @@ for n in driver_flags forced_e0_lpl huber local zipf05 uniform trafalgar trafalg
  cat $R/bal_trafalgar.json $R/bal_ladybug.json) > $P/r05_bal_end_to_end.txt
 fi
 if [ -d $T ]; then
-for n in ck1 det lpl huber huber_ck1 local_ck1 local zipf05_ck1 uniform_ck1 step2 step2_ckh final_huber final_local_huber; do
+for n in ck1 det det_step2 lpl huber huber_ck1 local_ck1 local zipf05_ck1 uniform_ck1 step2 step2_ckh final_huber final_local_huber; do
   cp $(newest $T/pmc_$n/fetch/*/*counter_collection.csv) $P/r05_pmc_fetch_size_$n.csv
   cp $(newest $T/pmc_$n/write/*/*counter_collection.csv) $P/r05_pmc_write_size_$n.csv
 done
 t() { python3 tools/pmc_to_traffic.py $P/r05_pmc_fetch_size_$1.csv $P/r05_pmc_write_size_$1.csv $2 $P/traffic.json; }
 t ck1 venice-1778:ldsacc:1:ck1
 t det venice-1778:ldsacc:1:ck7
+t det_step2 venice-1778:ldsacc:1:step2:ckh2
 t lpl venice-1778:ldsacc:1
 t huber venice-1778:ldsacc:1:HUBER
 t huber_ck1 venice-1778:ldsacc:1:HUBER:ck1

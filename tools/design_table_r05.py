@@ -12,7 +12,9 @@ ROWS = [("bench", "venice-1778 (headline, default command)"), ("bench_driver_fla
         ("bench_final_huber", "final-13682, HUBER"), ("bench_trafalgar", "trafalgar-257"),
         ("bench_trafalgar_per_term_kernels", "trafalgar-257, per-term kernels forced (`POVAR_RES=0`)"), ("bench_ladybug", "ladybug-49"),
         ("bench_ladybug_per_term_kernels", "ladybug-49, per-term kernels forced"), ("bench_deterministic", "venice-1778, `POVAR_DETERMINISTIC=1`"), ("bench_deterministic_huber", "venice-1778, HUBER, `POVAR_DETERMINISTIC=1`"),
-        ("bench_deterministic_gather", "venice-1778, `POVAR_DETERMINISTIC=1 POVAR_DET_CK=0` (gather form)")]
+        ("bench_deterministic_gather", "venice-1778, `POVAR_DETERMINISTIC=1 POVAR_DET_CK=0` (gather form)"),
+        ("bench_deterministic_step2", "venice-1778, step 2, `POVAR_DETERMINISTIC=1`"),
+        ("bench_deterministic_step2_gather", "venice-1778, step 2, `POVAR_DETERMINISTIC=1 POVAR_DET_CK=0` (gather form)")]
 lines = []
 lines.append("| workload | terms/s | term kernel(s) | pair time (events) | bytes per E0 (measured / every array once) | fraction (measured / once) |")
 lines.append("|---|---|---|---|---|---|")
@@ -27,7 +29,7 @@ for f, name in ROWS:
     if res:
         kern = f"`series_res` ({el['series_tune_us_per_term']['per_term_kernels']:.1f} / {el['series_tune_us_per_term']['resident']:.1f} µs per term timed)"
     elif step2:
-        kern = ("`e0_ck_h`" if el["e0_kernel_step2"] else "`e0_lpl_h`") + (f" (timed {el['e0_tune_us_step2']['e0_lpl_h']:.1f} / {el['e0_tune_us_step2']['e0_ck_h']:.1f} µs)" if el["e0_tune_us_step2"]["e0_ck_h"] > 0 else "")
+        kern = ("`e0_ck_h_det`" if el["e0_kernel_step2"] == 2 else "`lm_regular<OpE0H>` + `cm_scatter`" if "gather" in name else "`e0_ck_h`" if el["e0_kernel_step2"] else "`e0_lpl_h`") + (f" (timed {el['e0_tune_us_step2']['e0_lpl_h']:.1f} / {el['e0_tune_us_step2']['e0_ck_h']:.1f} µs)" if el["e0_tune_us_step2"]["e0_ck_h"] > 0 else "")
     else:
         kern = ("`e0_ck_det`" if el["e0_kernel"] == 7 else "`e0_lm_cached<false>` + `cm_scatter`" if "gather" in name else "`e0_ck`" if el["e0_kernel"] else "`e0_lpl`" if el["term_kernels"] == "lane per landmark" else "`e0_lm_cached`") + \
             (f" (timed {el['e0_tune_us']['e0_lpl']:.1f} / {el['e0_tune_us']['e0_ck']:.1f} µs)" if el["e0_tune_us"]["e0_ck"] > 0 else "")

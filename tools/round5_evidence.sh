@@ -49,6 +49,8 @@ $B --problem final-13682 --robust-norm HUBER --huber 20 --steps 5 --warmup 1 > $
 POVAR_DETERMINISTIC=1 $B --steps 40 > $out/bench_deterministic.json 2> /dev/null < /dev/null
 POVAR_DETERMINISTIC=1 POVAR_DET_CK=0 $B --steps 40 > $out/bench_deterministic_gather.json 2> /dev/null < /dev/null
 POVAR_DETERMINISTIC=1 $B --steps 40 --robust-norm HUBER > $out/bench_deterministic_huber.json 2> /dev/null < /dev/null
+POVAR_DETERMINISTIC=1 $B --steps 40 --step 2 > $out/bench_deterministic_step2.json 2> /dev/null < /dev/null
+POVAR_DETERMINISTIC=1 POVAR_DET_CK=0 $B --steps 40 --step 2 > $out/bench_deterministic_step2_gather.json 2> /dev/null < /dev/null
 (for a in "venice-1778 NONE" "venice-1778 HUBER" "trafalgar-257 NONE" "final-13682 HUBER 5"; do timeout 600 python3 tools/det_probe.py $a 2>&1; done) > $out/det_probe.txt < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/det_kt -- python3 tools/det_probe.py venice-1778 NONE 5 > $out/det_kt.out 2>&1 < /dev/null
 rm -rf $out/det_kt/*/*kernel_trace.csv

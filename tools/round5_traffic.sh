@@ -26,6 +26,7 @@ pmc_case uniform_ck1 1 --popularity uniform
 pmc_case step2 0 --step 2
 pmc_case step2_ckh 1 --step 2
 POVAR_DETERMINISTIC=1 pmc_case det 1
+POVAR_DETERMINISTIC=1 pmc_case det_step2 1 --step 2
 pmc_case final_huber 0 --problem final-13682 --robust-norm HUBER --huber 20
 pmc_case final_local_huber 0 --problem final-13682 --popularity local --robust-norm HUBER --huber 20
 ls $out
