@@ -25,9 +25,9 @@ _WITH_CAMERA_CHUNKS = {"test_gpu_step1", "test_gpu_step2", "test_gpu_fuzz", "tes
 # ... and a fourth time with the RESIDENT power series (series_res, one launch per solve_pOSE; round 5) forced for every
 # step-1 solve in the LDS-accumulating E0 mode of these modules (early exit, robust norms, long landmarks, fuzz)
 _WITH_RESIDENT_SERIES = {"test_gpu_step1", "test_gpu_fuzz"}
-# ... and a fifth time in the bit-reproducible mode (POVAR_DETERMINISTIC=1: gather-mode linearisation, the terms of step 1
-# through the fixed-point form of e0_ck on the lane-per-landmark layout; round 5)
-_WITH_DETERMINISTIC = {"test_gpu_step1", "test_gpu_fuzz"}
+# ... and a fifth time in the bit-reproducible mode (POVAR_DETERMINISTIC=1: gather-mode linearisation, the terms through
+# e0_ck_det / e0_ck_h_det on the lane-per-landmark layout; round 5)
+_WITH_DETERMINISTIC = {"test_gpu_step1", "test_gpu_step2", "test_gpu_fuzz"}
 
 
 def pytest_generate_tests(metafunc):
