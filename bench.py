@@ -544,7 +544,8 @@ def main():
                 (f":{args.popularity}" if args.popularity != "zipf1" else "") + \
                 (f":ltf{args.long_track_frac:g}" if args.long_track_frac > 0 else "") + (":file" if bal_path else "") + \
                 (f":ck{ctx.layout_info().e0_kernel}" if args.step == 1 and ctx.layout_info().e0_kernel > 0 else "") + \
-                (f":ckh{ctx.layout_info().e0_kernel_h}" if args.step == 2 and ctx.layout_info().e0_kernel_h > 0 else "") + (":resident" if series_resident else "")
+                (f":ckh{ctx.layout_info().e0_kernel_h}" if args.step == 2 and ctx.layout_info().e0_kernel_h > 0 else "") + (":resident" if series_resident else "") + \
+                (":gather" if os.environ.get("POVAR_DETERMINISTIC") == "1" and (ctx.layout_info().e0_kernel_h if args.step == 2 else ctx.layout_info().e0_kernel) == 0 else "")
             if key in tj:
                 if tj.get("_source_sha", {}).get(key) == kernel_source_sha():
                     traffic, traffic_note = tj[key], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/"
@@ -586,7 +587,8 @@ def main():
         "device_bytes": ctx.device_bytes(),
         "roofline": {
             "bound": "hbm",
-            "kernel": "E0 x (e0_ck_h_det + cam_cold_sum_binv_h: POVAR_DETERMINISTIC=1)" if args.step == 2 and ctx.layout_info().e0_kernel_h == 2 else
+            "kernel": "one term of series_res (resident power series: E0 x, B^-1, AXPY in ONE launch per solve)" if series_resident else
+                      "E0 x (e0_ck_h_det + cam_cold_sum_binv_h: POVAR_DETERMINISTIC=1)" if args.step == 2 and ctx.layout_info().e0_kernel_h == 2 else
                       "E0 x (e0_ck_det + cam_cold_sum_binv: POVAR_DETERMINISTIC=1)" if args.step == 1 and ctx.layout_info().e0_kernel == 7 else
                       "E0 x (e0_lm_cached<false> + cm_scatter: POVAR_DETERMINISTIC=1, gather form)" if os.environ.get("POVAR_DETERMINISTIC") == "1" else
                       {capi.E0_IMPLICIT: "E0 x (e0_lm_cached<false> + cm_scatter)",
