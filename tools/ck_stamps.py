@@ -71,10 +71,4 @@ order = np.argsort(dur)
 print("workgroup durations (k cycles): min %.1f  10 %% %.1f  median %.1f  90 %% %.1f  max %.1f;  slowest workgroups: %s" % (
     dur.min() / 1000, np.percentile(dur, 10) / 1000, np.median(dur) / 1000, np.percentile(dur, 90) / 1000, dur.max() / 1000,
     " ".join(f"{int(w)}:{dur[w] / 1000:.1f}" for w in order[-6:][::-1])))
-for xcd in range(8):
-    m = np.arange(li.grid) % 8 == xcd
-    st0 = s[m, :nw, 0].min(axis=1)
-    en = s[m, :nw, 8 * nb + 1].max(axis=1)
-    print(f"  XCD {xcd} (workgroups {xcd}, {xcd + 8}, ...): starts spread over {(st0.max() - st0.min()) / 1000:.1f} k cycles, first start -> last end {(en.max() - st0.min()) / 1000:.1f} k,"
-          f" median duration {np.median(en - st0) / 1000:.1f} k")
 ctx.close()

@@ -15,7 +15,7 @@ cp $(newest $R/e0_huber/kt/*/*kernel_stats.csv) $P/r05_kernel_stats_e0_lpl_vs_e0
 cp $R/e0_huber_summary.txt $P/r05_e0_lpl_vs_e0_ck_huber_summary.txt
 cp $(newest $R/step2_kt/*/*kernel_stats.csv) $P/r05_kernel_stats_step2_e0_lpl_h_vs_e0_ck_h.csv
 cp $(newest $R/res_kt/*/*kernel_stats.csv) $P/r05_kernel_stats_series_res_trafalgar.csv
-cp $R/stamps.txt $P/r05_e0_ck_phase_stamps.txt
+grep -v '^  XCD ' $R/stamps.txt > $P/r05_e0_ck_phase_stamps.txt   # (per-XCD start spreads: the CUs' s_memtime counters are not synchronised)
 cp $R/res_term_times.txt $P/r05_res_term_times.txt
 cp $R/res_stamps.txt $P/r05_res_phase_stamps.txt
 cp $R/sweep.txt $P/r05_e0_ck_graph_families.txt
