@@ -272,7 +272,7 @@ typedef struct {
   double ck_build_ms;   /* host time of the derivation from the lane-per-landmark layout */
   int32_t e0_auto;      /* 0: the E0 kernel was forced (POVAR_E0_CK, povar_set_e0_kernel); 1: the library will time e0_lpl and e0_ck
                            on this problem at the next power series; 2: it has (e0_kernel is its choice) */
-  float tune_lpl_us, tune_ck_us;  /* what that timing saw, microseconds per launch */
+  float tune_lpl_us, tune_ck_us;  /* what that timing saw: microseconds per term pair (the E0 kernel + the per-camera kernel behind it), the faster of two rounds */
   /* step 2 (solve_joint): the same pair of kernels for the homogeneous operator, on a layout instance of its own
    * (64 instead of 48 bytes of LDS per landmark slot: more batches, shorter chunks) */
   int32_t e0_kernel_h;  /* 0: e0_lpl_h, 1: e0_ck_h; with POVAR_DETERMINISTIC=1: 2 = e0_ck_h_det, 0 = the gather form */

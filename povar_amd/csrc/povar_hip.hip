@@ -1243,7 +1243,11 @@ int ck_autotune(povar_ctx* c) {
   c->ck_tuned = true;
   ensure_ck_w(c);
   HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));  // (a series that ended early leaves "done" set)
-  EventSet<4> ev;
+  // Two rounds of (warm-up + REPS launches) of each kernel, alternating, the FASTER round of each counts: one round's mean
+  // was seen 18 % off on the same box (Zipf(0.5): e0_ck 80.2 against 67.9 us in two processes -- clocks still ramping, the
+  // placement thread's uploads), enough to keep the slower kernel for the life of the layout.
+  constexpr int ROUNDS = 2;
+  EventSet<4 * ROUNDS> ev;
   HIP_TRY(ev.create());
   Dp da = ldsacc_dp(c, true);
   da.p2p_peer = nullptr;
@@ -1256,27 +1260,43 @@ int ck_autotune(povar_ctx* c) {
     ~Restore() { if (!done) { c->ck_variant = keep; c->ck_tuned = false; } }
   } restore{c, keep};
   c->ck_variant = 1;
+  // What is timed is the PAIR of a term -- the E0 kernel and the per-camera kernel behind it --: e0_lpl leaves its cold
+  // observations to the per-camera kernel (Zipf(0.5): 25 us there against 7 behind e0_ck; the E0 kernels alone were a draw
+  // in some processes and the slower pair was kept).  The per-camera kernel's outputs (accum, tmp, z) are what the series'
+  // first kernel writes anyway.
   auto run_lpl = [&]() {
     if (c->opt.robust_norm)
       hipLaunchKernelGGL(e0_lpl<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
     else
       hipLaunchKernelGGL(e0_lpl<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes(c->v2_max_slots), c->stream, da, c->v2_part.p);
+    hipLaunchKernelGGL(cam_cold_sum_binv<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, da, 0);
+  };
+  auto run_ck = [&]() {
+    launch_e0_ck(c, dk);
+    hipLaunchKernelGGL(cam_cold_sum_binv<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, dk, 0);
   };
   constexpr int REPS = 3;
-  run_lpl();
-  HIP_TRY(hipEventRecord(ev[0], c->stream));
-  for (int i = 0; i < REPS; ++i) run_lpl();
-  HIP_TRY(hipEventRecord(ev[1], c->stream));
-  launch_e0_ck(c, dk);
-  HIP_TRY(hipEventRecord(ev[2], c->stream));
-  for (int i = 0; i < REPS; ++i) launch_e0_ck(c, dk);
-  HIP_TRY(hipEventRecord(ev[3], c->stream));
+  for (int r = 0; r < ROUNDS; ++r) {
+    run_lpl();
+    HIP_TRY(hipEventRecord(ev[4 * r], c->stream));
+    for (int i = 0; i < REPS; ++i) run_lpl();
+    HIP_TRY(hipEventRecord(ev[4 * r + 1], c->stream));
+    run_ck();
+    HIP_TRY(hipEventRecord(ev[4 * r + 2], c->stream));
+    for (int i = 0; i < REPS; ++i) run_ck();
+    HIP_TRY(hipEventRecord(ev[4 * r + 3], c->stream));
+  }
   c->ck_variant = keep;
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipGetLastError());
-  float ms_lpl = 0, ms_ck = 0;
-  HIP_TRY(hipEventElapsedTime(&ms_lpl, ev[0], ev[1]));
-  HIP_TRY(hipEventElapsedTime(&ms_ck, ev[2], ev[3]));
+  float ms_lpl = 1e30f, ms_ck = 1e30f;
+  for (int r = 0; r < ROUNDS; ++r) {
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, ev[4 * r], ev[4 * r + 1]));
+    HIP_TRY(hipEventElapsedTime(&b, ev[4 * r + 2], ev[4 * r + 3]));
+    ms_lpl = std::min(ms_lpl, a);
+    ms_ck = std::min(ms_ck, b);
+  }
   restore.done = true;
   c->ck_tune_us[0] = 1e3f * ms_lpl / REPS;
   c->ck_tune_us[1] = 1e3f * ms_ck / REPS;
@@ -1295,7 +1315,8 @@ int ckh_autotune(povar_ctx* c) {
   }
   ensure_ck_w(c);
   HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
-  EventSet<4> ev;
+  constexpr int ROUNDS = 2;
+  EventSet<4 * ROUNDS> ev;
   HIP_TRY(ev.create());
   struct Restore {
     povar_ctx* c; bool done = false;
@@ -1309,21 +1330,33 @@ int ckh_autotune(povar_ctx* c) {
       hipLaunchKernelGGL(e0_lpl_h<true>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes_h(c->v2_max_slots), c->stream, da, c->v2_part.p);
     else
       hipLaunchKernelGGL(e0_lpl_h<false>, dim3(c->e0c_grid), dim3(E0C_BLOCK), lpl_lds_bytes_h(c->v2_max_slots), c->stream, da, c->v2_part.p);
+    hipLaunchKernelGGL(cam_cold_sum_binv_h<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, da, 0, (const double*)c->ncw.p);
+  };
+  auto run_ck = [&]() {
+    launch_e0_ck_h(c, dk);
+    hipLaunchKernelGGL(cam_cold_sum_binv_h<CCS_THREADS>, dim3(c->n_cams), dim3(CCS_THREADS), 0, c->stream, dk, 0, (const double*)c->ncw.p);
   };
   constexpr int REPS = 3;
-  run_lpl();
-  HIP_TRY(hipEventRecord(ev[0], c->stream));
-  for (int i = 0; i < REPS; ++i) run_lpl();
-  HIP_TRY(hipEventRecord(ev[1], c->stream));
-  launch_e0_ck_h(c, dk);
-  HIP_TRY(hipEventRecord(ev[2], c->stream));
-  for (int i = 0; i < REPS; ++i) launch_e0_ck_h(c, dk);
-  HIP_TRY(hipEventRecord(ev[3], c->stream));
+  for (int r = 0; r < ROUNDS; ++r) {  // (two alternating rounds of the term's pair, the faster one of each counts: see ck_autotune)
+    run_lpl();
+    HIP_TRY(hipEventRecord(ev[4 * r], c->stream));
+    for (int i = 0; i < REPS; ++i) run_lpl();
+    HIP_TRY(hipEventRecord(ev[4 * r + 1], c->stream));
+    run_ck();
+    HIP_TRY(hipEventRecord(ev[4 * r + 2], c->stream));
+    for (int i = 0; i < REPS; ++i) run_ck();
+    HIP_TRY(hipEventRecord(ev[4 * r + 3], c->stream));
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipGetLastError());
-  float ms_lpl = 0, ms_ck = 0;
-  HIP_TRY(hipEventElapsedTime(&ms_lpl, ev[0], ev[1]));
-  HIP_TRY(hipEventElapsedTime(&ms_ck, ev[2], ev[3]));
+  float ms_lpl = 1e30f, ms_ck = 1e30f;
+  for (int r = 0; r < ROUNDS; ++r) {
+    float ta = 0, tb = 0;
+    HIP_TRY(hipEventElapsedTime(&ta, ev[4 * r], ev[4 * r + 1]));
+    HIP_TRY(hipEventElapsedTime(&tb, ev[4 * r + 2], ev[4 * r + 3]));
+    ms_lpl = std::min(ms_lpl, ta);
+    ms_ck = std::min(ms_ck, tb);
+  }
   restore.done = true;
   c->ckh_tune_us[0] = 1e3f * ms_lpl / REPS;
   c->ckh_tune_us[1] = 1e3f * ms_ck / REPS;

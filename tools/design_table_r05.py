@@ -16,7 +16,7 @@ ROWS = [("bench", "venice-1778 (headline, default command)"), ("bench_driver_fla
         ("bench_deterministic_step2", "venice-1778, step 2, `POVAR_DETERMINISTIC=1`"),
         ("bench_deterministic_step2_gather", "venice-1778, step 2, `POVAR_DETERMINISTIC=1 POVAR_DET_CK=0` (gather form)")]
 lines = []
-lines.append("| workload | terms/s | term kernel(s) | pair time (events) | bytes per E0 (measured / every array once) | fraction (measured / once) |")
+lines.append("| workload | terms/s | term kernel(s) (the library's timing of the two pairs) | pair time (events) | bytes per E0 (measured / every array once) | fraction (measured / once) |")
 lines.append("|---|---|---|---|---|---|")
 for f, name in ROWS:
     path = os.path.join(ROOT, "profiles", f"r05_{f}.json")
