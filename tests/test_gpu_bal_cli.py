@@ -138,3 +138,34 @@ def test_bal_gpus_2_from_the_random_start(tmp_path):
     ca, cb = np.array(one["cost"]), np.array(two["cost"])
     assert np.abs(ca[:n1] / cb[:n1] - 1).max() <= 1e-3
     assert np.isfinite(ca[n1]) and np.isfinite(cb[n1]) and ca[n1] > 0 and cb[n1] > 0, (ca[n1], cb[n1])
+
+
+@pytest.mark.gpu
+def test_bal_is_bit_reproducible_with_povar_deterministic(tmp_path):
+    """POVAR_DETERMINISTIC=1 at the drop-in boundary: two runs of `bal`
+    -- file -> step-1 LM iterations -> step-2 LM iterations -> log -- on trafalgar-257 from the perturbed ground truth write
+    the SAME costs, digit for digit (the JSON log prints them with 17 significant digits), with the same accept / reject
+    sequence; the default mode ends on the same costs to 1e-6 (its sums are in arrival order, the LM loop amplifies the last
+    bits)."""
+    from povar_amd import synth
+    p = synth.make_bal_problem("trafalgar-257", init="gt", init_noise=0.02)
+    f = str(tmp_path / "problem-257-65132-gt.txt")
+    synth.write_data_custom(f, p)
+    extra = ["--max-num-iterations-step-1", "10", "--max-num-iterations-step-2", "6", "--power-sc-iterations", "20"]
+
+    def run(tag, det):
+        env = dict(os.environ)
+        env.pop("POVAR_DETERMINISTIC", None)
+        if det:
+            env["POVAR_DETERMINISTIC"] = "1"
+        log = str(tmp_path / f"{tag}.json")
+        cmd = [os.path.join(ROOT, "bin/bal"), "--input", f, "--log-log-path", log, "--quiet"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.load(open(log))
+
+    a, b, c = run("det1", True), run("det2", True), run("default", False)
+    assert a["cost"] == b["cost"] and a["step_is_successful"] == b["step_is_successful"] and a["iteration"] == b["iteration"]
+    assert len(a["cost"]) > 10
+    assert a["step_is_successful"] == c["step_is_successful"]
+    assert np.abs(np.array(a["cost"]) / np.array(c["cost"]) - 1).max() <= 1e-6
