@@ -113,6 +113,7 @@ def test_resident_series_follows_a_new_linearisation_and_damping():
     from povar_amd import capi
     p = _problem("trafalgar-257")
     ctx = _ctx(p)
+    _need_layout(ctx.layout_info())
     ctx.set_cameras(p.cams)
     ctx.init_landmarks_pose(ALPHA)
     for lam in (1e-4, 1e-2):
@@ -162,6 +163,7 @@ def test_resident_series_gives_up_and_the_per_term_kernels_take_over(monkeypatch
     monkeypatch.setenv("POVAR_RES_SPIN", "1")
     p = _problem("trafalgar-257")
     ctx = _ctx(p)
+    _need_layout(ctx.layout_info())
     ctx.set_cameras(p.cams)
     ctx.init_landmarks_pose(ALPHA)
     assert ctx.linearize_pose(ALPHA)

@@ -3,7 +3,7 @@
 # defaults only take for some problem sizes (round 3 found a stale-weights defect of RIPCG and a capture/upload race this
 # way).  Expected: all green (the test of the layout the library picks BY DEFAULT skips itself when the
 # environment forces the layout; the at-size oracle comparison runs in every mode).
-#   tools/forced_mode_suite.sh [ck|base]  (about 4 GPU-minutes per mode; "ck": only the modes that force the camera-chunk kernels,
+#   tools/forced_mode_suite.sh [ck|base|det]  (about 4 GPU-minutes per mode; "det": only the bit-reproducible mode's; "ck": only the modes that force the camera-chunk kernels,
 #                                          "base": only the others)
 cd "$(dirname "$0")/.." || exit 1
 # -rf --tb=line: every failure with the assertion that failed, not only the test name
@@ -22,6 +22,16 @@ run POVAR_NO_GRAPH=1
 run POVAR_RES=1
 run POVAR_RES=1 POVAR_RES_WGS=7 POVAR_NO_GRAPH=1
 fi
+if [ "${1:-all}" = "det" ] || [ "${1:-all}" = "all" ]; then
+# the bit-reproducible mode for every context (e0_ck_det / e0_ck_h_det wherever the layout allows; the tests about what the
+# mode pins skip themselves: tests/conftest.py), and its ticket order under stress: few accumulators, many batches / short
+# chunks, seven workgroups (dozens of tiles per wavefront: every accumulator's ticket chain runs over many rounds)
+run POVAR_DETERMINISTIC=1 POVAR_E0_V1=0
+run POVAR_DETERMINISTIC=1 POVAR_E0_V1=0 POVAR_HOT_ACC=24 POVAR_LPL_STRATEGY=range
+run POVAR_DETERMINISTIC=1 POVAR_E0_V1=0 POVAR_CK_NB=3 POVAR_CK_HMAX=5 POVAR_NO_GRAPH=1
+run POVAR_DETERMINISTIC=1 POVAR_E0_V1=0 POVAR_LPL_K0=2 POVAR_E0_WGS=7
+fi
+[ "${1:-all}" = "det" ] && exit 0
 [ "${1:-all}" = "base" ] && exit 0
 run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_LPL_PLACE=sync
 # the camera-chunk kernels (e0_ck, and e0_ck_h in every step-2 context) under stress: few accumulators (most chunks write their own record), many batches / short chunks,
