@@ -8,7 +8,7 @@
 cd "$(dirname "$0")/.." || exit 1
 # -rf --tb=line: every failure with the assertion that failed, not only the test name
 run() { echo "== $*"; env "$@" python3 -m pytest tests -q -m gpu -rf --tb=line 2>&1 | grep "FAILED\|Error\|assert\|passed\|failed"; }
-if [ "${1:-all}" != "ck" ]; then
+if [ "${1:-all}" = "all" ] || [ "${1:-all}" = "base" ]; then
 run POVAR_E0_V1=0
 run POVAR_E0_V1=0 POVAR_LPL_PLACE=async POVAR_COLD_Q_ROWS=1
 run POVAR_E0_V1=0 POVAR_HOT_ACC=8
