@@ -23,6 +23,7 @@ cp $R/shards.txt $P/r05_shard_term_times.txt
 cp $R/det_probe.txt $P/r05_det_probe.txt
 cp $(newest $R/det_kt/*/*kernel_stats.csv) $P/r05_kernel_stats_deterministic.csv
 cp $R/bench_default.json $P/r05_bench.json
+if ls $R/bench_kt/*/*kernel_stats.csv > /dev/null 2>&1; then cp $(newest $R/bench_kt/*/*kernel_stats.csv) $P/r05_kernel_stats_bench_default_cmd.csv; fi   # rocprofv3 --kernel-trace --stats of the bench command
 for n in driver_flags forced_e0_lpl huber local zipf05 uniform trafalgar trafalgar_per_term_kernels ladybug ladybug_per_term_kernels step2 step2_forced_e0_lpl_h step2_huber final_huber deterministic deterministic_gather deterministic_huber deterministic_step2 deterministic_step2_gather; do cp $R/bench_$n.json $P/r05_bench_$n.json; done
 (echo "# tools/run_bal_config.py venice-1778 --max-num-iterations-step-1 6 --max-num-iterations-step-2 4 --power-sc-iterations 20 --eta 0"
  cat $R/bal_venice.json
