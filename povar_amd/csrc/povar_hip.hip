@@ -1531,13 +1531,15 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   }
   // POVAR_DETERMINISTIC=1: run-to-run BIT-reproducible results for a given device count (SURVEY 8(e) "fixed reduction order
   // inside a GPU"), whatever E0 mode the caller asked for, and no run-time timing decides a kernel:
-  //   * linearisation, preparation, cost and step 2 run in the gather mode (POVAR_E0_IMPLICIT: per-landmark wavefront scans,
-  //     per-camera sums through the camera-major index -- no atomics anywhere);
-  //   * the terms of step 1's power series -- the hot path -- run e0_ck_det (povar_kernels_ck_det.hpp: the camera-chunk
-  //     kernel with the landmark sums in 64-bit fixed point -- integer adds are associative -- and the accumulator adds in
-  //     ticket order) + cam_cold_sum_binv (a fixed-order sum), on the landmark records and camera image the gather mode's
-  //     kernels leave in lane order anyway.  POVAR_DET_CK=0: the gather form there too (3.7 x slower
-  //     than the default mode on venice-1778, profiles/r05_experiments.txt; also what runs when the chunk layout does not fit).
+  //   * linearisation, preparation and cost of both steps run in the gather mode (POVAR_E0_IMPLICIT: per-landmark wavefront
+  //     scans, per-camera sums through the camera-major index -- no atomics anywhere);
+  //   * the terms of the power series -- the hot path -- run e0_ck_det (step 1) / e0_ck_h_det (step 2)
+  //     (povar_kernels_ck_det.hpp: the camera-chunk kernels with the landmark sums in 64-bit fixed point -- integer adds are
+  //     associative -- and the accumulator adds in ticket order) + cam_cold_sum_binv[_h] (a fixed-order sum), on the landmark
+  //     records and camera image the gather mode's kernels leave in lane order anyway.  POVAR_DET_CK=0: the gather form there
+  //     too (3.7 x slower than the default mode on venice-1778, profiles/r05_experiments.txt; also what runs when a chunk
+  //     layout does not fit);
+  //   * the rows are never placed on a host thread (when they arrive would decide the bits of every later solve).
   // The default mode accumulates in LDS in arrival order and is reproducible to rounding (1e-15), like the reference's
   // mutex order.
   if (const char* g = std::getenv("POVAR_DETERMINISTIC")) {
