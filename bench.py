@@ -13,6 +13,11 @@ reference's own definition of the figure: solve_reduced_system_time / linear_sol
 For N > 1 the landmarks are sharded over the ranks (strong scaling: the problem is fixed) and
 each term carries one RCCL all-reduce of the 12*n_cams vector.
 
+Timing: the warm-up is --warmup steps topped up to --warm-seconds (0.5 s) of solves, then the block of
+EXACTLY --steps steps (barrier + synchronize on both sides, maximum over the ranks) is run --repeats (5) times back to
+back; `value` / `ms_per_step` are the MEDIAN block, `value_min` / `value_max` / `block_ms` the spread, and
+`graph_us_per_term` the device time of one replayed term loop per term (event pairs on the library's stream).
+
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
   roofline     the E0 (SpMV) kernel pair against the HBM roofline in REAL bytes: `traffic` = PMC-measured HBM bytes
                per application (2 FETCH_SIZE + WRITE_SIZE, profiles/traffic.json) while that file's stamp matches
@@ -232,6 +237,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200,
                     help="timed steps (one step = one m-term solve; 200 x 1.3 ms: long enough for an external utilisation sampler to see)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed --steps block is run this many times back to back; `value` is the median block")
+    ap.add_argument("--warm-seconds", type=float, default=0.5,
+                    help="the warm-up is topped up to this much device work whatever --warmup says")
     ap.add_argument("--problem", default="venice-1778", choices=sorted(synth.BAL_SHAPES))
     ap.add_argument("--e0-mode", default="ldsacc", choices=["ldsacc", "implicit", "tiles", "tiles-ldsacc"],
                     help="E0 operator form: implicit tiles + LDS accumulation of hot cameras (default, fastest), "
@@ -464,15 +473,44 @@ def main():
         for _ in range(k):
             ctx.power_series_pose(m, 0.0, -1.0)
 
-    def timed():
-        run_steps(args.warmup)
+    def agree_max(x):
+        """the same number on every rank (the ranks run the same count of collectives)"""
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def warm_up():
+        """--warmup steps, then as many more as it takes to keep the device busy for WARM_S seconds: a fresh box needs a few
+        hundred milliseconds of work before its clocks and caches are where a long run has them (the driver's 5 warm-up
+        solves are 7 ms: BENCH_r05 measured 66.6 us per term where every longer run of the same box class gives 59-61)."""
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(max(args.warmup, 1))
+        barrier()
+        per_step = agree_max((time.perf_counter() - t0) / max(args.warmup, 1))
+        extra = int(min(max(args.warm_seconds / max(per_step, 1e-6) - args.warmup, 0), 20000))
+        run_steps(extra)
+        barrier()
+        return max(args.warmup, 1) + extra
+
+    def timed_block():
+        """EXACTLY --steps steps between two barrier + synchronize pairs; the maximum over the ranks"""
         barrier()
         t0 = time.perf_counter()
         run_steps(args.steps)
         barrier()
-        return time.perf_counter() - t0
+        return agree_max(time.perf_counter() - t0)
 
-    dt = timed()
+    def timed():
+        """the --steps block --repeats times (>= 5 by default), back to back after one warm-up: `value` is the MEDIAN block,
+        the fastest and the slowest are reported beside it"""
+        n_warm = warm_up()
+        return n_warm, [timed_block() for _ in range(max(args.repeats, 1))]
+
+    warm_steps, blocks = timed()
     if term_exchange.startswith("p2p"):
         # the solve is deterministic: the increment the timed loop ended with must still be the validated one; a
         # stale slab anywhere sends every rank back to the all-reduce and the timing is taken again
@@ -483,7 +521,17 @@ def main():
             term_exchange = f"all-reduce (peer-to-peer exchange dropped after the timed loop: increment off by {rel2:.1e})"
             if rank == 0:
                 print(f"[bench] {term_exchange}", file=sys.stderr)
-            dt = timed()
+            warm_steps, blocks = timed()
+    dt = float(np.median(blocks))
+    # the same --steps block once more with an event pair on the library's stream around every solve (povar_timings, kind
+    # "solve"): device time of the whole replayed term loop per term -- beside the host clock of the blocks above it says
+    # whether a slow line is a slow device or a slow host
+    ctx.timings_enable(True)
+    run_steps(args.steps)
+    barrier()
+    tim = ctx.timings()
+    ctx.timings_enable(False)
+    graph_us_per_term = 1e3 * tim.solve_ms / max(tim.solve_calls * m, 1)
     # per-kernel durations: the same K steps again with HIP events recorded on the library's stream
     # around every E0 / B^-1 / all-reduce launch (event mode launches kernel by kernel instead of
     # replaying the captured hipGraph, so it is kept out of the headline timing)
@@ -492,11 +540,6 @@ def main():
     barrier()
     prof = ctx.profile_get()
     ctx.profile_enable(False)
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     inc_main = ctx.get_increment()
     if rank == 0 and os.environ.get("POVAR_BENCH_DUMP_INC"):  # tests: sharded == unsharded increment
         np.save(os.environ["POVAR_BENCH_DUMP_INC"], inc_main)
@@ -562,6 +605,14 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        # `value` = the median of `repeats` blocks of exactly --steps steps (each between barrier + synchronize pairs, the
+        # maximum over the ranks), after `warmup_steps_run` untimed steps (--warmup, topped up to --warm-seconds of work)
+        "repeats": len(blocks),
+        "value_min": terms / max(blocks),
+        "value_max": terms / min(blocks),
+        "block_ms": [round(b * 1e3, 4) for b in blocks],
+        "warmup_steps_run": warm_steps,
+        "graph_us_per_term": graph_us_per_term,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,

@@ -38,6 +38,11 @@ def test_bench_json_contract():
     assert "full workload" in cb["sample"] and cb["cpu_model"]
     # 20 terms per step: value == steps * m / time
     assert abs(d["value"] - 20 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-6 * d["value"]
+    # `value` is the median of >= 5 blocks of exactly --steps steps behind a warm-up of >= 0.5 s of solves, whatever --warmup
+    # says; the device time of a replayed term loop per term is reported beside the host clock
+    assert d["repeats"] >= 5 and len(d["block_ms"]) == d["repeats"] and d["value_min"] <= d["value"] <= d["value_max"]
+    assert abs(sorted(d["block_ms"])[d["repeats"] // 2] - d["ms_per_step"] * d["steps"]) <= 1e-3 + 1e-6 * d["ms_per_step"] * d["steps"]
+    assert d["warmup_steps_run"] >= 100 and 0 < d["graph_us_per_term"] <= 1.05e3 * d["ms_per_step"] / 20
     assert d["secondary"]["rel_diff_vs_primary"] < 1e-10 and d["explicit_sc"]["cholesky_rc"] == 0
 
 
@@ -46,7 +51,7 @@ def _run_bench(extra_args, env_extra, dump):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     env = dict(os.environ, POVAR_BENCH_DUMP_INC=path, **env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--problem", "ladybug-49", "--steps", "3",
-                        "--warmup", "1", "--no-secondary"] + extra_args, capture_output=True, text=True, timeout=900,
+                        "--warmup", "1", "--no-secondary", "--warm-seconds", "0", "--repeats", "1"] + extra_args, capture_output=True, text=True, timeout=900,
                        cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -101,7 +106,7 @@ def test_bench_two_ranks_p2p_exchange(problem):
         env = dict(os.environ, POVAR_BENCH_DUMP_INC=path + tag + ".npy")
         for attempt in range(2 if tag == "p2p" else 1):  # (a fallback of the validated exchange may be retried once: see below)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--problem", problem, "--steps", "3",
-                                "--warmup", "1", "--no-secondary"] + extra, capture_output=True, text=True, timeout=900,
+                                "--warmup", "1", "--no-secondary", "--warm-seconds", "0", "--repeats", "1"] + extra, capture_output=True, text=True, timeout=900,
                                cwd=ROOT, env=env)
             assert r.returncode == 0, r.stderr[-3000:]
             d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])

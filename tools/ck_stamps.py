@@ -65,6 +65,29 @@ for b in range(nb):
               f"; it is {np.median(lag) / 1000:.1f} k cycles behind the workgroup's median wavefront (90 %: {np.percentile(lag, 90) / 1000:.1f});"
               f" last 'done' -> barrier open {np.median(bar - done.max(axis=1)) / 1000:.1f} k" +
               (f"; the last one walked a second tile in {int(two.sum())} of {li.grid} workgroups" if two is not None else ""))
+# Round 6: what happens between a wavefront's "fwd done" and the barrier behind the way forward opening (the
+# 4.3 - 4.6 k cycles between the LAST wavefront's arrival and the opening).  Stamps 24 + 4 b .. 26 + 4 b: G and the way back's
+# metadata requested / its first rows requested / s_waitcnt lgkmcnt(0) passed (LDS atomics and scalar loads drained).
+for b in range(min(nb, 4)):
+    if not (s[:, :nw, 24 + 4 * b] > 0).any():
+        continue
+    base = s[:, :nw, 8 * b + 4]
+    names2 = ((24 + 4 * b, "G + metadata requested"), (25 + 4 * b, "first rows back requested"), (26 + 4 * b, "lgkmcnt(0) passed"),
+              (8 * b + 5, "barrier open"))
+    print(f"b{b}: cycles after the wavefront's own 'fwd done' (median over workgroups; columns: wavefronts)")
+    for i, nm in names2:
+        v = np.median(s[:, :nw, i] - base, axis=0)
+        print(f"   {nm:26s}" + "".join(f"{x / 1000:7.2f}" for x in v))
+    # the LAST wavefront of each workgroup (the one the barrier waits for): its own intervals
+    last = base.argmax(axis=1)
+    rows = np.arange(li.grid)
+    prev = base[rows, last]
+    parts = []
+    for i, nm in names2:
+        cur = s[rows, last, i]
+        parts.append(f"{nm} +{np.median(cur - prev) / 1000:.2f} k")
+        prev = cur
+    print(f"   the last wavefront to finish its rows: " + ", ".join(parts))
 # the kernel ends with its slowest workgroup: duration (first wavefront's start -> flushed) over the workgroups
 dur = s[:, :nw, 8 * nb + 1].max(axis=1) - s[:, :nw, 0].min(axis=1)
 order = np.argsort(dur)
