@@ -566,7 +566,7 @@ def main():
     effective = bytes_e0 / (e0_ms * 1e-3) / 1e9 if e0_ms > 0 else 0.0
     li0 = ctx.layout_info()
     # "every array once": the chunk kernels read their 18-byte rows on every walk (e0_ck: 2, e0_ck_det: 3)
-    once_bytes = model_bytes - (li0.ck_rows * 64 * 18 * (2 if li0.e0_kernel == 7 else 1)
+    once_bytes = model_bytes - (li0.ck_rows * 64 * (10 if li0.ck_packed else 18) * (2 if li0.e0_kernel == 7 else 1)
                                 if args.step == 1 and li0.e0_kernel > 0 else 0)  # (step 2's rows are 2-4 bytes: no correction)
     if series_resident:
         # what ONE term of the resident kernel moves: every (workgroup, camera) pair reads the camera's z (192 B of granule
@@ -717,6 +717,9 @@ def main():
                                   "camera_chunks_step2": {"batches": li.ckh_batches, "landmark_slots": li.ckh_slots,
                                                           "chunks": li.ckh_chunks, "own_record_chunks": li.ckh_cold_chunks},
                                   "camera_chunks": {"batches": li.ck_batches, "landmark_slots": li.ck_slots, "rows": li.ck_rows,
+                                                    # image points as two int32 of micro-units (every observation a six-decimal
+                                                    # number, decoded bit for bit) instead of two doubles
+                                                    "packed_image_points": bool(li.ck_packed),
                                                     "chunks": li.ck_chunks, "own_record_chunks": li.ck_cold_chunks,
                                                     "partial_records": li.ck_part_rec, "build_ms": round(li.ck_build_ms, 1)}
                                   if li.ck_ready else None,

@@ -295,6 +295,9 @@ typedef struct {
   float tune_terms_us, tune_res_us;  /* what the timing saw, microseconds per term: per-term kernels, resident series */
   int32_t res_failed;   /* 1: a resident series gave up (its workgroups were not all on the device together); the
                            context repeated that series with the per-term kernels and stays on them */
+  int32_t ck_packed;    /* 1: the rows of the camera-chunk layout keep the image points packed (two int32 of micro-units,
+                           8 instead of 16 bytes per observation and walk): every observation of the problem is a six-decimal
+                           number -- what the reference's files hold, bal/bal_problem.cpp:373-375 -- and comes back bit for bit */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 /* The reference's constructor is a trivial allocation (sc/linearization_varproj.hpp:44-60); this library's builds the

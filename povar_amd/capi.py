@@ -58,7 +58,7 @@ class LayoutInfo(C.Structure):
                 ("res_max_cams", C.c_int32), ("res_max_lms", C.c_int32), ("res_max_chunks", C.c_int32),
                 ("res_max_oq", C.c_int32), ("res_order", C.c_int32),
                 ("res_lds_bytes", C.c_int32), ("res_build_ms", C.c_double), ("tune_terms_us", C.c_float),
-                ("tune_res_us", C.c_float), ("res_failed", C.c_int32)]
+                ("tune_res_us", C.c_float), ("res_failed", C.c_int32), ("ck_packed", C.c_int32)]
 
 
 class TimingsInfo(C.Structure):
@@ -78,7 +78,7 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(src_dir, f) for f in ("povar_hip.hip", "povar_kernels.hpp", "povar_kernels_joint.hpp",
                                                "povar_kernels_sc.hpp", "povar_kernels_chol.hpp", "lpl_layout.hpp",
                                                "ck_layout.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_joint.hpp",
-                                               "res_layout.hpp", "povar_kernels_res.hpp")] + [HEADER]
+                                               "res_layout.hpp", "povar_kernels_res.hpp", "povar_kernels_ck_det.hpp")] + [HEADER]
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)

@@ -21,6 +21,8 @@
 #pragma once
 
 #include <climits>
+#include <cmath>
+#include <cstring>
 
 #include "lpl_layout.hpp"
 
@@ -35,8 +37,36 @@ constexpr int CK_FLAG_DUP = 1;     // lanes of the tile share accumulators: segm
 constexpr int CK_FLAG_COLD = 2;    // some chunk of the tile writes its own partial record
 constexpr uint32_t CK_NONE = 0xffffu;  // 16-bit landmark slot of a row without observation
 
+// Packed image points.  The observations of a BAL / data_custom file are decimal numbers with six digits behind the point
+// (bal_problem.cpp:373-375 writes them with "%lf", the loader's strtod gives the nearest double: u = RN(k / 10^6) with an
+// integer k) -- 16 bytes per observation that carry 2 x 31 bits.  Where EVERY image point of a layout is such a number with
+// |k| < 2^31, the rows keep (k_u, k_v) as two int32 (8 bytes instead of 16: the rows are read on both walks of every term)
+// and the kernel rebuilds the double with ck_unpack_uv -- int -> double, one multiplication, two fused multiply-adds, all
+// correctly rounded IEEE operations, so host and device compute the same bits.  ck_pack_uv verifies bit-identity for every
+// entry with exactly that sequence; one entry that does not come back (any other kind of input: the ABI takes arbitrary
+// doubles) keeps the whole layout on the 16-byte rows.  Nothing is approximated either way.
+constexpr double CK_UV_SCALE = 1e6, CK_UV_INV = 1e-6;
+inline double ck_unpack_uv_host(int32_t k) {
+  const double kd = (double)k;
+  const double q0 = kd * CK_UV_INV;
+  const double r = std::fma(-q0, CK_UV_SCALE, kd);
+  return std::fma(r, CK_UV_INV, q0);
+}
+inline bool ck_pack_one(double x, int32_t& k) {
+  const double t = std::nearbyint(x * CK_UV_SCALE);
+  if (!(std::fabs(t) < 2147483647.0)) return false;  // (also NaN)
+  k = (int32_t)t;
+  const double y = ck_unpack_uv_host(k);
+  uint64_t a, b;
+  std::memcpy(&a, &x, 8);
+  std::memcpy(&b, &y, 8);
+  return a == b || (x == 0.0 && y == 0.0);  // (-0.0 is stored as 0: the operator reads u, v only through products and sums with them)
+}
+
 struct CkLayout {
   std::vector<double2> uv;       // [rows][64]
+  std::vector<int2> uvp;         // [rows][64] packed image points (ck_pack_uv; then uv is released)
+  bool packed = false;
   std::vector<uint32_t> li;      // [li_rows][64] 3 x landmark slot (16 bits each; CK_NONE: none) of rows 2q | 2q+1 << 16 of a tile
   std::vector<int> src;          // [rows][64] row slot of the lane-per-landmark layout this entry is (-1: none)
   std::vector<int4> tile;        // x: first row, y: height, z: flags, w: first li row
@@ -59,11 +89,33 @@ struct CkLayout {
   int slots = 64;                // landmark slots of a batch (multiple of 64; the same for every workgroup)
   int n_part_rec = 0, max_acc = 0;
   int64_t rows = 0, li_rows = 0;
+  size_t n_uv = 0;               // entries of the row arrays (uv or uvp, src): (rows + CK_HMAX) x 64
   // statistics
   int64_t n_chunks = 0, n_cold_chunks = 0, n_obs = 0;
   int max_tiles_bt = 0;          // most tiles of a (workgroup, batch)
   double extra_lanes = 0;        // bank collisions left: extra lanes per (row, half), summed over the rows
 };
+
+// packs K.uv into K.uvp if every entry survives the round trip; false (and nothing changed) otherwise
+inline bool ck_pack_uv(CkLayout& K, int n_threads) {
+  const size_t n = K.uv.size();
+  std::vector<int2> out(n);
+  const int pieces = (int)std::min<size_t>(std::max<size_t>(n >> 16, 1), 4096);
+  std::atomic<bool> ok{true};
+  lpl_parallel(pieces, n_threads, [&](int pc) {
+    const size_t i0 = n * (size_t)pc / pieces, i1 = n * (size_t)(pc + 1) / pieces;
+    for (size_t i = i0; i < i1 && ok.load(std::memory_order_relaxed); ++i) {
+      int32_t a = 0, b = 0;
+      if (!ck_pack_one(K.uv[i].x, a) || !ck_pack_one(K.uv[i].y, b)) { ok.store(false); return; }
+      out[i] = make_int2(a, b);
+    }
+  });
+  if (!ok.load()) return false;
+  K.uvp.swap(out);
+  std::vector<double2>().swap(K.uv);
+  K.packed = true;
+  return true;
+}
 
 inline size_t ck_lds_bytes(int slots, int n_acc, int ng = 1) { return 16 + (size_t)ng * slots * 48 + (size_t)n_acc * 104 + 64; }  // = ck_lds_bytes_dev
 
@@ -117,7 +169,8 @@ inline size_t ck_lds_bytes_shape(const CkShape& sh, int slots, int n_acc, int ng
   return 16 + (size_t)ng * slots * sh.slot_bytes + (size_t)n_acc * sh.acc_bytes + 64 + (sh.acc_bytes != 104 ? 16 : 0);
 }
 inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector<int>& cam_of_rank, int n_waves,
-                     CkLayout& K, bool place = true, int hmax = CK_HMAX, int ng = 1, const CkShape& shape = CkShape()) {
+                     CkLayout& K, bool place = true, int hmax = CK_HMAX, int ng = 1, const CkShape& shape = CkShape(),
+                     bool pack_uv = true) {
   int n_threads = std::min(lpl_effective_cpus(), 128);
   if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
   hmax = std::min(CK_HMAX, std::max(1, hmax));
@@ -376,6 +429,12 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
         K.lane_acc[(size_t)tile0_of[w] * WAVE + i] = a >= 0 ? a : ~cold_rec[(size_t)cold0_of[w] + (size_t)(~a)];
       }
     });
+  }
+  // ---- packed image points (e0_ck only: e0_ck_det keeps the 16-byte rows, step 2 reads none); POVAR_CK_PACK=0: never
+  K.n_uv = K.uv.size();
+  {
+    const char* e = std::getenv("POVAR_CK_PACK");
+    if (shape.need_uv && shape.slot_bytes == 48 && pack_uv && !(e && e[0] == '0')) ck_pack_uv(K, n_threads);
   }
   // ---- tickets of the run totals (e0_ck_det)
   K.tick.assign(K.tile.size() * WAVE, 0);

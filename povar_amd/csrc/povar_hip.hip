@@ -151,6 +151,8 @@ struct povar_ctx {
   // with them (pl_ck: built by the placement thread from the placed rows, swapped in together with them)
   struct CkDev {
     DevBuf<double2> uv;
+    DevBuf<int2> uvp;            // packed image points (CkLayout::uvp) instead of uv
+    bool packed = false;
     DevBuf<uint32_t> li;
     DevBuf<int> src, bt_off, slot_rec;
     DevBuf<int2> lane_meta;
@@ -165,8 +167,9 @@ struct povar_ctx {
     int64_t w_lin_id = -1;       // linearisation whose robust weights w holds
     bool ready = false;
     void release() {
-      uv.release(); li.release(); src.release(); lane_meta.release(); bt_off.release();
+      uv.release(); uvp.release(); li.release(); src.release(); lane_meta.release(); bt_off.release();
       slot_rec.release(); tile.release(); part_range.release(); part.release(); w.release();
+      packed = false;
       lcnt.release(); tick.release();
       ready = false;
     }
@@ -508,7 +511,7 @@ int ck_max_cams() {
 // an error: D.ready stays false, what was uploaded is released and the term loop stays on e0_lpl / e0_lpl_h.
 bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked, size_t* bytes, bool need_uv = true) {
   bool ok = true;
-  const bool usable = K.uv.size() * sizeof(double2) < (1ull << 32) && c->n_cams <= ck_max_cams();
+  const bool usable = K.n_uv * sizeof(double2) < (1ull << 32) && c->n_cams <= ck_max_cams();
   D.ready = false;
   if (!usable) return true;
   auto guarded = [&](auto&& fn) {
@@ -533,7 +536,9 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
     const int sg = K.lane_seg[i];
     meta[i] = make_int2(K.lane_cam[i] < 0 ? -1 : (K.lane_cam[i] | ((sg & 63) << 16) | (((sg >> 8) & 63) << 22)), K.lane_acc[i]);
   }
-  if (need_uv) up(D.uv, K.uv);  // (step 2's operator does not read the image coordinates)
+  D.packed = need_uv && K.packed;
+  if (D.packed) up(D.uvp, K.uvp);  // 8 bytes per observation where every image point is a six-decimal number (ck_pack_uv)
+  else if (need_uv) up(D.uv, K.uv);  // (step 2's operator does not read the image coordinates)
   up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_meta, meta);
   up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
   if (c->det_ck) { up(D.lcnt, K.lcnt_log2); up(D.tick, K.tick); }
@@ -548,9 +553,9 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
   return ok;
 }
 CkP ck_params(const povar_ctx* c, const povar_ctx::CkDev& D) {
-  return CkP{D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p,
-             D.nb, D.slots, (unsigned)(D.src.n * sizeof(double2)), (unsigned)(D.li.n * sizeof(uint32_t)),
-             D.lcnt.p, D.tick.p, D.max_acc};
+  return CkP{D.packed ? reinterpret_cast<const double2*>(D.uvp.p) : D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p,
+             D.nb, D.slots, (unsigned)(D.src.n * (D.packed ? sizeof(int2) : sizeof(double2))), (unsigned)(D.li.n * sizeof(uint32_t)),
+             D.lcnt.p, D.tick.p, D.max_acc, D.packed ? 1 : 0};
 }
 CkP ck_params(const povar_ctx* c) { return ck_params(c, c->ck); }
 // e0_ck instantiations (povar_ctx::ck_variant): wavefronts per workgroup, rows a tile keeps in flight, double-buffered
@@ -603,10 +608,14 @@ template <int NW, int SD, bool DB, int NG>
 void launch_e0_ck_t(povar_ctx* c, const Dp& da) {
   const CkP k = ck_params(c);
   const size_t lds = ck_lds_bytes(c->ck.slots, c->ck.max_acc, NG);
-  if (c->opt.robust_norm == POVAR_NORM_HUBER)  // (the kernel recomputes the weights; CAUCHY's are 1: compute_error_weight)
-    hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, true>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
-  else
-    hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, false>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+  const bool huber = c->opt.robust_norm == POVAR_NORM_HUBER;  // (the kernel recomputes the weights; CAUCHY's are 1: compute_error_weight)
+  if (c->ck.packed) {
+    if (huber) hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, true, true>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+    else hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, false, true>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+  } else {
+    if (huber) hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, true, false>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+    else hipLaunchKernelGGL((e0_ck<NW, SD, DB, NG, false, false>), dim3(c->e0c_grid), dim3(NW * 64), lds, c->stream, da, k, c->ck.part.p);
+  }
 }
 // an instantiation runs a layout whose batches fit its groups: the LDS holds ng batches at once
 bool ck_variant_fits(const povar_ctx* c, int variant) {
@@ -632,9 +641,11 @@ void launch_e0_ck(povar_ctx* c, const Dp& da) {
 }
 template <int NW, int SD, bool DB, int NG>
 hipError_t ck_set_lds_t() {
-  hipError_t e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, NG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, NG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, NG, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, NG, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, NG, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)e0_ck<NW, SD, DB, NG, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
+  return e;
 }
 hipError_t ck_set_lds_all() {
   hipError_t e = hipFuncSetAttribute((const void*)e0_ck_det<16, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES);
@@ -693,7 +704,7 @@ int res_upload(povar_ctx* c, const ResLayout& R) {
       (rc = upload(D.own_q, R.own_q, c)) || (rc = upload(D.oq_off, R.oq_off, c)) || (rc = upload(D.oq_rec, R.oq_rec, c)))
     return rc;
   // granule buffers: tag 0 everywhere (no launch has the number 0), the launch counter starts at 1
-  const size_t n_part = (size_t)std::max(R.n_rec, 1) * 12, n_z = (size_t)c->n_cams * 12, n_nrm = (size_t)RES_MAX_WG * 2;
+  const size_t n_part = (size_t)std::max(R.n_rec, 1) * 12, n_z = (size_t)c->n_cams * 12, n_nrm = (size_t)RES_MAX_WG * 2 * 2;  // (two halves: the norms are double-buffered by term parity)
   if (n_part * sizeof(uint4) >= (1ull << 32)) return fail(-1, "resident series: partial records exceed a buffer descriptor");
   HIP_TRY(D.part.alloc(n_part, &c->bytes));
   HIP_TRY(D.zbuf.alloc(n_z, &c->bytes));
@@ -2231,6 +2242,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
 
 int povar_power_series_begin(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;  // (a resident series that gave up is repeated BEFORE its state is overwritten / continued)
   HIP_TRY(hipMemsetAsync(c->flags.p + 1, 0, sizeof(int) * 3, c->stream));
   launch_binv(c, 0, 0);
   HIP_TRY(hipGetLastError());
@@ -2239,6 +2251,7 @@ int povar_power_series_begin(povar_ctx* c) {
 
 int povar_power_series_step(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;  // (a resident series that gave up is repeated BEFORE its state is overwritten / continued)
   int mode = 1;
   if (int rc = launch_e0(c, &mode, 0)) return rc;
   launch_binv(c, mode, 0);
@@ -2557,6 +2570,7 @@ int povar_error_homogeneous(povar_ctx* c, povar_residual_info* out) {
 
 int povar_linearize_homogeneous(povar_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;
   if (int rc = swap_in_placed_rows(c, false); rc < 0) return rc;
   TimeScope ts(c, 0);
   if (int rc = clear_flag0(c)) return rc;
@@ -2606,6 +2620,7 @@ int povar_linearize_homogeneous(povar_ctx* c) {
 
 int povar_prepare_joint(povar_ctx* c, double lambda) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = res_verify(c)) return rc;
   if (!c->linearized_h) return fail(-1, "povar_prepare_joint before povar_linearize_homogeneous");
   TimeScope ts(c, 1);
   c->joint = true;
@@ -2880,7 +2895,7 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
         // the 72-byte landmark records once, 8 bytes of lane metadata per chunk lane and pass, the partial records out
         // (one per workgroup slot + one per chunk of a camera without a slot); the per-camera kernel reads those back
         const int64_t part = (int64_t)c->ck.n_part_rec * 96;
-        lm = 2 * c->ck.rows * WAVE * 18 /* no weight array: recomputed (ck_huber_w) */ + (int64_t)c->d.v2.n_tiles * WAVE * 72 + cam_static +
+        lm = 2 * c->ck.rows * WAVE * (c->ck.packed ? 10 : 18) /* image point 16 bytes (8 packed) + slot 2; no weight array: recomputed (ck_huber_w) */ + (int64_t)c->d.v2.n_tiles * WAVE * 72 + cam_static +
              2 * (int64_t)(c->ck.lane_meta.n) * 8 + part;
         cm = part + tail;
         break;
@@ -3007,6 +3022,7 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->tune_terms_us = c->res_tune_us[0];
   out->tune_res_us = c->res_tune_us[1];
   out->res_failed = c->res_failed ? 1 : 0;
+  out->ck_packed = c->ck.ready && c->ck.packed ? 1 : 0;
   return 0;
 }
 

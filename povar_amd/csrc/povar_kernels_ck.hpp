@@ -28,7 +28,7 @@ namespace povar {
 constexpr int CK_ROWS = 16;  // = CK_HMAX of ck_layout.hpp: rows per chunk tile at most
 
 struct CkP {
-  const double2* uv;     // [rows][64]
+  const double2* uv;     // [rows][64] image points; or, packed (ck_layout.hpp: ck_pack_uv), int2 (k_u, k_v) with u = RN(k_u / 10^6)
   const uint32_t* li;    // [li_rows][64] two 16-bit words per entry: 3 x the landmark's slot (its first LDS double), 0xffff: none
   const double* w;       // [rows][64] robust weights (only with a robust norm)
   const int4* tile;      // first row, height, flags, first li row
@@ -37,12 +37,21 @@ struct CkP {
   const int* bt_off;     // [grid * nb + 1]
   const int* slot_rec;   // partial record of each workgroup slot
   int nb, slots;
-  unsigned uv_bytes, li_bytes;  // sizes of uv (= w's in doubles x 2) and li: the rows are read through buffer descriptors
+  unsigned uv_bytes, li_bytes;  // sizes of uv (16 bytes per entry, 8 packed; w's: 8) and li: the rows are read through buffer descriptors
   // the bit-reproducible form (e0_ck_det, povar_kernels_ck_det.hpp)
   const uint8_t* lcnt;     // [lpl tiles][64] ceil(log2(observations added into the lane's landmark slot)); 255: none
   const uint16_t* tick;    // [tiles][64] ticket of the lane's run total at its accumulator slot (last lane of a run with a slot)
   int max_acc;             // accumulator slots the LDS is laid out for
+  int uv_packed;           // uv holds packed image points (the PK instantiations of e0_ck)
 };
+// a packed image coordinate back to the double it was packed from: the sequence ck_pack_uv (ck_layout.hpp) verified on the host
+// for every entry -- int -> double, a multiplication, two fused multiply-adds: correctly rounded operations, the same bits
+__device__ inline double ck_unpack_uv(unsigned k) {
+  const double kd = (double)(int)k;
+  const double q0 = kd * 1e-6;
+  const double r = __builtin_fma(-q0, 1e6, kd);
+  return __builtin_fma(r, 1e-6, q0);
+}
 constexpr int CK_ACC_STRIDE = 13;  // doubles per accumulator slot in LDS (12 used)
 __host__ __device__ inline size_t ck_lds_bytes_dev(int slots, int n_acc, int ng) { return 16 + (size_t)ng * slots * 48 + (size_t)n_acc * CK_ACC_STRIDE * 8 + 64; }
 
@@ -145,10 +154,10 @@ __device__ inline CkRows ck_rows(const CkP& k) {
   CkRows R;
   R.uv = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(k.uv), 0, k.uv_bytes, 0x00020000);
   R.li = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(k.li), 0, k.li_bytes, 0x00020000);
-  R.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(k.w), 0, k.w ? k.uv_bytes / 2 : 0, 0x00020000);
+  R.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(k.w), 0, k.w ? (k.uv_packed ? k.uv_bytes : k.uv_bytes / 2) : 0, 0x00020000);
   return R;
 }
-template <int D, bool ROBUST>
+template <int D, bool ROBUST, bool PK = false>
 struct CkStream {
   double2 uv[D];
   uint32_t w[D];
@@ -169,9 +178,15 @@ struct CkStream {
     j = j < 0 ? 0 : (j >= h ? h - 1 : j);
     const unsigned ul = (unsigned)lane;
     const unsigned ro = (unsigned)(row0 + j) * (unsigned)(WAVE * 16), lo = (unsigned)(li0 + (j >> 1)) * (unsigned)(WAVE * 4);
-    typedef unsigned __attribute__((ext_vector_type(4))) u4;
-    const u4 a = __builtin_amdgcn_raw_buffer_load_b128(R.uv, ul * 16u, ro, 0);
-    uv[i] = make_double2(__longlong_as_double(((long long)a.y << 32) | a.x), __longlong_as_double(((long long)a.w << 32) | a.z));
+    if (PK) {  // packed image points: 8 bytes per observation
+      typedef unsigned __attribute__((ext_vector_type(2))) u2;
+      const u2 a = __builtin_amdgcn_raw_buffer_load_b64(R.uv, ul * 8u, ro >> 1, 0);
+      uv[i] = make_double2(ck_unpack_uv(a.x), ck_unpack_uv(a.y));
+    } else {
+      typedef unsigned __attribute__((ext_vector_type(4))) u4;
+      const u4 a = __builtin_amdgcn_raw_buffer_load_b128(R.uv, ul * 16u, ro, 0);
+      uv[i] = make_double2(__longlong_as_double(((long long)a.y << 32) | a.x), __longlong_as_double(((long long)a.w << 32) | a.z));
+    }
     w[i] = __builtin_amdgcn_raw_buffer_load_b32(R.li, ul * 4u, lo, 0);
   }
   // step n of the walk is row n (DIR = +1) or row h - 1 - n (DIR = -1: the way back starts with the rows the way forward
@@ -183,8 +198,8 @@ struct CkStream {
   }
 };
 // the rows of one tile (h >= 1); st has been started on the tile (steps 0 .. D-1 are in flight)
-template <int D, bool ROBUST>
-__device__ inline void ck_forward_step(const Dp& d, const CkRows& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+template <int D, bool ROBUST, bool PK>
+__device__ inline void ck_forward_step(const Dp& d, const CkRows& k, CkStream<D, ROBUST, PK>& st, int row0, int li0, int h, int lane,
                                        const double* zz, const double* P3, const double* lh, double* lu, int S, int j, int i) {
   const double2 uv = st.uv[i];
   const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
@@ -195,21 +210,21 @@ __device__ inline void ck_forward_step(const Dp& d, const CkRows& k, CkStream<D,
     ck_obs_forward(d, uv, rw, zz, P3, hx, hy, hz, lu, S, s);
   }
 }
-template <int D, bool ROBUST>
-__device__ inline void ck_forward_rows(const Dp& d, const CkRows& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+template <int D, bool ROBUST, bool PK>
+__device__ inline void ck_forward_rows(const Dp& d, const CkRows& k, CkStream<D, ROBUST, PK>& st, int row0, int li0, int h, int lane,
                                        const double* zz, const double* P3, const double* lh, double* lu, int S) {
   int n0 = 0;
 #pragma nounroll
   for (; n0 + D <= h; n0 += D) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) ck_forward_step<D, ROBUST>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S, n0 + i, i);
+    for (int i = 0; i < D; ++i) ck_forward_step<D, ROBUST, PK>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S, n0 + i, i);
   }
 #pragma unroll
   for (int i = 0; i < D - 1; ++i)  // the last h % D rows
-    if (n0 + i < h) ck_forward_step<D, ROBUST>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S, n0 + i, i);
+    if (n0 + i < h) ck_forward_step<D, ROBUST, PK>(d, k, st, row0, li0, h, lane, zz, P3, lh, lu, S, n0 + i, i);
 }
-template <int D, bool ROBUST>
-__device__ inline void ck_backward_step(const Dp& d, const CkRows& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+template <int D, bool ROBUST, bool PK>
+__device__ inline void ck_backward_step(const Dp& d, const CkRows& k, CkStream<D, ROBUST, PK>& st, int row0, int li0, int h, int lane,
                                         const double* P3, const double* lh, const double* lg, int S, double* y, int j, int i) {
   const double2 uv = st.uv[i];
   const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
@@ -221,18 +236,18 @@ __device__ inline void ck_backward_step(const Dp& d, const CkRows& k, CkStream<D
     ck_obs_backward(d, uv, rw, P3, hx, hy, hz, g, y);
   }
 }
-template <int D, bool ROBUST>
-__device__ inline void ck_backward_rows(const Dp& d, const CkRows& k, CkStream<D, ROBUST>& st, int row0, int li0, int h, int lane,
+template <int D, bool ROBUST, bool PK>
+__device__ inline void ck_backward_rows(const Dp& d, const CkRows& k, CkStream<D, ROBUST, PK>& st, int row0, int li0, int h, int lane,
                                         const double* P3, const double* lh, const double* lg, int S, double* y) {
   int n0 = 0;
 #pragma nounroll
   for (; n0 + D <= h; n0 += D) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) ck_backward_step<D, ROBUST>(d, k, st, row0, li0, h, lane, P3, lh, lg, S, y, h - 1 - (n0 + i), i);
+    for (int i = 0; i < D; ++i) ck_backward_step<D, ROBUST, PK>(d, k, st, row0, li0, h, lane, P3, lh, lg, S, y, h - 1 - (n0 + i), i);
   }
 #pragma unroll
   for (int i = 0; i < D - 1; ++i)
-    if (n0 + i < h) ck_backward_step<D, ROBUST>(d, k, st, row0, li0, h, lane, P3, lh, lg, S, y, h - 1 - (n0 + i), i);
+    if (n0 + i < h) ck_backward_step<D, ROBUST, PK>(d, k, st, row0, li0, h, lane, P3, lh, lg, S, y, h - 1 - (n0 + i), i);
 }
 
 // The lane's camera record, from the rank-ordered image the other E0 kernels stage into LDS (Dp::hot_rec: z (12), then
@@ -274,8 +289,27 @@ __device__ inline void ck_load_p(const Dp& d, int rank, double* P3) {
 
 // end of a tile's backward pass: the chunk sums go to the camera's accumulator in LDS (lanes that share one are summed
 // first) or, for a camera without a slot in this workgroup, to the chunk's own partial record
+// Partial records leave the kernel through PLAIN stores: the eight L2s gather a record's six 16-byte pieces (and the pieces of
+// neighbouring records) into whole lines and the release at the kernel's end writes them back in bulk.  Measured (round 6,
+// profiles/r06_experiments.txt B; venice-1778, us per term in the replayed graph): plain 60.4, write-through (sc1, aux 16: every
+// 16-byte piece its own fabric write) 64.4, non-temporal (aux 2) 65.0, both 67.0 -- which is also what a hand-over of the
+// records INSIDE the launch (per-camera arrival counters, the owner sums) would have to pay before anything else.
+#ifndef POVAR_CK_PART_AUX
+#define POVAR_CK_PART_AUX 0  // aux bits of the buffer store: 0 = plain, 16 = sc1 (agent scope, write-through), 2 = nt
+#endif
+typedef unsigned __attribute__((ext_vector_type(4))) ck_u4;
+__device__ inline __amdgpu_buffer_rsrc_t ck_part_rsrc(double* part_out) {
+  return __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 0x7ffffff0, 0x00020000);  // (records: 96 bytes x < 2^24)
+}
+__device__ inline void ck_store_part(__amdgpu_buffer_rsrc_t pr, unsigned byte_off, double a, double b) {
+  ck_u4 g;
+  g.x = (unsigned)__double2loint(a); g.y = (unsigned)__double2hiint(a); g.z = (unsigned)__double2loint(b); g.w = (unsigned)__double2hiint(b);
+  __builtin_amdgcn_raw_buffer_store_b128(g, pr, byte_off, 0, POVAR_CK_PART_AUX);
+}
+// end of a tile's backward pass: the chunk sums go to the camera's accumulator in LDS (lanes that share one are summed
+// first) or, for a camera without a slot in this workgroup, to the chunk's own partial record
 __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int rank, int acc_slot, int seg, double* acc, int n_acc,
-                                     double* part_out) {
+                                     __amdgpu_buffer_rsrc_t part_out) {
   if (flags & 1) seg_scan_steps<12>(y, lane, seg & 255, 4);  // (inclusive scan: the run's total is in its LAST lane)
   if (rank >= 0) {
     if (acc_slot >= 0) {
@@ -285,9 +319,9 @@ __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int r
           __hip_atomic_fetch_add(acc + acc_slot * CK_ACC_STRIDE + m, y[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     } else {
-      double2* o = reinterpret_cast<double2*>(part_out + (size_t)(~acc_slot) * 12);
+      const unsigned o = (unsigned)(~acc_slot) * 96u;
 #pragma unroll
-      for (int m = 0; m < 6; ++m) o[m] = make_double2(y[2 * m], y[2 * m + 1]);
+      for (int m = 0; m < 6; ++m) ck_store_part(part_out, o + 16u * m, y[2 * m], y[2 * m + 1]);
     }
   }
 }
@@ -311,12 +345,13 @@ __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int r
 //     that would hide which tile comes next.
 // NG groups of NW / NG wavefronts each (batch b belongs to group b % NG; the layout's batch count is a multiple of NG and the
 // LDS holds NG batches of landmark slots).
-template <int NW, int SD, bool DB, int NG, bool ROBUST>
+template <int NW, int SD, bool DB, int NG, bool ROBUST, bool PK>
 __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) {
   const int done = d.flags[1];
   extern __shared__ double ck_lds[];
   constexpr int GW = NW / NG;  // wavefronts of a group
   const CkRows R = ck_rows(k);
+  const __amdgpu_buffer_rsrc_t PR = ck_part_rsrc(part_out);
   const int S = k.slots;
   const int lane0 = threadIdx.x & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -395,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     int t = tile_of(tb0, 0);
     int rank = rank_next;
     double zz[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, P3[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (P3[9..11]: t, HUBER only)
-    CkStream<SD, ROBUST> st;
+    CkStream<SD, ROBUST, PK> st;
     st.clear();
     int row0 = 0, h = 0, fl = 0, li0 = 0;
     // (Order of the requests: the rows of a tile are requested after everything else of its phase.  The wait counters
@@ -410,12 +445,12 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     int tn = tile_of(tb0, 1);
     int rank_n = 0, rank_nn = 0;
     double zn[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, Pn[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    CkStream<SD, ROBUST> stn;
+    CkStream<SD, ROBUST, PK> stn;
     stn.clear();
     int row0n = 0, hnx = 0, fln = 0, li0n = 0;
     // ---- the way forward starts: record and first rows of the first tile (the metadata came with the last phase)
     if (t < tb1) {
-      row0 = tiles[4 * t]; h = tiles[4 * t + 1]; li0 = tiles[4 * t + 3];
+      row0 = tiles[4 * t]; h = tiles[4 * t + 1]; fl = tiles[4 * t + 2]; li0 = tiles[4 * t + 3];
       if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
       const int rk = rank < 0 ? 0 : rank;
       ck_load_z(d, rk, zz);
@@ -450,7 +485,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     auto request_next_fwd = [&]() {
       if (DB && tn < tb1) {
         const int tnn = tile_of(tb0, q_t + 2);
-        row0n = tiles[4 * tn]; hnx = tiles[4 * tn + 1]; li0n = tiles[4 * tn + 3];
+        row0n = tiles[4 * tn]; hnx = tiles[4 * tn + 1]; fln = tiles[4 * tn + 2]; li0n = tiles[4 * tn + 3];
         if (tnn < tb1) rank_nn = ck_rank(k.lane_meta[(size_t)tnn * WAVE + lane].x);
         const int rk = rank_n < 0 ? 0 : rank_n;
         ck_load_z(d, rk, zn);
@@ -462,7 +497,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     group_barrier();
     // ---- forward
     while (t < tb1) {
-      ck_forward_rows<SD, ROBUST>(d, R, st, row0, li0, h, lane, zz, P3, lh, lu, S);
+      ck_forward_rows<SD, ROBUST, PK>(d, R, st, row0, li0, h, lane, zz, P3, lh, lu, S);
       if (tn >= tb1) break;  // (t, q_t, rank, P3 stay on the last tile: the way back starts there)
       t = tn;
       ++q_t;
@@ -474,11 +509,11 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
 #pragma unroll
         for (int e = 0; e < (ROBUST ? 12 : 9); ++e) P3[e] = Pn[e];
         st = stn;
-        row0 = row0n; h = hnx; li0 = li0n;
+        row0 = row0n; h = hnx; fl = fln; li0 = li0n;
         rank_n = rank_nn;
         request_next_fwd();
       } else {
-        row0 = tiles[4 * t]; h = tiles[4 * t + 1]; li0 = tiles[4 * t + 3];
+        row0 = tiles[4 * t]; h = tiles[4 * t + 1]; fl = tiles[4 * t + 2]; li0 = tiles[4 * t + 3];
         if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
         const int rk = rank < 0 ? 0 : rank;
         ck_load_z(d, rk, zz);
@@ -507,9 +542,8 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     if (t < tb1) {
       const int2 me = k.lane_meta[(size_t)t * WAVE + lane];
       seg = ck_seg(me.x);
-      acc_slot = me.y;
-      fl = tiles[4 * t + 2];
-      if (tp < tb1) {
+      acc_slot = me.y;  // (fl: the tile's header word came with row0 / h / li0 -- a scalar load HERE sits in front of the barrier's
+      if (tp < tb1) {   //  lgkmcnt(0): 2.6 k cycles per batch in the stamps of round 6, profiles/r06_e0_ck_phase_stamps.txt)
         const int2 mp = k.lane_meta[(size_t)tp * WAVE + lane];
         rank_p = ck_rank(mp.x);
         seg_p = ck_seg(mp.x);
@@ -563,8 +597,8 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       double y[12];
 #pragma unroll
       for (int m = 0; m < 12; ++m) y[m] = 0;
-      ck_backward_rows<SD, ROBUST>(d, R, st, row0, li0, h, lane, P3, lh, lu, S, y);
-      ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, part_out);
+      ck_backward_rows<SD, ROBUST, PK>(d, R, st, row0, li0, h, lane, P3, lh, lu, S, y);
+      ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, PR);
       if (tp >= tb1) break;
       t = tp;
       --q_t;
@@ -596,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
   for (int i = threadIdx.x; i < n_acc * 6; i += NW * 64) {
     const int r = i / 6, m = 2 * (i % 6);
     const int rec = k.slot_rec[cam0 + r];
-    reinterpret_cast<double2*>(part_out + (size_t)rec * 12)[i % 6] = make_double2(acc[r * CK_ACC_STRIDE + m], acc[r * CK_ACC_STRIDE + m + 1]);
+    ck_store_part(PR, (unsigned)rec * 96u + 16u * (unsigned)(i % 6), acc[r * CK_ACC_STRIDE + m], acc[r * CK_ACC_STRIDE + m + 1]);
   }
   if (d.p2p_epoch && blockIdx.x == 0 && threadIdx.x == 0) *d.p2p_epoch += 1;  // one tick per term (as e0_lpl)
 }

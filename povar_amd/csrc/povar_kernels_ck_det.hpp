@@ -27,7 +27,10 @@
 namespace povar {
 
 constexpr int CK_FIX_BITS = 61;
-__device__ inline int ck_xp(double v) { return __builtin_amdgcn_frexp_exp(v); }  // |v| < 2^ck_xp(v)   (0, inf, nan: 0)
+// |v| < 2^ck_xp(v) for v > 0; an exact ZERO contributes no exponent (INT_MIN: a no-op for the maximum) -- frexp's 0 for it
+// would set the binary point of a landmark whose real contributions are tiny (late terms: 2^-40) forty bits too high and
+// leave the sum ~ 20 bits; inf / nan: 0 (the sum is garbage either way and the finiteness test downstream says so)
+__device__ inline int ck_xp(double v) { return v > 0.0 ? __builtin_amdgcn_frexp_exp(v) : (v == 0.0 ? INT_MIN : 0); }
 __device__ inline unsigned long long ck_fix(double x, int e) {  // x 2^e to the nearest integer, two's complement (|x 2^e| < 2^62)
   const double xs = __builtin_ldexp(x, e) + 0.5;
   const double hi = __builtin_floor(xs * 0x1p-32);

@@ -33,6 +33,12 @@
 //     workgroup that reads z_c has used it;
 //   * workgroup w's record of camera c of term i + 1 replaces that of term i after w has seen z_c of term i, which the
 //     owner publishes after it has read the record.
+//   * the norm granules of a workgroup (early-exit tests only) are DOUBLE-BUFFERED by the parity of the term their tag
+//     names: workgroup g publishes the norms tagged i + 1 once it has z tag i and the records of its cameras -- which does not
+//     wait for a workgroup s that contributes to none of g's cameras and may still be sweeping the norms tagged i.  With one
+//     buffer s would find tag i + 1 in g's slot, never match and spin out (the resident path lost, silently: ADVICE r05).
+//     With two, g cannot write tag i + 2 into the half of tag i before it has passed its own sweep of the norms tagged
+//     i + 1, which needs s's granule tagged i + 1, which s publishes only after its sweep of tag i.
 // Every spin is bounded (ResP::spin_limit): a launch whose workgroups are not all resident (another context's kernels on
 // the device) gives up, raises bit 2 of flags[0] and the library repeats the solve with the per-term kernels.
 #pragma once
@@ -62,7 +68,7 @@ struct ResP {
   const int* oq_rec;
   uint4* part;            // [n_rec][12] partial records, workgroup-major, one 16-byte granule pair per entry
   uint4* zbuf;            // [n_cams][12] z = sigma x of the current term, rows in popularity order
-  uint4* nrm;             // [RES_MAX_WG][2] squared norms of (term, sum) over the cameras a workgroup owns
+  uint4* nrm;             // [2][RES_MAX_WG][2] squared norms of (term, sum) over the cameras a workgroup owns, by term parity
   unsigned* launch;       // launch counter (the high bits of the tags)
   unsigned part_bytes, z_bytes, nrm_bytes;
   int W, m, want_norms, want_norm0;
@@ -83,6 +89,8 @@ __device__ inline ResBufs res_bufs(const ResP& k) {
   return B;
 }
 constexpr int RES_SC1 = 16;  // aux bits of the buffer instructions: sc1 (agent scope)
+// byte offset of norm granule pair e (0: term, 1: sum) of workgroup w in the half of the tag's parity
+__device__ inline unsigned res_nrm_off(unsigned tag, int w, int e) { return ((tag & 1u) * (unsigned)(2 * RES_MAX_WG) + (unsigned)(2 * w + e)) * 16u; }
 // one double as a granule pair {lo, tag, hi, tag}
 __device__ inline void res_put(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double v, unsigned tag) {
   res_u4 g;
@@ -220,8 +228,8 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
     if (t == 0) {
       double a = 0;
       for (int o = 0; o < nO; ++o) a += onrm[2 * o];
-      res_put(B.nrm, (unsigned)(2 * g) * 16u, a, tag0 | 1u);
-      res_put(B.nrm, (unsigned)(2 * g + 1) * 16u, a, tag0 | 1u);
+      res_put(B.nrm, res_nrm_off(tag0 | 1u, g, 0), a, tag0 | 1u);
+      res_put(B.nrm, res_nrm_off(tag0 | 1u, g, 1), a, tag0 | 1u);
     }
   }
   // the lane's chunks: rows, camera slot, P3
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
         double v[2] = {0, 0};
         bool ok = true;
         for (int w0 = 0; w0 < k.W; w0 += 64) {
-          const unsigned off[2] = {(unsigned)(2 * (w0 + lane)) * 16u, (unsigned)(2 * (w0 + lane) + 1) * 16u};
+          const unsigned off[2] = {res_nrm_off(tag, w0 + lane, 0), res_nrm_off(tag, w0 + lane, 1)};
           const bool act[2] = {w0 + lane < k.W, w0 + lane < k.W};
           double e2[2];
           ok = res_get<2>(B.nrm, off, act, tag, e2, k.spin_limit) && ok;
@@ -433,8 +441,8 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
     if (k.want_norms && t == 0) {
       double a = 0, b = 0;
       for (int o = 0; o < nO; ++o) { a += onrm[2 * o]; b += onrm[2 * o + 1]; }
-      res_put(B.nrm, (unsigned)(2 * g) * 16u, a, tag + 1u);
-      res_put(B.nrm, (unsigned)(2 * g + 1) * 16u, b, tag + 1u);
+      res_put(B.nrm, res_nrm_off(tag + 1u, g, 0), a, tag + 1u);
+      res_put(B.nrm, res_nrm_off(tag + 1u, g, 1), b, tag + 1u);
     }
   }
   // ---------------- epilogue: sum and last term of the owned cameras, status
@@ -444,6 +452,7 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
     const int c = k.own_cam[O0 + e / 12];
     d.accum[12 * (size_t)c + e % 12] = oacc[e];
     d.tmp[12 * (size_t)c + e % 12] = otmp[e];
+    store_z(d, c, e % 12, otmp[e] * osig[e]);  // z = sigma x of the last term, where the per-term kernels leave it (povar_power_series_step goes on from it)
   }
   if (t == 0) {
     if (ctl[0]) atomicOr(&d.flags[0], 4);

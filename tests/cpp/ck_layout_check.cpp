@@ -57,7 +57,29 @@ int main(int argc, char** argv) {
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   // ---- invariants
   CHECK((int)K.bt_off.size() == grid * K.nb + 1 && K.bt_off.back() == (int)K.tile.size());
-  CHECK((int64_t)K.uv.size() == (K.rows + CK_HMAX) * 64 && K.src.size() == K.uv.size() && (int64_t)K.li.size() == (K.li_rows + CK_HMAX) * 64);
+  // image points: 16-byte doubles, or packed (two int32 of micro-units) when every one of them is a six-decimal number
+  // (CK_CHECK_WANT_PACKED=0|1: what the caller expects of this problem); either way uv_at() must return the problem's bits
+  CHECK(K.packed ? (K.uv.empty() && K.uvp.size() == K.n_uv) : (K.uvp.empty() && K.uv.size() == K.n_uv));
+  if (const char* e = std::getenv("CK_CHECK_WANT_PACKED")) CHECK(K.packed == (e[0] == '1'));
+  if (step2) CHECK(!K.packed);
+  auto uv_at = [&](size_t idx) { return K.packed ? make_double2(ck_unpack_uv_host(K.uvp[idx].x), ck_unpack_uv_host(K.uvp[idx].y)) : K.uv[idx]; };
+  {  // the pack / unpack pair by itself: six-decimal numbers come back bit for bit, anything else is refused
+    int32_t k = 0;
+    const double good[] = {0.0, 1e-6, -1e-6, 332.65, -0.000001, 2147.483646, -2147.483646, 123.456789, 1999.999999};
+    for (double x : good) { CHECK(ck_pack_one(x, k)); const double y = ck_unpack_uv_host(k); CHECK(std::memcmp(&x, &y, 8) == 0 || x == 0.0); }
+    const double bad[] = {1e-7, 0.1234567, 2147.483648, -3000.0, 1.0 / 3.0, 332.65 + 1e-12};
+    for (double x : bad) CHECK(!ck_pack_one(x, k));
+    uint64_t state = 88172645463325252ull;
+    for (int i = 0; i < 200000; ++i) {  // k / 10^6 for random k: what strtod makes of a "%.6f" string
+      state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+      const int32_t kk = (int32_t)(state >> 33) - (1 << 30);
+      const double x = (double)kk / 1e6;
+      CHECK(ck_pack_one(x, k) && k == kk);
+      const double y = ck_unpack_uv_host(k);
+      CHECK(std::memcmp(&x, &y, 8) == 0);
+    }
+  }
+  CHECK((int64_t)K.n_uv == (K.rows + CK_HMAX) * 64 && K.src.size() == K.n_uv && (int64_t)K.li.size() == (K.li_rows + CK_HMAX) * 64);
   CHECK(ck_lds_bytes_shape(shape, K.slots, K.max_acc, K.ng) <= (size_t)CK_LDS_BYTES && K.nb % K.ng == 0 && K.slots <= shape.max_slots);
   std::vector<int> lm_of_obs(n_obs);
   for (int l = 0; l < n_lms; ++l)
@@ -95,7 +117,8 @@ int main(int argc, char** argv) {
             CHECK(i >= 0 && !seen[i]);
             seen[i] = 1;
             ++n_placed;
-            CHECK(K.uv[idx].x == obs[2 * (size_t)i] && K.uv[idx].y == obs[2 * (size_t)i + 1]);
+            const double2 uvi = uv_at(idx);
+            CHECK(std::memcmp(&uvi.x, &obs[2 * (size_t)i], 8) == 0 && std::memcmp(&uvi.y, &obs[2 * (size_t)i + 1], 8) == 0);
             CHECK(rank1[cam_idx[i]] - 1 == rank);
             // the landmark slot: tile (slot / 64) of this batch, a lane of the landmark
             const int lt = t0w + b + K.nb * (int)(li / 64);
@@ -165,10 +188,10 @@ int main(int argc, char** argv) {
     if (hist[h]) std::fprintf(stderr, "tiles of %2d rows: %lld\n", h, (long long)hist[h]);
   std::printf("{\"ok\": 1, \"nb\": %d, \"slots\": %d, \"tiles\": %zu, \"rows\": %lld, \"chunks\": %lld, \"cold_chunks\": %lld, "
               "\"obs_per_chunk\": %.3f, \"pad_frac\": %.4f, \"max_tiles_bt\": %d, \"part_rec\": %d, \"lpl_part_rec\": %d, "
-              "\"extra_lanes_per_half_row\": %.4f, \"lds_bytes\": %zu, \"build_ms\": %.1f, \"lpl_rows\": %lld}\n",
+              "\"extra_lanes_per_half_row\": %.4f, \"lds_bytes\": %zu, \"build_ms\": %.1f, \"lpl_rows\": %lld, \"packed\": %d}\n",
               K.nb, K.slots, K.tile.size(), (long long)K.rows, (long long)K.n_chunks, (long long)K.n_cold_chunks,
               (double)n_obs / std::max<int64_t>(K.n_chunks, 1), 1.0 - (double)n_obs / ((double)K.rows * 64), K.max_tiles_bt,
               K.n_part_rec, L.n_part_rec, K.extra_lanes / (2.0 * std::max<int64_t>(K.rows, 1)), ck_lds_bytes_shape(shape, K.slots, K.max_acc, K.ng), ms,
-              (long long)L.rows);
+              (long long)L.rows, K.packed ? 1 : 0);
   return 0;
 }

@@ -33,10 +33,30 @@ def _run(tmp_path, n_cams, lm_off, cam_idx, obs, grid, n_acc, n_waves=16, env=No
 def test_ck_layout_invariants_medium(tmp_path, grid, n_acc, n_waves):
     from povar_amd import synth
     p = synth.make_problem(300, 20000, 90000, seed=5)
-    s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, grid, n_acc, n_waves)
-    assert s["ok"] == 1 and s["lds_bytes"] <= 160 * 1024
+    # (the generator's observations are six-decimal numbers, as the reference's files hold them: the rows are packed)
+    s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, grid, n_acc, n_waves, env={"CK_CHECK_WANT_PACKED": "1"})
+    assert s["ok"] == 1 and s["lds_bytes"] <= 160 * 1024 and s["packed"] == 1
     if p.n_cams <= n_acc:
         assert s["cold_chunks"] == 0
+
+
+def test_ck_layout_packs_the_image_points_only_when_every_one_comes_back(tmp_path):
+    """Packed rows (two int32 of micro-units per observation) exist only where EVERY image point is RN(k / 10^6) with
+    |k| < 2^31 and the device's decode sequence returns its bits (the checker decodes every row and compares the bits with the
+    problem's): arbitrary doubles, one observation off by an ulp, a coordinate beyond 2147 px or POVAR_CK_PACK=0 keep the
+    16-byte rows."""
+    from povar_amd import synth
+    p = synth.make_problem(60, 3000, 14000, seed=11)
+    assert _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 16, 60, env={"CK_CHECK_WANT_PACKED": "1"})["packed"] == 1
+    assert _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 16, 60, env={"CK_CHECK_WANT_PACKED": "0", "POVAR_CK_PACK": "0"})["packed"] == 0
+    obs = p.obs.copy()
+    obs[777, 1] = np.nextafter(obs[777, 1], np.inf)
+    assert _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, obs, 16, 60, env={"CK_CHECK_WANT_PACKED": "0"})["packed"] == 0
+    obs = p.obs.copy()
+    obs[5, 0] = 2147.483648
+    assert _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, obs, 16, 60, env={"CK_CHECK_WANT_PACKED": "0"})["packed"] == 0
+    obs = p.obs + np.random.default_rng(1).normal(size=p.obs.shape) * 1e-9
+    assert _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, obs, 16, 60, env={"CK_CHECK_WANT_PACKED": "0"})["packed"] == 0
 
 
 def test_ck_layout_long_tracks_and_single_observation_landmarks(tmp_path):

@@ -204,3 +204,39 @@ def test_a_layout_the_chunk_kernels_cannot_run_is_not_an_error(monkeypatch, plac
     assert rel(ref.solve_pose(LAM, capi.POWER_VARPROJ, M)[0], inc) < 1e-10
     ctx.close()
     ref.close()
+
+
+def test_packed_image_points_are_the_same_operator(monkeypatch):
+    """Round 6: where every observation is a six-decimal number (the reference's files: bal_problem.cpp:373-375) the chunk rows
+    keep the image points as two int32 of micro-units and the kernel rebuilds the doubles bit for bit (ck_layout.hpp:
+    ck_pack_uv verifies every entry).  Packed against POVAR_CK_PACK=0 on the same problem: the same E0 x and the same 20-term
+    increment to the summation order of the LDS atomics; a problem with ONE observation that is not such a number keeps the
+    16-byte rows and still gives the oracle's answer."""
+    from povar_amd import capi, synth
+    monkeypatch.setenv("POVAR_E0_V1", "0")
+    monkeypatch.setenv("POVAR_LPL_PLACE", "sync")
+    p = synth.make_problem(300, 20000, 90000, seed=5)
+    x = np.random.default_rng(3).normal(size=12 * p.n_cams)
+    out = {}
+    for pack in ("1", "0"):
+        monkeypatch.setenv("POVAR_CK_PACK", pack)
+        for robust in ("NONE", "HUBER"):
+            ctx = _prepared(p, robust)
+            ctx.set_e0_kernel(1)
+            assert ctx.layout_info().ck_packed == int(pack)
+            out[pack, robust] = (ctx.right_mul_e0_pose(x), ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0])
+            ctx.close()
+    for robust in ("NONE", "HUBER"):
+        assert rel(out["1", robust][0], out["0", robust][0]) < 1e-14
+        assert rel(out["1", robust][1], out["0", robust][1]) < 1e-12
+    monkeypatch.delenv("POVAR_CK_PACK")
+    obs = p.obs.copy()
+    obs[12345, 0] += 1e-9
+    import dataclasses
+    q = dataclasses.replace(p, obs=obs) if dataclasses.is_dataclass(p) else type(p)(p.n_cams, p.n_lms, p.lm_off, p.cam_idx, obs, p.cams, p.lms)
+    ctx = _prepared(q)
+    ctx.set_e0_kernel(1)
+    assert ctx.layout_info().ck_packed == 0
+    y = ctx.right_mul_e0_pose(x)
+    ctx.close()
+    assert rel(y, out["0", "NONE"][0]) < 1e-9  # (one observation moved by 1e-9 px)
