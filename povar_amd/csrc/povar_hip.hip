@@ -227,7 +227,7 @@ struct povar_ctx {
   // state
   DevBuf<double4> cams4, cams_lin4, cams_bak4, lms4, lms_lin4, lms_bak4, jl_scale4, rres, q4;
   DevBuf<double> hll_inv, sw, sigma, diag2, G, binv, b, tmp, accum, z, y, inc, item_part,
-      item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec, ncw, cc_h, cc_part, hot_part, hot_rec;
+      item_partG, norm_part, norms, part, scal, stage, cm_h, lmrec, ncw, cc_h, cc_part, hot_part, hot_rec, zimg;
 
   // explicit-SC solvers (PCG / CHOLESKY / RIPCG), allocated on first use
   DevBuf<double> sc_dm_part, sc_dm, sc_bmat, sc_minv, sc_x, sc_r, sc_p, sc_q, sc_zv, sc_part, sc_s;
@@ -1933,6 +1933,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   ALLOC(cc_h, 4 * std::max<size_t>(L.cc_slot.size(), 1)); ALLOC(cc_part, 12 * (size_t)std::max(c->n_cold_items, 1));
   ALLOC(hot_part, (size_t)c->e0c_grid * c->n_hot_acc * 12);
   ALLOC(hot_rec, (size_t)std::max(n_cams, HOT_MAX) * HOT_REC_STRIDE);  // every camera, in popularity order
+  ALLOC(zimg, (size_t)n_cams * 12);  // z alone, by rank: what e0_ck gathers Z from (Dp::zimg)
   ALLOC(norm_part, 2 * (size_t)std::max(c->n_cam_blocks, n_cams)); ALLOC(norms, 4); ALLOC(flags, 4);
   ALLOC(part, n_part * 2 + 8 * 1024); ALLOC(scal, 8);  // + one slot set per workgroup of the lane-per-landmark kernels
   ALLOC(stage, std::max(3 * nl, 144 * nc));
@@ -1960,6 +1961,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   d.cmv = CmView{c->cm_slot.p, c->cm_h.p, n_obs, c->item_off.p, c->cam_item_off.p, c->item_part.p, c->n_items, nullptr};
   d.hot_part = nullptr; d.cam_hot = c->cam_hot.p; d.n_hot_acc = c->n_hot_acc; d.n_hot_wg = c->e0c_grid;
   d.hot_rec = c->hot_rec.p;
+  d.zimg = c->zimg.p;
   d.hot_cams = c->hot_cams.p; d.n_hot = std::min(n_cams, HOT_MAX);
   d.part_range = nullptr;
   d.p2p_peer = nullptr; d.p2p_epoch = nullptr; d.p2p_world = 1; d.p2p_rank = 0;
@@ -2007,7 +2009,7 @@ void povar_destroy(povar_ctx* c) {
   c->hll_inv.release(); c->sw.release(); c->sigma.release(); c->diag2.release(); c->G.release();
   c->binv.release(); c->b.release(); c->tmp.release(); c->accum.release(); c->z.release(); c->y.release();
   c->inc.release(); c->item_part.release(); c->item_partG.release(); c->norm_part.release();
-  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->ncw.release(); c->cc_h.release(); c->cc_part.release(); c->hot_part.release(); c->hot_rec.release();
+  c->norms.release(); c->part.release(); c->scal.release(); c->stage.release(); c->cm_h.release(); c->lmrec.release(); c->ncw.release(); c->cc_h.release(); c->cc_part.release(); c->hot_part.release(); c->hot_rec.release(); c->zimg.release();
   c->sc_dense.release(); c->sc_xpad.release(); c->sc_lm_slot0.release(); c->sc_lm_cnt.release(); c->sc_info.release();
   c->sc_dm_part.release(); c->sc_dm.release(); c->sc_bmat.release(); c->sc_minv.release(); c->sc_x.release();
   c->sc_r.release(); c->sc_p.release(); c->sc_q.release(); c->sc_zv.release(); c->sc_part.release(); c->sc_s.release();

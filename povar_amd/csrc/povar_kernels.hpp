@@ -127,6 +127,8 @@ struct Dp {
   const int* hot_cams;  // cameras cached in LDS by e0_lm_cached, most observed first
   double* hot_rec;      // [HOT_MAX][24] contiguous LDS image of the hot cameras' records: z_c (12, rewritten by
                         // every B^-1 kernel) then the static camera part (step 1: P[:, :3] (9), step 2: P (12))
+  double* zimg;         // [n_cams][12] z_c alone, by rank (step 1): what e0_ck gathers Z from -- lines of its own, so that the
+                        // per-camera step at e0_ck's head can hand z over inside the launch (sc1 stores, sc1 loads only)
   int n_hot;
   const int* long_lm;
   const int* long_first;
@@ -2614,7 +2616,10 @@ __global__ __launch_bounds__(K8_THREADS) void cam_build_binv(Dp d, double lambda
 __device__ inline void store_z(const Dp& d, int c, int j, double v) {
   d.z[12 * (size_t)c + j] = v;
   const int r = d.cam_hot[c];
-  if (r > 0) d.hot_rec[(size_t)(r - 1) * HOT_REC_STRIDE + j] = v;
+  if (r > 0) {
+    d.hot_rec[(size_t)(r - 1) * HOT_REC_STRIDE + j] = v;
+    if (d.zimg) d.zimg[(size_t)(r - 1) * 12 + j] = v;  // the z image e0_ck gathers from (povar_kernels_ck.hpp: ck_load_z_img)
+  }
 }
 
 // static part of the hot camera records (per linearisation): P[:, :3] row-major (step 1, hom = 0)

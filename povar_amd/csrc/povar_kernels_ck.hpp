@@ -52,6 +52,7 @@ __device__ inline double ck_unpack_uv(unsigned k) {
   const double r = __builtin_fma(-q0, 1e6, kd);
   return __builtin_fma(r, 1e-6, q0);
 }
+typedef unsigned __attribute__((ext_vector_type(4))) ck_u4;
 constexpr int CK_ACC_STRIDE = 13;  // doubles per accumulator slot in LDS (12 used)
 __host__ __device__ inline size_t ck_lds_bytes_dev(int slots, int n_acc, int ng) { return 16 + (size_t)ng * slots * 48 + (size_t)n_acc * CK_ACC_STRIDE * 8 + 64; }
 
@@ -264,6 +265,23 @@ __device__ inline void ck_load_z(const Dp& d, int rank, double* zz) {
     zz[2 * j + 1] = v.y;
   }
 }
+// ... the Z half from the z image (Dp::zimg: z alone in 96-byte rows by rank -- a row is one or two cache lines that hold
+// nothing but z, where the 192-byte records of the other kernels' image straddle three): six 16-byte loads through a buffer
+// descriptor built where it is used (four SGPRs that do not live through the row loops).  Plain loads: the hub cameras' rows are
+// gathered by every wavefront of every workgroup and live in the L1 -- agent-scope (sc1) loads, which a hand-over of z INSIDE
+// the launch would need, cost 3.7 us per term (profiles/r06_experiments.txt D).
+__device__ inline __amdgpu_buffer_rsrc_t ck_zimg_rsrc(const Dp& d) {
+  return __builtin_amdgcn_make_buffer_rsrc(d.zimg, 0, (unsigned)d.n_cams * 96u, 0x00020000);
+}
+__device__ inline void ck_load_z_img(const Dp& d, int rank, double* zz) {
+  const __amdgpu_buffer_rsrc_t ZR = ck_zimg_rsrc(d);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const ck_u4 a = __builtin_amdgcn_raw_buffer_load_b128(ZR, (unsigned)rank * 96u + 16u * j, 0, 0);
+    zz[2 * j] = __hiloint2double((int)a.y, (int)a.x);
+    zz[2 * j + 1] = __hiloint2double((int)a.w, (int)a.z);
+  }
+}
 __device__ inline void ck_load_p3(const Dp& d, int rank, double* P3) {
   const double2* r = reinterpret_cast<const double2*>(d.hot_rec + (size_t)rank * HOT_REC_STRIDE) + 6;
 #pragma unroll
@@ -297,7 +315,6 @@ __device__ inline void ck_load_p(const Dp& d, int rank, double* P3) {
 #ifndef POVAR_CK_PART_AUX
 #define POVAR_CK_PART_AUX 0  // aux bits of the buffer store: 0 = plain, 16 = sc1 (agent scope, write-through), 2 = nt
 #endif
-typedef unsigned __attribute__((ext_vector_type(4))) ck_u4;
 __device__ inline __amdgpu_buffer_rsrc_t ck_part_rsrc(double* part_out) {
   return __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 0x7ffffff0, 0x00020000);  // (records: 96 bytes x < 2^24)
 }
@@ -309,7 +326,7 @@ __device__ inline void ck_store_part(__amdgpu_buffer_rsrc_t pr, unsigned byte_of
 // end of a tile's backward pass: the chunk sums go to the camera's accumulator in LDS (lanes that share one are summed
 // first) or, for a camera without a slot in this workgroup, to the chunk's own partial record
 __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int rank, int acc_slot, int seg, double* acc, int n_acc,
-                                     __amdgpu_buffer_rsrc_t part_out) {
+                                     double* part_ptr) {
   if (flags & 1) seg_scan_steps<12>(y, lane, seg & 255, 4);  // (inclusive scan: the run's total is in its LAST lane)
   if (rank >= 0) {
     if (acc_slot >= 0) {
@@ -319,6 +336,7 @@ __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int r
           __hip_atomic_fetch_add(acc + acc_slot * CK_ACC_STRIDE + m, y[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     } else {
+      const __amdgpu_buffer_rsrc_t part_out = ck_part_rsrc(part_ptr);
       const unsigned o = (unsigned)(~acc_slot) * 96u;
 #pragma unroll
       for (int m = 0; m < 6; ++m) ck_store_part(part_out, o + 16u * m, y[2 * m], y[2 * m + 1]);
@@ -351,7 +369,6 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
   extern __shared__ double ck_lds[];
   constexpr int GW = NW / NG;  // wavefronts of a group
   const CkRows R = ck_rows(k);
-  const __amdgpu_buffer_rsrc_t PR = ck_part_rsrc(part_out);
   const int S = k.slots;
   const int lane0 = threadIdx.x & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -371,13 +388,10 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
   const int n_acc = v.wg_cam_off[blockIdx.x + 1] - cam0;
   const int t0 = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
   const int t1 = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
-  for (int i = threadIdx.x; i < n_acc * CK_ACC_STRIDE; i += NW * 64) acc[i] = 0;
-  if (NG > 1 && threadIdx.x < NG) gbase[threadIdx.x] = 0;
   typedef const int __attribute__((address_space(4))) * cint_p;
   const cint_p tiles = (cint_p)(uintptr_t)k.tile;
   const cint_p bt = (cint_p)(uintptr_t)k.bt_off;
   if (done) return;  // wave-uniform, before any barrier and any side effect
-  if (NG > 1) ck_barrier();  // accumulators and counters are zero before any group goes on (NG = 1: the first batch barrier)
   auto group_barrier = [&]() {
     if (NG > 1) ck_group_barrier(gcnt, ggen, GW, lane0);
     else ck_barrier();
@@ -403,7 +417,6 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
   // 4.1 k in the last one, which requests no next batch; now 4.0 k in both)
   int* lbt = reinterpret_cast<int*>(acc + (size_t)k.max_acc * CK_ACC_STRIDE);
   const bool bt_lds = k.nb + 1 <= 16;
-  if (bt_lds && (int)threadIdx.x <= k.nb) lbt[threadIdx.x] = k.bt_off[blockIdx.x * k.nb + threadIdx.x];
   auto bt_of = [&](int i, bool first) {
     return (bt_lds && !first) ? __builtin_amdgcn_readfirstlane(lbt[i]) : bt[blockIdx.x * k.nb + i];
   };
@@ -417,6 +430,10 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
   };
   request_first_meta(grp, lane0);
   request_h(grp, lane0);
+  for (int i = threadIdx.x; i < n_acc * CK_ACC_STRIDE; i += NW * 64) acc[i] = 0;
+  if (NG > 1 && threadIdx.x < NG) gbase[threadIdx.x] = 0;
+  if (bt_lds && (int)threadIdx.x <= k.nb) lbt[threadIdx.x] = k.bt_off[blockIdx.x * k.nb + threadIdx.x];
+  if (NG > 1) ck_barrier();  // accumulators and counters are zero before any group goes on (NG = 1: the first batch barrier)
   for (int b = grp; b < k.nb; b += NG) {
     // The lane number is made opaque per batch (and again per pass): every per-lane address of the body (a dozen 64-bit
     // pointers into the row, metadata and record arrays) is otherwise hoisted out of the batch loop as loop-invariant and
@@ -452,11 +469,10 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     if (t < tb1) {
       row0 = tiles[4 * t]; h = tiles[4 * t + 1]; fl = tiles[4 * t + 2]; li0 = tiles[4 * t + 3];
       if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
-      const int rk = rank < 0 ? 0 : rank;
-      ck_load_z(d, rk, zz);
-      ck_load_p<ROBUST>(d, rk, P3);
+      ck_load_p<ROBUST>(d, rank < 0 ? 0 : rank, P3);
       st.template start<1>(R, row0, li0, h, lane);
     }
+    if (t < tb1) ck_load_z_img(d, rank < 0 ? 0 : rank, zz);
     // ---- landmark coordinates of the batch into LDS (requested a phase ago), u = 0
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
@@ -488,13 +504,17 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         row0n = tiles[4 * tn]; hnx = tiles[4 * tn + 1]; fln = tiles[4 * tn + 2]; li0n = tiles[4 * tn + 3];
         if (tnn < tb1) rank_nn = ck_rank(k.lane_meta[(size_t)tnn * WAVE + lane].x);
         const int rk = rank_n < 0 ? 0 : rank_n;
-        ck_load_z(d, rk, zn);
+        ck_load_z_img(d, rk, zn);
         ck_load_p<ROBUST>(d, rk, Pn);
         stn.template start<1>(R, row0n, li0n, hnx, lane);
       }
     };
     request_next_fwd();
     group_barrier();
+    // (Z is the youngest request of the first tile: waited for HERE, once -- left to the row loop's first use the compiler
+    // merges the loop's entry and back-edge states into a wait for every outstanding load at the head of each row)
+#pragma unroll
+    for (int e = 0; e < 12; ++e) asm volatile("" : "+v"(zz[e]));
     // ---- forward
     while (t < tb1) {
       ck_forward_rows<SD, ROBUST, PK>(d, R, st, row0, li0, h, lane, zz, P3, lh, lu, S);
@@ -516,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
         row0 = tiles[4 * t]; h = tiles[4 * t + 1]; fl = tiles[4 * t + 2]; li0 = tiles[4 * t + 3];
         if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
         const int rk = rank < 0 ? 0 : rank;
-        ck_load_z(d, rk, zz);
+        ck_load_z_img(d, rk, zz);
         ck_load_p<ROBUST>(d, rk, P3);
         st.template start<1>(R, row0, li0, h, lane);
       }
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
 #pragma unroll
       for (int m = 0; m < 12; ++m) y[m] = 0;
       ck_backward_rows<SD, ROBUST, PK>(d, R, st, row0, li0, h, lane, P3, lh, lu, S, y);
-      ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, PR);
+      ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, part_out);
       if (tp >= tb1) break;
       t = tp;
       --q_t;
@@ -627,6 +647,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
   }
   if (NG > 1) ck_barrier();  // every group is done: the accumulators are complete
   // ---- accumulators -> this workgroup's partial records (camera-major in part_out)
+  const __amdgpu_buffer_rsrc_t PR = ck_part_rsrc(part_out);
   for (int i = threadIdx.x; i < n_acc * 6; i += NW * 64) {
     const int r = i / 6, m = 2 * (i % 6);
     const int rec = k.slot_rec[cam0 + r];

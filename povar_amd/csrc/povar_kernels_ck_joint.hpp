@@ -192,7 +192,6 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
   const int done = d.flags[1];
   extern __shared__ double ck_lds[];
   const CkRows R = ck_rows(k);
-  const __amdgpu_buffer_rsrc_t PR = ck_part_rsrc(part_out);  // (write-through stores: povar_kernels_ck.hpp)
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   double* lx = ck_lds + 2;                  // [4][CKH_STRIDE] X of the batch's landmarks
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
 #pragma unroll
       for (int m = 0; m < 12; ++m) y[m] = 0;
       ckh_backward_rows<SD, ROBUST>(R, st, row0, li0, h, lane, P, lx, lu, y);
-      ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, PR);
+      ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, part_out);
       if (tp >= tb1) break;
       t = tp;
       --q_t;
@@ -372,6 +371,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
     ck_barrier();  // the next batch overwrites X and U4; after the last one: the accumulators are complete
   }
   // ---- accumulators -> this workgroup's partial records (camera-major in part_out)
+  const __amdgpu_buffer_rsrc_t PR = ck_part_rsrc(part_out);
   for (int i = threadIdx.x; i < n_acc * 6; i += NW * 64) {
     const int r = i / 6, m = 2 * (i % 6);
     const int rc = k.slot_rec[cam0 + r];

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Diagnostic / experiment builds of the library from PATCHED copies of the sources (the shipping sources carry no stamp
 # and no experiment branch).  usage: tools/variants/build_variant.sh <patch name without .patch> [out name] [-D flags...]
+#   ck_head               the per-camera step of a term at the HEAD of the next e0_ck launch (round 6: built, measured, not shipped --
+#                         profiles/r06_experiments.txt D; POVAR_CK_HEAD=0|1, tools/r06_head_probe.py, tools/r06_head_ab.sh)
 #   ck_stamps             in-kernel s_memtime stamps of e0_ck's phases (tools/ck_stamps.py) + the timing-only experiment
 #                         branches of round 4 (-DPOVAR_CK_EXP_NOATOMIC, -DPOVAR_CK_EXP_NOBWDROWS, -DPOVAR_CK_EXP_NOBWDLDS)
 # (series_res has its own generator: tools/variants/res_stamps.py)
