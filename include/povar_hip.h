@@ -56,7 +56,37 @@ typedef struct {
   double jacobi_scaling_eps; /* effective epsilon, linearizor_base.cpp:94-100 (1e-5 if option is 0) */
   int32_t device;            /* HIP device ordinal */
   int32_t e0_mode;           /* POVAR_E0_* */
+  uint32_t flags;            /* POVAR_FLAG_* behaviour switches, 0 = the library's defaults (below) */
 } povar_options;
+
+/* povar_options.flags -- the behaviour switches of a context.  The reference passes every such switch through SolverOptions
+ * (bal/solver_options.hpp:95-305); this is that struct's place for the MI355X build's own.  The POVAR_* environment variables
+ * named beside them stay as OVERRIDES for diagnosis (a variable that is set wins over the flag). */
+enum {
+  /* run-to-run BIT-reproducible results for a given device count (fixed reduction order inside a GPU): the gather
+   * mode for linearisation / preparation / cost, the fixed-point, ticket-ordered camera-chunk kernels for the terms (1.26 x the
+   * default term on venice-1778), no row placement on a host thread, no timing decides a kernel.  [POVAR_DETERMINISTIC=1] */
+  POVAR_FLAG_DETERMINISTIC = 1u << 0,
+  /* with POVAR_FLAG_DETERMINISTIC: the terms in the gather form too (3.7 x the default term).  [POVAR_DET_CK=0] */
+  POVAR_FLAG_DET_GATHER_TERMS = 1u << 1,
+  /* launch the term loop kernel by kernel instead of replaying a captured hipGraph.  [POVAR_NO_GRAPH=1] */
+  POVAR_FLAG_NO_GRAPH = 1u << 2,
+  /* bits 4..7: per-term E0 kernel, as povar_set_e0_kernel: POVAR_FLAG_E0_KERNEL(k), k = -1 (field 0: the library times the
+   * kernels once per layout and keeps the faster), 0 = e0_lpl / e0_lpl_h, 1..6 = a camera-chunk instantiation.  [POVAR_E0_CK=k] */
+  POVAR_FLAG_E0_KERNEL_SHIFT = 4, POVAR_FLAG_E0_KERNEL_MASK = 0xFu << 4,
+  /* bits 8..9: the m-term loop, as povar_set_series_kernel: POVAR_FLAG_SERIES_KERNEL(m), m = -1 (field 0: timed), 0 = per-term
+   * kernels, 1 = the resident launch wherever the context allows it.  [POVAR_RES=m] */
+  POVAR_FLAG_SERIES_KERNEL_SHIFT = 8, POVAR_FLAG_SERIES_KERNEL_MASK = 0x3u << 8,
+  /* bits 12..13: LDS bank placement of the lane-per-landmark rows: POVAR_FLAG_PLACEMENT(p), p = 0 (by size: inside povar_create
+   * under 2^20 observations, on a host thread from there on), 1 = inside povar_create, 2 = on a host thread, 3 = none.
+   * [POVAR_LPL_PLACE=sync|async|none] */
+  POVAR_FLAG_PLACEMENT_SHIFT = 12, POVAR_FLAG_PLACEMENT_MASK = 0x3u << 12,
+  /* keep the 16-byte image points in the camera-chunk rows even where they pack (six-decimal observations).  [POVAR_CK_PACK=0] */
+  POVAR_FLAG_NO_PACKED_ROWS = 1u << 16
+};
+#define POVAR_FLAG_E0_KERNEL(k) ((((uint32_t)((k) + 1)) & 0xFu) << POVAR_FLAG_E0_KERNEL_SHIFT)
+#define POVAR_FLAG_SERIES_KERNEL(m) ((((uint32_t)((m) + 1)) & 0x3u) << POVAR_FLAG_SERIES_KERNEL_SHIFT)
+#define POVAR_FLAG_PLACEMENT(p) ((((uint32_t)(p)) & 0x3u) << POVAR_FLAG_PLACEMENT_SHIFT)
 
 /* ResidualInfo (bal/residual_info.hpp:59-92) */
 typedef struct {
@@ -317,13 +347,15 @@ int povar_layout_finalize(povar_ctx* ctx, int32_t wait);
  * keeps the faster one (povar_layout_info.e0_auto[_h], tune_*_us). */
 int povar_set_e0_kernel(povar_ctx* ctx, int32_t kernel);
 /* The m-term loop of solve_pOSE (sc/linearization_power_varproj.hpp:191-237) as per-term kernels inside a hipGraph
- * (mode 0) or as ONE resident launch that keeps the term-invariant operands on the chip (mode 1; contexts of up to about
- * a million observations in the LDS-accumulating E0 mode, without a communicator or with the peer-to-peer exchange);
+ * (mode 0) or as ONE resident launch that keeps the term-invariant operands on the chip (mode 1; contexts of up to 400 000
+ * observations -- POVAR_RES_MAX_OBS -- in the LDS-accumulating E0 mode, without peers: a context with a communicator of more
+ * than one rank or with the peer-to-peer exchange runs the per-term kernels);
  * -1 (default): the library times both once per context on the caller's prepared system and keeps the faster one
  * (povar_layout_info.res_auto, tune_terms_us, tune_res_us).  Environment: POVAR_RES=0|1. */
 int povar_set_series_kernel(povar_ctx* ctx, int32_t mode);
-/* Diagnostic builds only (-DPOVAR_CK_STAMPS, tools/ck_stamps.py): in-kernel s_memtime stamps of e0_ck's phases,
- * [workgroups][2 wavefronts][40]; the first call arms the collection.  The shipped library returns an error. */
+/* Diagnostic builds only (tools/variants/build_variant.sh ck_stamps -- a patched copy of the sources --, tools/ck_stamps.py):
+ * in-kernel s_memtime stamps of e0_ck's phases, [workgroups][16 wavefronts][40]; the first call arms the collection.  The
+ * shipped library executes no stamp and returns an error. */
 int povar_debug_ck_stamps(povar_ctx* ctx, uint64_t* out, int64_t n);
 
 /* ---- multi-GPU: landmarks sharded over ranks, one RCCL all-reduce per exchange step ---- */

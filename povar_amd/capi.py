@@ -28,7 +28,23 @@ SC_PCG, SC_CHOLESKY = 0, 1
 
 class Options(C.Structure):
     _fields_ = [("robust_norm", C.c_int32), ("huber_parameter", C.c_double),
-                ("jacobi_scaling_eps", C.c_double), ("device", C.c_int32), ("e0_mode", C.c_int32)]
+                ("jacobi_scaling_eps", C.c_double), ("device", C.c_int32), ("e0_mode", C.c_int32), ("flags", C.c_uint32)]
+
+
+# povar_options.flags (include/povar_hip.h: POVAR_FLAG_*)
+FLAG_DETERMINISTIC, FLAG_DET_GATHER_TERMS, FLAG_NO_GRAPH, FLAG_NO_PACKED_ROWS = 1 << 0, 1 << 1, 1 << 2, 1 << 16
+
+
+def flag_e0_kernel(k):
+    return ((k + 1) & 0xF) << 4
+
+
+def flag_series_kernel(m):
+    return ((m + 1) & 0x3) << 8
+
+
+def flag_placement(p):
+    return (p & 0x3) << 12
 
 
 class ResidualInfo(C.Structure):
@@ -126,7 +142,7 @@ class Context:
     """One povar_ctx: the device-resident linearizor state of one problem (or landmark shard)."""
 
     def __init__(self, n_cams, lm_off, cam_idx, obs, robust_norm="NONE", huber=1.0, eps=1e-5,
-                 device=0, e0_mode=E0_IMPLICIT):
+                 device=0, e0_mode=E0_IMPLICIT, flags=0):
         self.L = lib()
         self.lm_off = np.ascontiguousarray(lm_off, dtype=np.int32)
         self.cam_idx = np.ascontiguousarray(cam_idx, dtype=np.int32)
@@ -134,7 +150,7 @@ class Context:
         self.n_cams = int(n_cams)
         self.n_lms = self.lm_off.shape[0] - 1
         self.n_obs = self.cam_idx.shape[0]
-        opts = Options(NORM[robust_norm], huber, eps, device, e0_mode)
+        opts = Options(NORM[robust_norm], huber, eps, device, e0_mode, flags)
         self.h = C.c_void_p()
         self._chk(self.L.povar_create(C.byref(self.h), C.c_int32(self.n_cams), C.c_int32(self.n_lms),
                                       C.c_int64(self.n_obs), _p(self.lm_off), _p(self.cam_idx),

@@ -83,6 +83,7 @@ bool parse_bal_app_arguments(int argc, char** argv, BalAppOptions& o) {
   dbl("initial-vee", &o.solver.initial_vee);
   dbl("vee-factor", &o.solver.vee_factor);
   str("e0-mode", &o.solver.e0_mode);
+  flag["deterministic"] = &o.solver.deterministic;
   integer("device", &o.solver.device);
   integer("gpus", &o.solver.gpus);
 

@@ -55,8 +55,8 @@ std::string context_key(const BalProblem& p, const povar_options& o) {
     n_obs += (long)lm.obs.size();
   }
   char buf[256];
-  std::snprintf(buf, sizeof buf, "%d/%d/%ld/%016llx/norm%d/%.17g/%.17g/dev%d/e0%d", p.num_cameras(), p.num_landmarks(), n_obs, h,
-                o.robust_norm, o.huber_parameter, o.jacobi_scaling_eps, o.device, o.e0_mode);
+  std::snprintf(buf, sizeof buf, "%d/%d/%ld/%016llx/norm%d/%.17g/%.17g/dev%d/e0%d/f%x", p.num_cameras(), p.num_landmarks(), n_obs, h,
+                o.robust_norm, o.huber_parameter, o.jacobi_scaling_eps, o.device, o.e0_mode, o.flags);
   return buf;
 }
 
@@ -81,6 +81,7 @@ class LinearizorPowerVarprojHip : public Linearizor, public StateMirror {
     o.device = options.device;
     o.e0_mode = options.e0_mode == "tiles" ? POVAR_E0_TILES
                 : options.e0_mode == "implicit" ? POVAR_E0_IMPLICIT : POVAR_E0_IMPLICIT_LDSACC;
+    o.flags = options.deterministic ? POVAR_FLAG_DETERMINISTIC : 0u;
     // The reference builds a new linearizor for step 2 (its constructor only allocates: sc/linearization_varproj.hpp:
     // 44-60); the device context -- observation layout, camera sets, row placement under way -- depends on the
     // observations and these options only, so the one step 1 left behind is taken over.
@@ -439,6 +440,7 @@ class LinearizorPowerVarprojHipMulti : public Linearizor, public StateMirror {
     o.jacobi_scaling_eps = options.jacobi_scaling_epsilon > 0 ? options.jacobi_scaling_epsilon : 1e-5;
     o.e0_mode = options.e0_mode == "tiles" ? POVAR_E0_TILES
                 : options.e0_mode == "implicit" ? POVAR_E0_IMPLICIT : POVAR_E0_IMPLICIT_LDSACC;
+    o.flags = options.deterministic ? POVAR_FLAG_DETERMINISTIC : 0u;
     std::vector<int> lm_off, cam_idx;
     std::vector<double> obs;
     bal_problem.flatten(lm_off, cam_idx, obs);

@@ -52,6 +52,8 @@ struct SolverOptions {
   double vee_factor = 2.0;
   // MI355X build: which E0 operator form the device uses (not a reference option)
   std::string e0_mode = "ldsacc";  // "ldsacc" (fastest), "implicit" (bit-reproducible), "tiles" (stored tiles)
+  // bit-reproducible results run to run (povar_options.flags: POVAR_FLAG_DETERMINISTIC; 1.26 x the default term on venice-1778)
+  bool deterministic = false;
   int device = 0;
   // landmark shards = device contexts of ONE process (BASELINE configs 4 / 5: "landmarks sharded across 8 x MI355X"):
   // shard r runs on device (device + r) mod device count; one exchange step per power-series term (RCCL, or an in-process

@@ -212,6 +212,7 @@ struct povar_ctx {
   float ckh_tune_us[2] = {0, 0}; // e0_lpl_h, e0_ck_h
   bool ck_auto = true;           // the library picks e0_lpl or e0_ck by timing both on this problem (ck_autotune); false: forced
   bool ck_tuned = false;
+  bool ck_fresh[2] = {false, false};  // a timing of step 1 / step 2 finished on this rank since the ranks last agreed (tune_agree)
   float ck_tune_us[2] = {0, 0};  // what the timing saw: e0_lpl, e0_ck (microseconds per launch)
   DevBuf<double4> q4c;        // scatter scalars of the cold observations, in cold camera-major order
   DevBuf<int> lm_slot0, lm_cnt_dev;
@@ -662,6 +663,7 @@ hipError_t ck_set_lds_all() {
 // is a single observation -- final-13682).  Unless the caller has forced one, both are timed once per layout on the
 // problem itself: a warm-up and three launches each on the prepared system (they only write their partial records).
 int ck_autotune(povar_ctx* c);
+int tune_agree(povar_ctx* c, int step);
 
 // robust weights in chunk order (V2::w is written by the linearisation walk in lane-per-landmark order)
 void ensure_ck_w(povar_ctx* c) {
@@ -1312,6 +1314,32 @@ int ck_autotune(povar_ctx* c) {
   c->ck_tune_us[0] = 1e3f * ms_lpl / REPS;
   c->ck_tune_us[1] = 1e3f * ms_ck / REPS;
   c->ck_variant = ms_ck < 0.98f * ms_lpl ? 1 : 0;
+  c->ck_fresh[0] = true;
+  return 0;
+}
+
+// The ranks of a sharded run keep the SAME term kernel (each rank timed its own shard and ranks of one run could
+// end on different kernels -- a term then takes as long as the slower choice, and two runs of the same problem need not agree).
+// Every rank's prepare call ends in one all-reduce of four doubles through the context's exchange (RCCL or the host hook):
+// the timings of the ranks that have just timed (their sum decides, for everybody), how many did, and how many ranks have no
+// chunk layout (one is enough to keep every rank on e0_lpl).  Unconditional on anything a rank decides by itself -- when a
+// rank's placed rows arrive, and with them a new timing, differs from rank to rank; the collective does not.
+int tune_agree(povar_ctx* c, int step) {
+  // (the condition holds on every rank or on none: options and environment are the run's, not the rank's)
+  if (!sharded(c) || !c->ck_auto || c->deterministic || c->opt.e0_mode != POVAR_E0_IMPLICIT_LDSACC) return 0;
+  const bool fresh = c->ck_fresh[step];
+  const float* us = step ? c->ckh_tune_us : c->ck_tune_us;
+  const bool ready = c->use_lpl && (step ? c->ckh.ready : c->ck.ready);
+  double h[4] = {fresh ? us[0] : 0.0, fresh ? us[1] : 0.0, fresh ? 1.0 : 0.0, ready ? 0.0 : 1.0};
+  HIP_TRY(hipMemcpyAsync(c->scal.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (h is on this frame)
+  if (int rc = allreduce(c, c->scal.p, 4)) return rc;
+  HIP_TRY(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->ck_fresh[step] = false;
+  int& variant = step ? c->ckh_variant : c->ck_variant;
+  if (h[3] > 0) variant = 0;
+  else if (h[2] > 0) variant = h[1] < 0.98 * h[0] ? 1 : 0;
   return 0;
 }
 
@@ -1372,6 +1400,7 @@ int ckh_autotune(povar_ctx* c) {
   c->ckh_tune_us[0] = 1e3f * ms_lpl / REPS;
   c->ckh_tune_us[1] = 1e3f * ms_ck / REPS;
   c->ckh_variant = ms_ck < 0.98f * ms_lpl ? 1 : 0;
+  c->ck_fresh[1] = true;
   return 0;
 }
 
@@ -1553,17 +1582,21 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   //   * the rows are never placed on a host thread (when they arrive would decide the bits of every later solve).
   // The default mode accumulates in LDS in arrival order and is reproducible to rounding (1e-15), like the reference's
   // mutex order.
-  if (const char* g = std::getenv("POVAR_DETERMINISTIC")) {
-    if (g[0] == '1') {
-      c->opt.e0_mode = POVAR_E0_IMPLICIT;
-      c->ck_auto = false;
-      c->ck_variant = c->ckh_variant = 0;
-      c->res_mode = 0;
-      c->deterministic = true;
-      const char* k = std::getenv("POVAR_DET_CK");
-      c->det_ck = !(k && k[0] == '0');
-    }
+  // The switches come from povar_options.flags (include/povar_hip.h: POVAR_FLAG_*); an environment variable that is set
+  // overrides its flag (diagnosis, the forced-mode suites).
+  const uint32_t fl = options->flags;
+  bool want_det = (fl & POVAR_FLAG_DETERMINISTIC) != 0, det_gather = (fl & POVAR_FLAG_DET_GATHER_TERMS) != 0;
+  if (const char* g = std::getenv("POVAR_DETERMINISTIC")) want_det = g[0] == '1';
+  if (const char* k = std::getenv("POVAR_DET_CK")) det_gather = k[0] == '0';
+  if (want_det) {
+    c->opt.e0_mode = POVAR_E0_IMPLICIT;
+    c->ck_auto = false;
+    c->ck_variant = c->ckh_variant = 0;
+    c->res_mode = 0;
+    c->deterministic = true;
+    c->det_ck = !det_gather;
   }
+  if (fl & POVAR_FLAG_NO_GRAPH) c->use_graph = false;
   if (const char* g = std::getenv("POVAR_NO_GRAPH")) c->use_graph = !(g[0] == '1');
   if (const char* g = std::getenv("POVAR_NO_ERR_MEMO")) c->no_err_memo = g[0] == '1';
   if (const char* g = std::getenv("POVAR_GRAPH_COMM")) c->graph_with_comm = g[0] == '1';
@@ -1643,10 +1676,14 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     HIP_TRY_C(hipFuncSetAttribute((const void*)e0_ck_h<16, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
   }
   // per-term E0 kernel of step 1: e0_lpl (0) or an e0_ck instantiation (POVAR_E0_CK=<variant>, povar_set_e0_kernel)
-  if (const char* g = std::getenv("POVAR_E0_CK"); g && !c->deterministic) {
-    c->ck_variant = std::max(0, std::min(CK_VARIANTS, std::atoi(g)));
-    c->ckh_variant = c->ck_variant > 0 ? 1 : 0;  // (step 2 has one camera-chunk instantiation)
-    c->ck_auto = false;
+  {
+    int e0k = (int)((fl & POVAR_FLAG_E0_KERNEL_MASK) >> POVAR_FLAG_E0_KERNEL_SHIFT) - 1;  // -1: timed
+    if (const char* g = std::getenv("POVAR_E0_CK")) e0k = std::atoi(g);
+    if (e0k >= 0 && !c->deterministic) {
+      c->ck_variant = std::max(0, std::min(CK_VARIANTS, e0k));
+      c->ckh_variant = c->ck_variant > 0 ? 1 : 0;  // (step 2 has one camera-chunk instantiation)
+      c->ck_auto = false;
+    }
   }
   const bool want_ck = c->use_lpl && std::getenv("POVAR_NO_CK") == nullptr;
   // the camera-chunk layout is cut for the instantiation that will run it (its tiles are scheduled over its wavefronts)
@@ -1654,6 +1691,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   int ck_nw = ckv.nw / ckv.ng, ck_hmax = CK_HMAX;  // (wavefronts of one group)
   const int ck_ng = ckv.ng;
   const bool ck_place = std::getenv("POVAR_CK_NOPLACE") == nullptr;  // LDS bank placement of the chunk rows (ck_layout.hpp)
+  const bool ck_pack = !(fl & POVAR_FLAG_NO_PACKED_ROWS);            // packed image points where they pack (POVAR_CK_PACK=0 overrides inside build_ck)
   if (const char* e = std::getenv("POVAR_CK_HMAX")) ck_hmax = std::min(CK_HMAX, std::max(1, std::atoi(e)));
   const CkShape ck_shape1 = c->det_ck ? ck_shape_det() : CkShape();  // (step 1's layout: batches cut for the kernel that runs them)
   const CkShape ck_shape2 = c->det_ck ? ck_shape_step2_det() : ck_shape_step2();
@@ -1677,12 +1715,14 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     // lane-per-landmark layout of e0_lpl (lpl_layout.hpp)
     LplLayout V;
     int place_mode = n_obs >= (1 << 20) ? 2 : 1;  // 0 none, 1 in this call, 2 on a host thread
+    bool place_forced = false;
+    if (const uint32_t pf = (fl & POVAR_FLAG_PLACEMENT_MASK) >> POVAR_FLAG_PLACEMENT_SHIFT) { place_mode = pf == 3 ? 0 : (int)pf; place_forced = true; }
     if (std::getenv("POVAR_LPL_NOPLACE")) place_mode = 0;
-    if (const char* e = std::getenv("POVAR_LPL_PLACE")) place_mode = e[0] == 'n' ? 0 : e[0] == 's' ? 1 : e[0] == 'a' ? 2 : place_mode;
+    if (const char* e = std::getenv("POVAR_LPL_PLACE")) { place_mode = e[0] == 'n' ? 0 : e[0] == 's' ? 1 : e[0] == 'a' ? 2 : place_mode; place_forced = true; }
     // POVAR_DETERMINISTIC: never on a host thread -- WHEN the placed rows (and the chunk layout cut from them: another, equally
     // fixed summation order) arrive would depend on the host's timing, and with it the bits of every later solve.  None at
     // all unless asked for: the gather-mode kernels do not read these rows, e0_ck_det does not care about their order.
-    if (c->deterministic) place_mode = place_mode == 1 && std::getenv("POVAR_LPL_PLACE") ? 1 : 0;
+    if (c->deterministic) place_mode = place_mode == 1 && place_forced ? 1 : 0;
     build_lpl(n_cams, n_lms, lm_offsets, cam_idx, obs, L.cam_hot, L.slot_of_obs, (size_t)c->n_slots, c->e0c_grid,
               c->n_hot_acc, V, place_mode == 1);
     lap("build_lpl (lane/landmark)");
@@ -1697,7 +1737,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     if (place_mode == 2 && want_ck && !V.tile.empty()) {
       const auto tk = std::chrono::steady_clock::now();
       ck_nat.reset(new CkLayout());
-      build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, *ck_nat, ck_place, ck_hmax, ck_ng, ck_shape1);
+      build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, *ck_nat, ck_place, ck_hmax, ck_ng, ck_shape1, ck_pack);
       c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
       if (std::getenv("POVAR_CKH_EARLY") != nullptr) {
         ckh_nat.reset(new CkLayout());
@@ -1724,7 +1764,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       const int dev = options->device, grid = c->e0c_grid, n_acc = c->n_hot_acc;
       const size_t n_slots = (size_t)c->n_slots;
       c->placer_state.store(1);
-      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax, ck_ng, ck_place, ck_shape1, ck_shape2]() {
+      c->placer = std::thread([c, job, rows, n_tiles, dev, grid, n_acc, n_slots, n_cams, n_lms, want_ck, ck_nw, ck_hmax, ck_ng, ck_place, ck_pack, ck_shape1, ck_shape2]() {
         const auto t0 = std::chrono::steady_clock::now();
         LplLayout P;
         bool built = true;
@@ -1758,7 +1798,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
           try {
             const auto tk = std::chrono::steady_clock::now();
             CkLayout K;
-            build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, ck_place, ck_hmax, ck_ng, ck_shape1);
+            build_ck(P, n_cams, grid, job->cam_of_rank, ck_nw, K, ck_place, ck_hmax, ck_ng, ck_shape1, ck_pack);
             c->pl_ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
             if (!c->placer_cancel.load()) ck_upload(c, c->pl_ck, K, true, &c->pl_bytes);
             if (!c->placer_cancel.load()) {  // step 2's instance
@@ -1820,7 +1860,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
       } else {  // (step 2's, and both of the placed rows, come from the host thread with place_mode 2)
         const auto tk = std::chrono::steady_clock::now();
         CkLayout K;
-        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, ck_place, ck_hmax, ck_ng, ck_shape1);
+        build_ck(V, n_cams, c->e0c_grid, L.hot_cams, ck_nw, K, ck_place, ck_hmax, ck_ng, ck_shape1, ck_pack);
         c->ck.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk).count();
         if (!ck_upload(c, c->ck, K, false, &c->bytes)) { povar_destroy(c); return fail(-1, "camera-chunk layout: upload failed"); }
         CkLayout KH;  // step 2's instance: 64 bytes of LDS per landmark slot, no image coordinates
@@ -1838,6 +1878,7 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     // resident power series (res_layout.hpp): for contexts whose observations fit the lanes' registers.  POVAR_RES=0|1
     // forces the choice (default: timed against the per-term kernels at the first series), POVAR_RES_WGS the workgroups,
     // POVAR_RES_OBS_PER_WG the observations a workgroup gets on small problems before all CUs are used.
+    if (const uint32_t sf = (fl & POVAR_FLAG_SERIES_KERNEL_MASK) >> POVAR_FLAG_SERIES_KERNEL_SHIFT; sf && !c->deterministic) c->res_mode = (int)sf - 1;
     if (const char* e = std::getenv("POVAR_RES"); e && !c->deterministic) c->res_mode = e[0] == '1' ? 1 : 0;
     if (const char* e = std::getenv("POVAR_RES_SPIN")) c->res_spin_limit = (unsigned)std::max(1, std::atoi(e));
     // (measured, profiles/r05_res_term_times.txt: ahead of the per-term kernels up to a shard of 313 k observations, behind them
@@ -2238,6 +2279,7 @@ int povar_prepare_pose(povar_ctx* c, double lambda, int32_t solver_type) {
   // the one-off choice between the step-1 term kernels is part of the preparation, not of the first solve's time
   // (solve_reduced_system_time of the caller's log: bal_bundle_adjustment.cpp:355-360)
   if (int rc = ck_autotune(c)) return rc;
+  if (int rc = tune_agree(c, 0)) return rc;
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -2362,23 +2404,39 @@ static int res_verify(povar_ctx* c) {
 static int res_autotune(povar_ctx* c, int32_t m, double q_tol, double r_tol) {
   if (c->res_mode >= 0 || c->res_tuned || !res_possible(c) || m < 4 || m > 250) return 0;
   c->res_tuned = true;
-  EventSet<2> ev;
+  struct Restore {  // a failure below leaves the choice open and the timing to be repeated (as ck_autotune)
+    povar_ctx* c; bool done = false;
+    ~Restore() { if (!done) { c->res_tuned = false; c->res_choice = false; } }
+  } restore{c};
+  // Two alternating rounds of (warm-up + REPS series) of each form, the FASTER round of each counts -- one round's mean was
+  // seen 18 % off in some processes (ck_autotune) --, and both forms run all m terms: the tolerances are off while timing (an
+  // early exit would time a few terms of one form against a few of the other; the caller's series follows with its own)
+  (void)q_tol; (void)r_tol;
+  constexpr int ROUNDS = 2, REPS = 2;
+  EventSet<4 * ROUNDS> ev;
   HIP_TRY(ev.create());
-  constexpr int REPS = 2;
-  float ms[2] = {0, 0};
-  for (int which = 0; which < 2; ++which) {
-    if (int rc = run_series(c, m, q_tol, r_tol, which == 1)) return rc;
-    HIP_TRY(hipEventRecord(ev.e[0], c->stream));
-    for (int i = 0; i < REPS; ++i)
-      if (int rc = run_series(c, m, q_tol, r_tol, which == 1)) return rc;
-    HIP_TRY(hipEventRecord(ev.e[1], c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipEventElapsedTime(&ms[which], ev.e[0], ev.e[1]));
-    if (which == 1) {
-      if (int rc = res_verify(c)) return rc;
-      if (c->res_failed) { c->res_choice = false; return 0; }
+  for (int r = 0; r < ROUNDS; ++r)
+    for (int which = 0; which < 2; ++which) {
+      if (int rc = run_series(c, m, 0.0, -1.0, which == 1)) return rc;
+      HIP_TRY(hipEventRecord(ev[4 * r + 2 * which], c->stream));
+      for (int i = 0; i < REPS; ++i)
+        if (int rc = run_series(c, m, 0.0, -1.0, which == 1)) return rc;
+      HIP_TRY(hipEventRecord(ev[4 * r + 2 * which + 1], c->stream));
+      if (which == 1) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (int rc = res_verify(c)) return rc;
+        if (c->res_failed) { restore.done = true; c->res_choice = false; return 0; }
+      }
     }
-  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  float ms[2] = {1e30f, 1e30f};
+  for (int r = 0; r < ROUNDS; ++r)
+    for (int which = 0; which < 2; ++which) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, ev[4 * r + 2 * which], ev[4 * r + 2 * which + 1]));
+      ms[which] = std::min(ms[which], t);
+    }
+  restore.done = true;
   c->res_tune_us[0] = 1e3f * ms[0] / (REPS * m);
   c->res_tune_us[1] = 1e3f * ms[1] / (REPS * m);
   c->res_choice = ms[1] < 0.98f * ms[0];
@@ -2660,6 +2718,7 @@ int povar_prepare_joint(povar_ctx* c, double lambda) {
   hipLaunchKernelGGL(cam_build_binv_h, dim3(grid_for(c->n_cams, K8_CAMS_PER_WG)), dim3(K8_THREADS), 0, c->stream, c->d,
                      lambda, (const double*)c->ncw.p);
   if (int rc = ckh_autotune(c)) return rc;  // (as in povar_prepare_pose: the one-off kernel choice is preparation)
+  if (int rc = tune_agree(c, 1)) return rc;
   HIP_TRY(hipGetLastError());
   return 0;
 }

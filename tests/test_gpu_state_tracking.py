@@ -382,3 +382,46 @@ def test_povar_deterministic_is_bit_reproducible(monkeypatch, name, form, robust
     (c0, _), tc, ldc, cc, _ = run(False)
     assert np.linalg.norm(c0 - a0) <= 1e-10 * np.linalg.norm(a0) and abs(cc / ca - 1) < 1e-9
     assert np.linalg.norm(tc - ta) <= 1e-9 * np.linalg.norm(ta)
+
+
+def test_behaviour_switches_through_the_abi_flags_word(monkeypatch):
+    """the behaviour switches of a context are fields of povar_options.flags (include/povar_hip.h:
+    POVAR_FLAG_*, the reference's counterpart is SolverOptions, bal/solver_options.hpp:95-305) -- no environment variable
+    involved.  POVAR_FLAG_DETERMINISTIC through the C ABI: the fixed-point camera-chunk kernel (7) runs the terms, two contexts
+    give bit-identical increments; with POVAR_FLAG_DET_GATHER_TERMS the gather form (0) does; the kernel-choice fields pin the
+    E0 kernel and the series form; POVAR_FLAG_NO_PACKED_ROWS keeps the 16-byte image points; an environment variable that is
+    set still overrides its flag."""
+    from povar_amd import capi, synth
+    for k in ("POVAR_DETERMINISTIC", "POVAR_DET_CK", "POVAR_E0_CK", "POVAR_RES", "POVAR_LPL_PLACE", "POVAR_CK_PACK", "POVAR_E0_V1", "POVAR_NO_GRAPH"):
+        monkeypatch.delenv(k, raising=False)
+    p = synth.make_bal_problem("trafalgar-257")
+
+    def run(flags):
+        ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, p.obs, e0_mode=capi.E0_IMPLICIT_LDSACC, flags=flags)
+        ctx.layout_finalize(True)
+        ctx.set_cameras(p.cams)
+        ctx.init_landmarks_pose(0.01)
+        assert ctx.linearize_pose(0.01)
+        inc = ctx.solve_pose(1e-4, capi.POWER_VARPROJ, 20)[0]
+        li = ctx.layout_info()
+        ctx.close()
+        return inc, li
+
+    a, lia = run(capi.FLAG_DETERMINISTIC)
+    b, lib = run(capi.FLAG_DETERMINISTIC)
+    assert lia.e0_kernel == 7 and lia.e0_auto == 0 and lia.res_active == 0 and lia.ck_packed == 0
+    assert np.array_equal(a, b), "POVAR_FLAG_DETERMINISTIC: two contexts, two different increments"
+    g, lig = run(capi.FLAG_DETERMINISTIC | capi.FLAG_DET_GATHER_TERMS)
+    assert lig.e0_kernel == 0 and np.linalg.norm(g - a) <= 1e-12 * np.linalg.norm(a)
+    d, lid = run(0)
+    assert lid.e0_auto == 2 and lid.res_auto == 2 and np.linalg.norm(d - a) <= 1e-10 * np.linalg.norm(a)
+    for k in (0, 1, 3):
+        f, lif = run(capi.flag_e0_kernel(k) | capi.flag_series_kernel(0))
+        assert lif.e0_kernel == k and lif.e0_auto == 0 and lif.res_auto == 0 and lif.res_active == 0
+        assert np.linalg.norm(f - a) <= 1e-10 * np.linalg.norm(a)
+    r, lir = run(capi.flag_series_kernel(1))
+    assert lir.res_auto == 0 and lir.res_active == 1 and lir.res_failed == 0 and np.linalg.norm(r - a) <= 1e-10 * np.linalg.norm(a)
+    assert run(capi.flag_e0_kernel(1))[1].ck_packed == 1 and run(capi.flag_e0_kernel(1) | capi.FLAG_NO_PACKED_ROWS)[1].ck_packed == 0
+    assert run(capi.flag_placement(3))[1].placement == 0 and run(capi.flag_placement(1))[1].placement == 1
+    monkeypatch.setenv("POVAR_DETERMINISTIC", "0")  # the variable wins over the flag
+    assert run(capi.FLAG_DETERMINISTIC)[1].e0_kernel != 7

@@ -371,3 +371,36 @@ def test_landmark_order_invariance(seed, medium_problem):
         assert rel(b["sigma"], a["sigma"]) < 1e-13 and rel(b["inc"], a["inc"]) < 1e-10
         assert b["it_p"] == a["it_p"] and rel(b["pcg"], a["pcg"]) < 1e-9
         assert abs(a["ld"] - b["ld"]) <= 1e-9 * abs(a["ld"]) and rel(b["lms_new"], a["lms_new"][perm]) < 1e-9
+
+
+@pytest.mark.parametrize("e0_mode", [0, 2])
+def test_e0_and_b_against_exact_rational_arithmetic(e0_mode, _term_kernels):
+    """the HIP path against EXACT rational arithmetic evaluated straight from the reference's formulas
+    (tests/exact_rational.py: fractions.Fraction on the input doubles; bal_bundle_adjustment_helper.cpp:251-310,
+    landmark_block.hpp:517-536, linearization_power_varproj.hpp:377-396) on the 6-camera golden problem -- independent of the C
+    oracle and of the NumPy restatement.  E0_scaled x = sigma * E0 (sigma * x), b_scaled = sigma * b with the library's OWN
+    pose scaling taken as exact numbers (the scaling itself against a 60-digit evaluation): 1e-13, in every kernel family the
+    module runs in."""
+    import os
+    from fractions import Fraction as F
+    from povar_amd import capi
+    from exact_rational import ExactStep1, rel_err, sigma_60_digits
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step1_small_none.npz"))
+    n_c = int(g["n_cams"])
+    ex = ExactStep1(float(g["alpha"]), n_c, g["lm_off"], g["cam_idx"], g["obs"], g["cams"], g["lms"])
+    ctx = capi.Context(n_c, g["lm_off"], g["cam_idx"], g["obs"], eps=float(g["eps"]), e0_mode=e0_mode)
+    ctx.set_cameras(g["cams"])
+    ctx.set_landmarks(g["lms"])
+    assert ctx.linearize_pose(float(g["alpha"]))
+    ctx.prepare_pose(float(g["lam"]))
+    d = ex.diag2()
+    assert rel_err(ctx.get_buffer(capi.BUF_DIAG2), d) < 1e-14
+    sigma = ctx.get_buffer(capi.BUF_POSE_SCALING)
+    assert np.abs(sigma / np.array(sigma_60_digits(d, float(g["eps"]))) - 1).max() < 1e-14
+    sg = [F(float(t)) for t in sigma]
+    assert rel_err(ctx.get_buffer(capi.BUF_B), [s * t for s, t in zip(sg, ex.b())]) < 1e-13
+    x = np.random.default_rng(5).normal(size=12 * n_c)
+    y_exact = [s * t for s, t in zip(sg, ex.e0([F(float(a)) * s for a, s in zip(x, sg)]))]
+    y = ctx.right_mul_e0_pose(x)
+    assert rel_err(y, y_exact) < 1e-13, rel_err(y, y_exact)
+    ctx.close()

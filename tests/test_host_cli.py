@@ -22,7 +22,7 @@ def test_cli_flags_and_errors(binaries):
     r = subprocess.run([bal, "--help"], capture_output=True, text=True)
     for flag in ("--solver-type-step-1", "--solver-type-step-2", "--power-sc-iterations", "--max-num-iterations-step-1",
                  "--residual-robust-norm", "--residual-huber-parameter", "--eta", "--r-tolerance", "--alpha",
-                 "--initial-trust-region-radius", "--log-log-path", "--create-dataset", "--num-threads"):
+                 "--initial-trust-region-radius", "--log-log-path", "--create-dataset", "--num-threads", "--deterministic"):
         assert flag in r.stdout, flag
     assert subprocess.run([bal], capture_output=True).returncode != 0                      # missing --input
     assert subprocess.run([bal, "--input", "x", "--bogus", "1"], capture_output=True).returncode != 0

@@ -18,7 +18,7 @@ run POVAR_E0_V1=0 POVAR_LPL_STRATEGY=range POVAR_HOT_ACC=24 POVAR_LPL_PLACE=asyn
 run POVAR_E0_V1=0 POVAR_LPL_NOGRID=1 POVAR_LONG_SEPARATE=1 POVAR_HOT_ACC=40 POVAR_NO_ERR_MEMO=1
 run POVAR_PREPARE_V1=1 POVAR_NO_FUSE=1
 run POVAR_NO_GRAPH=1
-# the resident power series wherever a context allows it (step 1, LDS-accumulating E0 mode, up to 2^20 observations)
+# the resident power series wherever a context allows it (step 1, LDS-accumulating E0 mode, up to 400 000 observations: POVAR_RES_MAX_OBS; never with peers)
 run POVAR_RES=1
 run POVAR_RES=1 POVAR_RES_WGS=7 POVAR_NO_GRAPH=1
 fi
