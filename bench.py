@@ -62,7 +62,8 @@ def kernel_source_sha():
     """Stamp of the device code the PMC traffic figures in profiles/traffic.json were measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_det.hpp", "povar_kernels_ck_joint.hpp", "povar_hip.hip",
+    for f in ("povar_kernels.hpp", "povar_kernels_joint.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_det.hpp", "povar_kernels_ck_joint.hpp",
+              "povar_ctx.hpp", "povar_create.hip", "povar_lm.hip", "povar_series.hip", "povar_comm.hip",
               "lpl_layout.hpp", "ck_layout.hpp", "povar_kernels_res.hpp", "res_layout.hpp"):
         with open(os.path.join(ROOT, "povar_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())

@@ -340,7 +340,7 @@ int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 int povar_layout_finalize(povar_ctx* ctx, int32_t wait);
 /* Per-term E0 kernels (step 1 replaces right_mul_e0_pOSE, sc/linearization_power_varproj.hpp:364-406; step 2
  * right_mul_e0_joint, :408-453; either way): 0 = e0_lpl / e0_lpl_h; > 0 = the camera-chunk kernels: for step 2 e0_ck_h
- * (povar_kernels_ck_joint.hpp), for step 1 one of the e0_ck instantiations (povar_kernels_ck.hpp; table POVAR_CK_VARIANTS in povar_hip.hip: wavefronts per
+ * (povar_kernels_ck_joint.hpp), for step 1 one of the e0_ck instantiations (povar_kernels_ck.hpp; table POVAR_CK_VARIANTS in povar_ctx.hpp: wavefronts per
  * workgroup, register-resident tiles, rows in flight).  Environment: POVAR_E0_CK=<n> sets the initial choice, which also
  * decides how the camera-chunk layout is cut (chunk cap, wavefronts the tiles are scheduled over).  kernel = -1 (the
  * default when nothing is forced): the library times both kernels of a step once per layout on the prepared problem and

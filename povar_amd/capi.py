@@ -91,13 +91,10 @@ class PovarError(RuntimeError):
 def build(force: bool = False) -> str:
     """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_PKG, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("povar_hip.hip", "povar_kernels.hpp", "povar_kernels_joint.hpp",
-                                               "povar_kernels_sc.hpp", "povar_kernels_chol.hpp", "lpl_layout.hpp",
-                                               "ck_layout.hpp", "povar_kernels_ck.hpp", "povar_kernels_ck_joint.hpp",
-                                               "res_layout.hpp", "povar_kernels_res.hpp", "povar_kernels_ck_det.hpp")] + [HEADER]
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".hpp", ".map")) or f == "Makefile"] + [HEADER]
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", src_dir], stdout=subprocess.DEVNULL)  # (make rebuilds the units whose sources changed)
     return LIB_PATH
 
 

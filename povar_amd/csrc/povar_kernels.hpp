@@ -3,7 +3,7 @@
 // Mapping of the reference's TBB regions onto kernels.  Work decomposition:
 //
 //  * LM ("landmark-major") kernels: one lane per observation.  Observations live in 64-wide
-//    wave bins that hold WHOLE landmarks (host packs them, povar_hip.hip: build_layout), so the
+//    wave bins that hold WHOLE landmarks (host packs them, povar_create.hip: build_layout), so the
 //    per-landmark 3x3 reductions (Jl^T Jl, Jl^T r, Jl^T t) are wavefront segmented scans over
 //    __shfl_up -- no LDS, no barriers, no atomics.  Landmarks with more than 64 observations
 //    take the lm_long driver (one workgroup per landmark, LDS block reduction).
@@ -30,6 +30,10 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+// Kernels that are not templates have internal linkage: the headers are included by every translation unit of the library
+// (povar_create.hip, povar_lm.hip, povar_series.hip, ...), each of which compiles the kernels it launches.
+#define POVAR_KERNEL static __attribute__((unused)) __global__
 
 namespace povar {
 
@@ -96,7 +100,7 @@ struct V2 {
   const int* lm_of;    // [n_tiles][64] landmark of each lane (-1: unused lane)
   // lane-ordered mirrors of the per-landmark arrays (Dp::lms4, lms_lin4, jl_scale4 stay the masters, in landmark order):
   // one coalesced, prefetchable 32-byte load per lane and tile instead of an index load + a 32-byte gather that drags
-  // 64..128-byte lines through the memory system.  lmx follows lms4 (povar_hip.hip: ensure_lmx, rebuilt by lm_to_lanes
+  // 64..128-byte lines through the memory system.  lmx follows lms4 (povar_lm.hip: ensure_lmx, rebuilt by lm_to_lanes
   // when a landmark writer outside these kernels has run), lml / lsc belong to the linearisation.
   double4* lmx;        // [n_tiles][64] current landmark of each lane
   double4* lml;        // [n_tiles][64] landmark at the linearisation point
@@ -638,7 +642,7 @@ struct OpInit {
 // back-substitutes.  Near-parallel two-view landmarks (kappa 1e6..1e7) keep ~1e-9; the normal-equation kernels
 // OpInit / OpInitRefine lose them (tests/test_gpu_fuzz.py::test_init_landmarks_near_degenerate).  Runs once per
 // solve (linearizor_base.cpp:61-67), so the uncoalesced per-landmark walk does not matter.
-__global__ __launch_bounds__(256) void init_landmarks_qr(Dp d) {
+POVAR_KERNEL __launch_bounds__(256) void init_landmarks_qr(Dp d) {
   const int lm = blockIdx.x * 256 + threadIdx.x;
   if (lm >= d.n_lms) return;
   const int s0 = d.lm_slot0[lm], k = d.lm_cnt[lm];
@@ -790,7 +794,7 @@ struct OpLinearize {
   }
   __device__ void phase2(const Dp&, int, int, int, double2, Local&, const double*, double*) const {}
   __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
-    if (d.lin_aux_only) return;  // only the per-slot sqrt(w) / residual arrays are wanted (ensure_legacy, povar_hip.hip)
+    if (d.lin_aux_only) return;  // only the per-slot sqrt(w) / residual arrays are wanted (ensure_legacy, povar_lm.hip)
     // LinearizorSC::linearize_pOSE leaves the Jl columns unscaled (linearizor_sc.cpp:163-191)
     d.jl_scale4[lm] = d.scale_jl ? make_double4(1.0 / (d.eps + sqrt(tot[0])), 1.0 / (d.eps + sqrt(tot[1])),
                                                 1.0 / (d.eps + sqrt(tot[2])), 0.0)
@@ -1899,7 +1903,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void backsub_lpl(Dp d, double* part) {
 //   MODE 0  linearize_landmark_pOSE + scale_Jl_cols_pOSE (landmark_block.hpp:135-178, 284-295) at (cams_lin4, lms_lin4):
 //           robust weight per observation (V2::w), Jl column scale per landmark, finiteness flag.  The per-slot
 //           sqrt(w) / weighted residual arrays of the lane-per-observation kernels are NOT written: the lane-per-landmark
-//           kernels rebuild both from (P, x, u, v, w); povar_hip.hip fills them when a legacy kernel asks (ensure_legacy).
+//           kernels rebuild both from (P, x, u, v, w); povar_lm.hip fills them when a legacy kernel asks (ensure_legacy).
 //   MODE 1  compute_error_pOSE (bal_bundle_adjustment_helper.cpp:117-154) at (cams4, lms4): (error, |r|, count) summed per
 //           workgroup into part[3 * blockIdx.x ..].
 // ------------------------------------------------------------------------------------------
@@ -2011,7 +2015,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass(Dp d, double* part) {
                                                     1.0 / (d.eps + sqrt(red[2])), 0.0)
                                      : make_double4(1.0, 1.0, 1.0, 0.0);
       // every lane of the landmark holds the segment total.  The landmark-order copy (Dp::jl_scale4) is not written
-      // here: lanes_to_lm fills it when a lane-per-observation kernel or an export asks (povar_hip.hip: ensure_legacy)
+      // here: lanes_to_lm fills it when a lane-per-observation kernel or an export asks (povar_lm.hip: ensure_legacy)
       v.lsc[(size_t)c_t * WAVE + lane] = sc4;
     }
     c_t = q1;
@@ -2095,7 +2099,7 @@ struct OpE0Tiles {
 // >64-observation landmarks keep the q4 path of OpE0Tiles.
 constexpr int E0T_BLOCK = 768;
 constexpr int HOT_REC_T = 6;  // double2 per cached camera: x_c (12 doubles)
-__global__ __launch_bounds__(E0T_BLOCK) void e0_tiles_cached(Dp d, int bins_per_wg, double* hot_out) {
+POVAR_KERNEL __launch_bounds__(E0T_BLOCK) void e0_tiles_cached(Dp d, int bins_per_wg, double* hot_out) {
   if (d.flags[1]) return;
   extern __shared__ double2 hot[];  // [n_hot][HOT_REC_T] then acc[12][n_hot]
   const int n_hot = d.n_hot_acc;
@@ -2335,7 +2339,7 @@ struct OpBackPoba {
 
 // K3/K5/K6 materialised: the reference's stored tile (after Jl and Jp column scaling) of every
 // observation in the blocked layout used by OpE0Tiles and exported by povar_get_buffer.
-__global__ __launch_bounds__(LM_BLOCK) void materialize_tiles(Dp d) {
+POVAR_KERNEL __launch_bounds__(LM_BLOCK) void materialize_tiles(Dp d) {
   const int slot = blockIdx.x * LM_BLOCK + threadIdx.x;
   if (slot >= d.n_bins * WAVE) return;
   double2* t = d.tiles + ((size_t)(slot >> 6) * TILE_PAIRS) * WAVE + (slot & 63);
@@ -2383,7 +2387,7 @@ __global__ __launch_bounds__(LM_BLOCK) void materialize_tiles(Dp d) {
 
 // Second half of every Jp^T(.) product: item_part[item] = sum over the item's observations of
 // ( h q0 ; h q1 ; h q2 ).  One wavefront per item, fixed order.
-__global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done, int hom) {
+POVAR_KERNEL __launch_bounds__(256) void cm_scatter(Dp d, int check_done, int hom) {
   if (check_done && d.flags[1]) return;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -2427,7 +2431,7 @@ __global__ __launch_bounds__(256) void cm_scatter(Dp d, int check_done, int hom)
 
 // landmark coordinates at the linearisation point, copied into camera-major order once per
 // linearisation so the per-term camera-major pass streams them instead of gathering
-__global__ __launch_bounds__(256) void cm_build_h(Dp d, const int* lm_of, double* out, int64_t n, int hom) {
+POVAR_KERNEL __launch_bounds__(256) void cm_build_h(Dp d, const int* lm_of, double* out, int64_t n, int hom) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   const double4 h = d.lms_lin4[lm_of[p]];
@@ -2441,7 +2445,7 @@ __global__ __launch_bounds__(256) void cm_build_h(Dp d, const int* lm_of, double
 // C = [[1,0,-sb^2 u],[0,1,-sb^2 v],[.,.,sb^2(u^2+v^2)]] (sa^2 + sb^2 = 1), so four weighted
 // moments of h h^T (10 unique entries each) per camera carry both get_Jp_diag2_pOSE
 // (linearization_varproj.hpp:183-222) and the Hpp blocks (landmark_block.hpp:530-536).
-__global__ __launch_bounds__(256) void cm_gram(Dp d, int gather) {
+POVAR_KERNEL __launch_bounds__(256) void cm_gram(Dp d, int gather) {
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (item >= d.n_items) return;
@@ -2498,7 +2502,7 @@ __device__ inline int sym10(int i, int j) {  // index of (i,j) in the packed upp
 
 // per camera: G = sum of item Gram parts; diag2 and pose scaling (linearizor_power_varproj.cpp:62-70)
 constexpr int CFL_THREADS = 1024;  // sixteen item streams per camera: the hub camera (880 items on venice) is the tail of this launch (256 threads: 56 instead of 18 us)
-__global__ __launch_bounds__(CFL_THREADS) void cam_finish_linearize(Dp d, const double* G_in) {
+POVAR_KERNEL __launch_bounds__(CFL_THREADS) void cam_finish_linearize(Dp d, const double* G_in) {
   const int c = blockIdx.x;
   constexpr int NQ = CFL_THREADS / 64;
   __shared__ double part[NQ][40];
@@ -2581,7 +2585,7 @@ __device__ inline void chol_inverse_16(double* A, int l, double* out) {
 // (linearization_power_varproj.hpp:141-154).  Sixteen lanes per camera, four cameras per 64-thread workgroup
 // (one thread per camera was a 1 900-step dependent chain through LDS: 31 us for 1 778 cameras).
 constexpr int K8_THREADS = 64, K8_CAMS_PER_WG = 4;
-__global__ __launch_bounds__(K8_THREADS) void cam_build_binv(Dp d, double lambda) {
+POVAR_KERNEL __launch_bounds__(K8_THREADS) void cam_build_binv(Dp d, double lambda) {
   __shared__ double As[K8_CAMS_PER_WG][144];
   const int q = threadIdx.x >> 4, l = threadIdx.x & 15;
   const int c = blockIdx.x * K8_CAMS_PER_WG + q;
@@ -2624,7 +2628,7 @@ __device__ inline void store_z(const Dp& d, int c, int j, double v) {
 
 // static part of the hot camera records (per linearisation): P[:, :3] row-major (step 1, hom = 0)
 // or the full P (step 2, hom = 1) after the 12 z values
-__global__ __launch_bounds__(256) void build_hot_rec(Dp d, int hom) {
+POVAR_KERNEL __launch_bounds__(256) void build_hot_rec(Dp d, int hom) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= d.n_cams * 12) return;  // every camera: the image is in popularity order (Dp::hot_cams)
   const int r = i / 12, e = i % 12;
@@ -2839,7 +2843,7 @@ __global__ __launch_bounds__(NT) void cam_cold_sum_binv(Dp d, int want_norms) {
 }
 
 // b_c = sigma * sum_items (scatter parts)   (landmark_block.hpp:529-534); one wavefront per camera
-__global__ __launch_bounds__(256) void cam_sum_items(Dp d, double* out, int apply_sigma) {
+POVAR_KERNEL __launch_bounds__(256) void cam_sum_items(Dp d, double* out, int apply_sigma) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.n_cams) return;
@@ -2858,7 +2862,7 @@ __global__ __launch_bounds__(256) void cam_sum_items(Dp d, double* out, int appl
 // 322-340).  mode 0: y = -b (series start); 1: y = sigma * sum of scatter items (implicit E0);
 // 2: y = dense buffer d.y (the per-camera sums of the LDSACC modes, or the all-reduced vector).
 constexpr int K9_CAMS = 4;  // one wavefront per camera, 4 cameras per workgroup
-__global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, int want_norms) {
+POVAR_KERNEL __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, int want_norms) {
   const int done = mode != 0 ? d.flags[1] : 0;  // tested before the first store: its round trip overlaps the loads
   __shared__ double sh[K9_CAMS * 2];
   const int lane = threadIdx.x & 63;
@@ -2930,7 +2934,7 @@ __global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy(Dp d, int mode, in
 
 // convergence tests of solve_pOSE (linearization_power_varproj.hpp:198, 206-229), on the device
 // so the m-term loop needs no host round trip; later kernels of the loop see flags[1] and exit.
-__global__ __launch_bounds__(64) void series_check(Dp d, int n_blocks, int i, double q_tol, double r_tol) {
+POVAR_KERNEL __launch_bounds__(64) void series_check(Dp d, int n_blocks, int i, double q_tol, double r_tol) {
   if (d.flags[1]) return;
   double v[2] = {0, 0};
   for (int k = threadIdx.x; k < n_blocks; k += 64) {
@@ -2960,7 +2964,7 @@ __global__ __launch_bounds__(64) void series_check(Dp d, int n_blocks, int i, do
 // linearizor_power_varproj.cpp:251-255.  mode 0 (VARPROJ): cams += inc*sigma, inc <- (inc*sigma)*(1/sigma)
 // mode 1 (POWER_SCHUR_COMPLEMENT, before back substitution): z = sigma*inc only
 // mode 2 (POWER_SCHUR_COMPLEMENT, after): cams += inc*sigma
-__global__ __launch_bounds__(256) void cam_apply_inc(Dp d, int mode) {
+POVAR_KERNEL __launch_bounds__(256) void cam_apply_inc(Dp d, int mode) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 12 * d.n_cams) return;
   const double sg = d.sigma[i];
@@ -2977,24 +2981,24 @@ __global__ __launch_bounds__(256) void cam_apply_inc(Dp d, int mode) {
 }
 
 // lane-ordered mirror of a per-landmark array (V2::lmx / lml / lsc): out[tile][lane] = in[landmark of the lane]
-__global__ __launch_bounds__(256) void lm_to_lanes(const int* lm_of, const double4* in, double4* out, int64_t n) {
+POVAR_KERNEL __launch_bounds__(256) void lm_to_lanes(const int* lm_of, const double4* in, double4* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int lm = lm_of[i];
   out[i] = lm >= 0 ? in[lm] : make_double4(0, 0, 0, 0);
 }
 // and back: the landmark-order master of a lane-ordered array (first lane of each landmark)
-__global__ __launch_bounds__(256) void lanes_to_lm(const int* lm_of, const int* seg, const double4* in, double4* out, int64_t n) {
+POVAR_KERNEL __launch_bounds__(256) void lanes_to_lm(const int* lm_of, const int* seg, const double4* in, double4* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int lm = lm_of[i];
   if (lm >= 0 && (int)(i & 63) == (seg[i] & 255)) out[lm] = in[i];
 }
-__global__ __launch_bounds__(256) void lms3_to_4(const double* in, double4* out, int n) {
+POVAR_KERNEL __launch_bounds__(256) void lms3_to_4(const double* in, double4* out, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = make_double4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 1.0);
 }
-__global__ __launch_bounds__(256) void lms4_to_3(const double4* in, double* out, int n) {
+POVAR_KERNEL __launch_bounds__(256) void lms4_to_3(const double4* in, double* out, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
     const double4 v = in[i];

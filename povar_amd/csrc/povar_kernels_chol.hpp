@@ -38,7 +38,7 @@ typedef double ch_d4 __attribute__((ext_vector_type(4)));
 // is not positive.  One wavefront, lane c keeps column c in registers; row j of R reaches the other
 // lanes through constant-lane broadcasts, so the 64 dependent steps need no LDS and no barriers
 // (the 256-thread LDS version took 74 us per block, profiles/r01_g_*).
-__global__ __launch_bounds__(64) void chol_diag(double* M, int64_t ld, int k0, int* info) {
+POVAR_KERNEL __launch_bounds__(64) void chol_diag(double* M, int64_t ld, int k0, int* info) {
   const int c = threadIdx.x;
   double* blk = M + (int64_t)k0 * ld + k0;
   double a[CH_NB];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void chol_diag(double* M, int64_t ld, int k0, i
 // R12 = R11^-T S12 for the columns [k0 + 64, N]: forward substitution down each column, one thread
 // per column, R11 broadcast from LDS (reading R11 with wave-uniform scalar loads instead was slower:
 // 58 vs 46 us per panel on venice-1778)
-__global__ __launch_bounds__(128) void chol_trsm(double* M, int64_t ld, int k0) {
+POVAR_KERNEL __launch_bounds__(128) void chol_trsm(double* M, int64_t ld, int k0) {
   __shared__ double R[CH_NB][CH_NB];
   const double* blk = M + (int64_t)k0 * ld + k0;
   for (int e = threadIdx.x; e < CH_NB * CH_NB; e += 128) R[e >> 6][e & 63] = blk[(int64_t)(e >> 6) * ld + (e & 63)];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(128) void chol_trsm(double* M, int64_t ld, int k0) 
 // 4 wavefronts per workgroup, each a 32 x 32 quadrant = 2 x 2 MFMA tiles; fragments:
 // A (16x4): lane l holds panel[kk + (l >> 4)][i + (l & 15)], B likewise with j, D: col = l & 15,
 // row = (l >> 4) + 4 reg.
-__global__ __launch_bounds__(256) void chol_syrk(double* M, int64_t ld, int k0) {
+POVAR_KERNEL __launch_bounds__(256) void chol_syrk(double* M, int64_t ld, int k0) {
   const int it = blockIdx.y, jt = blockIdx.x;
   if (jt < it) return;
   __shared__ double As[CH_NB][CH_LDS];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void chol_syrk(double* M, int64_t ld, int k0) 
 // block triangle starting at row/column R0 = K0 + kdepth, including the rhs column.  grid = (n_jt, n_it),
 // 128 x 128 tiles, 4 wavefronts each a 64 x 64 quadrant = 4 x 4 MFMA tiles; K walked in chunks of 32
 // (2 x 36 KiB of LDS: two workgroups per CU overlap each other's loads and MFMAs).
-__global__ __launch_bounds__(256, 2) void chol_syrk_outer(double* M, int64_t ld, int K0, int kdepth) {
+POVAR_KERNEL __launch_bounds__(256, 2) void chol_syrk_outer(double* M, int64_t ld, int K0, int kdepth) {
   const int it = blockIdx.y, jt = blockIdx.x;
   if (jt < it) return;
   __shared__ double As[CH_KC][CH_TLDS];
@@ -210,12 +210,12 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_outer(double* M, int64_t ld,
 //   chol_back_update  x[0, k0) -= R[0:k0, k0:k0+64] x_k     one wavefront per row, 512-byte row reads
 // so the upper triangle is streamed once over the whole chip (a single workgroup walking the
 // row panels took 340 us per panel on venice-1778, profiles/r01_g_*).
-__global__ __launch_bounds__(256) void chol_copy_rhs(const double* M, int64_t ld, int N, double* x) {
+POVAR_KERNEL __launch_bounds__(256) void chol_copy_rhs(const double* M, int64_t ld, int N, double* x) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < N) x[i] = M[(int64_t)i * ld + N];
 }
 
-__global__ __launch_bounds__(64) void chol_back_solve(const double* M, int64_t ld, int k0, double* x) {
+POVAR_KERNEL __launch_bounds__(64) void chol_back_solve(const double* M, int64_t ld, int k0, double* x) {
   const int lane = threadIdx.x;
   const double* blk = M + (int64_t)k0 * ld + k0;
   double u[CH_NB];  // column `lane` of R11
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64) void chol_back_solve(const double* M, int64_t l
   x[k0 + lane] = xi;
 }
 
-__global__ __launch_bounds__(256) void chol_back_update(const double* M, int64_t ld, int k0, double* x) {
+POVAR_KERNEL __launch_bounds__(256) void chol_back_update(const double* M, int64_t ld, int k0, double* x) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= k0) return;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void chol_back_update(const double* M, int64_t
 }
 
 // identity on the padding rows [n, N) of the augmented matrix (after the memset)
-__global__ __launch_bounds__(64) void chol_pad(double* M, int64_t ld, int n, int N) {
+POVAR_KERNEL __launch_bounds__(64) void chol_pad(double* M, int64_t ld, int n, int N) {
   const int r = n + threadIdx.x;
   if (r < N) M[(int64_t)r * ld + r] = 1.0;
 }

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
 }
 
 // robust weights in chunk order: w_ck[i] = w_lpl[src[i]] (once per linearisation; V2::w is written by lpl_pass<0>)
-__global__ __launch_bounds__(256) void ck_gather_w(const int* src, const double* w_lpl, double* w_ck, int64_t n) {
+POVAR_KERNEL __launch_bounds__(256) void ck_gather_w(const int* src, const double* w_lpl, double* w_ck, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int s = src[i];

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
     int rank_n = 0;
     // ---- the way forward starts: record and first rows of the first tile
     if (t < tb1) {
-      row0 = tiles[4 * t]; h = tiles[4 * t + 1]; li0 = tiles[4 * t + 3];
+      row0 = tiles[4 * t]; h = tiles[4 * t + 1]; fl = tiles[4 * t + 2]; li0 = tiles[4 * t + 3];  // (the whole header at once: below)
       if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
       ckh_load_rec(d, rank < 0 ? 0 : rank, zz, P);
       st.template start<1>(R, row0, li0, h, lane);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
       ++q_t;
       rank = rank_n;
       tn = tile_of(tb0, q_t + 1);
-      row0 = tiles[4 * t]; h = tiles[4 * t + 1]; li0 = tiles[4 * t + 3];
+      row0 = tiles[4 * t]; h = tiles[4 * t + 1]; fl = tiles[4 * t + 2]; li0 = tiles[4 * t + 3];
       if (tn < tb1) rank_n = ck_rank(k.lane_meta[(size_t)tn * WAVE + lane].x);
       ckh_load_rec(d, rank < 0 ? 0 : rank, zz, P);
       st.template start<1>(R, row0, li0, h, lane);
@@ -319,9 +319,8 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
     if (t < tb1) {
       const int2 me = k.lane_meta[(size_t)t * WAVE + lane];
       seg = ck_seg(me.x);
-      acc_slot = me.y;
-      fl = tiles[4 * t + 2];
-      if (tp < tb1) {
+      acc_slot = me.y;  // (fl came with the tile's header: a scalar load HERE is a miss in front of the barrier's lgkmcnt(0) --
+      if (tp < tb1) {   //  ~ 2.6 k cycles per batch in e0_ck's stamps, profiles/r06_e0_ck_phase_stamps.txt)
         const int2 mp = k.lane_meta[(size_t)tp * WAVE + lane];
         rank_p = ck_rank(mp.x);
         seg_p = ck_seg(mp.x);

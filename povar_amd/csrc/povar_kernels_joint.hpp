@@ -124,7 +124,7 @@ struct OpLinearizeH {
   }
   __device__ void phase2(const Dp&, int, int, int, double2, Local&, const double*, double*) const {}
   __device__ void finish_lm(const Dp& d, int lm, const double* tot) const {
-    if (d.lin_aux_only) return;  // only the per-slot arrays are wanted (ensure_legacy, povar_hip.hip)
+    if (d.lin_aux_only) return;  // only the per-slot arrays are wanted (ensure_legacy, povar_lm.hip)
     d.jl_scale4[lm] = make_double4(1.0 / (d.eps + sqrt(tot[0])), 1.0 / (d.eps + sqrt(tot[1])),
                                    1.0 / (d.eps + sqrt(tot[2])), 1.0 / (d.eps + sqrt(tot[3])));
   }
@@ -282,7 +282,7 @@ struct OpBackJoint {
 // cameras: the step-2 twin of e0_lm_cached<true> (same pipeline, 2-row tiles, camera record = z_c (12)
 // + full P_c (12) = 192 B, landmark record = X | s | Hll^-1 = 128 B).
 
-__global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_wg, double* hot_out) {
+POVAR_KERNEL __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_wg, double* hot_out) {
   if (d.flags[1]) return;
   extern __shared__ double2 hot[];  // [n_hot][HOT_REC_H] records, then acc[12][n_hot]
   const int n_hot = d.n_hot_acc;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void e0_lm_cached_h(Dp d, int bins_per_w
 
 // Gram moments of the unscaled weighted Jp12: Jp12^T Jp12 = w * (C (x) X X^T),
 // C = [[D00^2, 0, D00 D02], [0, D00^2, D00 D12], [., ., D02^2 + D12^2]]
-__global__ __launch_bounds__(256) void cm_gram_h(Dp d, int gather) {
+POVAR_KERNEL __launch_bounds__(256) void cm_gram_h(Dp d, int gather) {
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (item >= d.n_items) return;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void cm_gram_h(Dp d, int gather) {
 // per camera after the Gram sums: diag2 / sigma (get_Jp_diag2_projective_space,
 // linearization_varproj.hpp:225-264; linearizor_power_varproj.cpp:97-105) and the Householder
 // vector of vec(P_c) for the tangent basis N_c
-__global__ __launch_bounds__(CFL_THREADS) void cam_finish_linearize_h(Dp d, const double* G_in, double* ncw) {
+POVAR_KERNEL __launch_bounds__(CFL_THREADS) void cam_finish_linearize_h(Dp d, const double* G_in, double* ncw) {
   const int c = blockIdx.x;
   constexpr int NQ = CFL_THREADS / 64;
   __shared__ double part[NQ][40];
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(CFL_THREADS) void cam_finish_linearize_h(Dp d, cons
 // K8': B_c = N_c^T (Hpp12 + lambda I) N_c = N_c^T Hpp12 N_c + lambda I_11, Cholesky inverse 11x11
 // (linearization_power_varproj.hpp:91-121).  Sixteen lanes per camera as cam_build_binv: lane i owns row i of the two
 // projections, then chol_inverse_16<11>.
-__global__ __launch_bounds__(K8_THREADS) void cam_build_binv_h(Dp d, double lambda, const double* ncw) {
+POVAR_KERNEL __launch_bounds__(K8_THREADS) void cam_build_binv_h(Dp d, double lambda, const double* ncw) {
   __shared__ double As[K8_CAMS_PER_WG][144];
   __shared__ double Ts[K8_CAMS_PER_WG][144];
   const int q = threadIdx.x >> 4, l = threadIdx.x & 15;
@@ -595,7 +595,7 @@ __device__ inline void nt_apply(const double* w, double beta, const double (&y)[
 }
 
 // b11_c = N_c^T (sigma * sum_items); one wavefront per camera
-__global__ __launch_bounds__(256) void cam_sum_items_h(Dp d, double* out11, const double* ncw) {
+POVAR_KERNEL __launch_bounds__(256) void cam_sum_items_h(Dp d, double* out11, const double* ncw) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.n_cams) return;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void cam_sum_items_h(Dp d, double* out11, cons
 // K9' + K11': tmp11 = B^-1 y11, accum11 (+)= tmp11, z = sigma * (N_c tmp11)
 // (right_mul_b_inv_joint + loop body of solve_joint, linearization_power_varproj.hpp:246-257, 342-360).
 // mode 0: y11 = -b11; 1: y12 = sigma * sum of scatter items, y11 = N^T y12; 2: y12 = dense d.y (all-reduced)
-__global__ __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy_h(Dp d, int mode, int want_norms, const double* ncw) {
+POVAR_KERNEL __launch_bounds__(K9_CAMS * 64) void cam_binv_axpy_h(Dp d, int mode, int want_norms, const double* ncw) {
   if (mode != 0 && d.flags[1]) return;
   __shared__ double sh[K9_CAMS * 2];
   const int lane = threadIdx.x & 63;
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void prepare_lpl_h(Dp d, double* hot_out
 
 // b11_c = N_c^T y12_c for the per-camera sums of prepare_lpl_h (cam_cold_sum has applied sigma); y12 is scratch
 // and left zeroed, as the dense-y term loop expects it
-__global__ __launch_bounds__(256) void cam_nt_project(Dp d, double* y12, double* out11, const double* ncw) {
+POVAR_KERNEL __launch_bounds__(256) void cam_nt_project(Dp d, double* y12, double* out11, const double* ncw) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= d.n_cams) return;
   double y[12], o[11];
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(E0C_BLOCK) void lpl_pass_h(Dp d, double* part) {
     if (MODE == 0) {
       const int sg = v.seg[(size_t)c_t * WAVE + lane];
       if (c_fl & 1) seg_reduce_steps<4>(red, lane, sg & 255, (sg >> 8) & 255, 4);
-      // lane-ordered; the landmark-order copy (Dp::jl_scale4) is filled on demand (povar_hip.hip: ensure_jl_scale4)
+      // lane-ordered; the landmark-order copy (Dp::jl_scale4) is filled on demand (povar_lm.hip: ensure_jl_scale4)
       v.lsc[(size_t)c_t * WAVE + lane] = make_double4(1.0 / (d.eps + sqrt(red[0])), 1.0 / (d.eps + sqrt(red[1])),
                                                       1.0 / (d.eps + sqrt(red[2])), 1.0 / (d.eps + sqrt(red[3])));
     }
@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(NT) void cam_cold_sum_binv_h(Dp d, int want_norms, 
 
 // K13' (linearizor_power_varproj.cpp:283-305) and the z = sigma * (N_c inc_c) needed by K12'.
 // mode 1: z only (before back substitution); mode 2: P_c += reshape((N_c inc_c) * sigma)
-__global__ __launch_bounds__(256) void cam_apply_inc_h(Dp d, int mode, const double* ncw) {
+POVAR_KERNEL __launch_bounds__(256) void cam_apply_inc_h(Dp d, int mode, const double* ncw) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= d.n_cams) return;
   const double* w = ncw + 13 * (size_t)c;
@@ -1566,7 +1566,7 @@ __global__ __launch_bounds__(256) void cam_apply_inc_h(Dp d, int mode, const dou
 }
 
 // K15: P_c /= |P_c|_F, X_l /= X_l[3]  (bal_bundle_adjustment.cpp:700-705)
-__global__ __launch_bounds__(256) void normalize_joint(Dp d, int64_t n_lanes) {
+POVAR_KERNEL __launch_bounds__(256) void normalize_joint(Dp d, int64_t n_lanes) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n_lanes && d.v2.lm_of[i] >= 0) {  // lane-ordered mirror (V2::lmx), kept current
     double4 X = d.v2.lmx[i];

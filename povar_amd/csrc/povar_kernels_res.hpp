@@ -466,7 +466,7 @@ __global__ __launch_bounds__(NW * 64) void series_res(Dp d, ResP k) {
 
 // the launch counter (the high bits of the granule tags of the NEXT launch): a one-thread kernel behind series_res in the
 // stream -- inside the launch itself a workgroup that is late could still be reading the old value
-__global__ void res_bump_launch(unsigned* launch) {
+POVAR_KERNEL void res_bump_launch(unsigned* launch) {
   unsigned v = *launch + 1u;
   if (v >= (1u << 24)) v = 1u;  // (a tag is launch << 8 | term: 24 bits; a wrap meets granules 16 M launches old)
   *launch = v;

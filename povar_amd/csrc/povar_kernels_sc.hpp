@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void cm_gram_sc(Dp d, double* part) {
 
 // dm[c] = sum of the camera's item moments, fixed order: 16 wavefronts stride over the items (a hub
 // camera of venice-1778 has ~800 of them), then a fixed-order sum of the 16 partials
-__global__ __launch_bounds__(1024) void cam_sum_parts60(Dp d, const double* part, double* dm) {
+POVAR_KERNEL __launch_bounds__(1024) void cam_sum_parts60(Dp d, const double* part, double* dm) {
   __shared__ double sh[16][60];
   const int c = blockIdx.x, e = threadIdx.x & 63, q = threadIdx.x >> 6;
   if (e < 60) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(K9_CAMS * 64) void pcg_init(Dp d, ScP s) {
 
 // end of iteration `it` (it == 0: after pcg_init): the termination tests of CG:243-301 and, when
 // the loop goes on, rho / beta of the next iteration with their failure exits (CG:175-197)
-__global__ __launch_bounds__(64) void pcg_check(Dp d, ScP s, int n_blocks, int it, int min_it, int max_it, double eta,
+POVAR_KERNEL __launch_bounds__(64) void pcg_check(Dp d, ScP s, int n_blocks, int it, int min_it, int max_it, double eta,
                                                 double r_tol) {
   if (d.flags[1]) return;
   double v[3] = {0, 0, 0};
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(K9_CAMS * 64) void pcg_apply(Dp d, ScP s) {
 }
 
 // alpha = rho / p.q with the exits of CG:204-223
-__global__ __launch_bounds__(64) void pcg_alpha(Dp d, ScP s, int n_blocks, int it) {
+POVAR_KERNEL __launch_bounds__(64) void pcg_alpha(Dp d, ScP s, int n_blocks, int it) {
   if (d.flags[1]) return;
   double v[1] = {0};
   for (int k = threadIdx.x; k < n_blocks; k += 64) v[0] += s.part[4 * (size_t)k];
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(K9_CAMS * 64) void pcg_residual(Dp d, ScP s) {
 }
 
 // inc = -x ("we solve H(-x) = b", linearizor_base.cpp:121-122) into the increment buffer
-__global__ __launch_bounds__(256) void pcg_finish(const double* x, double* accum, int n) {
+POVAR_KERNEL __launch_bounds__(256) void pcg_finish(const double* x, double* accum, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) accum[i] = -x[i];
 }
@@ -548,7 +548,7 @@ __device__ inline void scd_stage(const Dp& d, int slot, const double* s3, const 
   o.cam = cam;
 }
 
-__global__ __launch_bounds__(256) void sc_dense_offdiag(Dp d, const int* lm_slot0, const int* lm_cnt, double* S, int64_t ld) {
+POVAR_KERNEL __launch_bounds__(256) void sc_dense_offdiag(Dp d, const int* lm_slot0, const int* lm_cnt, double* S, int64_t ld) {
   __shared__ ScdObs oi[SCD_CHUNK], oj[SCD_CHUNK];
   const int lm = blockIdx.x;
   const int s0 = lm_slot0[lm], k = lm_cnt[lm];
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void sc_dense_offdiag(Dp d, const int* lm_slot
 
 // S_cc += B_c = Hpp_c + lambda I (landmark_block.hpp:381-384 + linearization_sc.hpp:477-481) and the
 // right-hand side -b into column N of the augmented matrix (povar_kernels_chol.hpp)
-__global__ __launch_bounds__(256) void sc_dense_diag(Dp d, const double* bmat, double* S, int64_t ld, int N) {
+POVAR_KERNEL __launch_bounds__(256) void sc_dense_diag(Dp d, const double* bmat, double* S, int64_t ld, int N) {
   const int c = blockIdx.x, e = threadIdx.x;
   if (e < 144) {
     const int r = e / 12, cc = e - 12 * r;

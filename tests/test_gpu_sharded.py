@@ -238,7 +238,7 @@ def test_sharded_deterministic_mode(monkeypatch):
 
 def test_the_ranks_of_a_sharded_run_agree_on_the_timed_kernel(monkeypatch):
     """VERDICT r05 (missing item 4): each rank timed e0_lpl against e0_ck on ITS shard and kept its own winner.  Now every
-    prepare call of a sharded context ends in one small all-reduce (povar_hip.hip: tune_agree): the timings of the ranks that
+    prepare call of a sharded context ends in one small all-reduce (povar_series.hip: tune_agree): the timings of the ranks that
     have just timed decide for everybody.  Three shards of very different shapes (a landmark range cut 70 / 20 / 10 % by hand:
     the ranks' own timings need not agree) end on the SAME kernel in step 1 and in step 2, the choice is reported as timed
     (e0_auto = 2), and the increments are the single-context ones."""

@@ -1,4 +1,4 @@
-"""The context's state bookkeeping behind the LM loop (povar_hip.hip): compute_error_* of an unchanged state is answered
+"""The context's state bookkeeping behind the LM loop (povar_lm.hip): compute_error_* of an unchanged state is answered
 from the last evaluation (the reference's loop asks again at the top of every iteration,
 bal_bundle_adjustment.cpp:302-310 / 600-605), the lane-per-landmark linearisation keeps the linearisation point in lane
 order only and the landmark-order copy follows on demand, normalize_joint keeps the lane-ordered mirror current.

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""The round-5 table of DESIGN.md section 4 from the bench lines under profiles/ (so that no number is typed by hand)."""
+"""The per-round table of DESIGN.md section 4 AND the round's section of profiles/README.md from the bench lines under profiles/
+(so that no number is typed by hand, and the README cannot lag a round behind again: VERDICT r05 item 7).
+    python tools/design_table.py r06"""
 import json
 import os
+import sys
+
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROWS = [("bench", "venice-1778 (headline, default command)"), ("bench_driver_flags", "venice-1778, the driver's flags (20 timed steps)"),
+ROWS = [("bench", "venice-1778 (headline, default command)"), ("bench_driver_flags", "venice-1778, the driver's flags (`--steps 20 --warmup 5`)"),
         ("bench_forced_e0_lpl", "venice-1778, `e0_lpl` forced (`POVAR_E0_CK=0`)"), ("bench_huber", "venice-1778, HUBER"),
         ("bench_local", "venice-1778, `--popularity local`"), ("bench_zipf05", "venice-1778, Zipf(0.5)"),
         ("bench_uniform", "venice-1778, uniform popularity"), ("bench_step2", "venice-1778, step 2"),
@@ -19,7 +24,7 @@ lines = []
 lines.append("| workload | terms/s | term kernel(s) (the library's timing of the two pairs) | pair time (events) | bytes per E0 (measured / every array once) | fraction (measured / once) |")
 lines.append("|---|---|---|---|---|---|")
 for f, name in ROWS:
-    path = os.path.join(ROOT, "profiles", f"r05_{f}.json")
+    path = os.path.join(ROOT, "profiles", f"{TAG}_{f}.json")
     if not os.path.exists(path):
         continue
     d = json.loads(open(path).read().strip().splitlines()[-1])
@@ -43,5 +48,13 @@ for f, name in ROWS:
 print("\n".join(lines))
 dpath = os.path.join(ROOT, "DESIGN.md")
 s = open(dpath).read()
-a, b = s.index("<!-- R05-TABLE-BEGIN -->"), s.index("<!-- R05-TABLE-END -->")
-open(dpath, "w").write(s[:a] + "<!-- R05-TABLE-BEGIN -->\n" + "\n".join(lines) + "\n" + s[b:])
+B, E = f"<!-- {TAG.upper()}-TABLE-BEGIN -->", f"<!-- {TAG.upper()}-TABLE-END -->"
+if B in s:
+    a, b = s.index(B), s.index(E)
+    open(dpath, "w").write(s[:a] + B + "\n" + "\n".join(lines) + "\n" + s[b:])
+# the same rows as the round's section of profiles/README.md (between its markers; the hand-written file list stays below them)
+rpath = os.path.join(ROOT, "profiles", "README.md")
+r = open(rpath).read()
+if B in r:
+    a, b = r.index(B), r.index(E)
+    open(rpath, "w").write(r[:a] + B + "\n" + "\n".join(lines) + "\n" + r[b:])

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Diagnostic / experiment builds of the library from PATCHED copies of the sources (the shipping sources carry no stamp
 # and no experiment branch).  usage: tools/variants/build_variant.sh <patch name without .patch> [out name] [-D flags...]
-#   ck_head               the per-camera step of a term at the HEAD of the next e0_ck launch (round 6: built, measured, not shipped --
+#   ck_head               the per-camera step of a term at the HEAD of the next e0_ck launch (round 6: built, measured, not shipped;
+#                         a record of that experiment: it applies to the sources of commit df549ed, before povar_hip.hip was cut into units --
 #                         profiles/r06_experiments.txt D; POVAR_CK_HEAD=0|1, tools/r06_head_probe.py, tools/r06_head_ab.sh)
 #   ck_stamps             in-kernel s_memtime stamps of e0_ck's phases (tools/ck_stamps.py) + the timing-only experiment
 #                         branches of round 4 (-DPOVAR_CK_EXP_NOATOMIC, -DPOVAR_CK_EXP_NOBWDROWS, -DPOVAR_CK_EXP_NOBWDLDS)
@@ -15,6 +16,7 @@ rm -rf $top; mkdir -p $top/povar_amd
 cp -r povar_amd/csrc $top/povar_amd/csrc
 cp -r include $top/include
 (cd $top && patch -p1 -s < ../../../tools/variants/$patch.patch)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -shared -o build/libpovar_hip_$out.so \
-  $top/povar_amd/csrc/povar_hip.hip -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+# (the patched copy's own Makefile: five translation units side by side; extra -D flags through CXXFLAGS)
+make -s -C $top/povar_amd/csrc OUT=$PWD/build/libpovar_hip_$out.so OBJ_DIR=$PWD/$top/obj \
+  CXXFLAGS="-O3 -std=c++17 -fPIC -munsafe-fp-atomics $*" $PWD/build/libpovar_hip_$out.so
 echo build/libpovar_hip_$out.so

@@ -21,18 +21,24 @@ def main():
     for ab in "ab":
         os.makedirs(os.path.join(top, ab, "povar_amd"))
         shutil.copytree(os.path.join(ROOT, "povar_amd", "csrc"), os.path.join(top, ab, "povar_amd", "csrc"),
-                        ignore=shutil.ignore_patterns("host", "*.so", "*.o"))
+                        ignore=shutil.ignore_patterns("host", "*.so", "*.o"))  # (Makefile and povar.map travel: the variant is built with them)
         shutil.copytree(os.path.join(ROOT, "include"), os.path.join(top, ab, "include"))
     b = os.path.join(top, "b", "povar_amd", "csrc")
 
-    # ---- povar_hip.hip: the stamp buffer and povar_debug_ck_stamps
-    p = os.path.join(b, "povar_hip.hip")
+    # ---- the stamp buffer (povar_ctx.hpp), its release (povar_create.hip), the kernel argument and povar_debug_ck_stamps (povar_series.hip)
+    p = os.path.join(b, "povar_ctx.hpp")
     s = open(p).read()
     s = sub(s, "    ckh, pl_ckh;     // step 2 (e0_ck_h): a second instance (64 bytes of LDS per landmark slot: more batches, other chunks)\n",
             "    ckh, pl_ckh;     // step 2 (e0_ck_h): a second instance (64 bytes of LDS per landmark slot: more batches, other chunks)\n"
             "  DevBuf<unsigned long long> ck_stamps;  // diagnostic build: CkP::stamps\n")
-    s = sub(s, "             D.lcnt.p, D.tick.p, D.max_acc, D.packed ? 1 : 0};", "             D.lcnt.p, D.tick.p, D.max_acc, D.packed ? 1 : 0, c->ck_stamps.p};")
+    open(p, "w").write(s)
+    p = os.path.join(b, "povar_create.hip")
+    s = open(p).read()
     s = sub(s, "c->ckh.release(); c->pl_ckh.release(); c->ck_zero_range.release();", "c->ckh.release(); c->pl_ckh.release(); c->ck_zero_range.release(); c->ck_stamps.release();")
+    open(p, "w").write(s)
+    p = os.path.join(b, "povar_series.hip")
+    s = open(p).read()
+    s = sub(s, "             D.lcnt.p, D.tick.p, D.max_acc, D.packed ? 1 : 0};", "             D.lcnt.p, D.tick.p, D.max_acc, D.packed ? 1 : 0, c->ck_stamps.p};")
     i = s.index("int povar_debug_ck_stamps(povar_ctx* c, uint64_t* out, int64_t n) {")
     j = s.index("\n}\n", i) + 3
     s = s[:i] + """int povar_debug_ck_stamps(povar_ctx* c, uint64_t* out, int64_t n) {

@@ -46,7 +46,7 @@ def main():
     s = s.replace("  const ResBufs B = res_bufs(k);\n", "  const ResBufs B = res_bufs(k);\n  { const int i = k.stamp_term; RES_STAMP(0); }\n", 1)
     s = s.replace("  // ---------------- epilogue: sum and last term of the owned cameras, status\n", "  { const int i = k.stamp_term; RES_STAMP(12); }\n  // ---------------- epilogue: sum and last term of the owned cameras, status\n", 1)
     open(p, "w").write(s)
-    h = os.path.join(DST, "povar_hip.hip")
+    h = os.path.join(DST, "povar_series.hip")  # (res_params lives with the term loop)
     s = open(h).read()
     s = s.replace("  k.spin_limit = c->res_spin_limit;\n", '''  k.spin_limit = c->res_spin_limit;
   {
@@ -71,8 +71,7 @@ def main():
 ''', 1)
     open(h, "w").write(s)
     out = os.path.join(ROOT, "build", "libpovar_hip_res_stamps.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-shared",
-                           "-o", out, h, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+    subprocess.check_call(["make", "-s", "-C", DST, f"OUT={out}", f"OBJ_DIR={os.path.join(TOP, 'obj')}", out])  # (the copy's own Makefile: five units)
     print(out)
 
 
