@@ -33,7 +33,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_k
 rm -rf $out/bench_kt/*/*kernel_trace.csv
 B="python3 bench.py"
 $B > $out/bench_default.json 2> $out/bench_default.err < /dev/null
-$B --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $out/bench_driver_flags.json 2> /dev/null < /dev/null
+$B --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_flags.json 2> /dev/null < /dev/null
 B="python3 bench.py --no-secondary --no-cpu-baseline"
 POVAR_E0_CK=0 $B > $out/bench_forced_e0_lpl.json 2> /dev/null < /dev/null
 $B --robust-norm HUBER > $out/bench_huber.json 2> /dev/null < /dev/null
