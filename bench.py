@@ -493,7 +493,9 @@ def main():
         barrier()
         per_step = agree_max((time.perf_counter() - t0) / max(args.warmup, 1))
         extra = int(min(max(args.warm_seconds / max(per_step, 1e-6) - args.warmup, 0), 20000))
-        run_steps(extra)
+        for at in range(0, extra, 64):  # (at most 64 replayed term loops queued at a time)
+            run_steps(min(64, extra - at))
+            ctx.synchronize()
         barrier()
         return max(args.warmup, 1) + extra
 

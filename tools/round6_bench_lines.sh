@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 B="python3 bench.py"
 $B > $out/bench_default.json 2> $out/bench_default.err < /dev/null
 $B --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_flags.json 2> /dev/null < /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_kt -- python3 bench.py --no-cpu-baseline --no-secondary > $out/bench_kt.json 2> $out/bench_kt.err < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_kt -- python3 bench.py --no-cpu-baseline --no-secondary --warm-seconds 0 --repeats 1 > $out/bench_kt.json 2> $out/bench_kt.err < /dev/null
 rm -rf $out/bench_kt/*/*kernel_trace.csv
 B="python3 bench.py --no-secondary --no-cpu-baseline"
 POVAR_E0_CK=0 $B > $out/bench_forced_e0_lpl.json 2> /dev/null < /dev/null
