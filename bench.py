@@ -723,6 +723,9 @@ def main():
                                                     # image points as two int32 of micro-units (every observation a six-decimal
                                                     # number, decoded bit for bit) instead of two doubles
                                                     "packed_image_points": bool(li.ck_packed),
+                                                    # chunks of cameras without a slot: q per observation in the cold view instead of
+                                                    # a partial record per chunk
+                                                    "cold_observations_through_the_cold_view": bool(li.ck_cold_q),
                                                     "chunks": li.ck_chunks, "own_record_chunks": li.ck_cold_chunks,
                                                     "partial_records": li.ck_part_rec, "build_ms": round(li.ck_build_ms, 1)}
                                   if li.ck_ready else None,

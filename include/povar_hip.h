@@ -328,6 +328,8 @@ typedef struct {
   int32_t ck_packed;    /* 1: the rows of the camera-chunk layout keep the image points packed (two int32 of micro-units,
                            8 instead of 16 bytes per observation and walk): every observation of the problem is a six-decimal
                            number -- what the reference's files hold, bal/bal_problem.cpp:373-375 -- and comes back bit for bit */
+  int32_t ck_cold_q;    /* 1: chunks of cameras without an accumulator slot leave q of each observation (32 bytes) in the cold
+                           camera-major view instead of a 96-byte partial record per chunk (layouts with at most 8 % cold observations) */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 /* The reference's constructor is a trivial allocation (sc/linearization_varproj.hpp:44-60); this library's builds the

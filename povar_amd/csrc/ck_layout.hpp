@@ -67,6 +67,13 @@ struct CkLayout {
   std::vector<double2> uv;       // [rows][64]
   std::vector<int2> uvp;         // [rows][64] packed image points (ck_pack_uv; then uv is released)
   bool packed = false;
+  // Chunks of a camera WITHOUT an accumulator slot ("cold": almost all of one observation) are 3 % of venice's observations and
+  // half of its partial records (130 919 of 257 972 x 96 bytes, written and read back every term), and most of the records on a
+  // graph without hubs.  With cold_q such a lane leaves only q = w C (P3 g) (32 bytes) of each observation at the observation's
+  // place in the parent layout's camera-major cold view (LplLayout::cpos), and the per-camera kernel forms h~ (x) q from the
+  // view's landmark copy as it does behind e0_lpl: 32 + 56 bytes per cold observation instead of 96 + 96.
+  std::vector<int> cpos;         // [rows][64] cold-view position of the entry (cold lanes only, -1 otherwise); empty without cold_q
+  bool cold_q = false;
   std::vector<uint32_t> li;      // [li_rows][64] 3 x landmark slot (16 bits each; CK_NONE: none) of rows 2q | 2q+1 << 16 of a tile
   std::vector<int> src;          // [rows][64] row slot of the lane-per-landmark layout this entry is (-1: none)
   std::vector<int4> tile;        // x: first row, y: height, z: flags, w: first li row
@@ -156,7 +163,10 @@ struct CkShape {
   int max_slots = INT_MAX;
   bool need_uv = true;   // (step 2's operator does not read the image coordinates)
   int acc_bytes = 104;   // LDS bytes per accumulator slot (13 doubles)
+  bool cold_q = false;   // chunks of cameras without a slot leave q per observation in the parent layout's cold view (CkLayout::cpos)
+                         // instead of a 96-byte record of their own (step 1's e0_ck; the other kernels keep the records)
 };
+inline CkShape ck_shape_step1() { CkShape s; s.cold_q = true; return s; }
 // e0_ck_det (povar_kernels_ck_det.hpp) keeps two more bytes per landmark slot (the sum's binary point) and per accumulator
 // slot (the ticket counter)
 inline CkShape ck_shape_det() { CkShape s; s.slot_bytes = 50; s.acc_bytes = 106; return s; }
@@ -168,9 +178,20 @@ inline size_t ck_lds_bytes_shape(const CkShape& sh, int slots, int n_acc, int ng
     return 16 + (size_t)sh.slot_bytes * sh.max_slots + (size_t)n_acc * sh.acc_bytes + 64 + (sh.acc_bytes != 104 ? 16 : 0);
   return 16 + (size_t)ng * slots * sh.slot_bytes + (size_t)n_acc * sh.acc_bytes + 64 + (sh.acc_bytes != 104 ? 16 : 0);
 }
+// cold_q pays where cold observations are few: the lanes that serve them walk their (one- or two-row) tiles without the row
+// prefetch and store 32 scattered bytes per observation.  venice-1778 Zipf(1) (3 % cold): 56.3 -> 55.0 us per term, `local` (1.5 %)
+// 53.3 -> 52.8; Zipf(0.5) (18 %): 77.7 -> 88.0, uniform popularity (31 %): 80.0 -> 115.2 (profiles/r06_cold_q_ab.txt) -- so only
+// up to CK_COLD_Q_MAX_PERCENT of the observations; beyond, a record per cold chunk.
+constexpr int CK_COLD_Q_MAX_PERCENT = 8;
 inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector<int>& cam_of_rank, int n_waves,
-                     CkLayout& K, bool place = true, int hmax = CK_HMAX, int ng = 1, const CkShape& shape = CkShape(),
+                     CkLayout& K, bool place = true, int hmax = CK_HMAX, int ng = 1, const CkShape& shape_in = CkShape(),
                      bool pack_uv = true) {
+  CkShape shape = shape_in;
+  if (shape.cold_q) {
+    int64_t n_obs_all = 0;
+    for (int c : L.cw) n_obs_all += c != -1;
+    if ((int64_t)L.cold_lm.size() * 100 > (int64_t)CK_COLD_Q_MAX_PERCENT * n_obs_all && !std::getenv("POVAR_CK_COLD_Q_ALWAYS")) shape.cold_q = false;
+  }
   int n_threads = std::min(lpl_effective_cpus(), 128);
   if (const char* e = std::getenv("POVAR_LAYOUT_THREADS")) n_threads = std::max(1, std::atoi(e));
   hmax = std::min(CK_HMAX, std::max(1, hmax));
@@ -199,10 +220,11 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
   struct WgOut {
     std::vector<double2> uv;
     std::vector<uint32_t> li;
+    std::vector<int> cpos;
     std::vector<int> src, lane_cam, lane_acc, lane_seg, bt_tiles;  // bt_tiles[b]: tiles of batch b
     std::vector<int4> tile;  // x, w: local row / li-row numbers
     std::vector<int> cold_rank;  // rank of every cold chunk, in the order their lanes say ~(index)
-    int64_t chunks = 0, obs = 0;
+    int64_t chunks = 0, obs = 0, n_cold_q = 0;
     double extra = 0;
   };
   std::vector<WgOut> out(grid);
@@ -281,6 +303,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
         int4 ti = make_int4((int)(o.uv.size() / WAVE), T, 0, (int)(o.li.size() / WAVE));
         const size_t r0 = o.uv.size(), q0 = o.li.size();
         o.uv.resize(r0 + (size_t)T * WAVE, make_double2(0, 0));
+        if (shape.cold_q) o.cpos.resize(r0 + (size_t)T * WAVE, -1);
         o.src.resize(r0 + (size_t)T * WAVE, -1);
         o.li.resize(q0 + (size_t)((T + 1) / 2) * WAVE, CK_NONE | (CK_NONE << 16));
         const size_t l0 = o.lane_cam.size();
@@ -298,8 +321,13 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
           const bool cold = ck.key >= n_acc_w;
           o.lane_cam[l0 + lane] = cold ? ck.key - n_acc_w : L.wg_cams[L.wg_cam_off[w] + ck.key];
           if (cold) {
-            o.lane_acc[l0 + lane] = ~(int)o.cold_rank.size();
-            o.cold_rank.push_back(ck.key - n_acc_w);
+            if (shape.cold_q) {
+              o.lane_acc[l0 + lane] = -1;  // no record: q goes to the cold view, observation by observation
+              ++o.n_cold_q;
+            } else {
+              o.lane_acc[l0 + lane] = ~(int)o.cold_rank.size();
+              o.cold_rank.push_back(ck.key - n_acc_w);
+            }
             ti.z |= CK_FLAG_COLD;
           } else {
             o.lane_acc[l0 + lane] = ck.key;
@@ -330,6 +358,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
             const size_t idx = r0 + (size_t)j * WAVE + lane;
             const size_t s = (size_t)ob.src;
             o.uv[idx] = L.uv[s];
+            if (shape.cold_q && cold) o.cpos[idx] = L.cpos[s];
             o.src[idx] = ob.src;
             uint32_t& word = o.li[q0 + (size_t)(j >> 1) * WAVE + lane];
             const uint32_t li3 = (uint32_t)shape.li_mul * (uint32_t)ob.li;  // step 1: the slot's first double in the [slot][3] LDS arrays
@@ -360,6 +389,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
   std::vector<int64_t> row0_of(grid), li0_of(grid);
   std::vector<int> tile0_of(grid), cold0_of(grid);
   int n_cold_chunks = 0;
+  int64_t n_cold_q = 0;
   for (int w = 0; w < grid; ++w) {
     const WgOut& o = out[w];
     row0_of[w] = K.rows;
@@ -367,6 +397,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     tile0_of[w] = (int)K.tile.size();
     cold0_of[w] = n_cold_chunks;
     n_cold_chunks += (int)o.cold_rank.size();
+    n_cold_q += o.n_cold_q;
     int t = (int)K.tile.size();
     for (int b = 0; b < nb; ++b) {
       K.bt_off[(size_t)w * nb + b] = t;
@@ -385,7 +416,8 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     K.extra_lanes += o.extra;
   }
   K.bt_off[(size_t)grid * nb] = (int)K.tile.size();
-  K.n_cold_chunks = n_cold_chunks;
+  K.n_cold_chunks = n_cold_chunks + n_cold_q;  // (statistics: chunks of cameras without a slot, with or without a record)
+  K.cold_q = shape.cold_q;
   auto clog2 = [](int n) { int e = 0; while ((1 << e) < n) ++e; return (uint8_t)(n == 0 ? 255 : e); };  // 255: nothing is added there
   K.lcnt_log2.resize(lcnt.size());
   for (size_t i = 0; i < lcnt.size(); ++i) K.lcnt_log2[i] = clog2(lcnt[i]);
@@ -413,6 +445,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     // (+ CK_HMAX rows of padding: the register-resident tiles of e0_ck load CK_HMAX rows whatever the tile's height)
     K.uv.assign((size_t)(K.rows + CK_HMAX) * WAVE, make_double2(0, 0));
     K.src.assign((size_t)(K.rows + CK_HMAX) * WAVE, -1);
+    if (shape.cold_q) K.cpos.assign((size_t)(K.rows + CK_HMAX) * WAVE, -1);
     K.li.assign((size_t)(K.li_rows + CK_HMAX) * WAVE, CK_NONE | (CK_NONE << 16));
     K.lane_cam.resize(K.tile.size() * WAVE);
     K.lane_acc.resize(K.tile.size() * WAVE);
@@ -421,12 +454,13 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
       const WgOut& o = out[w];
       std::copy(o.uv.begin(), o.uv.end(), K.uv.begin() + row0_of[w] * WAVE);
       std::copy(o.src.begin(), o.src.end(), K.src.begin() + row0_of[w] * WAVE);
+      if (shape.cold_q) std::copy(o.cpos.begin(), o.cpos.end(), K.cpos.begin() + row0_of[w] * WAVE);
       std::copy(o.li.begin(), o.li.end(), K.li.begin() + li0_of[w] * WAVE);
       std::copy(o.lane_cam.begin(), o.lane_cam.end(), K.lane_cam.begin() + (size_t)tile0_of[w] * WAVE);
       std::copy(o.lane_seg.begin(), o.lane_seg.end(), K.lane_seg.begin() + (size_t)tile0_of[w] * WAVE);
       for (size_t i = 0; i < o.lane_acc.size(); ++i) {
         const int a = o.lane_acc[i];
-        K.lane_acc[(size_t)tile0_of[w] * WAVE + i] = a >= 0 ? a : ~cold_rec[(size_t)cold0_of[w] + (size_t)(~a)];
+        K.lane_acc[(size_t)tile0_of[w] * WAVE + i] = a >= 0 ? a : shape.cold_q ? -1 : ~cold_rec[(size_t)cold0_of[w] + (size_t)(~a)];
       }
     });
   }

@@ -241,6 +241,8 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
   up(D.li, K.li); up(D.src, K.src); up(D.tile, K.tile); up(D.lane_meta, meta);
   up(D.bt_off, K.bt_off); up(D.slot_rec, K.slot_rec); up(D.part_range, K.part_range);
   if (c->det_ck) { up(D.lcnt, K.lcnt_log2); up(D.tick, K.tick); }
+  D.cold_q = K.cold_q;
+  if (K.cold_q) up(D.cpos, K.cpos);
   if (ok) guarded([&] { ok = D.part.alloc((size_t)std::max(K.n_part_rec, 1) * 12, bytes) == hipSuccess; });
   if (ok && c->opt.robust_norm && !need_uv)  // (step 2's kernel reads the weights in chunk order; step 1's recomputes them)
     guarded([&] { ok = D.w.alloc(std::max<size_t>(K.src.size(), 1), bytes) == hipSuccess; });  // (padded like the rows)
@@ -606,7 +608,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   const bool ck_place = std::getenv("POVAR_CK_NOPLACE") == nullptr;  // LDS bank placement of the chunk rows (ck_layout.hpp)
   const bool ck_pack = !(fl & POVAR_FLAG_NO_PACKED_ROWS);            // packed image points where they pack (POVAR_CK_PACK=0 overrides inside build_ck)
   if (const char* e = std::getenv("POVAR_CK_HMAX")) ck_hmax = std::min(CK_HMAX, std::max(1, std::atoi(e)));
-  const CkShape ck_shape1 = c->det_ck ? ck_shape_det() : CkShape();  // (step 1's layout: batches cut for the kernel that runs them)
+  // (step 1's layout: batches cut for the kernel that runs them; e0_ck leaves q of its cold observations in the parent's cold view)
+  const CkShape ck_shape1 = c->det_ck ? ck_shape_det() : std::getenv("POVAR_CK_COLD_RECORDS") ? CkShape() : ck_shape_step1();
   const CkShape ck_shape2 = c->det_ck ? ck_shape_step2_det() : ck_shape_step2();
 
   // The arrays of the lane-per-observation kernels (part B) are built on a second host thread while this one builds
@@ -1072,6 +1075,7 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->tune_res_us = c->res_tune_us[1];
   out->res_failed = c->res_failed ? 1 : 0;
   out->ck_packed = c->ck.ready && c->ck.packed ? 1 : 0;
+  out->ck_cold_q = c->ck.ready && c->ck.cold_q ? 1 : 0;
   return 0;
 }
 

@@ -157,6 +157,8 @@ struct povar_ctx {
     DevBuf<double2> uv;
     DevBuf<int2> uvp;            // packed image points (CkLayout::uvp) instead of uv
     bool packed = false;
+    DevBuf<int> cpos;            // cold-view positions of the entries of chunks without an accumulator slot (CkLayout::cpos)
+    bool cold_q = false;         // ... which leave q there instead of partial records of their own
     DevBuf<uint32_t> li;
     DevBuf<int> src, bt_off, slot_rec;
     DevBuf<int2> lane_meta;
@@ -171,6 +173,7 @@ struct povar_ctx {
     int64_t w_lin_id = -1;       // linearisation whose robust weights w holds
     bool ready = false;
     void release() {
+      cpos.release(); cold_q = false;
       uv.release(); uvp.release(); li.release(); src.release(); lane_meta.release(); bt_off.release();
       slot_rec.release(); tile.release(); part_range.release(); part.release(); w.release();
       packed = false;

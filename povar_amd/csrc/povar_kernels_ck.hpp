@@ -43,6 +43,8 @@ struct CkP {
   const uint16_t* tick;    // [tiles][64] ticket of the lane's run total at its accumulator slot (last lane of a run with a slot)
   int max_acc;             // accumulator slots the LDS is laid out for
   int uv_packed;           // uv holds packed image points (the PK instantiations of e0_ck)
+  const int* cpos;         // [rows][64] cold-view position of the entries of chunks WITHOUT an accumulator slot (CkLayout::cpos), or nullptr:
+  double4* q4c;            // ... such a lane stores q of every observation there (the per-camera kernel forms h~ (x) q), no record
 };
 // a packed image coordinate back to the double it was packed from: the sequence ck_pack_uv (ck_layout.hpp) verified on the host
 // for every entry -- int -> double, a multiplication, two fused multiply-adds: correctly rounded operations, the same bits
@@ -251,6 +253,42 @@ __device__ inline void ck_backward_rows(const Dp& d, const CkRows& k, CkStream<D
     if (n0 + i < h) ck_backward_step<D, ROBUST, PK>(d, k, st, row0, li0, h, lane, P3, lh, lg, S, y, h - 1 - (n0 + i), i);
 }
 
+// The way back over a tile that has lanes of cameras WITHOUT an accumulator slot, where those lanes leave q per observation in
+// the cold view (CkP::cpos / q4c) instead of a record of their own: such tiles are the last ones of a batch (chunks are sorted
+// by length, cold chunks are almost all of one observation: one or two rows), so the rows are read where they are used -- no
+// prefetch buffers, nothing of this loop in the registers of the row loops above.  Lanes WITH a slot accumulate y as always.
+template <bool ROBUST, bool PK>
+__device__ inline void ck_backward_rows_cold(const Dp& d, const CkP& k, const CkRows& R, int row0, int li0, int h, int lane,
+                                             const double* P3, const double* lh, const double* lg, bool cold_lane, double* y) {
+  for (int j = h - 1; j >= 0; --j) {
+    CkStream<2, ROBUST, PK> one;
+    one.load(R, row0, li0, j, h, lane, 0);
+    const int cp = cold_lane ? k.cpos[(size_t)(row0 + j) * WAVE + lane] : -1;
+    const double2 uv = one.uv[0];
+    const uint32_t s = (one.w[0] >> (16 * (j & 1))) & 0xffffu;
+    if (s != 0xffffu) {
+      const double hx = lh[s], hy = lh[s + 1], hz = lh[s + 2];
+      const double rw = ROBUST ? ck_huber_w(d, P3, hx, hy, hz, uv) : 1.0;
+      const double g[3] = {lg[s], lg[s + 1], lg[s + 2]};
+      LplObs o;
+      o.set(d, uv, rw);
+      double q[3];
+      lpl_backward(o, P3, g, q);
+      if (cp >= 0) {
+        k.q4c[cp] = make_double4(q[0], q[1], q[2], 0.0);
+      } else {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          y[4 * m] += hx * q[m];
+          y[4 * m + 1] += hy * q[m];
+          y[4 * m + 2] += hz * q[m];
+          y[4 * m + 3] += q[m];
+        }
+      }
+    }
+  }
+}
+
 // The lane's camera record, from the rank-ordered image the other E0 kernels stage into LDS (Dp::hot_rec: z (12), then
 // P3 row-major (9), 192-byte stride): 168 contiguous bytes = eleven 16-byte loads that touch two or three cache lines.
 // (A structure-of-arrays image -- one 8-byte load per entry, neighbouring ranks sharing lines -- was built first: the
@@ -335,7 +373,7 @@ __device__ inline void ck_flush_tile(double (&y)[12], int flags, int lane, int r
         for (int m = 0; m < 12; ++m)  // acc[slot][13]: one address register, twelve immediate offsets; odd stride: 32 bank classes
           __hip_atomic_fetch_add(acc + acc_slot * CK_ACC_STRIDE + m, y[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-    } else {
+    } else if (part_ptr) {  // (nullptr: the lane has left q of its observations in the cold view: ck_backward_rows_cold)
       const __amdgpu_buffer_rsrc_t part_out = ck_part_rsrc(part_ptr);
       const unsigned o = (unsigned)(~acc_slot) * 96u;
 #pragma unroll
@@ -617,8 +655,10 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       double y[12];
 #pragma unroll
       for (int m = 0; m < 12; ++m) y[m] = 0;
-      ck_backward_rows<SD, ROBUST, PK>(d, R, st, row0, li0, h, lane, P3, lh, lu, S, y);
-      ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, part_out);
+      const bool cold_q = k.cpos != nullptr && (fl & 2) != 0;  // (wave-uniform; 2 = CK_FLAG_COLD)
+      if (cold_q) ck_backward_rows_cold<ROBUST, PK>(d, k, R, row0, li0, h, lane, P3, lh, lu, rank >= 0 && acc_slot < 0, y);
+      else ck_backward_rows<SD, ROBUST, PK>(d, R, st, row0, li0, h, lane, P3, lh, lu, S, y);
+      ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, cold_q ? nullptr : part_out);
       if (tp >= tb1) break;
       t = tp;
       --q_t;

@@ -4,7 +4,7 @@
 CkP ck_params(const povar_ctx* c, const povar_ctx::CkDev& D) {
   return CkP{D.packed ? reinterpret_cast<const double2*>(D.uvp.p) : D.uv.p, D.li.p, D.w.p, D.tile.p, D.lane_meta.p, D.bt_off.p, D.slot_rec.p,
              D.nb, D.slots, (unsigned)(D.src.n * (D.packed ? sizeof(int2) : sizeof(double2))), (unsigned)(D.li.n * sizeof(uint32_t)),
-             D.lcnt.p, D.tick.p, D.max_acc, D.packed ? 1 : 0};
+             D.lcnt.p, D.tick.p, D.max_acc, D.packed ? 1 : 0, D.cold_q ? D.cpos.p : nullptr, c->q4c.p};
 }
 
 CkP ck_params(const povar_ctx* c) { return ck_params(c, c->ck); }
@@ -41,10 +41,12 @@ void ck_dp(const povar_ctx* c, Dp& da) {
   const povar_ctx::CkDev& D = c->joint ? c->ckh : c->ck;
   da.hot_part = D.part.p;
   da.part_range = D.part_range.p;
-  da.cmv.cam_range = c->ck_zero_range.p;
-  da.cmv.n = 0;
   da.cmv.src = nullptr;
   da.q_rows = 0;
+  if (D.cold_q) return;  // e0_ck's cold lanes left q in the lane-per-landmark layout's cold view (camera-major, at their own
+                         // positions): the per-camera kernel walks it as it does behind e0_lpl (ldsacc_dp has set h, n, cam_range, q4c)
+  da.cmv.cam_range = c->ck_zero_range.p;
+  da.cmv.n = 0;
 }
 
 template <int NW, int SD, bool DB, int NG>
@@ -891,6 +893,10 @@ int povar_e0_model_bytes(povar_ctx* c, int64_t* lm_kernel, int64_t* cam_kernel) 
         lm = 2 * c->ck.rows * WAVE * (c->ck.packed ? 10 : 18) /* image point 16 bytes (8 packed) + slot 2; no weight array: recomputed (ck_huber_w) */ + (int64_t)c->d.v2.n_tiles * WAVE * 72 + cam_static +
              2 * (int64_t)(c->ck.lane_meta.n) * 8 + part;
         cm = part + tail;
+        if (c->ck.cold_q) {  // cold observations: position 4 + q 32 bytes out of e0_ck, q 32 + landmark copy 24 into the per-camera kernel
+          lm += 36 * c->n_cold3;
+          cm += 56 * c->n_cold3;
+        }
         break;
       }
       if (ckh_active(c)) {

@@ -52,7 +52,8 @@ int main(int argc, char** argv) {
   const auto t0 = std::chrono::steady_clock::now();
   const int ng = std::getenv("CK_CHECK_NG") ? std::atoi(std::getenv("CK_CHECK_NG")) : 1;
   const bool step2 = std::getenv("CK_CHECK_STEP2") != nullptr;  // the shape of e0_ck_h's layout
-  const CkShape shape = step2 ? ck_shape_step2() : CkShape();
+  // step 1 as shipped (cold lanes leave q in the parent's cold view: CkLayout::cpos), or CK_CHECK_COLD_RECORDS=1: a record per cold chunk
+  const CkShape shape = step2 ? ck_shape_step2() : std::getenv("CK_CHECK_COLD_RECORDS") ? CkShape() : ck_shape_step1();
   build_ck(L, n_cams, grid, order, n_waves, K, std::getenv("CK_CHECK_NOPLACE") == nullptr, CK_HMAX, ng, shape);
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   // ---- invariants
@@ -87,7 +88,9 @@ int main(int argc, char** argv) {
   // observation of every lane-per-landmark row slot
   std::vector<int> obs_of_slot(L.uv.size(), -1);
   for (int64_t i = 0; i < n_obs; ++i) obs_of_slot[L.of_slot[i]] = (int)i;
-  std::vector<char> seen(n_obs, 0), rec_used(K.n_part_rec, 0);
+  std::vector<char> seen(n_obs, 0), rec_used(K.n_part_rec, 0), cold_seen(L.cold_lm.size(), 0);
+  int64_t n_cold_q = 0;
+  CHECK((!K.cold_q || shape.cold_q) && (K.cold_q ? K.cpos.size() == K.n_uv : K.cpos.empty()));  // (cold_q only up to 8 % cold observations)
   int64_t n_placed = 0, hist[CK_HMAX + 1] = {};
   for (int w = 0; w < grid; ++w) {
     const int nw = L.wg_cam_off[w + 1] - L.wg_cam_off[w];
@@ -131,6 +134,19 @@ int main(int argc, char** argv) {
             CHECK(acc < nw && L.wg_cams[L.wg_cam_off[w] + acc] == rank);
             for (int x = s_first; x <= s_last; ++x) CHECK(K.lane_acc[(size_t)t * 64 + x] == acc);
             if (s_first != s_last) CHECK(ti.z & CK_FLAG_DUP);
+          } else if (K.cold_q) {
+            // no record: every observation of the lane names its own place in the parent's cold view, inside its camera's run
+            CHECK(ti.z & CK_FLAG_COLD);
+            CHECK(acc == -1 && s_first == lane && s_last == lane);
+            const int cam = order[rank];
+            for (int j = 0; j < ti.y; ++j) {
+              const size_t idx = ((size_t)ti.x + j) * 64 + lane;
+              if (K.src[idx] < 0) continue;
+              const int cp = K.cpos[idx];
+              CHECK(cp == L.cpos[K.src[idx]] && cp >= L.cold_range[cam].x && cp < L.cold_range[cam].y && !cold_seen[cp]);
+              cold_seen[cp] = 1;
+              ++n_cold_q;
+            }
           } else {
             CHECK(ti.z & CK_FLAG_COLD);
             const int rec = ~acc, cam = order[rank];
@@ -138,6 +154,8 @@ int main(int argc, char** argv) {
             rec_used[rec] = 1;
             CHECK(s_first == lane && s_last == lane);
           }
+          if (acc >= 0 && K.cold_q)
+            for (int j = 0; j < ti.y; ++j) CHECK(K.cpos[((size_t)ti.x + j) * 64 + lane] == -1);
         }
       }
     for (int s = L.wg_cam_off[w]; s < L.wg_cam_off[w + 1]; ++s) {
@@ -148,6 +166,10 @@ int main(int argc, char** argv) {
   }
   CHECK(n_placed == n_obs);
   for (int r = 0; r < K.n_part_rec; ++r) CHECK(rec_used[r]);
+  if (K.cold_q) {  // every cold observation of the parent layout is written by exactly one lane; the records are the slots' alone
+    CHECK(n_cold_q == (int64_t)L.cold_lm.size() && K.n_part_rec == (int)L.wg_cams.size());
+    for (char c : cold_seen) CHECK(c);
+  }
   // ---- what the bit-reproducible kernel (e0_ck_det) reads on top: observation counts per landmark lane, tickets per run total
   CHECK(K.lcnt_log2.size() == L.tile.size() * 64 && K.tick.size() == K.tile.size() * 64);
   {
@@ -188,10 +210,10 @@ int main(int argc, char** argv) {
     if (hist[h]) std::fprintf(stderr, "tiles of %2d rows: %lld\n", h, (long long)hist[h]);
   std::printf("{\"ok\": 1, \"nb\": %d, \"slots\": %d, \"tiles\": %zu, \"rows\": %lld, \"chunks\": %lld, \"cold_chunks\": %lld, "
               "\"obs_per_chunk\": %.3f, \"pad_frac\": %.4f, \"max_tiles_bt\": %d, \"part_rec\": %d, \"lpl_part_rec\": %d, "
-              "\"extra_lanes_per_half_row\": %.4f, \"lds_bytes\": %zu, \"build_ms\": %.1f, \"lpl_rows\": %lld, \"packed\": %d}\n",
+              "\"extra_lanes_per_half_row\": %.4f, \"lds_bytes\": %zu, \"build_ms\": %.1f, \"lpl_rows\": %lld, \"packed\": %d, \"cold_q\": %d, \"cold_obs\": %zu}\n",
               K.nb, K.slots, K.tile.size(), (long long)K.rows, (long long)K.n_chunks, (long long)K.n_cold_chunks,
               (double)n_obs / std::max<int64_t>(K.n_chunks, 1), 1.0 - (double)n_obs / ((double)K.rows * 64), K.max_tiles_bt,
               K.n_part_rec, L.n_part_rec, K.extra_lanes / (2.0 * std::max<int64_t>(K.rows, 1)), ck_lds_bytes_shape(shape, K.slots, K.max_acc, K.ng), ms,
-              (long long)L.rows, K.packed ? 1 : 0);
+              (long long)L.rows, K.packed ? 1 : 0, K.cold_q ? 1 : 0, L.cold_lm.size());
   return 0;
 }

@@ -34,10 +34,17 @@ def test_ck_layout_invariants_medium(tmp_path, grid, n_acc, n_waves):
     from povar_amd import synth
     p = synth.make_problem(300, 20000, 90000, seed=5)
     # (the generator's observations are six-decimal numbers, as the reference's files hold them: the rows are packed)
-    s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, grid, n_acc, n_waves, env={"CK_CHECK_WANT_PACKED": "1"})
-    assert s["ok"] == 1 and s["lds_bytes"] <= 160 * 1024 and s["packed"] == 1
+    # (... and cold lanes leave q in the parent's cold view: forced here whatever the cold share, so that the invariants of that
+    # form are checked on layouts with few accumulator slots too; by itself the builder takes it up to 8 % cold observations)
+    s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, grid, n_acc, n_waves, env={"CK_CHECK_WANT_PACKED": "1", "POVAR_CK_COLD_Q_ALWAYS": "1"})
+    assert s["ok"] == 1 and s["lds_bytes"] <= 160 * 1024 and s["packed"] == 1 and s["cold_q"] == 1
+    auto = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, grid, n_acc, n_waves)
+    assert auto["ok"] == 1 and auto["cold_q"] == (1 if 100 * s["cold_obs"] <= 8 * p.n_obs else 0)
     if p.n_cams <= n_acc:
         assert s["cold_chunks"] == 0
+    # ... and the form with a partial record per cold chunk (e0_ck_det's layout, POVAR_CK_COLD_RECORDS=1)
+    r = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, grid, n_acc, n_waves, env={"CK_CHECK_COLD_RECORDS": "1"})
+    assert r["ok"] == 1 and r["cold_q"] == 0 and r["cold_chunks"] == s["cold_chunks"] and r["part_rec"] == s["part_rec"] + s["cold_chunks"]
 
 
 def test_ck_layout_packs_the_image_points_only_when_every_one_comes_back(tmp_path):

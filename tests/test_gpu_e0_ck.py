@@ -240,3 +240,39 @@ def test_packed_image_points_are_the_same_operator(monkeypatch):
     y = ctx.right_mul_e0_pose(x)
     ctx.close()
     assert rel(y, out["0", "NONE"][0]) < 1e-9  # (one observation moved by 1e-9 px)
+
+
+def test_cold_observations_through_the_cold_view_are_the_same_operator(monkeypatch):
+    """Round 6: a chunk of a camera WITHOUT an accumulator slot in its workgroup leaves q of each observation (32 bytes) at the
+    observation's place in the lane-per-landmark layout's cold camera-major view, and the per-camera kernel forms h~ (x) q as it
+    does behind e0_lpl -- instead of a 96-byte partial record per chunk (ck_layout.hpp: cold_q; by itself up to 8 % cold
+    observations).  Few accumulator slots (64: a third of the observations cold), several batches, both forms forced in turn:
+    the same E0 x, the same 20-term increment, NONE and HUBER; and the same against e0_lpl."""
+    from povar_amd import capi, synth
+    monkeypatch.setenv("POVAR_E0_V1", "0")
+    monkeypatch.setenv("POVAR_HOT_ACC", "64")
+    monkeypatch.setenv("POVAR_CK_NB", "3")
+    monkeypatch.setenv("POVAR_LPL_PLACE", "sync")
+    p = synth.make_problem(300, 20000, 90000, seed=5)
+    x = np.random.default_rng(3).normal(size=12 * p.n_cams)
+    out = {}
+    for form, env in (("cold view", {"POVAR_CK_COLD_Q_ALWAYS": "1"}), ("records", {"POVAR_CK_COLD_RECORDS": "1"})):
+        for k in ("POVAR_CK_COLD_Q_ALWAYS", "POVAR_CK_COLD_RECORDS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for robust in ("NONE", "HUBER"):
+            ctx = _prepared(p, robust)
+            li = ctx.layout_info()
+            assert li.ck_ready == 1 and li.ck_cold_chunks > 1000 and li.ck_cold_q == (1 if form == "cold view" else 0)
+            ctx.set_e0_kernel(0)
+            y_lpl = ctx.right_mul_e0_pose(x)
+            for kernel in (1, 3, 4):
+                ctx.set_e0_kernel(kernel)
+                assert rel(ctx.right_mul_e0_pose(x), y_lpl) < 1e-12, (form, robust, kernel)
+            ctx.set_e0_kernel(1)
+            out[form, robust] = (ctx.right_mul_e0_pose(x), ctx.solve_pose(LAM, capi.POWER_VARPROJ, M)[0])
+            ctx.close()
+    for robust in ("NONE", "HUBER"):
+        assert rel(out["cold view", robust][0], out["records", robust][0]) < 1e-13
+        assert rel(out["cold view", robust][1], out["records", robust][1]) < 1e-11

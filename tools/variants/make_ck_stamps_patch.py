@@ -38,7 +38,7 @@ def main():
     open(p, "w").write(s)
     p = os.path.join(b, "povar_series.hip")
     s = open(p).read()
-    s = sub(s, "             D.lcnt.p, D.tick.p, D.max_acc, D.packed ? 1 : 0};", "             D.lcnt.p, D.tick.p, D.max_acc, D.packed ? 1 : 0, c->ck_stamps.p};")
+    s = sub(s, "D.packed ? 1 : 0, D.cold_q ? D.cpos.p : nullptr, c->q4c.p};", "D.packed ? 1 : 0, D.cold_q ? D.cpos.p : nullptr, c->q4c.p, c->ck_stamps.p};")
     i = s.index("int povar_debug_ck_stamps(povar_ctx* c, uint64_t* out, int64_t n) {")
     j = s.index("\n}\n", i) + 3
     s = s[:i] + """int povar_debug_ck_stamps(povar_ctx* c, uint64_t* out, int64_t n) {
@@ -71,8 +71,8 @@ def main():
     # ---- povar_kernels_ck.hpp
     p = os.path.join(b, "povar_kernels_ck.hpp")
     s = open(p).read()
-    s = sub(s, "  int uv_packed;           // uv holds packed image points (the PK instantiations of e0_ck)\n};",
-            "  int uv_packed;           // uv holds packed image points (the PK instantiations of e0_ck)\n"
+    s = sub(s, "  double4* q4c;            // ... such a lane stores q of every observation there (the per-camera kernel forms h~ (x) q), no record\n};",
+            "  double4* q4c;            // ... such a lane stores q of every observation there (the per-camera kernel forms h~ (x) q), no record\n"
             "  unsigned long long* stamps;  // diagnostic build: [grid][16][CK_N_STAMPS] s_memtime stamps, else nullptr\n};\n"
             "constexpr int CK_N_STAMPS = 40;\n"
             "#ifndef POVAR_CK_NO_STAMPS  // (the timing-only experiment builds are compiled with -DPOVAR_CK_NO_STAMPS)\n"
