@@ -609,7 +609,10 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
   const bool ck_pack = !(fl & POVAR_FLAG_NO_PACKED_ROWS);            // packed image points where they pack (POVAR_CK_PACK=0 overrides inside build_ck)
   if (const char* e = std::getenv("POVAR_CK_HMAX")) ck_hmax = std::min(CK_HMAX, std::max(1, std::atoi(e)));
   // (step 1's layout: batches cut for the kernel that runs them; e0_ck leaves q of its cold observations in the parent's cold view)
-  const CkShape ck_shape1 = c->det_ck ? ck_shape_det() : std::getenv("POVAR_CK_COLD_RECORDS") ? CkShape() : ck_shape_step1();
+  // (not with the HUBER norm: e0_ck<..., ROBUST = true> has no cold loop -- povar_kernels_ck.hpp)
+  const CkShape ck_shape1 = c->det_ck ? ck_shape_det()
+                            : (std::getenv("POVAR_CK_COLD_RECORDS") || options->robust_norm == POVAR_NORM_HUBER) ? CkShape()
+                            : ck_shape_step1();
   const CkShape ck_shape2 = c->det_ck ? ck_shape_step2_det() : ck_shape_step2();
 
   // The arrays of the lane-per-observation kernels (part B) are built on a second host thread while this one builds

@@ -655,7 +655,10 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
       double y[12];
 #pragma unroll
       for (int m = 0; m < 12; ++m) y[m] = 0;
-      const bool cold_q = k.cpos != nullptr && (fl & 2) != 0;  // (wave-uniform; 2 = CK_FLAG_COLD)
+      // (wave-uniform; 2 = CK_FLAG_COLD.  Not in the instantiations that recompute a robust weight: they have no registers for the
+      //  cold loop beside their row loops -- ten spilled per lane at batch level, 30 MB of scratch traffic per launch -- and gain
+      //  nothing from the cold view; povar_create.hip keeps the records for them)
+      const bool cold_q = !ROBUST && k.cpos != nullptr && (fl & 2) != 0;
       if (cold_q) ck_backward_rows_cold<ROBUST, PK>(d, k, R, row0, li0, h, lane, P3, lh, lu, rank >= 0 && acc_slot < 0, y);
       else ck_backward_rows<SD, ROBUST, PK>(d, R, st, row0, li0, h, lane, P3, lh, lu, S, y);
       ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, cold_q ? nullptr : part_out);

@@ -247,7 +247,8 @@ def test_cold_observations_through_the_cold_view_are_the_same_operator(monkeypat
     observation's place in the lane-per-landmark layout's cold camera-major view, and the per-camera kernel forms h~ (x) q as it
     does behind e0_lpl -- instead of a 96-byte partial record per chunk (ck_layout.hpp: cold_q; by itself up to 8 % cold
     observations).  Few accumulator slots (64: a third of the observations cold), several batches, both forms forced in turn:
-    the same E0 x, the same 20-term increment, NONE and HUBER; and the same against e0_lpl."""
+    the same E0 x, the same 20-term increment; and the same against e0_lpl.  With the HUBER norm the kernel has no cold loop (its
+    instantiation has no registers for one) and the library keeps the records whatever the knob says."""
     from povar_amd import capi, synth
     monkeypatch.setenv("POVAR_E0_V1", "0")
     monkeypatch.setenv("POVAR_HOT_ACC", "64")
@@ -264,7 +265,8 @@ def test_cold_observations_through_the_cold_view_are_the_same_operator(monkeypat
         for robust in ("NONE", "HUBER"):
             ctx = _prepared(p, robust)
             li = ctx.layout_info()
-            assert li.ck_ready == 1 and li.ck_cold_chunks > 1000 and li.ck_cold_q == (1 if form == "cold view" else 0)
+            assert li.ck_ready == 1 and li.ck_cold_chunks > 1000
+            assert li.ck_cold_q == (1 if form == "cold view" and robust == "NONE" else 0)
             ctx.set_e0_kernel(0)
             y_lpl = ctx.right_mul_e0_pose(x)
             for kernel in (1, 3, 4):

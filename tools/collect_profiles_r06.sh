@@ -39,19 +39,5 @@ for n in ck1 det det_step2 lpl huber huber_ck1 local_ck1 local zipf05_ck1 unifor
   cp $(newest $T/pmc_$n/fetch/*/*counter_collection.csv) $P/r06_pmc_fetch_size_$n.csv
   cp $(newest $T/pmc_$n/write/*/*counter_collection.csv) $P/r06_pmc_write_size_$n.csv
 done
-t() { python3 tools/pmc_to_traffic.py $P/r06_pmc_fetch_size_$1.csv $P/r06_pmc_write_size_$1.csv $2 $P/traffic.json; }
-t ck1 venice-1778:ldsacc:1:ck1
-t det venice-1778:ldsacc:1:ck7
-t det_step2 venice-1778:ldsacc:1:step2:ckh2
-t lpl venice-1778:ldsacc:1
-t huber venice-1778:ldsacc:1:HUBER
-t huber_ck1 venice-1778:ldsacc:1:HUBER:ck1
-t local_ck1 venice-1778:ldsacc:1:local:ck1
-t local venice-1778:ldsacc:1:local
-t zipf05_ck1 venice-1778:ldsacc:1:zipf0.5:ck1
-t uniform_ck1 venice-1778:ldsacc:1:uniform:ck1
-t step2 venice-1778:ldsacc:1:step2
-t step2_ckh venice-1778:ldsacc:1:step2:ckh1
-t final_huber final-13682:ldsacc:1:HUBER
-t final_local_huber final-13682:ldsacc:1:HUBER:local
+bash tools/stamp_traffic_r06.sh
 fi
