@@ -718,7 +718,8 @@ def main():
                                   "e0_kernel_step2": li.e0_kernel_h,
                                   "e0_tune_us_step2": {"e0_lpl_h": round(li.tune_lpl_h_us, 2), "e0_ck_h": round(li.tune_ck_h_us, 2)},
                                   "camera_chunks_step2": {"batches": li.ckh_batches, "landmark_slots": li.ckh_slots,
-                                                          "chunks": li.ckh_chunks, "own_record_chunks": li.ckh_cold_chunks},
+                                                          "chunks": li.ckh_chunks, "own_record_chunks": li.ckh_cold_chunks,
+                                                          "lds_stride": li.ckh_stride, "accumulators": li.ckh_accumulators},
                                   "camera_chunks": {"batches": li.ck_batches, "landmark_slots": li.ck_slots, "rows": li.ck_rows,
                                                     # image points as two int32 of micro-units (every observation a six-decimal
                                                     # number, decoded bit for bit) instead of two doubles

@@ -330,6 +330,11 @@ typedef struct {
                            number -- what the reference's files hold, bal/bal_problem.cpp:373-375 -- and comes back bit for bit */
   int32_t ck_cold_q;    /* 1: chunks of cameras without an accumulator slot leave q of each observation (32 bytes) in the cold
                            camera-major view instead of a 96-byte partial record per chunk (layouts with at most 8 % cold observations) */
+  int32_t ckh_stride;   /* step 2's camera-chunk layout: landmark slots the LDS arrays of e0_ck_h are cut for -- 1536, or 2048 where
+                           that saves a landmark batch (then with ckh_accumulators < lds_slots: the workgroup keeps the accumulator
+                           slots of its most observed cameras, the other cameras' chunks write records of their own) */
+  int32_t ckh_accumulators;      /* accumulator slots per workgroup at most */
+  int64_t ckh_capped_obs;        /* observations of cameras that have a slot in the lane-per-landmark layout but none here */
 } povar_layout_info;
 int povar_get_layout_info(povar_ctx* ctx, povar_layout_info* out);
 /* The reference's constructor is a trivial allocation (sc/linearization_varproj.hpp:44-60); this library's builds the

@@ -74,7 +74,8 @@ class LayoutInfo(C.Structure):
                 ("res_max_cams", C.c_int32), ("res_max_lms", C.c_int32), ("res_max_chunks", C.c_int32),
                 ("res_max_oq", C.c_int32), ("res_order", C.c_int32),
                 ("res_lds_bytes", C.c_int32), ("res_build_ms", C.c_double), ("tune_terms_us", C.c_float),
-                ("tune_res_us", C.c_float), ("res_failed", C.c_int32), ("ck_packed", C.c_int32), ("ck_cold_q", C.c_int32)]
+                ("tune_res_us", C.c_float), ("res_failed", C.c_int32), ("ck_packed", C.c_int32), ("ck_cold_q", C.c_int32),
+                ("ckh_stride", C.c_int32), ("ckh_accumulators", C.c_int32), ("ckh_capped_obs", C.c_int64)]
 
 
 class TimingsInfo(C.Structure):

@@ -94,7 +94,9 @@ struct CkLayout {
   int li_mul = 3;                // the slot words hold li_mul x slot (CkShape)
   int ng = 1;                    // of which ng are in LDS at the same time (groups of wavefronts)
   int slots = 64;                // landmark slots of a batch (multiple of 64; the same for every workgroup)
-  int n_part_rec = 0, max_acc = 0;
+  int stride = 0;                // fixed-stride shapes (step 2): the component stride of the LDS arrays the layout was cut for
+  int n_part_rec = 0, max_acc = 0;  // max_acc: accumulator slots a workgroup has at most (the parent layout's, or the wide stride's cap)
+  int64_t n_capped_obs = 0;      // observations of cameras with a slot in the parent layout but none here (wide stride)
   int64_t rows = 0, li_rows = 0;
   size_t n_uv = 0;               // entries of the row arrays (uv or uvp, src): (rows + CK_HMAX) x 64
   // statistics
@@ -165,14 +167,25 @@ struct CkShape {
   int acc_bytes = 104;   // LDS bytes per accumulator slot (13 doubles)
   bool cold_q = false;   // chunks of cameras without a slot leave q per observation in the parent layout's cold view (CkLayout::cpos)
                          // instead of a 96-byte record of their own (step 1's e0_ck; the other kernels keep the records)
+  int wide_slots = 0;    // fixed-stride shapes: a second stride, taken where it saves a landmark batch; the accumulators that no
+                         // longer fit beside it are given up (the workgroup keeps the slots of its most observed cameras)
 };
 inline CkShape ck_shape_step1() { CkShape s; s.cold_q = true; return s; }
 // e0_ck_det (povar_kernels_ck_det.hpp) keeps two more bytes per landmark slot (the sum's binary point) and per accumulator
 // slot (the ticket counter)
 inline CkShape ck_shape_det() { CkShape s; s.slot_bytes = 50; s.acc_bytes = 106; return s; }
 inline CkShape ck_shape_step2_det();
-inline CkShape ck_shape_step2() { return CkShape{64, 1, 1536, false}; }  // 1536 = CKH_STRIDE (povar_kernels_ck_joint.hpp)
-inline CkShape ck_shape_step2_det() { CkShape s = ck_shape_step2(); s.slot_bytes = 66; s.acc_bytes = 106; return s; }  // (e0_ck_h_det)
+// 1536 = CKH_STRIDE, 2048 = CKH_STRIDE_WIDE (povar_kernels_ck_joint.hpp); POVAR_CKH_STRIDE=1536|2048 forces one
+inline CkShape ck_shape_step2() {
+  CkShape s{64, 1, 1536, false};
+  s.wide_slots = 2048;
+  if (const char* e = std::getenv("POVAR_CKH_STRIDE")) {
+    if (std::atoi(e) == 2048) s.max_slots = 2048;
+    s.wide_slots = 0;
+  }
+  return s;
+}
+inline CkShape ck_shape_step2_det() { CkShape s{64, 1, 1536, false}; s.slot_bytes = 66; s.acc_bytes = 106; return s; }  // (e0_ck_h_det: one stride)
 inline size_t ck_lds_bytes_shape(const CkShape& sh, int slots, int n_acc, int ng) {
   if (sh.max_slots != INT_MAX)  // = ckh_lds_bytes[_det]
     return 16 + (size_t)sh.slot_bytes * sh.max_slots + (size_t)n_acc * sh.acc_bytes + 64 + (sh.acc_bytes != 104 ? 16 : 0);
@@ -208,6 +221,14 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     max_acc = std::max(max_acc, L.wg_cam_off[w + 1] - L.wg_cam_off[w]);
   }
   ng = std::max(ng, 1);
+  if (shape.max_slots != INT_MAX) {
+    // fixed stride: the wide one where it saves a batch; then as many accumulators as fit beside the landmark slots
+    auto batches = [&](int ms) { int n = 1; while (WAVE * ((max_tiles_w + n - 1) / n) > ms && n < max_tiles_w) ++n; return n; };
+    if (shape.wide_slots > shape.max_slots && batches(shape.wide_slots) < batches(shape.max_slots)) shape.max_slots = shape.wide_slots;
+    const size_t fixed = ck_lds_bytes_shape(shape, 0, 0, ng);
+    max_acc = std::min(max_acc, (int)(((size_t)CK_LDS_BYTES - fixed) / (size_t)shape.acc_bytes));
+    K.stride = shape.max_slots;
+  }
   int nb = ng;
   while ((ck_lds_bytes_shape(shape, WAVE * ((max_tiles_w + nb - 1) / nb), max_acc, ng) > (size_t)CK_LDS_BYTES ||
           WAVE * ((max_tiles_w + nb - 1) / nb) > shape.max_slots) && nb < max_tiles_w) nb += ng;
@@ -224,17 +245,45 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     std::vector<int> src, lane_cam, lane_acc, lane_seg, bt_tiles;  // bt_tiles[b]: tiles of batch b
     std::vector<int4> tile;  // x, w: local row / li-row numbers
     std::vector<int> cold_rank;  // rank of every cold chunk, in the order their lanes say ~(index)
-    int64_t chunks = 0, obs = 0, n_cold_q = 0;
+    int64_t chunks = 0, obs = 0, n_cold_q = 0, capped = 0;
     double extra = 0;
   };
   std::vector<WgOut> out(grid);
+  std::vector<std::vector<int>> acc_rank_of(grid);
   std::vector<int> lcnt(L.tile.size() * WAVE, 0);  // (every workgroup writes its own tiles)
   lpl_parallel(grid, n_threads, [&](int w) {
     WgOut& o = out[w];
     o.bt_tiles.assign(nb, 0);
     const int t0 = L.wg_tile_off[w], t1 = L.wg_tile_off[w + 1];
     struct Ob { int key, li, src; };  // key: accumulator slot, or n_acc_w + rank for a camera without one
-    const int n_acc_w = L.wg_cam_off[w + 1] - L.wg_cam_off[w];
+    // accumulator slots: the parent layout's, or -- where the LDS beside a wide stride holds fewer -- those of the cameras this
+    // workgroup observes most (acc_of_slot: parent slot -> accumulator or -1; acc_rank: accumulator -> popularity rank)
+    const int n_par_w = L.wg_cam_off[w + 1] - L.wg_cam_off[w];
+    const int n_acc_w = std::min(n_par_w, max_acc);
+    std::vector<int> acc_of_slot(n_par_w);
+    std::vector<int>& acc_rank = acc_rank_of[w];
+    acc_rank.resize(n_acc_w);
+    if (n_acc_w == n_par_w) {
+      for (int sl = 0; sl < n_par_w; ++sl) { acc_of_slot[sl] = sl; acc_rank[sl] = L.wg_cams[L.wg_cam_off[w] + sl]; }
+    } else {
+      std::vector<long> cnt(n_par_w, 0);
+      for (int t = L.wg_tile_off[w]; t < L.wg_tile_off[w + 1]; ++t) {
+        const int4 ti = L.tile[t];
+        for (size_t idx = (size_t)ti.x * WAVE; idx < ((size_t)ti.x + ti.y) * WAVE; ++idx)
+          if (L.cw[idx] >= 0) cnt[lpl_cw_slot(L.cw[idx])]++;
+      }
+      std::vector<int> by_cnt(n_par_w);
+      for (int sl = 0; sl < n_par_w; ++sl) by_cnt[sl] = sl;
+      std::stable_sort(by_cnt.begin(), by_cnt.end(), [&](int a, int c) { return cnt[a] > cnt[c]; });
+      std::vector<char> keep(n_par_w, 0);
+      for (int i = 0; i < n_acc_w; ++i) keep[by_cnt[i]] = 1;
+      int a = 0;
+      for (int sl = 0; sl < n_par_w; ++sl) {  // (kept slots stay in the parent's order: its deal over the LDS banks)
+        acc_of_slot[sl] = keep[sl] ? a : -1;
+        if (keep[sl]) acc_rank[a++] = L.wg_cams[L.wg_cam_off[w] + sl];
+        else o.capped += cnt[sl];
+      }
+    }
     std::vector<Ob> obs;
     std::vector<int> counts, first_of;
     struct Chunk { int key, first, len; };
@@ -252,7 +301,12 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
             const int cw = L.cw[idx];
             if (cw == -1) continue;
             Ob ob;
-            ob.key = cw >= 0 ? lpl_cw_slot(cw) : n_acc_w + (-2 - cw);
+            if (cw >= 0) {
+              const int sl = lpl_cw_slot(cw), a = acc_of_slot[sl];
+              ob.key = a >= 0 ? a : n_acc_w + L.wg_cams[L.wg_cam_off[w] + sl];
+            } else {
+              ob.key = n_acc_w + (-2 - cw);
+            }
             ob.li = slot0 + (L.seg[(size_t)t * WAVE + lane] & 255);  // a landmark dealt over several lanes: its first lane's slot
             ob.src = (int)idx;
             obs.push_back(ob);
@@ -288,7 +342,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
       }
       // inside a length: by popularity rank -- the lanes of a tile gather their camera records from the rank-ordered
       // image, and neighbouring ranks share cache lines (in slot order every lane of a gather hit a line of its own)
-      auto rank_of = [&](int key) { return key >= n_acc_w ? key - n_acc_w : L.wg_cams[L.wg_cam_off[w] + key]; };
+      auto rank_of = [&](int key) { return key >= n_acc_w ? key - n_acc_w : acc_rank[key]; };
       std::stable_sort(chunks.begin(), chunks.end(), [&](const Chunk& a, const Chunk& c) {
         if (a.len != c.len) return a.len > c.len;
         const int ra = rank_of(a.key), rc = rank_of(c.key);
@@ -319,7 +373,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
           const int lane = q - c0, half = lane >> 5;
           const Chunk& ck = chunks[q];
           const bool cold = ck.key >= n_acc_w;
-          o.lane_cam[l0 + lane] = cold ? ck.key - n_acc_w : L.wg_cams[L.wg_cam_off[w] + ck.key];
+          o.lane_cam[l0 + lane] = cold ? ck.key - n_acc_w : acc_rank[ck.key];
           if (cold) {
             if (shape.cold_q) {
               o.lane_acc[l0 + lane] = -1;  // no record: q goes to the cold view, observation by observation
@@ -413,6 +467,7 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     K.li_rows += (int64_t)(o.li.size() / WAVE);
     K.n_chunks += o.chunks;
     K.n_obs += o.obs;
+    K.n_capped_obs += o.capped;
     K.extra_lanes += o.extra;
   }
   K.bt_off[(size_t)grid * nb] = (int)K.tile.size();
@@ -424,7 +479,8 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
 
   // ---- partial records, camera-major: a camera's workgroup slots first, then its cold chunks
   std::vector<int> n_rec(n_cams, 0);  // by rank
-  for (size_t s = 0; s < L.wg_cams.size(); ++s) n_rec[L.wg_cams[s]]++;
+  for (int w = 0; w < grid; ++w)
+    for (int r0 : acc_rank_of[w]) n_rec[r0]++;
   std::vector<int> n_slot_rec(n_rec);
   for (int w = 0; w < grid; ++w)
     for (int r0 : out[w].cold_rank) n_rec[r0]++;
@@ -436,7 +492,8 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
   K.slot_rec.assign(L.wg_cams.size(), 0);
   {
     std::vector<int> next(first.begin(), first.end() - 1);
-    for (size_t s = 0; s < L.wg_cams.size(); ++s) K.slot_rec[s] = next[L.wg_cams[s]]++;
+    for (int w = 0; w < grid; ++w)  // (indexed by the parent's wg_cam_off + accumulator: a capped workgroup uses the first entries of its range)
+      for (size_t a = 0; a < acc_rank_of[w].size(); ++a) K.slot_rec[(size_t)L.wg_cam_off[w] + a] = next[acc_rank_of[w][a]]++;
     // cold chunks: record numbers in workgroup order (deterministic whatever the thread count)
     std::vector<int> cold_rec((size_t)n_cold_chunks);
     for (int w = 0; w < grid; ++w)

@@ -247,6 +247,7 @@ bool ck_upload(povar_ctx* c, povar_ctx::CkDev& D, const CkLayout& K, bool locked
   if (ok && c->opt.robust_norm && !need_uv)  // (step 2's kernel reads the weights in chunk order; step 1's recomputes them)
     guarded([&] { ok = D.w.alloc(std::max<size_t>(K.src.size(), 1), bytes) == hipSuccess; });  // (padded like the rows)
   D.nb = K.nb; D.slots = K.slots; D.n_part_rec = K.n_part_rec; D.max_acc = K.max_acc; D.max_tiles_bt = K.max_tiles_bt;
+  D.stride = K.stride; D.n_capped_obs = K.n_capped_obs;
   D.rows = K.rows; D.li_rows = K.li_rows; D.n_chunks = K.n_chunks; D.n_cold_chunks = K.n_cold_chunks;
   D.w_lin_id = -1;
   D.ready = ok && !(locked && c->placer_cancel.load());
@@ -589,6 +590,8 @@ int povar_create(povar_ctx** out, int32_t n_cams, int32_t n_lms, int64_t n_obs,
     HIP_TRY_C(ck_set_lds_all());
     HIP_TRY_C(hipFuncSetAttribute((const void*)e0_ck_h<16, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
     HIP_TRY_C(hipFuncSetAttribute((const void*)e0_ck_h<16, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_ck_h<16, 2, false, CKH_STRIDE_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
+    HIP_TRY_C(hipFuncSetAttribute((const void*)e0_ck_h<16, 2, true, CKH_STRIDE_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_LDS_BYTES));
   }
   // per-term E0 kernel of step 1: e0_lpl (0) or an e0_ck instantiation (POVAR_E0_CK=<variant>, povar_set_e0_kernel)
   {
@@ -1049,7 +1052,7 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->tune_lpl_us = c->ck_tune_us[0];
   out->tune_ck_us = c->ck_tune_us[1];
   out->e0_kernel_h = c->ckh_variant > 0 && c->ckh.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
-                     c->ckh.slots <= CKH_STRIDE ? 1 : 0;
+                     c->ckh.slots <= c->ckh.stride ? 1 : 0;
   if (c->deterministic) out->e0_kernel_h = ckh_det_possible(c) ? 2 : 0;  // (2: e0_ck_h_det)
   out->ckh_ready = c->ckh.ready ? 1 : 0;
   out->ckh_batches = c->ckh.nb;
@@ -1079,6 +1082,9 @@ int povar_get_layout_info(povar_ctx* c, povar_layout_info* out) {
   out->res_failed = c->res_failed ? 1 : 0;
   out->ck_packed = c->ck.ready && c->ck.packed ? 1 : 0;
   out->ck_cold_q = c->ck.ready && c->ck.cold_q ? 1 : 0;
+  out->ckh_stride = c->ckh.ready ? c->ckh.stride : 0;
+  out->ckh_accumulators = c->ckh.ready ? c->ckh.max_acc : 0;
+  out->ckh_capped_obs = c->ckh.ready ? c->ckh.n_capped_obs : 0;
   return 0;
 }
 

@@ -168,6 +168,8 @@ struct povar_ctx {
     DevBuf<uint8_t> lcnt;        // e0_ck_det: ceil(log2(observations)) per landmark lane
     DevBuf<uint16_t> tick;       // e0_ck_det: ticket of every run total
     int nb = 0, slots = 0, n_part_rec = 0, max_acc = 0, max_tiles_bt = 0;
+    int stride = 0;              // step 2: CKH_STRIDE or CKH_STRIDE_WIDE, whichever the layout was cut for (CkLayout::stride)
+    int64_t n_capped_obs = 0;
     int64_t rows = 0, li_rows = 0, n_chunks = 0, n_cold_chunks = 0;
     double build_ms = 0;
     int64_t w_lin_id = -1;       // linearisation whose robust weights w holds

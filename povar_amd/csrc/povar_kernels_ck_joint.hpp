@@ -28,9 +28,14 @@
 
 namespace povar {
 
-constexpr int CKH_STRIDE = 1536;   // landmark slots of a batch at most; component stride of the LDS arrays
+// Two strides (round 6): 1536 slots leave room for every accumulator the parent layout has (629 > HOT_ACC_MAX); 2048 slots
+// leave 314 -- the layout takes them where they save a landmark batch (venice-1778: 3 883 landmarks per workgroup, three
+// batches of 1 344 slots -> two of 2 048: 71.1 -> 68.1 us per term although 291 accumulators instead of 501 turn 178 k more
+// chunks into chunks with a record of their own; a batch costs ~ 7 us, the accumulators ~ 4: profiles/r06_ckh_stride_ab.txt).
+constexpr int CKH_STRIDE = 1536;        // landmark slots of a batch at most; component stride of the LDS arrays
+constexpr int CKH_STRIDE_WIDE = 2048;   // the same with fewer accumulators beside them (e0_ck_h only; e0_ck_h_det keeps 1536)
 constexpr int CKH_REC = 14;        // = LPL_REC_H: doubles per landmark lane in V2::lmrec (step 2): X (4), s (4), Hll^-1 (6)
-__host__ __device__ inline size_t ckh_lds_bytes(int n_acc) { return 16 + (size_t)8 * CKH_STRIDE * 8 + (size_t)n_acc * CK_ACC_STRIDE * 8 + 64; }
+__host__ __device__ inline size_t ckh_lds_bytes(int n_acc, int stride = CKH_STRIDE) { return 16 + (size_t)8 * stride * 8 + (size_t)n_acc * CK_ACC_STRIDE * 8 + 64; }
 
 // rows of a tile: the landmark-slot words (two 16-bit slots per word) and, with a robust norm, the weights
 template <int D, bool ROBUST>
@@ -96,7 +101,7 @@ __device__ inline Hom ckh_project(const Cam& P, const double4& X) {
 // J4 = sw D P with D = [D00 0 D02; 0 D00 D12] (hom_jl4 with unit column scale) is never formed:
 //   J4^T t = P^T (D^T t),   J4 g = D (P g)       (12 + 4 operations each instead of 16 + 8)
 // one observation forward: U4_l += J4^T t,  t = sw D (Z X)
-template <bool ROBUST>
+template <bool ROBUST, int CKH_STRIDE = povar::CKH_STRIDE>
 __device__ inline void ckh_obs_forward(const Cam& P, const double4 (&zz)[3], double w, const double* lx, double* lu, uint32_t s) {
   const double4 X = make_double4(lx[s], lx[CKH_STRIDE + s], lx[2 * CKH_STRIDE + s], lx[3 * CKH_STRIDE + s]);
   const double sw = ROBUST ? sqrt(w) : 1.0;
@@ -110,7 +115,7 @@ __device__ inline void ckh_obs_forward(const Cam& P, const double4 (&zz)[3], dou
   __hip_atomic_fetch_add(lu + 3 * CKH_STRIDE + s, P.r0.w * e0 + P.r1.w * e1 + P.r2.w * e2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // one observation backward: y_c += X (x) q,  q = hom_q(J4 G4)
-template <bool ROBUST>
+template <bool ROBUST, int CKH_STRIDE = povar::CKH_STRIDE>
 __device__ inline void ckh_obs_backward(const Cam& P, double w, const double* lx, const double* lg, uint32_t s, double (&y)[12]) {
   const double4 X = make_double4(lx[s], lx[CKH_STRIDE + s], lx[2 * CKH_STRIDE + s], lx[3 * CKH_STRIDE + s]);
   const double4 G = make_double4(lg[s], lg[CKH_STRIDE + s], lg[2 * CKH_STRIDE + s], lg[3 * CKH_STRIDE + s]);
@@ -125,14 +130,14 @@ __device__ inline void ckh_obs_backward(const Cam& P, double w, const double* lx
   y[8] += X.x * q.z; y[9] += X.y * q.z; y[10] += X.z * q.z; y[11] += X.w * q.z;
 }
 
-template <int D, bool ROBUST>
+template <int D, bool ROBUST, int CKH_STRIDE = povar::CKH_STRIDE>
 __device__ inline void ckh_forward_rows(const CkRows& R, CkStreamH<D, ROBUST>& st, int row0, int li0, int h, int lane,
                                         const Cam& P, const double4 (&zz)[3], const double* lx, double* lu) {
   auto step = [&](int j, int i) {
     const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
     const double rw = ROBUST ? st.rw[i] : 1.0;
     st.load(R, row0, li0, j + D, h, lane, i);
-    if (s != 0xffffu) ckh_obs_forward<ROBUST>(P, zz, rw, lx, lu, s);
+    if (s != 0xffffu) ckh_obs_forward<ROBUST, CKH_STRIDE>(P, zz, rw, lx, lu, s);
   };
   int n0 = 0;
 #pragma nounroll
@@ -144,14 +149,14 @@ __device__ inline void ckh_forward_rows(const CkRows& R, CkStreamH<D, ROBUST>& s
   for (int i = 0; i < D - 1; ++i)
     if (n0 + i < h) step(n0 + i, i);
 }
-template <int D, bool ROBUST>
+template <int D, bool ROBUST, int CKH_STRIDE = povar::CKH_STRIDE>
 __device__ inline void ckh_backward_rows(const CkRows& R, CkStreamH<D, ROBUST>& st, int row0, int li0, int h, int lane,
                                          const Cam& P, const double* lx, const double* lg, double (&y)[12]) {
   auto step = [&](int j, int i) {
     const uint32_t s = (st.w[i] >> (16 * (j & 1))) & 0xffffu;
     const double rw = ROBUST ? st.rw[i] : 1.0;
     st.load(R, row0, li0, j - D, h, lane, i);
-    if (s != 0xffffu) ckh_obs_backward<ROBUST>(P, rw, lx, lg, s, y);
+    if (s != 0xffffu) ckh_obs_backward<ROBUST, CKH_STRIDE>(P, rw, lx, lg, s, y);
   };
   int n0 = 0;
 #pragma nounroll
@@ -166,6 +171,7 @@ __device__ inline void ckh_backward_rows(const CkRows& R, CkStreamH<D, ROBUST>& 
 
 // Between the passes, per landmark slot (the lane that owns it): U4 -> G4 = s .* (N_l Hll^-1 N_l^T (s .* U4)).
 // rec: entries 4..13 of the landmark's record (s (4), Hll^-1 upper triangle (6)); X and U4 are in LDS.
+template <int CKH_STRIDE = povar::CKH_STRIDE>
 __device__ inline void ckh_landmark_step(double* lx, double* lu, int s, const double (&rec)[10]) {
   const double4 X = make_double4(lx[s], lx[CKH_STRIDE + s], lx[2 * CKH_STRIDE + s], lx[3 * CKH_STRIDE + s]);
   double hw[4], hbeta;
@@ -186,8 +192,9 @@ __device__ inline void ckh_landmark_step(double* lx, double* lu, int s, const do
   lu[3 * CKH_STRIDE + s] = rec[3] * (g3[2] - gw * hw[3]);
 }
 
-// NW wavefronts per workgroup, SD rows in flight per tile (as e0_ck; one group of wavefronts)
-template <int NW, int SD, bool ROBUST>
+// NW wavefronts per workgroup, SD rows in flight per tile (as e0_ck; one group of wavefronts); CKH_STRIDE: see above -- with the
+// wide stride the layout uses the first k.max_acc accumulator slots of the parent layout only (the others' chunks have records)
+template <int NW, int SD, bool ROBUST, int CKH_STRIDE = povar::CKH_STRIDE>
 __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out) {
   const int done = d.flags[1];
   extern __shared__ double ck_lds[];
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
   double* acc = lu + 4 * CKH_STRIDE;        // [n_acc][13]
   const V2& v = d.v2;
   const int cam0 = v.wg_cam_off[blockIdx.x];
-  const int n_acc = v.wg_cam_off[blockIdx.x + 1] - cam0;
+  const int n_acc = min(v.wg_cam_off[blockIdx.x + 1] - cam0, k.max_acc);
   const int t0 = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x]);
   const int t1 = __builtin_amdgcn_readfirstlane(v.wg_tile_off[blockIdx.x + 1]);
   for (int i = threadIdx.x; i < n_acc * CK_ACC_STRIDE; i += NW * 64) acc[i] = 0;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
     ck_barrier();
     // ---- forward
     while (t < tb1) {
-      ckh_forward_rows<SD, ROBUST>(R, st, row0, li0, h, lane, P, zz, lx, lu);
+      ckh_forward_rows<SD, ROBUST, CKH_STRIDE>(R, st, row0, li0, h, lane, P, zz, lx, lu);
       if (tn >= tb1) break;  // (t, q_t, rank, P stay on the last tile: the way back starts there)
       t = tn;
       ++q_t;
@@ -335,14 +342,14 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
 #pragma unroll
     for (int q = 0; q < HM; ++q) {
       const int m = wave + q * NW;
-      if (t0 + b + k.nb * m < t1) ckh_landmark_step(lx, lu, m * WAVE + lane, rec[q]);
+      if (t0 + b + k.nb * m < t1) ckh_landmark_step<CKH_STRIDE>(lx, lu, m * WAVE + lane, rec[q]);
     }
     for (int m = wave + HM * NW; t0 + b + k.nb * m < t1; m += NW) {
       const double* rp = v.lmrec + ((size_t)(t0 + b + k.nb * m) * CKH_REC + 4) * WAVE + lane;
       double r2[10];
 #pragma unroll
       for (int e = 0; e < 10; ++e) r2[e] = rp[e * WAVE];
-      ckh_landmark_step(lx, lu, m * WAVE + lane, r2);
+      ckh_landmark_step<CKH_STRIDE>(lx, lu, m * WAVE + lane, r2);
     }
     ck_barrier();
     // ---- backward: the wavefront's tiles in reverse
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_h(Dp d, CkP k, double* part_out
       double y[12];
 #pragma unroll
       for (int m = 0; m < 12; ++m) y[m] = 0;
-      ckh_backward_rows<SD, ROBUST>(R, st, row0, li0, h, lane, P, lx, lu, y);
+      ckh_backward_rows<SD, ROBUST, CKH_STRIDE>(R, st, row0, li0, h, lane, P, lx, lu, y);
       ck_flush_tile(y, fl, lane, rank, acc_slot, seg, acc, n_acc, part_out);
       if (tp >= tb1) break;
       t = tp;

@@ -27,13 +27,14 @@ bool ck_active(const povar_ctx* c) {
 
 bool ckh_det_possible(const povar_ctx* c) {
   return c->det_ck && c->ckh.ready && c->ckh.lcnt.p && c->ckh.tick.p && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT &&
-         c->ckh.slots <= CKH_STRIDE && ckh_lds_bytes_det(c->ckh.max_acc) <= (size_t)CK_LDS_BYTES;
+         c->ckh.stride == CKH_STRIDE && c->ckh.slots <= CKH_STRIDE && ckh_lds_bytes_det(c->ckh.max_acc) <= (size_t)CK_LDS_BYTES;
 }
 
 bool ckh_active(const povar_ctx* c) {
   if (c->deterministic) return c->joint && ckh_det_possible(c);
   return c->joint && c->ckh_variant > 0 && c->ckh.ready && c->use_lpl && c->opt.e0_mode == POVAR_E0_IMPLICIT_LDSACC &&
-         c->ckh.slots <= CKH_STRIDE && ckh_lds_bytes(c->ckh.max_acc) <= (size_t)CK_LDS_BYTES;
+         (c->ckh.stride == CKH_STRIDE || c->ckh.stride == CKH_STRIDE_WIDE) && c->ckh.slots <= c->ckh.stride &&
+         ckh_lds_bytes(c->ckh.max_acc, c->ckh.stride) <= (size_t)CK_LDS_BYTES;
 }
 
 // the per-camera kernels behind e0_ck / e0_ck_h: partial records only (its own table), no per-observation cold view
@@ -133,7 +134,14 @@ void launch_e0_ck_h(povar_ctx* c, const Dp& da) {
       hipLaunchKernelGGL((e0_ck_h_det<16, 2, false>), dim3(c->e0c_grid), dim3(1024), ldsd, c->stream, da, k, c->ckh.part.p);
     return;
   }
-  const size_t lds = ckh_lds_bytes(c->ckh.max_acc);
+  const size_t lds = ckh_lds_bytes(c->ckh.max_acc, c->ckh.stride);
+  if (c->ckh.stride == CKH_STRIDE_WIDE) {  // two landmark batches instead of three, fewer accumulators (povar_kernels_ck_joint.hpp)
+    if (c->opt.robust_norm)
+      hipLaunchKernelGGL((e0_ck_h<16, 2, true, CKH_STRIDE_WIDE>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ckh.part.p);
+    else
+      hipLaunchKernelGGL((e0_ck_h<16, 2, false, CKH_STRIDE_WIDE>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ckh.part.p);
+    return;
+  }
   if (c->opt.robust_norm)
     hipLaunchKernelGGL((e0_ck_h<16, 2, true>), dim3(c->e0c_grid), dim3(1024), lds, c->stream, da, k, c->ckh.part.p);
   else

@@ -81,7 +81,17 @@ int main(int argc, char** argv) {
     }
   }
   CHECK((int64_t)K.n_uv == (K.rows + CK_HMAX) * 64 && K.src.size() == K.n_uv && (int64_t)K.li.size() == (K.li_rows + CK_HMAX) * 64);
-  CHECK(ck_lds_bytes_shape(shape, K.slots, K.max_acc, K.ng) <= (size_t)CK_LDS_BYTES && K.nb % K.ng == 0 && K.slots <= shape.max_slots);
+  // (a fixed-stride shape may have taken its wide stride: K.stride; the accumulators are then capped by what fits beside it)
+  CkShape shape_k = shape;
+  if (shape.max_slots != INT_MAX) {
+    CHECK(K.stride == shape.max_slots || (shape.wide_slots > 0 && K.stride == shape.wide_slots));
+    shape_k.max_slots = K.stride;
+  } else {
+    CHECK(K.stride == 0);
+  }
+  CHECK(ck_lds_bytes_shape(shape_k, K.slots, K.max_acc, K.ng) <= (size_t)CK_LDS_BYTES && K.nb % K.ng == 0 && K.slots <= shape_k.max_slots);
+  if (const char* e = std::getenv("CK_CHECK_WANT_STRIDE")) CHECK(K.stride == std::atoi(e));
+  int64_t n_capped = 0;
   std::vector<int> lm_of_obs(n_obs);
   for (int l = 0; l < n_lms; ++l)
     for (int i = lm_off[l]; i < lm_off[l + 1]; ++i) lm_of_obs[i] = l;
@@ -93,7 +103,10 @@ int main(int argc, char** argv) {
   CHECK((!K.cold_q || shape.cold_q) && (K.cold_q ? K.cpos.size() == K.n_uv : K.cpos.empty()));  // (cold_q only up to 8 % cold observations)
   int64_t n_placed = 0, hist[CK_HMAX + 1] = {};
   for (int w = 0; w < grid; ++w) {
-    const int nw = L.wg_cam_off[w + 1] - L.wg_cam_off[w];
+    const int n_par = L.wg_cam_off[w + 1] - L.wg_cam_off[w];
+    const int nw = std::min(n_par, K.max_acc);  // accumulator slots of this workgroup (all of the parent's unless capped)
+    std::vector<int> rank_of_acc(nw, -1);      // every accumulator serves ONE camera, a camera with one has no cold chunk here
+    std::vector<char> cold_here(n_cams, 0);
     const int t0w = L.wg_tile_off[w];
     for (int b = 0; b < K.nb; ++b)
       for (int t = K.bt_off[(size_t)w * K.nb + b]; t < K.bt_off[(size_t)w * K.nb + b + 1]; ++t) {
@@ -131,7 +144,13 @@ int main(int argc, char** argv) {
           if (rank < 0) { CHECK(n_lane == 0); continue; }
           CHECK(n_lane >= 1);
           if (acc >= 0) {
-            CHECK(acc < nw && L.wg_cams[L.wg_cam_off[w] + acc] == rank);
+            CHECK(acc < nw && (rank_of_acc[acc] < 0 || rank_of_acc[acc] == rank));
+            rank_of_acc[acc] = rank;
+            if (nw == n_par) CHECK(L.wg_cams[L.wg_cam_off[w] + acc] == rank);
+            {  // the record the accumulator is flushed to is one of this camera's
+              const int rec = K.slot_rec[(size_t)L.wg_cam_off[w] + acc], cam = order[rank];
+              CHECK(rec >= K.part_range[cam].x && rec < K.part_range[cam].y);
+            }
             for (int x = s_first; x <= s_last; ++x) CHECK(K.lane_acc[(size_t)t * 64 + x] == acc);
             if (s_first != s_last) CHECK(ti.z & CK_FLAG_DUP);
           } else if (K.cold_q) {
@@ -149,6 +168,11 @@ int main(int argc, char** argv) {
             }
           } else {
             CHECK(ti.z & CK_FLAG_COLD);
+            cold_here[rank] = 1;
+            for (int j = 0; j < ti.y; ++j) {  // (observations of a camera with a slot in the parent layout but none here)
+              const size_t idx = ((size_t)ti.x + j) * 64 + lane;
+              if (K.src[idx] >= 0 && L.cw[K.src[idx]] >= 0) ++n_capped;
+            }
             const int rec = ~acc, cam = order[rank];
             CHECK(rec >= K.part_range[cam].x && rec < K.part_range[cam].y && !rec_used[rec]);
             rec_used[rec] = 1;
@@ -158,13 +182,20 @@ int main(int argc, char** argv) {
             for (int j = 0; j < ti.y; ++j) CHECK(K.cpos[((size_t)ti.x + j) * 64 + lane] == -1);
         }
       }
-    for (int s = L.wg_cam_off[w]; s < L.wg_cam_off[w + 1]; ++s) {
-      const int rec = K.slot_rec[s], cam = order[L.wg_cams[s]];
-      CHECK(rec >= K.part_range[cam].x && rec < K.part_range[cam].y && !rec_used[rec]);
+    for (int a = 0; a < nw; ++a) {
+      const int rec = K.slot_rec[(size_t)L.wg_cam_off[w] + a];
+      CHECK(rec >= 0 && rec < K.n_part_rec && !rec_used[rec]);
       rec_used[rec] = 1;
+      if (nw == n_par) {
+        const int cam = order[L.wg_cams[L.wg_cam_off[w] + a]];
+        CHECK(rec >= K.part_range[cam].x && rec < K.part_range[cam].y);
+      }
+      if (rank_of_acc[a] >= 0) CHECK(!cold_here[rank_of_acc[a]]);
     }
+    for (int a = 0; a < nw; ++a)
+      for (int c = a + 1; c < nw; ++c) CHECK(rank_of_acc[a] < 0 || rank_of_acc[a] != rank_of_acc[c]);
   }
-  CHECK(n_placed == n_obs);
+  CHECK(n_placed == n_obs && n_capped == K.n_capped_obs);
   for (int r = 0; r < K.n_part_rec; ++r) CHECK(rec_used[r]);
   if (K.cold_q) {  // every cold observation of the parent layout is written by exactly one lane; the records are the slots' alone
     CHECK(n_cold_q == (int64_t)L.cold_lm.size() && K.n_part_rec == (int)L.wg_cams.size());
@@ -210,10 +241,10 @@ int main(int argc, char** argv) {
     if (hist[h]) std::fprintf(stderr, "tiles of %2d rows: %lld\n", h, (long long)hist[h]);
   std::printf("{\"ok\": 1, \"nb\": %d, \"slots\": %d, \"tiles\": %zu, \"rows\": %lld, \"chunks\": %lld, \"cold_chunks\": %lld, "
               "\"obs_per_chunk\": %.3f, \"pad_frac\": %.4f, \"max_tiles_bt\": %d, \"part_rec\": %d, \"lpl_part_rec\": %d, "
-              "\"extra_lanes_per_half_row\": %.4f, \"lds_bytes\": %zu, \"build_ms\": %.1f, \"lpl_rows\": %lld, \"packed\": %d, \"cold_q\": %d, \"cold_obs\": %zu}\n",
+              "\"extra_lanes_per_half_row\": %.4f, \"lds_bytes\": %zu, \"build_ms\": %.1f, \"lpl_rows\": %lld, \"packed\": %d, \"cold_q\": %d, \"cold_obs\": %zu, \"stride\": %d, \"max_acc\": %d, \"capped_obs\": %lld}\n",
               K.nb, K.slots, K.tile.size(), (long long)K.rows, (long long)K.n_chunks, (long long)K.n_cold_chunks,
               (double)n_obs / std::max<int64_t>(K.n_chunks, 1), 1.0 - (double)n_obs / ((double)K.rows * 64), K.max_tiles_bt,
-              K.n_part_rec, L.n_part_rec, K.extra_lanes / (2.0 * std::max<int64_t>(K.rows, 1)), ck_lds_bytes_shape(shape, K.slots, K.max_acc, K.ng), ms,
-              (long long)L.rows, K.packed ? 1 : 0, K.cold_q ? 1 : 0, L.cold_lm.size());
+              K.n_part_rec, L.n_part_rec, K.extra_lanes / (2.0 * std::max<int64_t>(K.rows, 1)), ck_lds_bytes_shape(shape_k, K.slots, K.max_acc, K.ng), ms,
+              (long long)L.rows, K.packed ? 1 : 0, K.cold_q ? 1 : 0, L.cold_lm.size(), K.stride, K.max_acc, (long long)K.n_capped_obs);
   return 0;
 }

@@ -93,13 +93,29 @@ def test_ck_layout_venice_shape(tmp_path):
 
 def test_ck_layout_step2_shape(tmp_path):
     """The instance e0_ck_h (step 2) runs: 64 bytes of LDS per landmark slot in component-major arrays with a compile-time
-    stride of 1536 slots -- more batches than step 1's, at most 1536 slots each, the slot words hold the slot itself."""
+    stride -- 1536 slots, or 2048 where that saves a landmark batch; then the accumulators that no longer fit beside the slots
+    are given up: a workgroup keeps those of its most observed cameras, the other cameras' chunks get records of their own
+    (the checker: every accumulator serves one camera, a camera with one has no cold chunk in that workgroup, every record is
+    used once, the capped observations are counted)."""
     from povar_amd import synth
     p = synth.make_problem(300, 20000, 90000, seed=5)
     for grid, n_acc in ((256, 520), (7, 40), (1, 520)):
         s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, grid, n_acc, env={"CK_CHECK_STEP2": "1"})
-        assert s["ok"] == 1 and s["slots"] <= 1536 and s["lds_bytes"] <= 160 * 1024
+        assert s["ok"] == 1 and s["slots"] <= s["stride"] and s["lds_bytes"] <= 160 * 1024
+    # 20 000 landmarks over 12 workgroups: 31 lane tiles each -- two batches of 1536 slots or one of 2048; 300 cameras fit beside either
+    s = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 12, 520, env={"CK_CHECK_STEP2": "1"})
+    assert s["ok"] == 1 and s["stride"] == 2048 and s["nb"] == 1 and s["capped_obs"] == 0 and s["max_acc"] <= 314
+    f = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 12, 520, env={"CK_CHECK_STEP2": "1", "POVAR_CKH_STRIDE": "1536"})
+    assert f["ok"] == 1 and f["stride"] == 1536 and f["nb"] == 2
+    # ... and with 700 cameras (501 slots in the parent layout at most) the wide stride caps the accumulators at 314
+    q = synth.make_problem(700, 20000, 90000, seed=6)
+    s = _run(tmp_path, q.n_cams, q.lm_off, q.cam_idx, q.obs, 12, 520, env={"CK_CHECK_STEP2": "1"})
+    assert s["ok"] == 1 and s["stride"] == 2048 and s["nb"] == 1 and s["max_acc"] == 314 and s["capped_obs"] > 0
+    f = _run(tmp_path, q.n_cams, q.lm_off, q.cam_idx, q.obs, 12, 520, env={"CK_CHECK_STEP2": "1", "POVAR_CKH_STRIDE": "1536"})
+    assert f["ok"] == 1 and f["capped_obs"] == 0 and f["max_acc"] > 314 and f["cold_chunks"] < s["cold_chunks"]
     p = synth.make_bal_problem("venice-1778")
     s1 = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 256, 520, env={"LPL_CHECK_NOPLACE": "1"})
     s2 = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 256, 520, env={"LPL_CHECK_NOPLACE": "1", "CK_CHECK_STEP2": "1"})
-    assert s2["ok"] == 1 and s2["nb"] == 3 > s1["nb"] and s2["slots"] <= 1536 and s2["obs_per_chunk"] > 4.5
+    assert s2["ok"] == 1 and s2["nb"] == 2 == s1["nb"] and s2["stride"] == 2048 and s2["max_acc"] == 314 and s2["obs_per_chunk"] > 4.5
+    s3 = _run(tmp_path, p.n_cams, p.lm_off, p.cam_idx, p.obs, 256, 520, env={"LPL_CHECK_NOPLACE": "1", "CK_CHECK_STEP2": "1", "POVAR_CKH_STRIDE": "1536"})
+    assert s3["ok"] == 1 and s3["nb"] == 3 and s3["slots"] <= 1536 and s3["capped_obs"] == 0

@@ -278,3 +278,58 @@ def test_cold_observations_through_the_cold_view_are_the_same_operator(monkeypat
     for robust in ("NONE", "HUBER"):
         assert rel(out["cold view", robust][0], out["records", robust][0]) < 1e-13
         assert rel(out["cold view", robust][1], out["records", robust][1]) < 1e-11
+
+
+def test_step2_wide_stride_with_capped_accumulators_is_the_same_operator(monkeypatch):
+    """Round 6: e0_ck_h with LDS arrays cut for 2048 landmark slots instead of 1536 where that saves a landmark batch (venice:
+    three batches -> two) -- then only 314 accumulators fit beside them: a workgroup keeps those of its most observed cameras,
+    the chunks of the other cameras get records of their own (ck_layout.hpp: CkShape::wide_slots).  700 cameras over 12
+    workgroups (one batch of 2048 slots against two of 1536; the parent layout has more than 314 camera slots per workgroup):
+    the library takes the wide stride by itself, and the 20-term step-2 increment is the same with either stride forced and
+    with e0_lpl_h, NONE and HUBER."""
+    from povar_amd import capi, synth
+    monkeypatch.setenv("POVAR_E0_V1", "0")
+    monkeypatch.setenv("POVAR_E0_WGS", "12")
+    monkeypatch.setenv("POVAR_LPL_PLACE", "sync")
+    p = synth.make_problem(700, 20000, 90000, seed=6)
+    rng = np.random.default_rng(11)
+    cams = rng.normal(size=(p.n_cams, 12))
+    cams[:, 8:11] *= 0.1
+    cams[:, 11] = 5 + rng.random(p.n_cams)
+    cams /= np.linalg.norm(cams, axis=1, keepdims=True)
+    lms_h = np.concatenate([rng.normal(size=(p.n_lms, 3)), np.ones((p.n_lms, 1))], 1)
+    obs = p.obs / 500.0
+    out = {}
+    for stride in (None, "1536", "2048"):
+        monkeypatch.delenv("POVAR_CKH_STRIDE", raising=False)
+        if stride:
+            monkeypatch.setenv("POVAR_CKH_STRIDE", stride)
+        for robust in ("NONE", "HUBER"):
+            ctx = capi.Context(p.n_cams, p.lm_off, p.cam_idx, obs, robust_norm=robust, huber=0.5, e0_mode=capi.E0_IMPLICIT_LDSACC)
+            li = ctx.layout_info()
+            assert li.ckh_ready == 1 and li.ckh_stride == int(stride or 2048) and li.ckh_slots <= li.ckh_stride
+            if li.ckh_stride == 2048:
+                assert li.ckh_batches == 1 and li.ckh_accumulators == 314 < li.lds_slots and li.ckh_capped_obs > 0
+            else:
+                assert li.ckh_batches == 2 and li.ckh_accumulators == li.lds_slots and li.ckh_capped_obs == 0
+            ctx.set_cameras(cams)
+            ctx.set_landmarks_homogeneous(lms_h)
+            assert ctx.linearize_homogeneous()
+            ctx.prepare_joint(LAM)
+            res = {}
+            for kernel in (0, 1):
+                ctx.set_e0_kernel(kernel)
+                assert ctx.layout_info().e0_kernel_h == kernel
+                ctx.power_series_begin()
+                ctx.power_series_step()
+                t1 = ctx.get_term(11).copy()
+                inc, it, st, rc = ctx.solve_joint(LAM, M)
+                assert rc == 0 and it == M
+                res[kernel] = (t1, inc)
+            assert rel(res[1][0], res[0][0]) < 1e-12 and rel(res[1][1], res[0][1]) < 1e-10, (stride, robust)
+            out[stride, robust] = res[1]
+            ctx.close()
+    for robust in ("NONE", "HUBER"):
+        assert rel(out["2048", robust][0], out["1536", robust][0]) < 1e-12
+        assert rel(out["2048", robust][1], out["1536", robust][1]) < 1e-10
+        assert np.array_equal(out[None, robust][1], out["2048", robust][1]) or rel(out[None, robust][1], out["2048", robust][1]) < 1e-12
