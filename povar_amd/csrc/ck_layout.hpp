@@ -227,6 +227,9 @@ inline void build_ck(const LplLayout& L, int n_cams, int grid, const std::vector
     if (shape.wide_slots > shape.max_slots && batches(shape.wide_slots) < batches(shape.max_slots)) shape.max_slots = shape.wide_slots;
     const size_t fixed = ck_lds_bytes_shape(shape, 0, 0, ng);
     max_acc = std::min(max_acc, (int)(((size_t)CK_LDS_BYTES - fixed) / (size_t)shape.acc_bytes));
+    // (POVAR_CKH_ACC_CAP=<n>: stress knob of tools/forced_mode_suite.sh -- capped accumulators on problems with few cameras too)
+    if (const char* e = std::getenv("POVAR_CKH_ACC_CAP"))
+      if (shape.acc_bytes == 104) max_acc = std::min(max_acc, std::max(1, std::atoi(e)));
     K.stride = shape.max_slots;
   }
   int nb = ng;

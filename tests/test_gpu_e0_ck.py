@@ -291,6 +291,8 @@ def test_step2_wide_stride_with_capped_accumulators_is_the_same_operator(monkeyp
     monkeypatch.setenv("POVAR_E0_V1", "0")
     monkeypatch.setenv("POVAR_E0_WGS", "12")
     monkeypatch.setenv("POVAR_LPL_PLACE", "sync")
+    for k in ("POVAR_CKH_ACC_CAP", "POVAR_HOT_ACC", "POVAR_CK_NB", "POVAR_LPL_K0", "POVAR_LPL_STRATEGY"):  # (tools/forced_mode_suite.sh)
+        monkeypatch.delenv(k, raising=False)
     p = synth.make_problem(700, 20000, 90000, seed=6)
     rng = np.random.default_rng(11)
     cams = rng.normal(size=(p.n_cams, 12))

@@ -38,6 +38,8 @@ run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_LPL_PLACE=sync
 # seven workgroups (dozens of tiles per wavefront), the two-group instantiation, the 12-wavefront one on a layout cut for it
 run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_HOT_ACC=24 POVAR_LPL_STRATEGY=range
 run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_CK_NB=3 POVAR_CK_HMAX=5 POVAR_LPL_PLACE=async
+# step 2's wide stride with a dozen accumulators per workgroup: most cameras of every step-2 context lose their slot (round 6)
+run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_CKH_STRIDE=2048 POVAR_CKH_ACC_CAP=12 POVAR_LPL_PLACE=sync
 run POVAR_E0_V1=0 POVAR_E0_CK=1 POVAR_LPL_K0=2 POVAR_E0_WGS=7
 run POVAR_E0_V1=0 POVAR_E0_CK=4 POVAR_CK_NB=4
 run POVAR_E0_V1=0 POVAR_E0_CK=3 POVAR_NO_GRAPH=1
