@@ -434,7 +434,13 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     if (NG > 1) ck_group_barrier(gcnt, ggen, GW, lane0);
     else ck_barrier();
   };
-  auto tile_of = [&](int tb0, int q) { return tb0 + q * GW + ((q & 1) ? GW - 1 - wave : wave); };
+  // Which tile of a round a wavefront walks: consecutive wavefronts sit on the four SIMDs in turn and a SIMD issues for its oldest
+  // wavefront first, so with "wavefront w walks tile w" SIMD 0 hosted the longest tile of every group of four and its wavefronts 4
+  // and 8 closed the way forward 4 k cycles behind the median in 225 of 256 workgroups (profiles/r06_e0_ck_phase_stamps.txt).
+  // The groups of four are dealt in alternating direction instead: h0 + h7 + h8 + h15 on SIMD 0, h3 + h4 + h11 + h12 on SIMD 3
+  // (53.98 -> 53.55 us per term on venice, profiles/r06_snake_ab.txt).
+  const int wave_t = (wave & ~3) | (((wave >> 2) & 1) ? 3 - (wave & 3) : (wave & 3));
+  auto tile_of = [&](int tb0, int q) { return tb0 + q * GW + ((q & 1) ? GW - 1 - wave_t : wave_t); };
   constexpr int HM = 32 / NW > 0 ? 32 / NW : 1;  // slot tiles per wavefront whose h~ / G are requested a phase ahead
   double hn[HM][3];
   auto request_h = [&](int b, int lane) {
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck(Dp d, CkP k, double* part_out) 
     rank_next = 0;
     if (b < k.nb) {
       const int tb0 = bt_of(b, b == grp), tb1 = bt_of(b + 1, b == grp);
-      if (tb0 + wave < tb1) rank_next = ck_rank(k.lane_meta[(size_t)(tb0 + wave) * WAVE + lane].x);
+      if (tb0 + wave_t < tb1) rank_next = ck_rank(k.lane_meta[(size_t)(tb0 + wave_t) * WAVE + lane].x);
     }
   };
   request_first_meta(grp, lane0);

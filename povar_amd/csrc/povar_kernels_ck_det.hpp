@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NW * 64) void e0_ck_det(Dp d, CkP k, double* part_o
   const cint_p tiles = (cint_p)(uintptr_t)k.tile;
   const cint_p bt = (cint_p)(uintptr_t)k.bt_off;
   if (done) return;  // wave-uniform, before any barrier and any side effect
-  auto tile_of = [&](int tb0, int q) { return tb0 + q * NW + ((q & 1) ? NW - 1 - wave : wave); };  // (as e0_ck)
+  auto tile_of = [&](int tb0, int q) { return tb0 + q * NW + ((q & 1) ? NW - 1 - wave : wave); };  // (e0_ck's walk without its deal over the SIMDs: the layout's ticket order is cut for this one)
   for (int b = 0; b < k.nb; ++b) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));  // (per-lane addresses are not carried across the batches: povar_kernels_ck.hpp)
