@@ -29,9 +29,10 @@
 namespace povar {
 
 // Two strides (round 6): 1536 slots leave room for every accumulator the parent layout has (629 > HOT_ACC_MAX); 2048 slots
-// leave 314 -- the layout takes them where they save a landmark batch (venice-1778: 3 883 landmarks per workgroup, three
-// batches of 1 344 slots -> two of 2 048: 71.1 -> 68.1 us per term although 291 accumulators instead of 501 turn 178 k more
-// chunks into chunks with a record of their own; a batch costs ~ 7 us, the accumulators ~ 4: profiles/r06_ckh_stride_ab.txt).
+// leave 314 -- the layout takes them where they save a landmark batch and keeps, per workgroup, the accumulators of the cameras
+// it observes most (ck_layout.hpp: CkShape::wide_slots).  venice-1778 (3 883 landmarks per workgroup): three batches of 1 344
+// slots -> two of 2 048, 70.7 -> 64.9 us per term although 314 accumulators instead of 501 turn 87 k more chunks into chunks
+// with a record of their own; a batch costs ~ 7 us, the accumulators ~ 2 (profiles/r06_ckh_stride_ab.txt).
 constexpr int CKH_STRIDE = 1536;        // landmark slots of a batch at most; component stride of the LDS arrays
 constexpr int CKH_STRIDE_WIDE = 2048;   // the same with fewer accumulators beside them (e0_ck_h only; e0_ck_h_det keeps 1536)
 constexpr int CKH_REC = 14;        // = LPL_REC_H: doubles per landmark lane in V2::lmrec (step 2): X (4), s (4), Hll^-1 (6)
