@@ -6,6 +6,8 @@
 #                         profiles/r06_experiments.txt D; POVAR_CK_HEAD=0|1, tools/r06_head_probe.py, tools/r06_head_ab.sh)
 #   ck_stamps             in-kernel s_memtime stamps of e0_ck's phases (tools/ck_stamps.py) + the timing-only experiment
 #                         branches of round 4 (-DPOVAR_CK_EXP_NOATOMIC, -DPOVAR_CK_EXP_NOBWDROWS, -DPOVAR_CK_EXP_NOBWDLDS)
+#   ck_touch              one extra load per wavefront that touches G's cache lines ahead of the landmark step (round 6: +5.2 us per term as
+#                         the batch's first request, +2.8 behind the first tile's requests; profiles/r06_touch_prefetch_ab.txt, tools/r06_variant_ab.sh)
 # (series_res has its own generator: tools/variants/res_stamps.py)
 set -e
 cd "$(dirname "$0")/../.."
