@@ -8,6 +8,7 @@
 #                         branches of round 4 (-DPOVAR_CK_EXP_NOATOMIC, -DPOVAR_CK_EXP_NOBWDROWS, -DPOVAR_CK_EXP_NOBWDLDS)
 #   ck_touch              one extra load per wavefront that touches G's cache lines ahead of the landmark step (round 6: +5.2 us per term as
 #                         the batch's first request, +2.8 behind the first tile's requests; profiles/r06_touch_prefetch_ab.txt, tools/r06_variant_ab.sh)
+#   ck_soa16              z and P3 of the camera records in piece-major images of 16-byte pieces (round 6: +1.8 us per term; profiles/r06_soa16_ab.txt)
 # (series_res has its own generator: tools/variants/res_stamps.py)
 set -e
 cd "$(dirname "$0")/../.."
