@@ -9,6 +9,7 @@
 #   ck_touch              one extra load per wavefront that touches G's cache lines ahead of the landmark step (round 6: +5.2 us per term as
 #                         the batch's first request, +2.8 behind the first tile's requests; profiles/r06_touch_prefetch_ab.txt, tools/r06_variant_ab.sh)
 #   ck_soa16              z and P3 of the camera records in piece-major images of 16-byte pieces (round 6: +1.8 us per term; profiles/r06_soa16_ab.txt)
+#   ck_wperm              the tile of a round each wavefront walks from POVAR_CK_WPERM (round 6: tools/r06_wperm_sweep.sh, profiles/r06_wperm_sweep.txt)
 # (series_res has its own generator: tools/variants/res_stamps.py)
 set -e
 cd "$(dirname "$0")/../.."
