@@ -10,6 +10,7 @@
 #                         the batch's first request, +2.8 behind the first tile's requests; profiles/r06_touch_prefetch_ab.txt, tools/r06_variant_ab.sh)
 #   ck_soa16              z and P3 of the camera records in piece-major images of 16-byte pieces (round 6: +1.8 us per term; profiles/r06_soa16_ab.txt)
 #   ck_wperm              the tile of a round each wavefront walks from POVAR_CK_WPERM (round 6: tools/r06_wperm_sweep.sh, profiles/r06_wperm_sweep.txt)
+#   ck_rows128            z and the static half of the camera records in 128-byte rows (round 6: +1.8 us per term; profiles/r06_rows128_ab.txt)
 # (series_res has its own generator: tools/variants/res_stamps.py)
 set -e
 cd "$(dirname "$0")/../.."
