@@ -29,7 +29,7 @@ POVAR_LIB=build/libpovar_hip_stamps.so POVAR_E0_CK=1 timeout 300 python3 tools/c
  POVAR_RES_MAX_OBS=2000000 timeout 200 python3 tools/res_stamps_report.py venice-1778 8 2>&1 | sed -E "s/at median +[0-9]+ +min +[0-9]+ +max +[0-9]+//") > $out/res_stamps.txt 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/res_kt -- python3 tools/res_term_time.py trafalgar-257 > $out/res_kt.out 2>&1 < /dev/null
 rm -rf $out/res_kt/*/*kernel_trace.csv
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_kt -- python3 bench.py --no-cpu-baseline --no-secondary > $out/bench_kt.json 2> $out/bench_kt.err < /dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_kt -- python3 bench.py --no-cpu-baseline --no-secondary --warm-seconds 0 --repeats 1 > $out/bench_kt.json 2> $out/bench_kt.err < /dev/null
 rm -rf $out/bench_kt/*/*kernel_trace.csv
 B="python3 bench.py"
 $B > $out/bench_default.json 2> $out/bench_default.err < /dev/null
